@@ -1,0 +1,409 @@
+// bvc_api.hip -- host side of libbvc: the C ABI declared in include/bvc.h.
+// One context = one gfx950 device + one HIP stream + device scratch.  No CPU fallback exists: every
+// compute entry point launches the HIP kernels or fails with an error code.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bvc_internal.h"
+
+using namespace bvc;
+
+struct bvc_ctx {
+    int device = -1;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    QualLut *d_lut = nullptr;
+    uint32_t *d_counts = nullptr;      // [sites][512] scratch between the two stages
+    size_t counts_cap = 0;
+    uint32_t *d_grp_counts = nullptr;  // [sites][groups + 1][512] in group mode
+    size_t grp_counts_cap = 0;
+    char *d_stage = nullptr;           // staging for BVC_PTR_HOST calls
+    size_t stage_cap = 0;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;   // free events
+    struct Triple { hipEvent_t a, b, c; int64_t sites; };
+    std::vector<Triple> ev_pending;
+    bvc_profile prof{};
+    std::string err;
+};
+
+namespace {
+
+int fail(bvc_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        ctx->err = what;
+        if (e != hipSuccess) { ctx->err += ": "; ctx->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+
+#define BVC_HIP(ctx, call)                                                         \
+    do {                                                                           \
+        hipError_t e__ = (call);                                                   \
+        if (e__ != hipSuccess) return fail((ctx), BVC_ERR_DEVICE, #call, e__);     \
+    } while (0)
+
+int ensure(bvc_ctx *ctx, void **buf, size_t *cap, size_t need)
+{
+    if (need <= *cap) return BVC_OK;
+    if (*buf) {
+        BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BVC_HIP(ctx, hipFree(*buf));
+        *buf = nullptr; *cap = 0;
+    }
+    size_t want = need + need / 4;
+    if (hipMalloc(buf, want) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc(buf, need) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, BVC_ERR_ALLOC, "device scratch allocation failed"); }
+        want = need;
+    }
+    *cap = want;
+    return BVC_OK;
+}
+
+hipEvent_t take_event(bvc_ctx *ctx)
+{
+    if (!ctx->ev_pool.empty()) { hipEvent_t e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+// The two stages on device pointers.  comb/n_comb may be null.
+int run_dense_device(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                     const int8_t *bases, const int8_t *quals, const int8_t *ref_base, double min_af,
+                     bvc_site_result *results)
+{
+    int rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_counts), &ctx->counts_cap,
+                    (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t));
+    if (rc != BVC_OK) return rc;
+    const int split = choose_hist_split(n_sites, n_samples, ctx->n_cu);
+    bvc_ctx::Triple t{nullptr, nullptr, nullptr, n_sites};
+    if (ctx->profiling) { t.a = take_event(ctx); t.b = take_event(ctx); t.c = take_event(ctx); }
+    if (split > 1)
+        BVC_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t), ctx->stream));
+    if (t.a) BVC_HIP(ctx, hipEventRecord(t.a, ctx->stream));
+    BVC_HIP(ctx, launch_hist_dense(ctx->stream, n_sites, n_samples, row_stride, bases, quals, nullptr, 0,
+                                   ctx->d_counts, split));
+    if (t.b) BVC_HIP(ctx, hipEventRecord(t.b, ctx->stream));
+    BVC_HIP(ctx, launch_lrt(ctx->stream, n_sites, ctx->d_counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut,
+                            nullptr, nullptr, results));
+    if (t.c) { BVC_HIP(ctx, hipEventRecord(t.c, ctx->stream)); ctx->ev_pending.push_back(t); }
+    return BVC_OK;
+}
+
+int check_common(bvc_ctx *ctx, int64_t n_sites, const void *a, const void *b, const void *c, const void *d)
+{
+    if (!ctx) return BVC_ERR_ARG;
+    if (n_sites < 0) return fail(ctx, BVC_ERR_ARG, "n_sites < 0");
+    if (n_sites > 0 && (!a || !b || !c || !d)) return fail(ctx, BVC_ERR_ARG, "null data pointer");
+    if (n_sites > (int64_t)0x7FFFFFFF / 64) return fail(ctx, BVC_ERR_ARG, "too many sites in one call (split the tile)");
+    BVC_HIP(ctx, hipSetDevice(ctx->device));
+    return BVC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *bvc_version(void) { return "libbvc 0.1.0 (gfx950)"; }
+
+int bvc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int bvc_create(bvc_ctx **out, int device)
+{
+    if (!out) return BVC_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return BVC_ERR_NO_DEVICE; }
+    if (device < 0 || device >= n) return BVC_ERR_NO_DEVICE;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return BVC_ERR_DEVICE;
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) return BVC_ERR_NO_DEVICE;   // code objects are gfx950 only
+    bvc_ctx *ctx = new (std::nothrow) bvc_ctx();
+    if (!ctx) return BVC_ERR_ALLOC;
+    ctx->device = device;
+    ctx->n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return BVC_ERR_DEVICE; }
+    // likelihood table from the host's exp(), as the CPU path computes it (src/BaseType.cpp:13,15)
+    QualLut lut;
+    for (int q = 0; q < 128; ++q) {
+        const double eps = std::exp(-0.23025850929940458 * q);   // MLN10TO10, src/BaseType.h:10
+        const double a = 1.0 - eps, e = eps / 3.0;
+        lut.e[q] = e;
+        lut.d[q] = a - e;
+    }
+    if (hipMalloc(reinterpret_cast<void **>(&ctx->d_lut), sizeof(QualLut)) != hipSuccess ||
+        hipMemcpy(ctx->d_lut, &lut, sizeof(QualLut), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ctx->d_lut) (void)hipFree(ctx->d_lut);
+        delete ctx;
+        return BVC_ERR_ALLOC;
+    }
+    *out = ctx;
+    return BVC_OK;
+}
+
+void bvc_destroy(bvc_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->ev_pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.c); }
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->d_lut) (void)hipFree(ctx->d_lut);
+    if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+    if (ctx->d_grp_counts) (void)hipFree(ctx->d_grp_counts);
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    delete ctx;
+}
+
+const char *bvc_last_error(const bvc_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int bvc_set_stream(bvc_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return BVC_ERR_ARG;
+    BVC_HIP(ctx, hipSetDevice(ctx->device));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return BVC_OK;
+}
+
+int bvc_synchronize(bvc_ctx *ctx)
+{
+    if (!ctx) return BVC_ERR_ARG;
+    BVC_HIP(ctx, hipSetDevice(ctx->device));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BVC_OK;
+}
+
+int bvc_set_profiling(bvc_ctx *ctx, int on)
+{
+    if (!ctx) return BVC_ERR_ARG;
+    ctx->profiling = on != 0;
+    return BVC_OK;
+}
+
+int bvc_get_profile(bvc_ctx *ctx, bvc_profile *out, int reset)
+{
+    if (!ctx || !out) return BVC_ERR_ARG;
+    BVC_HIP(ctx, hipSetDevice(ctx->device));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &t : ctx->ev_pending) {
+        float ms1 = 0.f, ms2 = 0.f;
+        BVC_HIP(ctx, hipEventElapsedTime(&ms1, t.a, t.b));
+        BVC_HIP(ctx, hipEventElapsedTime(&ms2, t.b, t.c));
+        ctx->prof.hist_ms += ms1; ctx->prof.em_ms += ms2;
+        ctx->prof.hist_launches += 1; ctx->prof.em_launches += 1; ctx->prof.sites += t.sites;
+        ctx->ev_pool.push_back(t.a); ctx->ev_pool.push_back(t.b); ctx->ev_pool.push_back(t.c);
+    }
+    ctx->ev_pending.clear();
+    *out = ctx->prof;
+    if (reset) ctx->prof = bvc_profile{};
+    return BVC_OK;
+}
+
+int bvc_lrt_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                  const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
+                  double min_af, bvc_site_result *results, uint32_t flags)
+{
+    int rc = check_common(ctx, n_sites, bases, quals, ref_base, results);
+    if (rc != BVC_OK) return rc;
+    if (n_samples < 0 || row_stride < n_samples) return fail(ctx, BVC_ERR_ARG, "need 0 <= n_samples <= row_stride");
+    if (n_sites == 0) return BVC_OK;
+    if (flags & BVC_PTR_DEVICE)
+        return run_dense_device(ctx, n_sites, n_samples, row_stride, bases, quals, ref_base, min_af, results);
+
+    // host pointers: stage site chunks of at most ~1 GiB per array through device memory
+    const int64_t row_bytes = row_stride > 0 ? row_stride : 1;
+    int64_t chunk = ((int64_t)1 << 30) / row_bytes;
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_sites) chunk = n_sites;
+    const size_t arr = (size_t)chunk * (size_t)row_stride;
+    const size_t arr_al = (arr + 255) & ~(size_t)255;
+    const size_t ref_al = ((size_t)chunk + 255) & ~(size_t)255;
+    const size_t need = 2 * arr_al + ref_al + (size_t)chunk * sizeof(bvc_site_result) + 256;
+    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage), &ctx->stage_cap, need);
+    if (rc != BVC_OK) return rc;
+    int8_t *d_b = reinterpret_cast<int8_t *>(ctx->d_stage);
+    int8_t *d_q = d_b + arr_al;
+    int8_t *d_r = d_q + arr_al;
+    bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(d_r + ref_al);
+    for (int64_t s0 = 0; s0 < n_sites; s0 += chunk) {
+        const int64_t ns = (n_sites - s0 < chunk) ? n_sites - s0 : chunk;
+        // the last row may be shorter than row_stride in the caller's allocation: copy exactly what is addressed
+        const size_t bytes = (size_t)(ns - 1) * (size_t)row_stride + (size_t)n_samples;
+        BVC_HIP(ctx, hipMemcpyAsync(d_b, bases + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP(ctx, hipMemcpyAsync(d_q, quals + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base + s0, (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
+        rc = run_dense_device(ctx, ns, n_samples, row_stride, d_b, d_q, d_r, min_af, d_res);
+        if (rc != BVC_OK) return rc;
+        BVC_HIP(ctx, hipMemcpyAsync(results + s0, d_res, (size_t)ns * sizeof(bvc_site_result),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return BVC_OK;
+}
+
+int bvc_hist_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                   const int8_t *bases, const int8_t *quals, uint32_t *counts, uint32_t flags)
+{
+    int rc = check_common(ctx, n_sites, bases, quals, counts, counts);
+    if (rc != BVC_OK) return rc;
+    if (n_samples < 0 || row_stride < n_samples) return fail(ctx, BVC_ERR_ARG, "need 0 <= n_samples <= row_stride");
+    if (n_sites == 0) return BVC_OK;
+    const int split = choose_hist_split(n_sites, n_samples, ctx->n_cu);
+    const size_t cbytes = (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t);
+    if (flags & BVC_PTR_DEVICE) {
+        if (split > 1) BVC_HIP(ctx, hipMemsetAsync(counts, 0, cbytes, ctx->stream));
+        BVC_HIP(ctx, launch_hist_dense(ctx->stream, n_sites, n_samples, row_stride, bases, quals, nullptr, 0, counts, split));
+        return BVC_OK;
+    }
+    const size_t bytes = (size_t)(n_sites - 1) * (size_t)row_stride + (size_t)n_samples;
+    const size_t arr_al = (bytes + 255) & ~(size_t)255;
+    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage), &ctx->stage_cap, 2 * arr_al + cbytes + 256);
+    if (rc != BVC_OK) return rc;
+    int8_t *d_b = reinterpret_cast<int8_t *>(ctx->d_stage);
+    int8_t *d_q = d_b + arr_al;
+    uint32_t *d_c = reinterpret_cast<uint32_t *>(d_q + arr_al);
+    BVC_HIP(ctx, hipMemcpyAsync(d_b, bases, bytes, hipMemcpyHostToDevice, ctx->stream));
+    BVC_HIP(ctx, hipMemcpyAsync(d_q, quals, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (split > 1) BVC_HIP(ctx, hipMemsetAsync(d_c, 0, cbytes, ctx->stream));
+    BVC_HIP(ctx, launch_hist_dense(ctx->stream, n_sites, n_samples, row_stride, d_b, d_q, nullptr, 0, d_c, split));
+    BVC_HIP(ctx, hipMemcpyAsync(counts, d_c, cbytes, hipMemcpyDeviceToHost, ctx->stream));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BVC_OK;
+}
+
+int bvc_lrt_hist(bvc_ctx *ctx, int64_t n_sites, const uint32_t *counts, const int8_t *ref_base,
+                 double min_af, const int8_t *base_comb, const uint8_t *n_comb,
+                 bvc_site_result *results, uint32_t flags)
+{
+    int rc = check_common(ctx, n_sites, counts, ref_base, results, results);
+    if (rc != BVC_OK) return rc;
+    if ((base_comb == nullptr) != (n_comb == nullptr)) return fail(ctx, BVC_ERR_ARG, "base_comb and n_comb go together");
+    if (n_sites == 0) return BVC_OK;
+    if (flags & BVC_PTR_DEVICE) {
+        BVC_HIP(ctx, launch_lrt(ctx->stream, n_sites, counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut, base_comb,
+                                n_comb, results));
+        return BVC_OK;
+    }
+    if (base_comb)
+        for (int64_t s = 0; s < n_sites; ++s) {
+            if (n_comb[s] > 4) return fail(ctx, BVC_ERR_ARG, "n_comb > 4");
+            for (int c = 0; c < n_comb[s]; ++c)
+                if (base_comb[s * 4 + c] < 0 || base_comb[s * 4 + c] > 3) return fail(ctx, BVC_ERR_ARG, "base_comb entry outside 0..3");
+        }
+    const size_t cbytes = (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t);
+    const size_t sa = ((size_t)n_sites + 255) & ~(size_t)255;
+    const size_t ca = ((size_t)n_sites * 4 + 255) & ~(size_t)255;
+    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage), &ctx->stage_cap,
+                cbytes + 2 * sa + ca + (size_t)n_sites * sizeof(bvc_site_result) + 256);
+    if (rc != BVC_OK) return rc;
+    uint32_t *d_c = reinterpret_cast<uint32_t *>(ctx->d_stage);
+    int8_t *d_r = reinterpret_cast<int8_t *>(ctx->d_stage + cbytes);
+    uint8_t *d_nc = reinterpret_cast<uint8_t *>(d_r + sa);
+    int8_t *d_cb = reinterpret_cast<int8_t *>(d_nc + sa);
+    bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(d_cb + ca);
+    BVC_HIP(ctx, hipMemcpyAsync(d_c, counts, cbytes, hipMemcpyHostToDevice, ctx->stream));
+    BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
+    if (base_comb) {
+        BVC_HIP(ctx, hipMemcpyAsync(d_nc, n_comb, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP(ctx, hipMemcpyAsync(d_cb, base_comb, (size_t)n_sites * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    BVC_HIP(ctx, launch_lrt(ctx->stream, n_sites, d_c, BVC_NCLASS, d_r, min_af, ctx->d_lut,
+                            base_comb ? d_cb : nullptr, base_comb ? d_nc : nullptr, d_res));
+    BVC_HIP(ctx, hipMemcpyAsync(results, d_res, (size_t)n_sites * sizeof(bvc_site_result), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BVC_OK;
+}
+
+int bvc_lrt_csr(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
+                const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
+                double min_af, bvc_site_result *results, uint32_t flags)
+{
+    int rc = check_common(ctx, n_sites, offsets, ref_base, results, results);
+    if (rc != BVC_OK) return rc;
+    if (n_sites == 0) return BVC_OK;
+    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_counts), &ctx->counts_cap,
+                (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t));
+    if (rc != BVC_OK) return rc;
+    if (flags & BVC_PTR_DEVICE) {
+        if (!bases || !quals) return fail(ctx, BVC_ERR_ARG, "null data pointer");
+        BVC_HIP(ctx, launch_hist_csr(ctx->stream, n_sites, offsets, bases, quals, ctx->d_counts));
+        BVC_HIP(ctx, launch_lrt(ctx->stream, n_sites, ctx->d_counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut,
+                                nullptr, nullptr, results));
+        return BVC_OK;
+    }
+    const int64_t total = offsets[n_sites];
+    if (offsets[0] != 0 || total < 0) return fail(ctx, BVC_ERR_ARG, "offsets must start at 0 and be non-decreasing");
+    for (int64_t s = 0; s < n_sites; ++s)
+        if (offsets[s + 1] < offsets[s]) return fail(ctx, BVC_ERR_ARG, "offsets must start at 0 and be non-decreasing");
+    if (total > 0 && (!bases || !quals)) return fail(ctx, BVC_ERR_ARG, "null data pointer");
+    const size_t ta = ((size_t)total + 255) & ~(size_t)255;
+    const size_t oa = ((size_t)(n_sites + 1) * 8 + 255) & ~(size_t)255;
+    const size_t sa = ((size_t)n_sites + 255) & ~(size_t)255;
+    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage), &ctx->stage_cap,
+                oa + 2 * ta + sa + (size_t)n_sites * sizeof(bvc_site_result) + 256);
+    if (rc != BVC_OK) return rc;
+    int64_t *d_o = reinterpret_cast<int64_t *>(ctx->d_stage);
+    int8_t *d_b = reinterpret_cast<int8_t *>(ctx->d_stage + oa);
+    int8_t *d_q = d_b + ta;
+    int8_t *d_r = d_q + ta;
+    bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(d_r + sa);
+    BVC_HIP(ctx, hipMemcpyAsync(d_o, offsets, (size_t)(n_sites + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (total > 0) {
+        BVC_HIP(ctx, hipMemcpyAsync(d_b, bases, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP(ctx, hipMemcpyAsync(d_q, quals, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+    }
+    BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
+    BVC_HIP(ctx, launch_hist_csr(ctx->stream, n_sites, d_o, d_b, d_q, ctx->d_counts));
+    BVC_HIP(ctx, launch_lrt(ctx->stream, n_sites, ctx->d_counts, BVC_NCLASS, d_r, min_af, ctx->d_lut, nullptr,
+                            nullptr, d_res));
+    BVC_HIP(ctx, hipMemcpyAsync(results, d_res, (size_t)n_sites * sizeof(bvc_site_result), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BVC_OK;
+}
+
+int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                         const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
+                         double min_af, const uint8_t *group_of_sample, int32_t n_groups,
+                         bvc_site_result *results, bvc_group_result *grp_results, uint32_t flags)
+{
+    int rc = check_common(ctx, n_sites, bases, quals, ref_base, results);
+    if (rc != BVC_OK) return rc;
+    (void)n_samples; (void)row_stride; (void)min_af; (void)group_of_sample; (void)n_groups; (void)grp_results; (void)flags;
+    return fail(ctx, BVC_ERR_ARG, "bvc_lrt_dense_groups: not implemented yet");
+}
+
+int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites, int64_t n_samples,
+                    int64_t row_stride, uint32_t cov_thr16, int8_t *bases, int8_t *quals, int8_t *ref_base)
+{
+    int rc = check_common(ctx, n_sites, bases, quals, ref_base, ref_base);
+    if (rc != BVC_OK) return rc;
+    if (n_samples < 0 || row_stride < n_samples) return fail(ctx, BVC_ERR_ARG, "need 0 <= n_samples <= row_stride");
+    BVC_HIP(ctx, launch_synth_dense(ctx->stream, seed, site0, n_sites, n_samples, row_stride, cov_thr16, bases, quals,
+                                    ref_base));
+    return BVC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// bvc_device.h -- wave64 device helpers for the basetype kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bvc {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kRow = 16;           // DPP row: one base's classes live on one row of 16 lanes
+
+// ---- cross-lane movement -------------------------------------------------------------------------
+// DPP controls (ISA: quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141)
+constexpr int kDppXor1 = 0xB1;     // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;     // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;
+constexpr int kDppMirror = 0x140;
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = dpp_i32<CTRL>(__double2loint(v));
+    const int hi = dpp_i32<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the 16 lanes of a DPP row, result in every lane of the row.  Each step adds the partner's
+// value to the lane's own, and IEEE addition commutes, so all 16 lanes end with the same bits.
+__device__ __forceinline__ double row_sum(double v)
+{
+    v += dpp_f64<kDppXor1>(v);
+    v += dpp_f64<kDppXor2>(v);
+    v += dpp_f64<kDppHalfMirror>(v);
+    v += dpp_f64<kDppMirror>(v);
+    return v;
+}
+
+__device__ __forceinline__ int row_sum(int v)
+{
+    v += dpp_i32<kDppXor1>(v);
+    v += dpp_i32<kDppXor2>(v);
+    v += dpp_i32<kDppHalfMirror>(v);
+    v += dpp_i32<kDppMirror>(v);
+    return v;
+}
+
+__device__ __forceinline__ int row_max(int v)
+{
+    v = max(v, dpp_i32<kDppXor1>(v));
+    v = max(v, dpp_i32<kDppXor2>(v));
+    v = max(v, dpp_i32<kDppHalfMirror>(v));
+    v = max(v, dpp_i32<kDppMirror>(v));
+    return v;
+}
+
+// Value held by `lane` (compile-time), broadcast through SGPRs: wave-uniform by construction.
+template <int LANE>
+__device__ __forceinline__ double lane_value(double v)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), LANE);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), LANE);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum of the four row values (each already uniform within its row), fixed order -> uniform result.
+__device__ __forceinline__ double rows_total(double v)
+{
+    return ((lane_value<0>(v) + lane_value<16>(v)) + lane_value<32>(v)) + lane_value<48>(v);
+}
+
+__device__ __forceinline__ double uniform(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// ---- chi-square survival function, df = 1 --------------------------------------------------------
+// The reference's chisf(x, 1) = kf_gammaq(0.5, x/2) (src/Algorithm.cpp:3-7; htslib kfunc.c, absent from
+// the reference tree).  Same published algorithm as the reference links against: Lanczos-type
+// log-gamma, power series for P when z <= 1 or z < s, modified-Lentz continued fraction for Q otherwise;
+// stop at 1e-14 or 100 terms.
+__device__ inline double kf_lgamma_dev(double z)
+{
+    double x = 0.0;
+    x += 0.1659470187408462e-06 / (z + 7);
+    x += 0.9934937113930748e-05 / (z + 6);
+    x -= 0.1385710331296526 / (z + 5);
+    x += 12.50734324009056 / (z + 4);
+    x -= 176.6150291498386 / (z + 3);
+    x += 771.3234287757674 / (z + 2);
+    x -= 1259.139216722289 / (z + 1);
+    x += 676.5203681218835 / z;
+    x += 0.9999999999995183;
+    return log(x) - 5.58106146679532777 - z + (z - 0.5) * log(z + 6.5);
+}
+
+__device__ inline double kf_gammaq_dev(double s, double z)
+{
+    constexpr double kEps = 1e-14, kTiny = 1e-290;
+    if (z <= 1.0 || z < s) {
+        double term = 1.0, sum = 1.0;
+        for (int k = 1; k < 100; ++k) {
+            term *= z / (s + k);
+            sum += term;
+            if (term / sum < kEps) break;
+        }
+        return 1.0 - exp(s * log(z) - z - kf_lgamma_dev(s + 1.0) + log(sum));
+    }
+    double f = 1.0 + z - s, C = f, D = 0.0;
+    for (int j = 1; j < 100; ++j) {
+        const double a = j * (s - j), b = (j << 1) + 1 + z - s;
+        D = b + a * D;
+        if (D < kTiny) D = kTiny;
+        C = b + a / C;
+        if (C < kTiny) C = kTiny;
+        D = 1.0 / D;
+        const double d = C * D;
+        f *= d;
+        if (fabs(d - 1.0) < kEps) break;
+    }
+    return exp(s * log(z) - z - kf_lgamma_dev(s) - log(f));
+}
+
+}  // namespace bvc

@@ -1,0 +1,49 @@
+// bvc_internal.h -- launcher prototypes shared by the translation units of libbvc (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bvc.h"
+
+namespace bvc {
+
+// Base-quality -> likelihood table, built on the HOST with the same libm exp() the CPU path uses
+// (src/BaseType.cpp:13,15) and uploaded once per context:
+//   e[q] = eps/3          likelihood of a non-matching base
+//   d[q] = (1-eps) - e[q] matching minus non-matching likelihood
+struct QualLut {
+    double d[128];
+    double e[128];
+};
+
+// Stage 1: dense pileup rows -> per-site class counts.  counts must be zeroed by the caller when split > 1.
+hipError_t launch_hist_dense(hipStream_t stream, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                             const int8_t *bases, const int8_t *quals, const uint8_t *group_of_sample,
+                             int n_groups, uint32_t *counts, int split);
+// Number of sample-range splits per site launch_hist_dense should use for this shape (1 = none).
+int choose_hist_split(int64_t n_sites, int64_t n_samples, int n_cu);
+
+hipError_t launch_hist_csr(hipStream_t stream, int64_t n_sites, const int64_t *offsets,
+                           const int8_t *bases, const int8_t *quals, uint32_t *counts);
+
+// Stage 2: EM + LRT, one wavefront per (site, histogram).
+//   hist_stride: uint32 elements between consecutive sites' histograms; hist_sub: which 512-block inside it.
+//   comb/n_comb: optional per-site candidate list (SetBase); comb_from: optional results array whose
+//   {ref}+alt_bases define the candidates and whose `called` gates the run (group mode).
+hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *counts, int64_t hist_stride,
+                      const int8_t *ref_base, double min_af, const QualLut *lut,
+                      const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results);
+
+hipError_t launch_lrt_groups(hipStream_t stream, int64_t n_sites, int n_groups, const uint32_t *grp_counts,
+                             const int8_t *ref_base, double min_af, const QualLut *lut,
+                             const bvc_site_result *overall, bvc_group_result *grp_results);
+
+// Sum the per-group histograms (+ the "no group" one) into the overall histogram of each site.
+hipError_t launch_sum_groups(hipStream_t stream, int64_t n_sites, int n_hist, const uint32_t *grp_counts,
+                             uint32_t *counts);
+
+hipError_t launch_synth_dense(hipStream_t stream, uint64_t seed, int64_t site0, int64_t n_sites,
+                              int64_t n_samples, int64_t row_stride, uint32_t cov_thr16,
+                              int8_t *bases, int8_t *quals, int8_t *ref_base);
+
+}  // namespace bvc

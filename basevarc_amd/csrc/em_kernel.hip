@@ -1,0 +1,430 @@
+// em_kernel.hip -- stage 2 of the basetype path on gfx950: EM over four allele frequencies and the
+// nested likelihood-ratio test, run on a site's (base, qual) count histogram by ONE wavefront.
+//
+// Follows, with the per-sample sums regrouped by class (a class = all samples with equal base and qual,
+// which have identical likelihood rows):
+//   BaseType::SetAlleleFreq  /root/reference/src/BaseType.cpp:25-39
+//   BaseType::UpdateF        /root/reference/src/BaseType.cpp:41-71
+//   BaseType::LRT            /root/reference/src/BaseType.cpp:73-139
+//   combs_                   /root/reference/src/BaseType.cpp:237-255
+//   singleEM / EM / delta    /root/reference/src/Algorithm.cpp:69-130
+//
+// Lane layout: the wave's four DPP rows of 16 lanes own the four bases; lane (b, t) holds the
+// t-th, (t+16)-th ... non-empty quality class of base b in registers.  For a class of base b with
+// likelihoods a = 1-eps (match) and e = eps/3 (mismatch), d = a - e:
+//   marginal      m   = f_b * d + F * e                       F = f_A + f_C + f_G + f_T
+//   M step        f_j' = f_j / N * (D_j + E)                  D_j = sum_{c in j} n_c d_c / m_c
+//                                                             E   = sum_c       n_c e_c / m_c
+//   stop rule     delta = sum_c n_c |log m_c' - log m_c| < 1e-3
+// FP64 throughout; no MFMA (nothing here is a dense contraction).
+#include "bvc_device.h"
+#include "bvc_internal.h"
+
+namespace bvc {
+namespace {
+
+constexpr int kMaxSlots = 8;              // 128 quality values / 16 lanes per row
+constexpr double kLrtThreshold = 24.0;    // LRT_THRESHOLD, src/BaseType.h:9
+constexpr int kEmIters = 100;             // src/BaseType.cpp:46
+constexpr double kEmEpsilon = 0.001;      // src/BaseType.cpp:45
+
+struct Slots {
+    double n[kMaxSlots];    // class count (0 for an empty slot)
+    double d[kMaxSlots];
+    double e[kMaxSlots];
+    double lm[kMaxSlots];   // log of the class marginal from the previous pass
+};
+
+struct PassOut {
+    double ex[4];           // expect_allele_prob after the pass (wave-uniform)
+    double delta;           // sum_c n_c |log m_c' - log m_c| (wave-uniform)
+};
+
+// k-subsets of positions 0..n-1 in lexicographic order (what combs_ yields), as 4-bit position masks
+// packed least-significant first; count returned through `cnt`.
+__device__ __forceinline__ uint32_t subset_masks(int n, int k, int &cnt)
+{
+    switch (n * 8 + k) {
+    case 1 * 8 + 1: cnt = 1; return 0x1u;
+    case 2 * 8 + 2: cnt = 1; return 0x3u;
+    case 2 * 8 + 1: cnt = 2; return 0x21u;
+    case 3 * 8 + 3: cnt = 1; return 0x7u;
+    case 3 * 8 + 2: cnt = 3; return 0x653u;
+    case 3 * 8 + 1: cnt = 3; return 0x421u;
+    case 4 * 8 + 4: cnt = 1; return 0xFu;
+    case 4 * 8 + 3: cnt = 4; return 0xEDB7u;
+    case 4 * 8 + 2: cnt = 6; return 0xCA6953u;
+    case 4 * 8 + 1: cnt = 4; return 0x8421u;
+    default: cnt = 0; return 0u;
+    }
+}
+
+__device__ __forceinline__ double pick4(const double (&v)[4], int j)
+{
+    return j == 0 ? v[0] : (j == 1 ? v[1] : (j == 2 ? v[2] : v[3]));
+}
+
+__device__ __forceinline__ int pick4(const int (&v)[4], int j)
+{
+    return j == 0 ? v[0] : (j == 1 ? v[1] : (j == 2 ? v[2] : v[3]));
+}
+
+// One E+M pass (singleEM, src/Algorithm.cpp:69-93) plus the delta of delta_bylog (:103-113).
+// On the first pass of a fit S.lm is stale and the returned delta is ignored by the caller.
+__device__ __forceinline__ PassOut em_pass(Slots &S, int nslots, int row, const double (&f)[4],
+                                           double inv_n)
+{
+    const double fb = pick4(f, row);
+    const double F = ((f[0] + f[1]) + f[2]) + f[3];
+    double acc_d = 0.0, acc_e = 0.0, acc_delta = 0.0;
+#pragma unroll
+    for (int k = 0; k < kMaxSlots; ++k) {
+        if (k < nslots) {
+            const double m = fma(fb, S.d[k], F * S.e[k]);
+            const double r = S.n[k] / m;
+            acc_d = fma(r, S.d[k], acc_d);
+            acc_e = fma(r, S.e[k], acc_e);
+            const double lm = log(m);
+            acc_delta = fma(S.n[k], fabs(lm - S.lm[k]), acc_delta);
+            S.lm[k] = lm;
+        }
+    }
+    const double drow = row_sum(acc_d);
+    const double etot = rows_total(row_sum(acc_e));
+    PassOut o;
+    o.ex[0] = f[0] * inv_n * (lane_value<0>(drow) + etot);
+    o.ex[1] = f[1] * inv_n * (lane_value<16>(drow) + etot);
+    o.ex[2] = f[2] * inv_n * (lane_value<32>(drow) + etot);
+    o.ex[3] = f[3] * inv_n * (lane_value<48>(drow) + etot);
+    o.delta = rows_total(row_sum(acc_delta));
+    return o;
+}
+
+// EM (src/Algorithm.cpp:115-130) followed by UpdateF's log-likelihood sum (src/BaseType.cpp:58-62).
+// f holds the initial frequencies; on return ex = expect_allele_prob of the last pass (one M step ahead
+// of the frequencies the returned log-likelihood was computed with, as in the reference).
+__device__ __forceinline__ double em_fit(Slots &S, int nslots, int row, double (&f)[4], double inv_n,
+                                         double (&ex)[4], int &passes)
+{
+    PassOut o;
+    for (int it = 0;; ++it) {                  // pass 0 + at most kEmIters update passes
+        o = em_pass(S, nslots, row, f, inv_n);
+        passes += 1;
+        if (it > 0 && o.delta < kEmEpsilon) break;   // NaN never converges, as in the reference
+        if (it == kEmIters) break;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = o.ex[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ex[j] = o.ex[j];
+    double ll = 0.0;
+#pragma unroll
+    for (int k = 0; k < kMaxSlots; ++k)
+        if (k < nslots) ll = fma(S.n[k], S.lm[k], ll);
+    return rows_total(row_sum(ll));
+}
+
+struct SiteOut {
+    double var_qual, chi, depth_total, lr_alt;
+    double af[3], base_frq[4];
+    int depth[4];
+    int n_passes, n_fits;
+    int alt_base[3], n_alt, called, n_kept, kept[4], status;
+};
+
+// The whole per-site computation for one wavefront.  `hist` points at 512 class counts.
+// comb_list: candidate bases packed 4 bits each in SetBase order; n_comb entries.
+__device__ void lrt_site(const uint32_t *__restrict__ hist, int ref, double min_af,
+                         uint32_t comb_list, int n_comb, const QualLut *__restrict__ lut,
+                         uint32_t *s_n, uint8_t *s_q, SiteOut &out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int row = lane >> 4, t = lane & 15;
+
+    // ---- load the histogram, compact each base's non-empty classes (order: ascending qual) ----------
+    int cnt_row = 0, depth_lane = 0;
+#pragma unroll
+    for (int lvl = 0; lvl < 8; ++lvl) {
+        const int q = t + 16 * lvl;
+        const uint32_t c = hist[row * 128 + q];
+        const uint64_t nzmask = __ballot(c != 0);
+        const uint32_t rowbits = (uint32_t)(nzmask >> (16 * row)) & 0xFFFFu;
+        if (c != 0) {
+            const int pos = cnt_row + __popc(rowbits & ((1u << t) - 1u));
+            s_n[row * 128 + pos] = c;
+            s_q[row * 128 + pos] = (uint8_t)q;
+        }
+        cnt_row += __popc(rowbits);
+        depth_lane += (int)c;
+    }
+    const int depth_row = row_sum(depth_lane);
+    int depth[4];
+    depth[0] = __builtin_amdgcn_readlane(depth_row, 0);
+    depth[1] = __builtin_amdgcn_readlane(depth_row, 16);
+    depth[2] = __builtin_amdgcn_readlane(depth_row, 32);
+    depth[3] = __builtin_amdgcn_readlane(depth_row, 48);
+    int maxcnt = max(max(__builtin_amdgcn_readlane(cnt_row, 0), __builtin_amdgcn_readlane(cnt_row, 16)),
+                     max(__builtin_amdgcn_readlane(cnt_row, 32), __builtin_amdgcn_readlane(cnt_row, 48)));
+    const int nslots = (maxcnt + 15) >> 4;
+    __syncthreads();                           // single-wave workgroup: orders the LDS writes above
+
+    Slots S;
+#pragma unroll
+    for (int k = 0; k < kMaxSlots; ++k) {
+        const int idx = t + 16 * k;
+        S.n[k] = 0.0; S.d[k] = 0.0; S.e[k] = 1.0; S.lm[k] = 0.0;
+        if (k < nslots && idx < cnt_row) {
+            const int q = s_q[row * 128 + idx];
+            S.n[k] = (double)s_n[row * 128 + idx];
+            S.d[k] = lut->d[q];
+            S.e[k] = lut->e[q];
+        }
+    }
+
+    // ---- BaseType::LRT ---------------------------------------------------------------------------
+    const int total_i = depth[0] + depth[1] + depth[2] + depth[3];
+    const double depth_total = (double)total_i;
+    out = SiteOut{};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out.depth[j] = depth[j];
+    out.depth_total = depth_total;
+    if (total_i == 0) return;                                   // src/BaseType.cpp:75
+    const double inv_n = 1.0 / depth_total;
+
+    // candidate list: bases of base_comb whose count frequency >= min_af (:77-83)
+    uint32_t blist = 0;
+    int n = 0;
+    for (int c = 0; c < n_comb; ++c) {
+        const int b = (comb_list >> (4 * c)) & 3;
+        if ((double)pick4(depth, b) / depth_total >= min_af) { blist |= (uint32_t)b << (4 * n); ++n; }
+    }
+    if (n == 0) return;                                          // :84
+
+    int passes = 0, fits = 0;
+    double base_frq[4] = {0, 0, 0, 0};
+    double lr_alt = 0.0, chi = 0.0;
+    int status = 0;
+
+    // fit of one subset given as a mask over base codes; returns false when UpdateF skips it (:54)
+    auto fit_set = [&](uint32_t setmask, double &loglik, double (&ex)[4]) __attribute__((always_inline)) -> bool {
+        int depth_sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) depth_sum += ((setmask >> j) & 1u) ? depth[j] : 0;
+        double f[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            f[j] = (depth_sum > 0 && ((setmask >> j) & 1u)) ? (double)depth[j] / (double)depth_sum : 0.0;
+        const double freq_sum = ((f[0] + f[1]) + f[2]) + f[3];
+        if (freq_sum == 0) return false;
+        loglik = em_fit(S, nslots, row, f, inv_n, ex, passes);
+        fits += 1;
+        return true;
+    };
+
+    // Level k = n is the full model (:88-90); levels n-1 .. 1 are the nested reduction (:93-110).
+    bool full_level = true;
+    for (int k = n; k > 0; --k) {
+        int ncomb = 0;
+        const uint32_t masks = subset_masks(n, k, ncomb);
+        int n_fit = 0, i_min = 0;
+        double best_chi = 0.0, best_lr = 0.0, best_bp[4] = {0, 0, 0, 0};
+        for (int c = 0; c < ncomb; ++c) {
+            const uint32_t pm = (masks >> (4 * c)) & 0xFu;
+            uint32_t setmask = 0;
+            for (int p = 0; p < 4; ++p)
+                if ((pm >> p) & 1u) setmask |= 1u << ((blist >> (4 * p)) & 3u);
+            double ex[4], ll;
+            if (!fit_set(setmask, ll, ex)) continue;
+            const double chi_c = 2.0 * (lr_alt - ll);
+            if (n_fit == 0 || chi_c < best_chi) {                // std::min_element: first minimum, '<'
+                best_chi = chi_c; best_lr = ll; i_min = n_fit;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) best_bp[j] = ex[j];
+            }
+            ++n_fit;
+        }
+        if (n_fit == 0) { status = 1; break; }                   // reference: bp[0] / min_element on empty
+        lr_alt = best_lr;
+        if (full_level) {
+            full_level = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) base_frq[j] = best_bp[j];
+            continue;
+        }
+        chi = best_chi;
+        if (chi < kLrtThreshold) {
+            // bases = bc[i_min]: indexed over ALL subsets although lr/bp skip zero-coverage ones
+            const uint32_t pm = (masks >> (4 * i_min)) & 0xFu;
+            uint32_t nl = 0;
+            int nn = 0;
+            for (int p = 0; p < 4; ++p)
+                if ((pm >> p) & 1u) { nl |= ((blist >> (4 * p)) & 3u) << (4 * nn); ++nn; }
+            blist = nl;
+            n = k;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) base_frq[j] = best_bp[j];
+        } else {
+            break;
+        }
+    }
+    if (status == 1 && full_level) { out.status = 1; out.n_passes = passes; out.n_fits = fits; return; }
+
+    out.status = status;
+    out.n_passes = passes;
+    out.n_fits = fits;
+    out.lr_alt = lr_alt;
+    out.chi = chi;
+    out.n_kept = n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { out.base_frq[j] = base_frq[j]; out.kept[j] = (j < n) ? (int)((blist >> (4 * j)) & 3u) : 0; }
+    int n_alt = 0;
+    int a0 = 0, a1 = 0, a2 = 0;
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {                                // :111-116
+        const int b = (blist >> (4 * p)) & 3;
+        if (p < n && b != ref && n_alt < 3) {
+            const double fr = pick4(base_frq, b);
+            if (n_alt == 0) { a0 = b; g0 = fr; } else if (n_alt == 1) { a1 = b; g1 = fr; } else { a2 = b; g2 = fr; }
+            ++n_alt;
+        }
+    }
+    out.alt_base[0] = a0; out.alt_base[1] = a1; out.alt_base[2] = a2;
+    out.af[0] = g0; out.af[1] = g1; out.af[2] = g2;
+    out.n_alt = n_alt;
+    if (n_alt > 0) {                                             // :117-135
+        const double r = (double)pick4(depth, (int)(blist & 3u)) / depth_total;
+        double vq;
+        if (n == 1 && depth_total > 10 && r > 0.5) {
+            vq = 5000.0;
+        } else if (chi <= 0) {
+            vq = 0.0;
+        } else {
+            const double p = kf_gammaq_dev(0.5, chi / 2.0);      // chisf(chi, 1), src/Algorithm.cpp:3-7
+            vq = (p != 0.0) ? -10 * log10(p) : 10000.0;          // NaN != 0 -> NaN, like `if (chi_prob)`
+            if (vq == 0) vq = 0.0;
+        }
+        out.var_qual = vq;
+        out.called = 1;
+    }
+}
+
+__device__ __forceinline__ void store_result(bvc_site_result *dst, const SiteOut &o)
+{
+    bvc_site_result r;
+    r.var_qual = o.var_qual; r.chi = o.chi; r.depth_total = o.depth_total; r.lr_alt = o.lr_alt;
+    for (int j = 0; j < 3; ++j) { r.af[j] = o.af[j]; r.alt_base[j] = (int8_t)o.alt_base[j]; }
+    for (int j = 0; j < 4; ++j) { r.base_frq[j] = o.base_frq[j]; r.depth[j] = o.depth[j]; r.kept[j] = (int8_t)o.kept[j]; }
+    r.n_passes = o.n_passes; r.n_alt = (uint8_t)o.n_alt; r.called = (uint8_t)o.called;
+    r.n_kept = (uint8_t)o.n_kept; r.status = (uint8_t)o.status; r.n_fits = (uint8_t)o.n_fits;
+    *dst = r;
+}
+
+__global__ __launch_bounds__(64) void lrt_kernel(int64_t n_sites, const uint32_t *__restrict__ counts,
+                                                 int64_t hist_stride, const int8_t *__restrict__ ref_base,
+                                                 double min_af, const QualLut *__restrict__ lut,
+                                                 const int8_t *__restrict__ comb,
+                                                 const uint8_t *__restrict__ n_comb,
+                                                 bvc_site_result *__restrict__ results)
+{
+    __shared__ uint32_t s_n[512];
+    __shared__ uint8_t s_q[512];
+    const int64_t site = blockIdx.x;
+    if (site >= n_sites) return;
+    uint32_t list = 0x3210u;                                     // default base_comb, src/BaseType.h:79
+    int nc = 4;
+    if (comb) {
+        nc = min((int)n_comb[site], 4);
+        list = 0;
+        for (int c = 0; c < nc; ++c) list |= (uint32_t)(comb[site * 4 + c] & 3) << (4 * c);
+    }
+    SiteOut o;
+    lrt_site(counts + site * hist_stride, ref_base[site], min_af, list, nc, lut, s_n, s_q, o);
+    if ((threadIdx.x & 63) == 0) store_result(results + site, o);
+}
+
+// Caller's --group loop (src/BaseVarC.cpp:617-661): one wavefront per (site, group).
+__global__ __launch_bounds__(64) void lrt_groups_kernel(int64_t n_sites, int n_groups,
+                                                        const uint32_t *__restrict__ grp_counts,
+                                                        const int8_t *__restrict__ ref_base, double min_af,
+                                                        const QualLut *__restrict__ lut,
+                                                        const bvc_site_result *__restrict__ overall,
+                                                        bvc_group_result *__restrict__ grp_results)
+{
+    __shared__ uint32_t s_n[512];
+    __shared__ uint8_t s_q[512];
+    const int64_t site = blockIdx.x / n_groups;
+    const int g = (int)(blockIdx.x % n_groups);
+    if (site >= n_sites) return;
+    const uint32_t *hist = grp_counts + (site * (n_groups + 1) + g) * BVC_NCLASS;
+    const bvc_site_result ov = overall[site];
+    const int ref = ref_base[site];
+    uint32_t list = (uint32_t)(ref & 3);                         // base_comb = {ref} + alt_bases (:614-615)
+    int nc = 1;
+    for (int i = 0; i < ov.n_alt && i < 3; ++i) { list |= (uint32_t)(ov.alt_base[i] & 3) << (4 * nc); ++nc; }
+    SiteOut o;
+    // Always run the histogram load (depths are reported for every group, :640); the LRT itself only when
+    // the overall call succeeded and the group has covered samples (:633-636, :641).
+    const double eff_min_af = min_af;
+    lrt_site(hist, ref, eff_min_af, list, ov.called ? nc : 0, lut, s_n, s_q, o);
+    if ((threadIdx.x & 63) == 0) {
+        bvc_group_result r;
+        for (int j = 0; j < 4; ++j) r.depth[j] = o.depth[j];
+        for (int j = 0; j < 7; ++j) r.pad[j] = 0;
+        r.ran = (ov.called && o.depth_total > 0) ? 1 : 0;
+        for (int i = 0; i < 3; ++i) {
+            double af = 0.0;                                     // literal 0 when the group lacks the ALT (:650)
+            if (r.ran && i < ov.n_alt)
+                for (int tt = 0; tt < o.n_alt; ++tt)
+                    if (o.alt_base[tt] == ov.alt_base[i]) af = o.af[tt];
+            r.af[i] = af;
+        }
+        grp_results[site * n_groups + g] = r;
+    }
+}
+
+__global__ void sum_groups_kernel(int64_t total, int n_hist, const uint32_t *__restrict__ grp_counts,
+                                  uint32_t *__restrict__ counts)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over n_sites * 512
+    if (i >= total) return;
+    const int64_t site = i / BVC_NCLASS;
+    const int key = (int)(i % BVC_NCLASS);
+    uint32_t s = 0;
+    for (int h = 0; h < n_hist; ++h) s += grp_counts[(site * n_hist + h) * BVC_NCLASS + key];
+    counts[i] = s;
+}
+
+}  // namespace
+
+hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *counts, int64_t hist_stride,
+                      const int8_t *ref_base, double min_af, const QualLut *lut,
+                      const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results)
+{
+    if (n_sites <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lrt_kernel, dim3((unsigned)n_sites), dim3(64), 0, stream, n_sites, counts, hist_stride,
+                       ref_base, min_af, lut, comb, n_comb, results);
+    return hipGetLastError();
+}
+
+hipError_t launch_lrt_groups(hipStream_t stream, int64_t n_sites, int n_groups, const uint32_t *grp_counts,
+                             const int8_t *ref_base, double min_af, const QualLut *lut,
+                             const bvc_site_result *overall, bvc_group_result *grp_results)
+{
+    if (n_sites <= 0 || n_groups <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lrt_groups_kernel, dim3((unsigned)(n_sites * n_groups)), dim3(64), 0, stream, n_sites,
+                       n_groups, grp_counts, ref_base, min_af, lut, overall, grp_results);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_groups(hipStream_t stream, int64_t n_sites, int n_hist, const uint32_t *grp_counts,
+                             uint32_t *counts)
+{
+    const int64_t total = n_sites * BVC_NCLASS;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, total,
+                       n_hist, grp_counts, counts);
+    return hipGetLastError();
+}
+
+}  // namespace bvc

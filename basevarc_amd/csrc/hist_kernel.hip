@@ -1,0 +1,238 @@
+// hist_kernel.hip -- stage 1 of the basetype path on gfx950: one streaming pass over a site's base and
+// base-quality bytes, counted into a (base, qual) histogram in LDS.
+//
+// This replaces the per-sample likelihood table the reference materialises in the BaseType constructor
+// (/root/reference/src/BaseType.cpp:5-23: 4 doubles per sample) and re-reads ~700 times per site in
+// singleEM (/root/reference/src/Algorithm.cpp:69-93): a sample's likelihood row depends only on its
+// (base, qual) pair, so the 512 class counts carry everything the EM and the LRT need.
+//
+// HBM-bound by design: 2 bytes per (site, sample), each read exactly once with 16-byte loads per lane.
+// The LDS histogram is replicated kCopies times with copy = lane % kCopies, laid out [class][copy], so the
+// bank of an update is lane % 32 whatever the data are: the heavily skewed keys of real pileups (>90 %
+// reference base, a handful of quality values) cannot cause bank or same-address conflicts.
+#include "bvc_device.h"
+#include "bvc_internal.h"
+
+namespace bvc {
+namespace {
+
+constexpr int kHistThreads = 512;
+constexpr int kCopies = 32;                         // one copy per LDS bank
+constexpr int kLdsWords = BVC_NCLASS * kCopies;     // 16384 words = 64 KiB
+constexpr int kUnroll = 4;                          // 16-byte loads in flight per lane and array
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void count_word(uint32_t *__restrict__ hist, uint32_t bw, uint32_t qw, uint32_t lane_off)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t b = (bw >> (8 * i)) & 0xFFu;
+        const uint32_t q = (qw >> (8 * i)) & 0xFFu;
+        const uint32_t key = (b << 7) | q;                       // class = base * 128 + qual
+        __hip_atomic_fetch_add(&hist[key * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+__device__ __forceinline__ void count_word_checked(uint32_t *__restrict__ hist, uint32_t bw, uint32_t qw,
+                                                   uint32_t lane_off)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t b = (bw >> (8 * i)) & 0xFFu;
+        const uint32_t q = (qw >> (8 * i)) & 0xFFu;
+        if (b < 4u && q < 128u)                                   // covered sample
+            __hip_atomic_fetch_add(&hist[((b << 7) | q) * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// 16 samples of one lane.  The common case (every sample of the wave covered) skips the per-sample test.
+__device__ __forceinline__ void count_chunk(uint32_t *__restrict__ hist, const u32x4 b, const u32x4 q,
+                                            uint32_t lane_off)
+{
+    const uint32_t bad = ((b.x | b.y | b.z | b.w) & 0xFCFCFCFCu) | ((q.x | q.y | q.z | q.w) & 0x80808080u);
+    if (__ballot(bad != 0) == 0) {
+        count_word(hist, b.x, q.x, lane_off); count_word(hist, b.y, q.y, lane_off);
+        count_word(hist, b.z, q.z, lane_off); count_word(hist, b.w, q.w, lane_off);
+    } else {
+        count_word_checked(hist, b.x, q.x, lane_off); count_word_checked(hist, b.y, q.y, lane_off);
+        count_word_checked(hist, b.z, q.z, lane_off); count_word_checked(hist, b.w, q.w, lane_off);
+    }
+}
+
+// One workgroup per (site, split).  ALIGNED: row starts and n16 chunks are 16-byte aligned.
+template <bool ALIGNED>
+__global__ __launch_bounds__(kHistThreads) void hist_dense_kernel(
+    int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *__restrict__ bases,
+    const int8_t *__restrict__ quals, uint32_t *__restrict__ counts, int split)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [class][copy]
+    const int tid = threadIdx.x;
+    const uint32_t lane_off = (uint32_t)(tid & (kCopies - 1));
+
+    for (int i = tid * 4; i < kLdsWords; i += kHistThreads * 4)
+        *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    const int64_t n_work = n_sites * split;
+    for (int64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const int64_t site = w / split;
+        const int part = (int)(w % split);
+        const int8_t *brow = bases + site * row_stride;
+        const int8_t *qrow = quals + site * row_stride;
+        // sample range of this part, in 16-sample chunks; the last part also takes the ragged tail
+        const int64_t n16 = n_samples >> 4;
+        const int64_t c0 = n16 * part / split, c1 = n16 * (part + 1) / split;
+
+        if (ALIGNED) {
+            const u32x4 *bv = reinterpret_cast<const u32x4 *>(brow);
+            const u32x4 *qv = reinterpret_cast<const u32x4 *>(qrow);
+            int64_t c = c0 + tid;
+            // main loop: kUnroll independent 16-byte loads per array in flight, then the LDS updates
+            for (; c + (int64_t)(kUnroll - 1) * kHistThreads < c1; c += (int64_t)kUnroll * kHistThreads) {
+                u32x4 b[kUnroll], q[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    b[u] = __builtin_nontemporal_load(&bv[c + (int64_t)u * kHistThreads]);
+                    q[u] = __builtin_nontemporal_load(&qv[c + (int64_t)u * kHistThreads]);
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) count_chunk(hist, b[u], q[u], lane_off);
+            }
+            for (; c < c1; c += kHistThreads) {
+                const u32x4 b = __builtin_nontemporal_load(&bv[c]);
+                const u32x4 q = __builtin_nontemporal_load(&qv[c]);
+                // not every lane of the wave is here: per-sample test, no wave-wide vote
+                count_word_checked(hist, b.x, q.x, lane_off); count_word_checked(hist, b.y, q.y, lane_off);
+                count_word_checked(hist, b.z, q.z, lane_off); count_word_checked(hist, b.w, q.w, lane_off);
+            }
+        } else {
+            for (int64_t i = c0 * 16 + tid; i < c1 * 16; i += kHistThreads) {
+                const uint32_t b = (uint8_t)brow[i], q = (uint8_t)qrow[i];
+                if (b < 4u && q < 128u)
+                    __hip_atomic_fetch_add(&hist[((b << 7) | q) * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (part == split - 1) {
+            for (int64_t i = (n16 << 4) + tid; i < n_samples; i += kHistThreads) {
+                const uint32_t b = (uint8_t)brow[i], q = (uint8_t)qrow[i];
+                if (b < 4u && q < 128u)
+                    __hip_atomic_fetch_add(&hist[((b << 7) | q) * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+
+        // fold the copies of each class, publish, and clear for the next site
+        for (int key = tid; key < BVC_NCLASS; key += kHistThreads) {
+            uint32_t s = 0;
+#pragma unroll
+            for (int v = 0; v < kCopies; v += 4) {
+                // rotate the starting copy by the key so that the 16 lanes of a ds_read_b128 group spread over banks
+                const int cc = (v + 4 * (key & 7)) & (kCopies - 1);
+                u32x4 *p = reinterpret_cast<u32x4 *>(&hist[key * kCopies + cc]);
+                const u32x4 x = *p;
+                s += x.x + x.y + x.z + x.w;
+                *p = u32x4{0u, 0u, 0u, 0u};
+            }
+            if (split == 1) counts[site * BVC_NCLASS + key] = s;
+            else if (s) atomicAdd(&counts[site * BVC_NCLASS + key], s);
+        }
+        __syncthreads();
+    }
+}
+
+// Ragged pileup: site s owns elements offsets[s] .. offsets[s+1]).  Byte loads (rows start anywhere).
+__global__ __launch_bounds__(kHistThreads) void hist_csr_kernel(
+    int64_t n_sites, const int64_t *__restrict__ offsets, const int8_t *__restrict__ bases,
+    const int8_t *__restrict__ quals, uint32_t *__restrict__ counts)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    const int tid = threadIdx.x;
+    const uint32_t lane_off = (uint32_t)(tid & (kCopies - 1));
+    for (int i = tid * 4; i < kLdsWords; i += kHistThreads * 4)
+        *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
+        const int64_t o0 = offsets[site], o1 = offsets[site + 1];
+        for (int64_t i = o0 + tid; i < o1; i += kHistThreads) {
+            const uint32_t b = (uint8_t)bases[i], q = (uint8_t)quals[i];
+            if (b < 4u && q < 128u)
+                __hip_atomic_fetch_add(&hist[((b << 7) | q) * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        for (int key = tid; key < BVC_NCLASS; key += kHistThreads) {
+            uint32_t s = 0;
+            for (int v = 0; v < kCopies; ++v) {
+                s += hist[key * kCopies + v];
+                hist[key * kCopies + v] = 0;
+            }
+            counts[site * BVC_NCLASS + key] = s;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+int choose_hist_split(int64_t n_sites, int64_t n_samples, int n_cu)
+{
+    // Two 512-thread workgroups fit a CU (2 x 64 KiB LDS).  With fewer sites than that, cut each site's
+    // sample range so the whole chip streams; parts are merged with global atomics on 512 words.
+    const int64_t want = (int64_t)n_cu * 4;
+    if (n_sites >= want || n_samples < (1 << 16)) return 1;
+    int64_t split = (want + n_sites - 1) / n_sites;
+    const int64_t max_split = n_samples / (1 << 15);             // keep >= 32k samples per part
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    if (split > 64) split = 64;
+    return (int)split;
+}
+
+hipError_t launch_hist_dense(hipStream_t stream, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                             const int8_t *bases, const int8_t *quals, const uint8_t *group_of_sample,
+                             int n_groups, uint32_t *counts, int split)
+{
+    (void)group_of_sample; (void)n_groups;
+    if (n_sites <= 0) return hipSuccess;
+    static bool attr_done[2] = {false, false};
+    const bool aligned = ((reinterpret_cast<uintptr_t>(bases) | reinterpret_cast<uintptr_t>(quals)) & 15u) == 0 &&
+                         (row_stride & 15) == 0;
+    const size_t lds = (size_t)kLdsWords * sizeof(uint32_t);
+    auto kern = aligned ? hist_dense_kernel<true> : hist_dense_kernel<false>;
+    if (!attr_done[aligned]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[aligned] = true;
+    }
+    const int64_t n_work = n_sites * split;
+    const int64_t grid = n_work < 4096 ? n_work : 4096;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kHistThreads), lds, stream, n_sites, n_samples,
+                       row_stride, bases, quals, counts, split);
+    return hipGetLastError();
+}
+
+hipError_t launch_hist_csr(hipStream_t stream, int64_t n_sites, const int64_t *offsets,
+                           const int8_t *bases, const int8_t *quals, uint32_t *counts)
+{
+    if (n_sites <= 0) return hipSuccess;
+    static bool attr_done = false;
+    const size_t lds = (size_t)kLdsWords * sizeof(uint32_t);
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(hist_csr_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int64_t grid = n_sites < 4096 ? n_sites : 4096;
+    hipLaunchKernelGGL(hist_csr_kernel, dim3((unsigned)grid), dim3(kHistThreads), lds, stream, n_sites, offsets,
+                       bases, quals, counts);
+    return hipGetLastError();
+}
+
+}  // namespace bvc

@@ -1,0 +1,246 @@
+"""ctypes binding of libbvc.so (include/bvc.h).  Device memory, streams and multi-process plumbing come
+from torch; the arithmetic is all inside the library's HIP kernels."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libbvc.so")
+
+BVC_PTR_HOST = 0
+BVC_PTR_DEVICE = 1
+NCLASS = 512
+
+
+class BvcError(RuntimeError):
+    pass
+
+
+class SiteResult(C.Structure):          # bvc_site_result, 120 bytes
+    _fields_ = [
+        ("var_qual", C.c_double), ("chi", C.c_double), ("depth_total", C.c_double),
+        ("af", C.c_double * 3), ("lr_alt", C.c_double), ("base_frq", C.c_double * 4),
+        ("depth", C.c_int32 * 4), ("n_passes", C.c_int32), ("alt_base", C.c_int8 * 3),
+        ("n_alt", C.c_uint8), ("called", C.c_uint8), ("n_kept", C.c_uint8), ("kept", C.c_int8 * 4),
+        ("status", C.c_uint8), ("n_fits", C.c_uint8),
+    ]
+
+
+class GroupResult(C.Structure):         # bvc_group_result, 48 bytes
+    _fields_ = [("af", C.c_double * 3), ("depth", C.c_int32 * 4), ("ran", C.c_uint8), ("pad", C.c_uint8 * 7)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("hist_ms", C.c_double), ("em_ms", C.c_double), ("hist_launches", C.c_int64),
+                ("em_launches", C.c_int64), ("sites", C.c_int64)]
+
+
+SITE_DTYPE = np.dtype([
+    ("var_qual", "<f8"), ("chi", "<f8"), ("depth_total", "<f8"), ("af", "<f8", (3,)), ("lr_alt", "<f8"),
+    ("base_frq", "<f8", (4,)), ("depth", "<i4", (4,)), ("n_passes", "<i4"), ("alt_base", "i1", (3,)),
+    ("n_alt", "u1"), ("called", "u1"), ("n_kept", "u1"), ("kept", "i1", (4,)), ("status", "u1"), ("n_fits", "u1"),
+])
+GROUP_DTYPE = np.dtype([("af", "<f8", (3,)), ("depth", "<i4", (4,)), ("ran", "u1"), ("pad", "u1", (7,))])
+assert SITE_DTYPE.itemsize == C.sizeof(SiteResult) == 120
+assert GROUP_DTYPE.itemsize == C.sizeof(GroupResult) == 48
+
+EXPORTS = [
+    "bvc_version", "bvc_device_count", "bvc_create", "bvc_destroy", "bvc_last_error", "bvc_set_stream",
+    "bvc_synchronize", "bvc_set_profiling", "bvc_get_profile", "bvc_lrt_dense", "bvc_lrt_dense_groups",
+    "bvc_lrt_csr", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense",
+]
+
+_lib = None
+
+
+def library_path():
+    return _LIB
+
+
+def load_library():
+    """Loads libbvc.so.  Raises if it has not been built (there is no fallback implementation)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise BvcError(f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); basevarc_amd has no CPU fallback")
+    L = C.CDLL(_LIB)
+    vp, i64, u32, i32, dbl = C.c_void_p, C.c_int64, C.c_uint32, C.c_int32, C.c_double
+    L.bvc_version.restype = C.c_char_p
+    L.bvc_device_count.restype = C.c_int
+    L.bvc_create.restype = C.c_int; L.bvc_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.bvc_destroy.restype = None; L.bvc_destroy.argtypes = [vp]
+    L.bvc_last_error.restype = C.c_char_p; L.bvc_last_error.argtypes = [vp]
+    L.bvc_set_stream.restype = C.c_int; L.bvc_set_stream.argtypes = [vp, vp]
+    L.bvc_synchronize.restype = C.c_int; L.bvc_synchronize.argtypes = [vp]
+    L.bvc_set_profiling.restype = C.c_int; L.bvc_set_profiling.argtypes = [vp, C.c_int]
+    L.bvc_get_profile.restype = C.c_int; L.bvc_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
+    L.bvc_lrt_dense.restype = C.c_int
+    L.bvc_lrt_dense.argtypes = [vp, i64, i64, i64, vp, vp, vp, dbl, vp, u32]
+    L.bvc_lrt_dense_groups.restype = C.c_int
+    L.bvc_lrt_dense_groups.argtypes = [vp, i64, i64, i64, vp, vp, vp, dbl, vp, i32, vp, vp, u32]
+    L.bvc_lrt_csr.restype = C.c_int
+    L.bvc_lrt_csr.argtypes = [vp, i64, vp, vp, vp, vp, dbl, vp, u32]
+    L.bvc_hist_dense.restype = C.c_int
+    L.bvc_hist_dense.argtypes = [vp, i64, i64, i64, vp, vp, vp, u32]
+    L.bvc_lrt_hist.restype = C.c_int
+    L.bvc_lrt_hist.argtypes = [vp, i64, vp, vp, dbl, vp, vp, vp, u32]
+    L.bvc_synth_dense.restype = C.c_int
+    L.bvc_synth_dense.argtypes = [vp, C.c_uint64, i64, i64, i64, i64, u32, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _np_ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _dev_ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One bvc_ctx: one gfx950 device + one HIP stream.  Not shared between threads."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.bvc_create(C.byref(h), int(device))
+        if rc != 0:
+            raise BvcError(f"bvc_create(device={device}) failed with code {rc}: no usable gfx950 device "
+                           "(libbvc has no CPU fallback)")
+        self._h = h
+        self.device = int(device)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.bvc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BvcError(f"libbvc error {rc}: {self._L.bvc_last_error(self._h).decode()}")
+
+    # ---- plumbing
+    def set_stream(self, stream):
+        """stream: a torch.cuda.Stream, a raw hipStream_t integer, or None for the default stream."""
+        raw = 0 if stream is None else int(getattr(stream, "cuda_stream", stream))
+        self._check(self._L.bvc_set_stream(self._h, C.c_void_p(raw)))
+
+    def synchronize(self):
+        self._check(self._L.bvc_synchronize(self._h))
+
+    def set_profiling(self, on=True):
+        self._check(self._L.bvc_set_profiling(self._h, int(bool(on))))
+
+    def profile(self, reset=False):
+        p = Profile()
+        self._check(self._L.bvc_get_profile(self._h, C.byref(p), int(bool(reset))))
+        return dict(hist_ms=p.hist_ms, em_ms=p.em_ms, hist_launches=p.hist_launches,
+                    em_launches=p.em_launches, sites=p.sites)
+
+    # ---- host-pointer calls (numpy in, numpy structured array out)
+    def lrt_dense(self, bases, quals, ref_base, min_af):
+        b = np.ascontiguousarray(bases, dtype=np.int8)
+        q = np.ascontiguousarray(quals, dtype=np.int8)
+        r = np.ascontiguousarray(ref_base, dtype=np.int8)
+        if b.ndim != 2 or b.shape != q.shape or r.shape != (b.shape[0],):
+            raise ValueError("bases/quals must be [n_sites, n_samples] and ref_base [n_sites]")
+        out = np.zeros(b.shape[0], dtype=SITE_DTYPE)
+        self._check(self._L.bvc_lrt_dense(self._h, b.shape[0], b.shape[1], b.shape[1], _np_ptr(b), _np_ptr(q),
+                                          _np_ptr(r), float(min_af), _np_ptr(out), BVC_PTR_HOST))
+        return out
+
+    def lrt_dense_groups(self, bases, quals, ref_base, min_af, group_of_sample, n_groups):
+        b = np.ascontiguousarray(bases, dtype=np.int8)
+        q = np.ascontiguousarray(quals, dtype=np.int8)
+        r = np.ascontiguousarray(ref_base, dtype=np.int8)
+        g = np.ascontiguousarray(group_of_sample, dtype=np.uint8)
+        if b.ndim != 2 or b.shape != q.shape or r.shape != (b.shape[0],) or g.shape != (b.shape[1],):
+            raise ValueError("shape mismatch")
+        out = np.zeros(b.shape[0], dtype=SITE_DTYPE)
+        gout = np.zeros((b.shape[0], n_groups), dtype=GROUP_DTYPE)
+        self._check(self._L.bvc_lrt_dense_groups(self._h, b.shape[0], b.shape[1], b.shape[1], _np_ptr(b),
+                                                 _np_ptr(q), _np_ptr(r), float(min_af), _np_ptr(g), int(n_groups),
+                                                 _np_ptr(out), _np_ptr(gout), BVC_PTR_HOST))
+        return out, gout
+
+    def lrt_csr(self, offsets, bases, quals, ref_base, min_af):
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        b = np.ascontiguousarray(bases, dtype=np.int8)
+        q = np.ascontiguousarray(quals, dtype=np.int8)
+        r = np.ascontiguousarray(ref_base, dtype=np.int8)
+        n = len(o) - 1
+        out = np.zeros(n, dtype=SITE_DTYPE)
+        self._check(self._L.bvc_lrt_csr(self._h, n, _np_ptr(o), _np_ptr(b), _np_ptr(q), _np_ptr(r), float(min_af),
+                                        _np_ptr(out), BVC_PTR_HOST))
+        return out
+
+    def hist_dense(self, bases, quals):
+        b = np.ascontiguousarray(bases, dtype=np.int8)
+        q = np.ascontiguousarray(quals, dtype=np.int8)
+        out = np.zeros((b.shape[0], NCLASS), dtype=np.uint32)
+        self._check(self._L.bvc_hist_dense(self._h, b.shape[0], b.shape[1], b.shape[1], _np_ptr(b), _np_ptr(q),
+                                           _np_ptr(out), BVC_PTR_HOST))
+        return out
+
+    def lrt_hist(self, counts, ref_base, min_af, base_comb=None, n_comb=None):
+        c = np.ascontiguousarray(counts, dtype=np.uint32).reshape(-1, NCLASS)
+        r = np.ascontiguousarray(ref_base, dtype=np.int8)
+        out = np.zeros(c.shape[0], dtype=SITE_DTYPE)
+        cb = nc = None
+        if base_comb is not None:
+            cb = np.ascontiguousarray(base_comb, dtype=np.int8).reshape(-1, 4)
+            nc = np.ascontiguousarray(n_comb, dtype=np.uint8)
+        self._check(self._L.bvc_lrt_hist(self._h, c.shape[0], _np_ptr(c), _np_ptr(r), float(min_af),
+                                         _np_ptr(cb) if cb is not None else None,
+                                         _np_ptr(nc) if nc is not None else None, _np_ptr(out), BVC_PTR_HOST))
+        return out
+
+    # ---- device-pointer calls (torch tensors on this context's device; asynchronous on the stream)
+    def lrt_dense_device(self, bases_t, quals_t, ref_t, min_af, results_t=None):
+        """bases_t/quals_t: int8 [n_sites, row_stride]-strided CUDA tensors; results_t: uint8 [n_sites*120]."""
+        import torch
+        ns, n = bases_t.shape
+        stride = bases_t.stride(0)
+        assert bases_t.stride(1) == 1 and quals_t.stride(1) == 1 and quals_t.stride(0) == stride
+        if results_t is None:
+            results_t = torch.empty(ns * SITE_DTYPE.itemsize, dtype=torch.uint8, device=bases_t.device)
+        self._check(self._L.bvc_lrt_dense(self._h, ns, n, stride, _dev_ptr(bases_t), _dev_ptr(quals_t),
+                                          _dev_ptr(ref_t), float(min_af), _dev_ptr(results_t), BVC_PTR_DEVICE))
+        return results_t
+
+    def hist_dense_device(self, bases_t, quals_t, counts_t=None):
+        import torch
+        ns, n = bases_t.shape
+        if counts_t is None:
+            counts_t = torch.empty((ns, NCLASS), dtype=torch.int32, device=bases_t.device)
+        self._check(self._L.bvc_hist_dense(self._h, ns, n, bases_t.stride(0), _dev_ptr(bases_t), _dev_ptr(quals_t),
+                                           _dev_ptr(counts_t), BVC_PTR_DEVICE))
+        return counts_t
+
+    def synth_dense_device(self, seed, site0, bases_t, quals_t, ref_t, cov_thr16=65536):
+        ns, n = bases_t.shape
+        self._check(self._L.bvc_synth_dense(self._h, int(seed), int(site0), ns, n, bases_t.stride(0), int(cov_thr16),
+                                            _dev_ptr(bases_t), _dev_ptr(quals_t), _dev_ptr(ref_t)))
+
+
+def results_from_tensor(results_t):
+    """uint8 CUDA/CPU tensor of packed bvc_site_result -> numpy structured array (synchronises)."""
+    return results_t.cpu().numpy().view(SITE_DTYPE)

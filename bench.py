@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the basetype hot path on MI355X (BASELINE.json metric: sites/s at N = 1e6 samples).
+
+Workload (BASELINE.json configs[2]): synthetic pileup, 1e5 sites x 1e6 samples = 200 GB of base/qual
+bytes, generated ON the device by the library's counter-based generator and kept resident in HBM as
+tiles of `--tile-sites` sites.  One step = one tile through the whole path
+(bvc_lrt_dense: histogram kernel -> EM/LRT kernel -> result records in HBM); step i uses tile i mod T.
+A tile (8 GB) is 30x the 256 MiB Infinity Cache, so every step streams from HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+
+Sites shard across GPUs with no collective (each rank owns its own site range; weak scaling: per-GPU
+work is fixed).  torch.distributed is used only for the barriers and the max-over-ranks of the time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--samples", type=int, default=1_000_000, help="samples per site (N)")
+    p.add_argument("--total-sites", type=int, default=100_000, help="sites resident in HBM per GPU")
+    p.add_argument("--tile-sites", type=int, default=4000, help="sites per step")
+    p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--cpu-sites", type=int, default=-1, help="sites for the CPU baseline (-1: one per core, 0: skip)")
+    p.add_argument("--no-verify", action="store_true", help="skip the post-run spot check against the oracle")
+    return p.parse_args()
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)          # RCCL; used for barrier + max only
+
+    from basevarc_amd import Context
+    from basevarc_amd.lib import SITE_DTYPE, results_from_tensor
+
+    n = a.samples
+    stride = (n + 15) // 16 * 16
+    min_af = min(0.001, 100.0 / n)                               # src/BaseVarC.cpp:541-543
+    ctx = Context(local_rank, stream=torch.cuda.current_stream())
+
+    # ---- resident dataset: as many tiles of the 1e5-site workload as fit (all 25 on a 288 GB MI355X)
+    want_tiles = max(1, (a.total_sites + a.tile_sites - 1) // a.tile_sites)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    tile_bytes = 2 * a.tile_sites * stride
+    fit = int((free_b - (6 << 30)) // tile_bytes)
+    n_tiles = max(1, min(want_tiles, fit))
+    site_base = rank * a.total_sites                             # each rank owns its own site range
+    tiles = []
+    for t in range(n_tiles):
+        b = torch.empty((a.tile_sites, stride), dtype=torch.int8, device=dev)
+        q = torch.empty((a.tile_sites, stride), dtype=torch.int8, device=dev)
+        r = torch.empty(a.tile_sites, dtype=torch.int8, device=dev)
+        ctx.synth_dense_device(a.seed, site_base + t * a.tile_sites, b[:, :n], q[:, :n], r)
+        tiles.append((b[:, :n], q[:, :n], r))
+    results = [torch.empty(a.tile_sites * SITE_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(n_tiles)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        b, q, r = tiles[i % n_tiles]
+        ctx.lrt_dense_device(b, q, r, min_af, results[i % n_tiles])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(n_tiles - 1 - (i % n_tiles))
+    barrier()
+    ctx.set_profiling(True)
+    ctx.profile(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile(reset=True)
+    ctx.set_profiling(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    sites_total = a.steps * a.tile_sites * world
+    value = sites_total / dt
+    hist_ms = prof["hist_ms"] / max(1, prof["hist_launches"])
+    em_ms = prof["em_ms"] / max(1, prof["em_launches"])
+    alg_bytes = 2.0 * a.tile_sites * n                           # 2 B per (site, sample), read once
+    achieved = alg_bytes / (hist_ms * 1e-3) / 1e9 if hist_ms > 0 else 0.0
+
+    out = {
+        "metric": "sites/sec at N=1e6 samples; achieved HBM GB/s vs roofline",
+        "value": value, "unit": "sites/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"synthetic pileup {a.total_sites} sites x {n} samples per GPU (BASELINE configs[2]), "
+                        f"dense coverage, Q10-40, 20% polymorphic; step = tile of {a.tile_sites} sites",
+            "n_samples": n, "sites_per_step": a.tile_sites, "resident_tiles": n_tiles,
+            "resident_GB_per_gpu": round(n_tiles * tile_bytes / 1e9, 1), "min_af": min_af,
+            "sharding": f"sites x{world}, no collective", "seed": a.seed,
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "hist_dense_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a, n),
+            "avg_launch_ms": hist_ms, "algorithmic_bytes_per_launch": alg_bytes,
+        },
+        "kernels_ms_per_step": {"hist_dense_kernel": hist_ms, "lrt_kernel": em_ms},
+    }
+
+    if rank == 0 and not a.no_verify:
+        out["verified"] = spot_check(ctx, tiles, results, min_af, a, np)
+    if rank == 0 and world == 1 and a.cpu_sites != 0:
+        out["cpu_baseline"] = cpu_baseline(tiles[0], min_af, a, np)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def pmc_traffic(a, n):
+    """HBM bytes per hist-kernel launch from a committed rocprofv3 --pmc pass (profiles/pmc_traffic.json),
+    corrected as MI355X_MICROARCH.md prescribes; null when no such pass matches this workload."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(p))
+        if d.get("n_samples") == n and d.get("sites_per_launch") == a.tile_sites:
+            return d.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def spot_check(ctx, tiles, results, min_af, a, np):
+    """After the timed region: 64 sites of the last processed tile against the oracle's histogram form."""
+    from basevarc_amd.lib import results_from_tensor
+    from oracle import orc
+    i = (a.steps - 1) % len(tiles)
+    b, q, r = tiles[i]
+    res = results_from_tensor(results[i])
+    pick = np.linspace(0, a.tile_sites - 1, 64).astype(int)
+    bad = 0
+    for s in pick:
+        cnt = orc.dense_hist(b[s].cpu().numpy(), q[s].cpu().numpy())
+        e = orc.hist_lrt(cnt, int(r[s].item()), min_af)
+        g = res[s]
+        ok = (int(g["called"]) == e["called"] and [int(x) for x in g["depth"]] == e["depth"]
+              and [int(g["alt_base"][k]) for k in range(g["n_alt"])] == e["alt_base"]
+              and all(abs(float(g["af"][k]) - e["af"][k]) <= 1e-6 for k in range(e["n_alt"]))
+              and abs(float(g["var_qual"]) - e["var_qual"]) <= 1e-6 * max(1.0, abs(e["var_qual"])))
+        bad += not ok
+    return {"sites_checked": int(len(pick)), "mismatches": int(bad)}
+
+
+def cpu_baseline(tile, min_af, a, np):
+    """The faithful per-sample CPU port (oracle/basetype_oracle.c) on a bounded sample of the same
+    workload: one site per host thread (about 20 s each at N = 1e6)."""
+    from oracle import orc
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    k = a.cpu_sites if a.cpu_sites > 0 else cores
+    b, q, r = tile
+    hb, hq, hr = b[:k].cpu().numpy(), q[:k].cpu().numpy(), r[:k].cpu().numpy()
+    t0 = time.perf_counter()
+    _, used = orc.dense_batch(hb, hq, hr, min_af, use_hist=False, threads=min(cores, k))
+    dt = time.perf_counter() - t0
+    return {"value": k / dt, "unit": "sites/s", "cores": int(used), "kind": "port",
+            "sample": f"first {k} sites of tile 0 at N={a.samples}, one site per thread, faithful per-sample "
+                      f"restatement of BaseType ctor+LRT+EM (oracle/basetype_oracle.c), {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+/*
+ * bvc.h -- C ABI of libbvc, the MI355X (gfx950) implementation of BaseVarC's per-site
+ * basetype hot path.
+ *
+ * What it replaces in the reference (paths under /root/reference):
+ *   - class BaseType: constructor, SetBase, LRT and the public result fields
+ *       src/BaseType.h:59-74, src/BaseType.cpp:5-139, 237-255
+ *   - EM / singleEM / delta_bylog and chisf
+ *       src/Algorithm.cpp:3-7, 69-130
+ *   - the per-site call sites in bt_f
+ *       src/BaseVarC.cpp:612-615 (overall call), :617-661 (per-group calls)
+ *
+ * The reference has no FFI: BaseType is a C++ object built and consumed once per site on the caller's
+ * stack.  Launching device work per site is not viable, so the ABI is batched: the caller hands over a
+ * TILE of sites in site-major layout and receives one fixed-size record per site holding exactly the
+ * fields bt_f and WriteVcf read from a BaseType (var_qual, depth_total, alt_bases, depth, af_lrt;
+ * src/BaseType.cpp:145-147, 200-212, 221, 226) plus a few diagnostics used for parity pinning.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every entry point returns BVC_OK (0) or a negative code
+ *     and bvc_last_error(ctx) gives the text.  "No call" (LRT() == false) is called = 0, not an error.
+ *   - the caller owns all input/output buffers; the library owns only device scratch inside the context.
+ *   - one context = one device + one HIP stream; contexts are independent (one per host thread, as
+ *     bt_f runs on T std::threads in the reference, src/BaseVarC.cpp:263-266).
+ *   - there is NO CPU fallback: without a usable gfx950 device bvc_create fails.
+ */
+#ifndef BVC_H
+#define BVC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BVC_OK               0
+#define BVC_ERR_ARG         -1   /* bad argument (null pointer, negative size, base_comb out of range ...) */
+#define BVC_ERR_DEVICE      -2   /* HIP runtime error; text in bvc_last_error */
+#define BVC_ERR_NO_DEVICE   -3   /* no gfx950 device / device index out of range */
+#define BVC_ERR_ALLOC       -4   /* device or host allocation failed */
+
+/* flags for the compute entry points */
+#define BVC_PTR_HOST    0u       /* every data pointer is host memory; the call is synchronous */
+#define BVC_PTR_DEVICE  1u       /* every data pointer is device memory; the call is asynchronous on the
+                                    context's stream (bvc_synchronize or a stream sync completes it) */
+
+#define BVC_NCLASS 512           /* (base, qual) classes per site: base * 128 + qual */
+#define BVC_MAX_GROUPS 32
+
+typedef struct bvc_ctx bvc_ctx;
+
+/* One record per site: what a BaseType holds after LRT() (src/BaseType.h:70-74). 120 bytes. */
+typedef struct bvc_site_result {
+    double  var_qual;       /* BaseType::var_qual */
+    double  chi;            /* chi_sqrt_t when LRT() left its loop (src/BaseType.cpp:101) -- diagnostic */
+    double  depth_total;    /* BaseType::depth_total */
+    double  af[3];          /* af_lrt[alt_base[i]], i < n_alt */
+    double  lr_alt;         /* lr_alt_t at exit -- diagnostic */
+    double  base_frq[4];    /* fitted frequencies of the accepted model, indexed by base -- diagnostic */
+    int32_t depth[4];       /* BaseType::depth[A,C,G,T] */
+    int32_t n_passes;       /* number of E+M passes run (singleEM calls) -- diagnostic */
+    int8_t  alt_base[3];    /* BaseType::alt_bases, in the reference's order */
+    uint8_t n_alt;
+    uint8_t called;         /* return value of LRT() */
+    uint8_t n_kept;         /* size of the accepted model */
+    int8_t  kept[4];        /* bases of the accepted model (`bases` at exit) */
+    uint8_t status;         /* 0 ok; 1 = the reference's behaviour is undefined for this input
+                               (bp[0] / min_element on an empty vector, only reachable with min_af <= 0) */
+    uint8_t n_fits;         /* EM() calls -- diagnostic */
+} bvc_site_result;
+
+/* Per (site, group) record for the caller's --group loop (src/BaseVarC.cpp:617-661). 48 bytes. */
+typedef struct bvc_group_result {
+    double  af[3];          /* <group>_AF for overall alt i: gr_bt.af_lrt[alt] or 0 when absent (:646-652) */
+    int32_t depth[4];       /* na:nc:ng:nt of the group's covered samples (:640) */
+    uint8_t ran;            /* 1 when the group's BaseType was built and LRT() run (:641-644) */
+    uint8_t pad[7];
+} bvc_group_result;
+
+typedef struct bvc_profile {
+    double  hist_ms;        /* summed HIP-event time of the pileup->histogram kernel since the last reset */
+    double  em_ms;          /* summed HIP-event time of the EM/LRT kernel */
+    int64_t hist_launches;
+    int64_t em_launches;
+    int64_t sites;
+} bvc_profile;
+
+/* ---- context -------------------------------------------------------------------------------------- */
+const char *bvc_version(void);
+/* Number of usable gfx950 devices (0 when there is none or the HIP runtime cannot start). */
+int  bvc_device_count(void);
+int  bvc_create(bvc_ctx **out, int device);
+void bvc_destroy(bvc_ctx *ctx);
+const char *bvc_last_error(const bvc_ctx *ctx);
+/* Run on the caller's HIP stream (hipStream_t passed as void*; NULL = the device's default stream). */
+int  bvc_set_stream(bvc_ctx *ctx, void *hip_stream);
+int  bvc_synchronize(bvc_ctx *ctx);
+/* HIP-event timing of each kernel (adds two event records per launch). */
+int  bvc_set_profiling(bvc_ctx *ctx, int on);
+int  bvc_get_profile(bvc_ctx *ctx, bvc_profile *out, int reset);
+
+/* ---- the hot path --------------------------------------------------------------------------------- */
+/*
+ * Dense tile: bases[s * row_stride + i], quals[...] for site s < n_sites, sample i < n_samples.
+ * A sample is covered iff its base byte is 0..3 (A,C,G,T) and its qual byte is 0..127; anything else
+ * (the caller's "no read / N / indel" cases, src/BaseVarC.cpp:427, 551-559) is skipped.
+ * Equivalent per site to:  BaseType bt(bases, quals, ref_base[s], min_af); bt.LRT();
+ * (src/BaseVarC.cpp:612-613).  min_af is the caller's value (src/BaseVarC.cpp:541-543).
+ */
+int bvc_lrt_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                  const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
+                  double min_af, bvc_site_result *results, uint32_t flags);
+
+/*
+ * Dense tile with population groups: additionally, for every group g < n_groups, the depth counts and --
+ * when the overall call succeeded -- BaseType gr(bases_g, quals_g, ref, min_af);
+ * gr.SetBase({ref} + alt_bases); gr.LRT()  (src/BaseVarC.cpp:617-661).
+ * group_of_sample[i] >= n_groups means "in no group" (src/BaseVarC.cpp:352-356).
+ * grp_results is [n_sites][n_groups].
+ */
+int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                         const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
+                         double min_af, const uint8_t *group_of_sample, int32_t n_groups,
+                         bvc_site_result *results, bvc_group_result *grp_results, uint32_t flags);
+
+/*
+ * Ragged (CSR) pileup: site s owns bases[offsets[s] .. offsets[s+1]) -- exactly the vectors bt_f builds
+ * (src/BaseVarC.cpp:550-559).  Every element must be a covered observation or it is skipped as above.
+ */
+int bvc_lrt_csr(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
+                const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
+                double min_af, bvc_site_result *results, uint32_t flags);
+
+/* ---- the two stages on their own (used by the parity tests; also valid entry points) -------------- */
+/* Stage 1: counts[s * 512 + base * 128 + qual] = number of covered samples of that class (exact). */
+int bvc_hist_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                   const int8_t *bases, const int8_t *quals, uint32_t *counts, uint32_t flags);
+/* Stage 2: EM + LRT on per-site class counts.  base_comb (optional): [n_sites][4] candidate bases in
+ * SetBase order with n_comb[s] entries used; NULL means the default {A,C,G,T} (src/BaseType.h:79). */
+int bvc_lrt_hist(bvc_ctx *ctx, int64_t n_sites, const uint32_t *counts, const int8_t *ref_base,
+                 double min_af, const int8_t *base_comb, const uint8_t *n_comb,
+                 bvc_site_result *results, uint32_t flags);
+
+/* ---- synthetic pileup generator (benchmark / test input); device pointers only ------ */
+/* Fills sites site0 .. site0+n_sites-1.  cov_thr16 = 65536 gives dense coverage; smaller values leave
+ * a sample uncovered (base = -1) with probability 1 - cov_thr16/65536.  Integer arithmetic only. */
+int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites, int64_t n_samples,
+                    int64_t row_stride, uint32_t cov_thr16, int8_t *bases, int8_t *quals,
+                    int8_t *ref_base);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BVC_H */

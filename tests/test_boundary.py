@@ -1,0 +1,96 @@
+"""CPU-side checks of the drop-in boundary: the C ABI library builds for gfx950, loads, and exports
+every symbol include/bvc.h declares; struct layouts match; golden fixtures are reproducible.
+No compute call is made here (there is no GPU in the build container and no CPU fallback in the product)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from basevarc_amd import build as b
+    return b.build()
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "bvc.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(bvc_[a-z_]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_all_exported(built_lib):
+    syms = declared_symbols()
+    assert len(syms) >= 15
+    L = C.CDLL(built_lib)
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/bvc.h but not exported by libbvc.so"
+    from basevarc_amd import lib as bl
+    assert sorted(bl.EXPORTS) == syms
+
+
+def test_library_contains_gfx950_code_object(built_lib):
+    blob = open(built_lib, "rb").read()
+    assert b"gfx950" in blob
+    assert b"hist_dense_kernel" in blob and b"lrt_kernel" in blob
+
+
+def test_struct_layouts_match_header():
+    from basevarc_amd import lib as bl
+    assert C.sizeof(bl.SiteResult) == 120 and bl.SITE_DTYPE.itemsize == 120
+    assert C.sizeof(bl.GroupResult) == 48 and bl.GROUP_DTYPE.itemsize == 48
+    for name, dt in (("var_qual", 0), ("chi", 8), ("depth_total", 16), ("af", 24), ("lr_alt", 48),
+                     ("base_frq", 56), ("depth", 88), ("n_passes", 104), ("alt_base", 108), ("n_alt", 111),
+                     ("called", 112), ("n_kept", 113), ("kept", 114), ("status", 118), ("n_fits", 119)):
+        assert getattr(bl.SiteResult, name).offset == dt == bl.SITE_DTYPE.fields[name][1], name
+    # the C compiler agrees with ctypes/numpy
+    import subprocess, tempfile
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "bvc.h"\nint main(){printf("%zu %zu %zu %zu\\n",' \
+          'sizeof(bvc_site_result),sizeof(bvc_group_result),offsetof(bvc_site_result,alt_base),' \
+          'offsetof(bvc_group_result,ran));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+    assert out == ["120", "48", "108", "40"]
+
+
+def test_no_gpu_means_loud_failure_not_fallback(built_lib):
+    """Without a device the product refuses to run; it never silently computes on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from basevarc_amd import BvcError, Context, lib as bl
+    assert bl.load_library().bvc_device_count() == 0
+    with pytest.raises(BvcError):
+        Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "basevarc_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".inc")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in txt.replace("test oracle", "").replace("the oracle", "").lower() or \
+                    not re.search(r"(import|include|from)\s+[\"<]?\.*oracle", txt), f
+
+
+def test_oracle_reproduces_golden_fixtures():
+    from oracle import orc
+    from tests.golden.golden_io import load_golden
+    for name in ("basetype_random.npz", "basetype_edge.npz"):
+        g = load_golden(name)
+        for i, e in enumerate(g["expected"]):
+            b = g["bases"][g["offsets"][i]:g["offsets"][i + 1]]
+            q = g["quals"][g["offsets"][i]:g["offsets"][i + 1]]
+            if len(b) > 6000:
+                continue
+            r = orc.basetype_lrt(b, q, int(g["ref"][i]), float(g["min_af"][i]))
+            for k in ("called", "alt_base", "kept", "depth", "n_passes", "n_fits", "status"):
+                assert r[k] == e[k], (name, i, k)
+            np.testing.assert_array_equal(np.array(r["af"]), np.array(e["af"]))
+            assert (r["var_qual"] == e["var_qual"]) or (np.isnan(r["var_qual"]) and np.isnan(e["var_qual"]))

@@ -1,0 +1,281 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of
+include/bvc.h, against the CPU oracle on the same seeded inputs.
+
+Bars: class counts, depths, calls, ALT lists and EM pass counts bit-exact; AF within 1e-6 absolute;
+chi / var_qual within 1e-6 relative (BASELINE.json north_star: "identical ref/alt calls and AF/LRT
+within 1e-6").
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests.sitegen import caller_min_af, random_site
+
+pytestmark = pytest.mark.gpu
+
+AF_ATOL = 1e-6
+QUAL_RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from basevarc_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def assert_site_matches(rec, exp, where=""):
+    """rec: numpy record of bvc_site_result; exp: oracle dict."""
+    assert int(rec["status"]) == exp["status"], where
+    assert [int(x) for x in rec["depth"]] == exp["depth"], where
+    assert float(rec["depth_total"]) == exp["depth_total"], where
+    assert int(rec["called"]) == exp["called"], where
+    assert int(rec["n_alt"]) == exp["n_alt"], where
+    assert [int(rec["alt_base"][i]) for i in range(rec["n_alt"])] == exp["alt_base"], where
+    assert [int(rec["kept"][i]) for i in range(rec["n_kept"])] == exp["kept"], where
+    assert int(rec["n_fits"]) == exp["n_fits"], where
+    assert int(rec["n_passes"]) == exp["n_passes"], where
+    for i in range(exp["n_alt"]):
+        a, b = float(rec["af"][i]), exp["af"][i]
+        assert (math.isnan(a) and math.isnan(b)) or abs(a - b) <= AF_ATOL, (where, a, b)
+    for name in ("chi", "var_qual"):
+        a, b = float(rec[name]), exp[name]
+        if math.isnan(b):
+            assert math.isnan(a), (where, name, a, b)
+        else:
+            assert a == pytest.approx(b, rel=QUAL_RTOL, abs=1e-6), (where, name)
+
+
+def pad_rows(sites, width=None, fill=-1):
+    width = width or max(len(b) for b, _, _ in sites)
+    B = np.full((len(sites), width), fill, dtype=np.int8)
+    Q = np.zeros((len(sites), width), dtype=np.int8)
+    R = np.zeros(len(sites), dtype=np.int8)
+    for s, (b, q, r) in enumerate(sites):
+        B[s, :len(b)] = b
+        Q[s, :len(q)] = q
+        R[s] = r
+    return B, Q, R
+
+
+# ------------------------------------------------------------------ stage 1: histogram, bit-exact
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 4096, 8192 + 5, 70000, 262144 + 48])
+def test_hist_exact(ctx, n):
+    rng = np.random.default_rng(n)
+    ns = 5
+    B = rng.integers(0, 4, (ns, n)).astype(np.int8)
+    Q = rng.integers(0, 128, (ns, n)).astype(np.int8)
+    # uncovered / invalid bytes of every kind in some rows: base 4 (N), -1, 127; negative quals
+    for s, frac in enumerate([0.0, 0.001, 0.5, 0.999, 0.0]):
+        m = rng.random(n) < frac
+        B[s, m] = rng.choice(np.array([4, -1, 127, -128], dtype=np.int8), m.sum())
+        m2 = rng.random(n) < frac / 2
+        Q[s, m2] = rng.integers(-128, 0, m2.sum())
+    got = ctx.hist_dense(B, Q)
+    for s in range(ns):
+        exp = orc.dense_hist(B[s], Q[s])
+        assert np.array_equal(got[s], exp), (n, s)
+
+
+def test_hist_exact_skewed_keys(ctx):
+    """Real pileups: >90 % one base, few quality values -- the worst case for histogram contention."""
+    n = 300000
+    B = np.zeros((3, n), dtype=np.int8)
+    Q = np.full((3, n), 37, dtype=np.int8)
+    B[1, ::1000] = 2
+    Q[2, :] = np.where(np.arange(n) % 7 == 0, 11, 37)
+    got = ctx.hist_dense(B, Q)
+    for s in range(3):
+        assert np.array_equal(got[s], orc.dense_hist(B[s], Q[s]))
+    assert got[0, 37] == n
+
+
+# ------------------------------------------------------------------ whole path vs faithful oracle
+@pytest.mark.parametrize("nind", [1, 2, 3, 5, 12, 60, 500, 5000])
+def test_lrt_matches_oracle_random_sites(ctx, nind):
+    rng = np.random.default_rng(100 + nind)
+    sites = []
+    for af, af2 in ((0.0, 0.0), (1e-3, 0.0), (0.01, 0.0), (0.05, 0.0), (0.2, 0.02), (0.5, 0.1)):
+        for _ in range(4 if nind <= 500 else 2):
+            sites.append(random_site(rng, nind, af=af, second_af=af2, qlo=2, qhi=41))
+    B, Q, R = pad_rows(sites)
+    m = caller_min_af(nind)
+    got = ctx.lrt_dense(B, Q, R, m)
+    for s, (b, q, r) in enumerate(sites):
+        assert_site_matches(got[s], orc.basetype_lrt(b, q, r, m), where=f"nind={nind} site={s}")
+
+
+def test_lrt_edge_cases(ctx):
+    cases = [
+        ([], [], 0),                                             # depth_total == 0
+        ([2] * 40, [30] * 40, 2),                                # only the reference base
+        ([1] * 11, [30] * 11, 0),                                # mono-allelic non-ref, depth > 10 -> 5000
+        ([1] * 10, [30] * 10, 0),                                # depth <= 10 -> chi branch, chi = 0
+        (list(np.repeat([0, 1, 2, 3], 50)), [35] * 200, 0),      # all four bases kept
+        ([0] * 30 + [1] * 4 + [2] * 4, [30] * 38, 0),            # tie in chi: first minimum
+        ([1, 1, 1], [0, 0, 0], 0),                               # Q = 0 on a matching base: NaN propagates
+        ([0, 0, 0, 1], [0, 5, 0, 0], 0),                         # Q = 0 mixed with a second base
+        ([3], [40], 3), ([3], [40], 0),                          # single observation
+        ([0, 1], [93, 93], 0),                                   # highest BAM quality
+        ([0] * 5 + [1] * 5, [127] * 10, 0),                      # highest int8 quality
+    ]
+    sites = [(np.array(b, dtype=np.int8), np.array(q, dtype=np.int8), r) for b, q, r in cases]
+    B, Q, R = pad_rows(sites, width=256)
+    got = ctx.lrt_dense(B, Q, R, 0.001)
+    for s, (b, q, r) in enumerate(sites):
+        assert_site_matches(got[s], orc.basetype_lrt(b, q, r, 0.001), where=f"edge case {s}")
+
+
+def test_chi_sweep_and_saturation(ctx):
+    """var_qual over the whole chi range: below 24, near 24, large, and the 10000 saturation."""
+    rng = np.random.default_rng(5)
+    sites = []
+    for nind, af in ((300, 0.012), (300, 0.02), (2000, 0.01), (20000, 0.05), (20000, 0.4), (60000, 0.3)):
+        for _ in range(6 if nind <= 2000 else 2):
+            sites.append(random_site(rng, nind, af=af))
+    B, Q, R = pad_rows(sites)
+    got = ctx.lrt_dense(B, Q, R, 0.001)
+    seen = set()
+    for s, (b, q, r) in enumerate(sites):
+        exp = orc.basetype_lrt(b, q, r, 0.001)
+        assert_site_matches(got[s], exp, where=f"chi sweep {s}")
+        if exp["called"]:
+            seen.add("sat" if exp["var_qual"] == 10000.0 else ("mid" if exp["var_qual"] < 5000 else "other"))
+    assert {"sat", "mid"} <= seen
+
+
+def test_set_base_and_min_af_filter(ctx):
+    """SetBase-restricted candidate lists (the group call) and the min_af filter, through bvc_lrt_hist."""
+    rng = np.random.default_rng(9)
+    counts, refs, combs, ncs, exps = [], [], [], [], []
+    for _ in range(24):
+        nind = int(rng.choice([30, 400, 3000]))
+        b, q, ref = random_site(rng, nind, af=float(rng.choice([0.0, 0.05, 0.3])), second_af=0.03)
+        k = int(rng.integers(1, 5))
+        comb = [ref] + [x for x in rng.permutation(4) if x != ref][:k - 1]
+        m = float(rng.choice([0.001, 0.02, 0.2]))
+        counts.append(orc.dense_hist(b, q)); refs.append(ref)
+        combs.append(comb + [0] * (4 - len(comb))); ncs.append(len(comb))
+        exps.append((orc.basetype_lrt(b, q, ref, m, base_comb=comb), m))
+    for m in (0.001, 0.02, 0.2):
+        idx = [i for i, e in enumerate(exps) if e[1] == m]
+        got = ctx.lrt_hist(np.array([counts[i] for i in idx]), [refs[i] for i in idx], m,
+                           np.array([combs[i] for i in idx], dtype=np.int8), [ncs[i] for i in idx])
+        for j, i in enumerate(idx):
+            assert_site_matches(got[j], exps[i][0], where=f"setbase {i}")
+
+
+def test_basetype_facade_reads_like_the_reference(ctx):
+    from basevarc_amd import BaseType
+    rng = np.random.default_rng(2)
+    b, q, ref = random_site(rng, 800, af=0.1)
+    bt = BaseType(b, q, ref, 0.001, ctx=ctx)
+    ok = bt.LRT()
+    exp = orc.basetype_lrt(b, q, ref, 0.001)
+    assert ok == bool(exp["called"]) and bt.alt_bases == exp["alt_base"]
+    assert bt.depth == {j: exp["depth"][j] for j in range(4)} and bt.depth_total == exp["depth_total"]
+    for a, f in zip(exp["alt_base"], exp["af"]):
+        assert bt.af_lrt[a] == pytest.approx(f, abs=AF_ATOL)
+    assert bt.var_qual == pytest.approx(exp["var_qual"], rel=QUAL_RTOL)
+    gr = BaseType(b[:300], q[:300], ref, 0.001, ctx=ctx)
+    gr.SetBase([ref] + bt.alt_bases)
+    gr.LRT()
+    expg = orc.basetype_lrt(b[:300], q[:300], ref, 0.001, base_comb=[ref] + exp["alt_base"])
+    assert gr.alt_bases == expg["alt_base"]
+    with pytest.raises(RuntimeError):
+        gr.LRT()
+
+
+def test_csr_matches_dense(ctx):
+    rng = np.random.default_rng(21)
+    sites = [random_site(rng, int(n), af=0.05) for n in rng.integers(0, 900, 40)]
+    offs = np.zeros(len(sites) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(b) for b, _, _ in sites])
+    B = np.concatenate([b for b, _, _ in sites]); Q = np.concatenate([q for _, q, _ in sites])
+    R = np.array([r for _, _, r in sites], dtype=np.int8)
+    got = ctx.lrt_csr(offs, B, Q, R, 0.001)
+    for s, (b, q, r) in enumerate(sites):
+        assert_site_matches(got[s], orc.basetype_lrt(b, q, r, 0.001), where=f"csr {s}")
+
+
+# ------------------------------------------------------------------ golden fixtures (tests/golden)
+def test_golden_fixtures(ctx):
+    from tests.golden.golden_io import load_golden
+    for name in ("basetype_random.npz", "basetype_edge.npz"):
+        g = load_golden(name)
+        for m in np.unique(g["min_af"]):
+            idx = np.nonzero(g["min_af"] == m)[0]
+            sites = [(g["bases"][g["offsets"][i]:g["offsets"][i + 1]],
+                      g["quals"][g["offsets"][i]:g["offsets"][i + 1]], int(g["ref"][i])) for i in idx]
+            B, Q, R = pad_rows(sites, width=max(1, max(len(b) for b, _, _ in sites)))
+            got = ctx.lrt_dense(B, Q, R, float(m))
+            for j, i in enumerate(idx):
+                assert_site_matches(got[j], g["expected"][i], where=f"{name}[{i}]")
+
+
+# ------------------------------------------------------------------ synthetic generator + configs
+def test_device_generator_is_bit_identical_to_cpu(ctx):
+    import torch
+    for n, cov in ((4096, 65536), (10000, 65536), (1000 + 7, 6554)):
+        stride = (n + 15) // 16 * 16
+        b = torch.empty((6, stride), dtype=torch.int8, device="cuda")
+        q = torch.empty((6, stride), dtype=torch.int8, device="cuda")
+        r = torch.empty(6, dtype=torch.int8, device="cuda")
+        ctx.synth_dense_device(3, 1000, b[:, :n], q[:, :n], r, cov_thr16=cov)
+        ctx.synchronize()
+        eb, eq, er = orc.synth_tile(3, 1000, 6, n, cov_thr16=cov)
+        assert np.array_equal(b[:, :n].cpu().numpy(), eb)
+        assert np.array_equal(q[:, :n].cpu().numpy(), eq)
+        assert np.array_equal(r.cpu().numpy(), er)
+
+
+def test_config2_1e4_sites_by_1e4_samples(ctx):
+    """BASELINE.json configs[1]: synthetic 1e4 sites x 1e4 samples, EM to convergence, vs the CPU path."""
+    import torch
+    from basevarc_amd.lib import results_from_tensor
+    ns, n = 10000, 10000
+    m = caller_min_af(n)
+    b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    r = torch.empty(ns, dtype=torch.int8, device="cuda")
+    ctx.synth_dense_device(1, 0, b, q, r)
+    res = results_from_tensor(ctx.lrt_dense_device(b, q, r, m))
+    hb, hq, hr = b.cpu().numpy(), q.cpu().numpy(), r.cpu().numpy()
+    # every site against the histogram form of the oracle (fast) ...
+    exp_h, _ = orc.dense_batch(hb, hq, hr, m, use_hist=True)
+    for s in range(ns):
+        assert_site_matches(res[s], exp_h[s], where=f"config2 hist-oracle site {s}")
+    # ... and a 400-site sample against the faithful per-sample oracle (77 ms/site/core)
+    pick = np.random.default_rng(0).choice(ns, 400, replace=False)
+    exp_f, _ = orc.dense_batch(hb[pick], hq[pick], hr[pick], m, use_hist=False)
+    for j, s in enumerate(pick):
+        assert_site_matches(res[s], exp_f[j], where=f"config2 faithful site {s}")
+    called = int(res["called"].sum())
+    assert 0.05 * ns < called < 0.5 * ns          # ~20 % polymorphic sites in the mixture
+
+
+def test_full_size_sites_1e6_samples(ctx):
+    """configs[2] shape (N = 1e6 samples per site): exact histogram, and the LRT against the oracle."""
+    import torch
+    from basevarc_amd.lib import results_from_tensor
+    ns, n = 24, 1_000_000
+    m = caller_min_af(n)
+    b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    r = torch.empty(ns, dtype=torch.int8, device="cuda")
+    ctx.synth_dense_device(2, 5000, b, q, r)
+    counts = ctx.hist_dense_device(b, q).cpu().numpy().view(np.uint32)
+    res = results_from_tensor(ctx.lrt_dense_device(b, q, r, m))
+    hb, hq, hr = b.cpu().numpy(), q.cpu().numpy(), r.cpu().numpy()
+    for s in range(ns):
+        key = hb[s].astype(np.int64) * 128 + hq[s]
+        assert np.array_equal(counts[s], np.bincount(key, minlength=512).astype(np.uint32)), s
+        assert counts[s].sum() == n                    # checksum of the histogram = sample count
+        assert_site_matches(res[s], orc.hist_lrt(counts[s], hr[s], m), where=f"1e6 hist-oracle site {s}")
+    # faithful per-sample oracle on 4 sites (about 20 s each, run in parallel on the host cores)
+    exp_f, _ = orc.dense_batch(hb[:4], hq[:4], hr[:4], m, use_hist=False)
+    for s in range(4):
+        assert_site_matches(res[s], exp_f[s], where=f"1e6 faithful site {s}")
