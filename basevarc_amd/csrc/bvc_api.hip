@@ -391,8 +391,63 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
 {
     int rc = check_common(ctx, n_sites, bases, quals, ref_base, results);
     if (rc != BVC_OK) return rc;
-    (void)n_samples; (void)row_stride; (void)min_af; (void)group_of_sample; (void)n_groups; (void)grp_results; (void)flags;
-    return fail(ctx, BVC_ERR_ARG, "bvc_lrt_dense_groups: not implemented yet");
+    if (n_samples < 0 || row_stride < n_samples) return fail(ctx, BVC_ERR_ARG, "need 0 <= n_samples <= row_stride");
+    if (n_groups < 1 || n_groups > BVC_MAX_GROUPS) return fail(ctx, BVC_ERR_ARG, "n_groups must be 1..32");
+    if (!group_of_sample || !grp_results) return fail(ctx, BVC_ERR_ARG, "null group pointer");
+    if (n_sites == 0) return BVC_OK;
+    const int n_hist = n_groups + 1;
+
+    auto run_device = [&](int64_t ns, const int8_t *b, const int8_t *q, const int8_t *r, const uint8_t *g,
+                          bvc_site_result *res, bvc_group_result *gres) -> int {
+        int rc2 = ensure(ctx, reinterpret_cast<void **>(&ctx->d_counts), &ctx->counts_cap,
+                         (size_t)ns * BVC_NCLASS * sizeof(uint32_t));
+        if (rc2 != BVC_OK) return rc2;
+        rc2 = ensure(ctx, reinterpret_cast<void **>(&ctx->d_grp_counts), &ctx->grp_counts_cap,
+                     (size_t)ns * n_hist * BVC_NCLASS * sizeof(uint32_t));
+        if (rc2 != BVC_OK) return rc2;
+        BVC_HIP(ctx, launch_hist_dense(ctx->stream, ns, n_samples, row_stride, b, q, g, n_groups, ctx->d_grp_counts, 1));
+        BVC_HIP(ctx, launch_sum_groups(ctx->stream, ns, n_hist, ctx->d_grp_counts, ctx->d_counts));
+        BVC_HIP(ctx, launch_lrt(ctx->stream, ns, ctx->d_counts, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res));
+        BVC_HIP(ctx, launch_lrt_groups(ctx->stream, ns, n_groups, ctx->d_grp_counts, r, min_af, ctx->d_lut, res, gres));
+        return BVC_OK;
+    };
+
+    if (flags & BVC_PTR_DEVICE)
+        return run_device(n_sites, bases, quals, ref_base, group_of_sample, results, grp_results);
+
+    const int64_t row_bytes = row_stride > 0 ? row_stride : 1;
+    int64_t chunk = ((int64_t)1 << 30) / row_bytes;
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_sites) chunk = n_sites;
+    const size_t arr_al = ((size_t)chunk * (size_t)row_stride + 255) & ~(size_t)255;
+    const size_t ref_al = ((size_t)chunk + 255) & ~(size_t)255;
+    const size_t g_al = ((size_t)n_samples + 255) & ~(size_t)255;
+    const size_t res_al = ((size_t)chunk * sizeof(bvc_site_result) + 255) & ~(size_t)255;
+    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage), &ctx->stage_cap,
+                2 * arr_al + ref_al + g_al + res_al + (size_t)chunk * n_groups * sizeof(bvc_group_result) + 256);
+    if (rc != BVC_OK) return rc;
+    int8_t *d_b = reinterpret_cast<int8_t *>(ctx->d_stage);
+    int8_t *d_q = d_b + arr_al;
+    int8_t *d_r = d_q + arr_al;
+    uint8_t *d_g = reinterpret_cast<uint8_t *>(d_r + ref_al);
+    bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(d_g + g_al);
+    bvc_group_result *d_gres = reinterpret_cast<bvc_group_result *>(reinterpret_cast<char *>(d_res) + res_al);
+    BVC_HIP(ctx, hipMemcpyAsync(d_g, group_of_sample, (size_t)n_samples, hipMemcpyHostToDevice, ctx->stream));
+    for (int64_t s0 = 0; s0 < n_sites; s0 += chunk) {
+        const int64_t ns = (n_sites - s0 < chunk) ? n_sites - s0 : chunk;
+        const size_t bytes = (size_t)(ns - 1) * (size_t)row_stride + (size_t)n_samples;
+        BVC_HIP(ctx, hipMemcpyAsync(d_b, bases + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP(ctx, hipMemcpyAsync(d_q, quals + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base + s0, (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
+        rc = run_device(ns, d_b, d_q, d_r, d_g, d_res, d_gres);
+        if (rc != BVC_OK) return rc;
+        BVC_HIP(ctx, hipMemcpyAsync(results + s0, d_res, (size_t)ns * sizeof(bvc_site_result), hipMemcpyDeviceToHost,
+                                    ctx->stream));
+        BVC_HIP(ctx, hipMemcpyAsync(grp_results + s0 * n_groups, d_gres, (size_t)ns * n_groups * sizeof(bvc_group_result),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return BVC_OK;
 }
 
 int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites, int64_t n_samples,

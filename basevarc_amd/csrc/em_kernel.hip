@@ -361,7 +361,9 @@ __global__ __launch_bounds__(64) void lrt_groups_kernel(int64_t n_sites, int n_g
     const int ref = ref_base[site];
     uint32_t list = (uint32_t)(ref & 3);                         // base_comb = {ref} + alt_bases (:614-615)
     int nc = 1;
-    for (int i = 0; i < ov.n_alt && i < 3; ++i) { list |= (uint32_t)(ov.alt_base[i] & 3) << (4 * nc); ++nc; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (i < ov.n_alt) { list |= (uint32_t)(ov.alt_base[i] & 3) << (4 * nc); ++nc; }
     SiteOut o;
     // Always run the histogram load (depths are reported for every group, :640); the LRT itself only when
     // the overall call succeeded and the group has covered samples (:633-636, :641).
@@ -372,11 +374,14 @@ __global__ __launch_bounds__(64) void lrt_groups_kernel(int64_t n_sites, int n_g
         for (int j = 0; j < 4; ++j) r.depth[j] = o.depth[j];
         for (int j = 0; j < 7; ++j) r.pad[j] = 0;
         r.ran = (ov.called && o.depth_total > 0) ? 1 : 0;
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
             double af = 0.0;                                     // literal 0 when the group lacks the ALT (:650)
-            if (r.ran && i < ov.n_alt)
-                for (int tt = 0; tt < o.n_alt; ++tt)
-                    if (o.alt_base[tt] == ov.alt_base[i]) af = o.af[tt];
+            if (r.ran && i < ov.n_alt) {
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt)
+                    if (tt < o.n_alt && o.alt_base[tt] == ov.alt_base[i]) af = o.af[tt];
+            }
             r.af[i] = af;
         }
         grp_results[site * n_groups + g] = r;

@@ -145,6 +145,67 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_kernel(
     }
 }
 
+// Group mode (--group, /root/reference/src/BaseVarC.cpp:617-661): one pass builds n_groups + 1 histograms per
+// site (the last one collects samples that belong to no group, :352-356).  LDS holds [hist][class][copy]
+// with as many copies as fit 64 KiB (copies = 1 << log2c); fewer copies than banks means some conflicts,
+// which the spread of keys over groups softens.
+template <bool ALIGNED>
+__global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
+    int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *__restrict__ bases,
+    const int8_t *__restrict__ quals, const uint8_t *__restrict__ group_of_sample, int n_groups, int log2c,
+    uint32_t *__restrict__ grp_counts)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    const int tid = threadIdx.x;
+    const int n_hist = n_groups + 1;
+    const int words = (n_hist * BVC_NCLASS) << log2c;
+    const uint32_t lane_off = (uint32_t)tid & ((1u << log2c) - 1u);
+    for (int i = tid; i < words; i += kHistThreads) hist[i] = 0;
+    __syncthreads();
+
+    auto add = [&](uint32_t b, uint32_t q, uint32_t g) {
+        if (b < 4u && q < 128u) {
+            const uint32_t h = g < (uint32_t)n_groups ? g : (uint32_t)n_groups;
+            __hip_atomic_fetch_add(&hist[(((h << 9) | (b << 7) | q) << log2c) + lane_off], 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+
+    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
+        const int8_t *brow = bases + site * row_stride;
+        const int8_t *qrow = quals + site * row_stride;
+        const int64_t n16 = ALIGNED ? (n_samples >> 4) : 0;
+        if (ALIGNED) {
+            const u32x4 *bv = reinterpret_cast<const u32x4 *>(brow);
+            const u32x4 *qv = reinterpret_cast<const u32x4 *>(qrow);
+            const u32x4 *gv = reinterpret_cast<const u32x4 *>(group_of_sample);
+            for (int64_t c = tid; c < n16; c += kHistThreads) {
+                const u32x4 b = __builtin_nontemporal_load(&bv[c]);
+                const u32x4 q = __builtin_nontemporal_load(&qv[c]);
+                const u32x4 g = gv[c];
+                const uint32_t bw[4] = {b.x, b.y, b.z, b.w}, qw[4] = {q.x, q.y, q.z, q.w}, gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        add((bw[w] >> (8 * k)) & 0xFFu, (qw[w] >> (8 * k)) & 0xFFu, (gw[w] >> (8 * k)) & 0xFFu);
+            }
+        }
+        for (int64_t i = (n16 << 4) + tid; i < n_samples; i += kHistThreads)
+            add((uint8_t)brow[i], (uint8_t)qrow[i], group_of_sample[i]);
+        __syncthreads();
+        for (int key = tid; key < n_hist * BVC_NCLASS; key += kHistThreads) {
+            uint32_t s = 0;
+            for (int v = 0; v < (1 << log2c); ++v) {
+                s += hist[(key << log2c) + v];
+                hist[(key << log2c) + v] = 0;
+            }
+            grp_counts[site * n_hist * BVC_NCLASS + key] = s;
+        }
+        __syncthreads();
+    }
+}
+
 // Ragged pileup: site s owns elements offsets[s] .. offsets[s+1]).  Byte loads (rows start anywhere).
 __global__ __launch_bounds__(kHistThreads) void hist_csr_kernel(
     int64_t n_sites, const int64_t *__restrict__ offsets, const int8_t *__restrict__ bases,
@@ -197,12 +258,29 @@ hipError_t launch_hist_dense(hipStream_t stream, int64_t n_sites, int64_t n_samp
                              const int8_t *bases, const int8_t *quals, const uint8_t *group_of_sample,
                              int n_groups, uint32_t *counts, int split)
 {
-    (void)group_of_sample; (void)n_groups;
     if (n_sites <= 0) return hipSuccess;
     static bool attr_done[2] = {false, false};
+    static bool gattr_done[2] = {false, false};
     const bool aligned = ((reinterpret_cast<uintptr_t>(bases) | reinterpret_cast<uintptr_t>(quals)) & 15u) == 0 &&
                          (row_stride & 15) == 0;
     const size_t lds = (size_t)kLdsWords * sizeof(uint32_t);
+    if (group_of_sample) {                       // counts = [site][n_groups + 1][512]
+        const bool galigned = aligned && (reinterpret_cast<uintptr_t>(group_of_sample) & 15u) == 0;
+        int log2c = 0;
+        while (log2c < 5 && (size_t)(n_groups + 1) * BVC_NCLASS * (2u << log2c) <= (size_t)kLdsWords) ++log2c;
+        auto gk = galigned ? hist_dense_groups_kernel<true> : hist_dense_groups_kernel<false>;
+        if (!gattr_done[galigned]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gk),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)lds);
+            if (e != hipSuccess) return e;
+            gattr_done[galigned] = true;
+        }
+        const size_t glds = ((size_t)(n_groups + 1) * BVC_NCLASS << log2c) * sizeof(uint32_t);
+        const int64_t ggrid = n_sites < 4096 ? n_sites : 4096;
+        hipLaunchKernelGGL(gk, dim3((unsigned)ggrid), dim3(kHistThreads), glds, stream, n_sites, n_samples,
+                           row_stride, bases, quals, group_of_sample, n_groups, log2c, counts);
+        return hipGetLastError();
+    }
     auto kern = aligned ? hist_dense_kernel<true> : hist_dense_kernel<false>;
     if (!attr_done[aligned]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

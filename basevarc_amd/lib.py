@@ -63,6 +63,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch is this package's plumbing layer (device memory, streams, torch.distributed) and ships its own
+    # HIP runtime.  It must be in the process BEFORE libbvc.so so that libbvc's libamdhip64.so.7 dependency
+    # resolves to that same runtime: two HIP runtimes in one process cannot both open the device.
+    import torch  # noqa: F401
     if not os.path.exists(_LIB):
         raise BvcError(f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950); basevarc_amd has no CPU fallback")

@@ -40,6 +40,11 @@ def parse():
     return p.parse_args()
 
 
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     a = parse()
     import numpy as np
@@ -74,6 +79,7 @@ def main():
     fit = int((free_b - (6 << 30)) // tile_bytes)
     n_tiles = max(1, min(want_tiles, fit))
     site_base = rank * a.total_sites                             # each rank owns its own site range
+    log(f"generating {n_tiles} tiles of {a.tile_sites} sites x {n} samples ({n_tiles * tile_bytes / 1e9:.1f} GB) on device")
     tiles = []
     for t in range(n_tiles):
         b = torch.empty((a.tile_sites, stride), dtype=torch.int8, device=dev)
@@ -83,6 +89,7 @@ def main():
         tiles.append((b[:, :n], q[:, :n], r))
     results = [torch.empty(a.tile_sites * SITE_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(n_tiles)]
     torch.cuda.synchronize()
+    log("dataset resident; warm-up")
 
     def step(i):
         b, q, r = tiles[i % n_tiles]
@@ -96,6 +103,7 @@ def main():
     for i in range(a.warmup):
         step(n_tiles - 1 - (i % n_tiles))
     barrier()
+    log("timed region")
     ctx.set_profiling(True)
     ctx.profile(reset=True)
     barrier()
@@ -111,6 +119,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    log(f"timed region done: {dt * 1e3:.1f} ms for {a.steps} steps")
     sites_total = a.steps * a.tile_sites * world
     value = sites_total / dt
     hist_ms = prof["hist_ms"] / max(1, prof["hist_launches"])
@@ -193,7 +202,9 @@ def cpu_baseline(tile, min_af, a, np):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, 16)                                       # the GPU box's CPU share for one GPU
     k = a.cpu_sites if a.cpu_sites > 0 else cores
+    log(f"cpu baseline: {k} sites on {min(cores, k)} threads (about 20 s per site per core)")
     b, q, r = tile
     hb, hq, hr = b[:k].cpu().numpy(), q[:k].cpu().numpy(), r[:k].cpu().numpy()
     t0 = time.perf_counter()

@@ -27,8 +27,14 @@ def ctx():
     c.close()
 
 
-def assert_site_matches(rec, exp, where=""):
-    """rec: numpy record of bvc_site_result; exp: oracle dict."""
+def assert_site_matches(rec, exp, where="", path_strict=True):
+    """rec: numpy record of bvc_site_result; exp: oracle dict.
+
+    path_strict also compares the diagnostics n_fits / n_passes.  They are bit-exact except when two
+    subsets of a level tie in chi to rounding (two pure-error alleles whose fitted frequencies both reach
+    ~1e-17: which one the nested test drops first is decided by the last bits of a sum over samples).
+    Either order ends in the same model, calls and AF; only the diagnostics differ.  The tile-sized tests
+    therefore pass path_strict=False and bound the fraction of such sites instead."""
     assert int(rec["status"]) == exp["status"], where
     assert [int(x) for x in rec["depth"]] == exp["depth"], where
     assert float(rec["depth_total"]) == exp["depth_total"], where
@@ -36,17 +42,23 @@ def assert_site_matches(rec, exp, where=""):
     assert int(rec["n_alt"]) == exp["n_alt"], where
     assert [int(rec["alt_base"][i]) for i in range(rec["n_alt"])] == exp["alt_base"], where
     assert [int(rec["kept"][i]) for i in range(rec["n_kept"])] == exp["kept"], where
-    assert int(rec["n_fits"]) == exp["n_fits"], where
-    assert int(rec["n_passes"]) == exp["n_passes"], where
+    if path_strict:
+        assert int(rec["n_fits"]) == exp["n_fits"], where
+        assert int(rec["n_passes"]) == exp["n_passes"], where
     for i in range(exp["n_alt"]):
         a, b = float(rec["af"][i]), exp["af"][i]
         assert (math.isnan(a) and math.isnan(b)) or abs(a - b) <= AF_ATOL, (where, a, b)
+    # chi is a difference of two log-likelihoods, each a sum over all samples.  The per-sample CPU path
+    # adds them one by one, which drifts by up to N*u*|loglik| (N = 1e6: ~1e-5); the histogram sum does
+    # not.  The absolute floor below is 2e-10*|loglik|: invisible at the depths of the reference's test
+    # data (|loglik| ~ 1e1..1e3), ~1.5e-5 at N = 1e6.
+    floor = 1e-6 + 2e-10 * abs(exp["lr_alt"])
     for name in ("chi", "var_qual"):
         a, b = float(rec[name]), exp[name]
         if math.isnan(b):
             assert math.isnan(a), (where, name, a, b)
         else:
-            assert a == pytest.approx(b, rel=QUAL_RTOL, abs=1e-6), (where, name)
+            assert a == pytest.approx(b, rel=QUAL_RTOL, abs=floor), (where, name)
 
 
 def pad_rows(sites, width=None, fill=-1):
@@ -201,6 +213,34 @@ def test_csr_matches_dense(ctx):
         assert_site_matches(got[s], orc.basetype_lrt(b, q, r, 0.001), where=f"csr {s}")
 
 
+def test_group_mode_matches_callers_group_loop(ctx):
+    """bvc_lrt_dense_groups vs the caller's --group loop (src/BaseVarC.cpp:617-661) restated in the oracle."""
+    rng = np.random.default_rng(33)
+    for n, k in ((600, 3), (5000, 5), (40000 + 7, 5), (3000, 1), (2000, 32)):
+        ns = 12
+        grp = (rng.integers(0, k, n)).astype(np.uint8)
+        grp[rng.random(n) < 0.1] = 255                       # ~10 % of samples in no group
+        sites = []
+        for s in range(ns):
+            b, q, r = random_site(rng, n, af=[0.0, 0.02, 0.3][s % 3], second_af=0.05 if s % 4 == 0 else 0.0)
+            if s % 3 == 1:                                   # ALT confined to group 0 -> literal 0 elsewhere
+                alt = (r + 1) % 4
+                b = np.where((b != r) & (grp != 0), r, b).astype(np.int8)
+                b[(grp == 0) & (rng.random(n) < 0.3)] = alt
+            if s == 5:
+                b[rng.random(n) < 0.5] = -1                  # uncovered samples
+            sites.append((b, q, r))
+        B, Q, R = pad_rows(sites)
+        m = caller_min_af(n)
+        res, gres = ctx.lrt_dense_groups(B, Q, R, m, grp, k)
+        for s, (b, q, r) in enumerate(sites):
+            o, gd, ga, ran = orc.dense_site_groups(b, q, r, m, grp, k)
+            assert_site_matches(res[s], o, where=f"groups overall n={n} site={s}")
+            assert np.array_equal(gres[s]["depth"], gd), (n, s)
+            assert np.array_equal(gres[s]["ran"], ran), (n, s)
+            np.testing.assert_allclose(gres[s]["af"], ga, rtol=0, atol=AF_ATOL, err_msg=f"n={n} site={s}")
+
+
 # ------------------------------------------------------------------ golden fixtures (tests/golden)
 def test_golden_fixtures(ctx):
     from tests.golden.golden_io import load_golden
@@ -247,12 +287,14 @@ def test_config2_1e4_sites_by_1e4_samples(ctx):
     # every site against the histogram form of the oracle (fast) ...
     exp_h, _ = orc.dense_batch(hb, hq, hr, m, use_hist=True)
     for s in range(ns):
-        assert_site_matches(res[s], exp_h[s], where=f"config2 hist-oracle site {s}")
+        assert_site_matches(res[s], exp_h[s], where=f"config2 hist-oracle site {s}", path_strict=False)
+    same_path = np.mean([int(res[s]["n_passes"]) == exp_h[s]["n_passes"] for s in range(ns)])
+    assert same_path > 0.99, same_path
     # ... and a 400-site sample against the faithful per-sample oracle (77 ms/site/core)
     pick = np.random.default_rng(0).choice(ns, 400, replace=False)
     exp_f, _ = orc.dense_batch(hb[pick], hq[pick], hr[pick], m, use_hist=False)
     for j, s in enumerate(pick):
-        assert_site_matches(res[s], exp_f[j], where=f"config2 faithful site {s}")
+        assert_site_matches(res[s], exp_f[j], where=f"config2 faithful site {s}", path_strict=False)
     called = int(res["called"].sum())
     assert 0.05 * ns < called < 0.5 * ns          # ~20 % polymorphic sites in the mixture
 
@@ -274,8 +316,9 @@ def test_full_size_sites_1e6_samples(ctx):
         key = hb[s].astype(np.int64) * 128 + hq[s]
         assert np.array_equal(counts[s], np.bincount(key, minlength=512).astype(np.uint32)), s
         assert counts[s].sum() == n                    # checksum of the histogram = sample count
-        assert_site_matches(res[s], orc.hist_lrt(counts[s], hr[s], m), where=f"1e6 hist-oracle site {s}")
+        assert_site_matches(res[s], orc.hist_lrt(counts[s], hr[s], m), where=f"1e6 hist-oracle site {s}",
+                            path_strict=False)
     # faithful per-sample oracle on 4 sites (about 20 s each, run in parallel on the host cores)
     exp_f, _ = orc.dense_batch(hb[:4], hq[:4], hr[:4], m, use_hist=False)
     for s in range(4):
-        assert_site_matches(res[s], exp_f[s], where=f"1e6 faithful site {s}")
+        assert_site_matches(res[s], exp_f[s], where=f"1e6 faithful site {s}", path_strict=False)
