@@ -146,9 +146,8 @@ int bvc_create(bvc_ctx **out, int device)
     QualLut lut;
     for (int q = 0; q < 128; ++q) {
         const double eps = std::exp(-0.23025850929940458 * q);   // MLN10TO10, src/BaseType.h:10
-        const double a = 1.0 - eps, e = eps / 3.0;
-        lut.e[q] = e;
-        lut.d[q] = a - e;
+        lut.a[q] = 1.0 - eps;
+        lut.e[q] = eps / 3.0;
     }
     if (hipMalloc(reinterpret_cast<void **>(&ctx->d_lut), sizeof(QualLut)) != hipSuccess ||
         hipMemcpy(ctx->d_lut, &lut, sizeof(QualLut), hipMemcpyHostToDevice) != hipSuccess) {

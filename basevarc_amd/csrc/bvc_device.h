@@ -80,6 +80,85 @@ __device__ __forceinline__ double uniform(double v)
     return __hiloint2double(hi, lo);
 }
 
+// ---- gfx950 cross-row exchange ---------------------------------------------------------------------
+// v_permlane32_swap vdst, src0: lanes [63:32] of vdst <-> lanes [31:0] of src0.
+// v_permlane16_swap vdst, src0: odd rows of vdst <-> even rows of src0.
+// Passing (x, y) and ADDING the two results gives, with no select:
+//   swap32: lanes 0-31: x[l] + y[l+32]      lanes 32-63: y[l] + x[l-32]
+//   swap16: even rows : x[l] + y[l+16]      odd rows   : y[l] + x[l-16]
+// so (x, x) is a pair sum and (x, y) sums x over one half/row-pair and y over the other.
+struct DPair { double a, b; };
+
+__device__ __forceinline__ DPair swap32(double x, double y)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return DPair{__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1])};
+}
+
+__device__ __forceinline__ DPair swap16(double x, double y)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return DPair{__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1])};
+}
+
+// ---- FP64 helpers for the EM inner loop ------------------------------------------------------------
+// 1/x for x in the normal range: v_rcp_f64 (about single precision) + two Newton steps.  No scaling or
+// fix-up: x is a mixture probability in (0, 1].  x = 0 gives NaN (inf * 0 in the first step), which is
+// what the reference's 0/0 gives (src/Algorithm.cpp:81-82).
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double t = fma(-x, y, 1.0);
+    y = fma(y, t, y);
+    t = fma(-x, y, 1.0);
+    y = fma(y, t, y);
+    return y;
+}
+
+// log1p(u) for |u| <= 2^-6 by its Taylor series to u^8 (truncation < 5e-16 relative).
+constexpr double kLog1pMaxU = 0.015625;
+__device__ __forceinline__ double log1p_small(double u)
+{
+    double p = -1.0 / 8.0;
+    p = fma(p, u, 1.0 / 7.0);
+    p = fma(p, u, -1.0 / 6.0);
+    p = fma(p, u, 1.0 / 5.0);
+    p = fma(p, u, -1.0 / 4.0);
+    p = fma(p, u, 1.0 / 3.0);
+    p = fma(p, u, -1.0 / 2.0);
+    p = fma(p, u, 1.0);
+    return u * p;
+}
+
+// Natural log of a positive finite double (about 2 ulp): frexp, then 2*atanh((m-1)/(m+1)) on
+// m in [sqrt(1/2), sqrt(2)).  0 -> -inf, NaN -> NaN.
+__device__ __forceinline__ double log_pos(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);
+    int ex = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    ex = low ? ex - 1 : ex;
+    const double s = (m - 1.0) * fast_rcp(m + 1.0);
+    const double s2 = s * s;
+    double p = 1.0 / 21.0;
+    p = fma(p, s2, 1.0 / 19.0);
+    p = fma(p, s2, 1.0 / 17.0);
+    p = fma(p, s2, 1.0 / 15.0);
+    p = fma(p, s2, 1.0 / 13.0);
+    p = fma(p, s2, 1.0 / 11.0);
+    p = fma(p, s2, 1.0 / 9.0);
+    p = fma(p, s2, 1.0 / 7.0);
+    p = fma(p, s2, 1.0 / 5.0);
+    p = fma(p, s2, 1.0 / 3.0);
+    const double lm = 2.0 * fma(s * s2, p, s);
+    const double e = (double)ex;
+    const double r = fma(e, 6.93147180369123816490e-01, fma(e, 1.90821492927058770002e-10, lm));
+    return x == 0.0 ? -__builtin_huge_val() : r;
+}
+
 // ---- chi-square survival function, df = 1 --------------------------------------------------------
 // The reference's chisf(x, 1) = kf_gammaq(0.5, x/2) (src/Algorithm.cpp:3-7; htslib kfunc.c, absent from
 // the reference tree).  Same published algorithm as the reference links against: Lanczos-type

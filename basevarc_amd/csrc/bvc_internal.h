@@ -9,10 +9,10 @@ namespace bvc {
 
 // Base-quality -> likelihood table, built on the HOST with the same libm exp() the CPU path uses
 // (src/BaseType.cpp:13,15) and uploaded once per context:
-//   e[q] = eps/3          likelihood of a non-matching base
-//   d[q] = (1-eps) - e[q] matching minus non-matching likelihood
+//   a[q] = 1 - eps   likelihood of the observed base given the matching allele
+//   e[q] = eps / 3   likelihood given any other allele
 struct QualLut {
-    double d[128];
+    double a[128];
     double e[128];
 };
 

@@ -30,14 +30,9 @@ constexpr double kEmEpsilon = 0.001;      // src/BaseType.cpp:45
 
 struct Slots {
     double n[kMaxSlots];    // class count (0 for an empty slot)
-    double d[kMaxSlots];
-    double e[kMaxSlots];
-    double lm[kMaxSlots];   // log of the class marginal from the previous pass
-};
-
-struct PassOut {
-    double ex[4];           // expect_allele_prob after the pass (wave-uniform)
-    double delta;           // sum_c n_c |log m_c' - log m_c| (wave-uniform)
+    double a[kMaxSlots];    // 1 - eps : likelihood when the allele matches the class's base
+    double e[kMaxSlots];    // eps / 3 : likelihood when it does not
+    double yp[kMaxSlots];   // 1 / (class marginal) from the previous pass
 };
 
 // k-subsets of positions 0..n-1 in lexicographic order (what combs_ yields), as 4-bit position masks
@@ -69,58 +64,89 @@ __device__ __forceinline__ int pick4(const int (&v)[4], int j)
     return j == 0 ? v[0] : (j == 1 ? v[1] : (j == 2 ? v[2] : v[3]));
 }
 
-// One E+M pass (singleEM, src/Algorithm.cpp:69-93) plus the delta of delta_bylog (:103-113).
-// On the first pass of a fit S.lm is stale and the returned delta is ignored by the caller.
-__device__ __forceinline__ PassOut em_pass(Slots &S, int nslots, int row, const double (&f)[4],
-                                           double inv_n)
+// Frequencies live per lane: fb = frequency of the lane's own base, g = sum of the other three.  The class
+// marginal is m = fb * a + g * e -- the reference's sum_j f_j * L_ij with the three equal terms grouped;
+// every term is non-negative, so nothing cancels (src/Algorithm.cpp:74-78).
+struct Freq {
+    double fb, g;
+};
+
+// Sum of the other three rows' values of a row-uniform x: two swap steps, additions only.
+__device__ __forceinline__ double others_sum(double x, int lane)
 {
-    const double fb = pick4(f, row);
-    const double F = ((f[0] + f[1]) + f[2]) + f[3];
+    const DPair p = swap16(x, x);                       // even rows: a = own, b = partner; odd rows: a = partner, b = own
+    const double partner = (lane & 16) ? p.a : p.b;
+    const double pair = p.a + p.b;
+    const DPair q = swap32(pair, pair);                 // lower half: a = own pair, b = other pair; upper: the reverse
+    const double other_pair = (lane & 32) ? q.a : q.b;
+    return partner + other_pair;
+}
+
+struct PassOut {
+    double ex_own;          // expect_allele_prob of the lane's own base (uniform within the row)
+    double delta;           // sum_c n_c |log m_c' - log m_c| (wave-uniform)
+};
+
+// One E+M pass (singleEM, src/Algorithm.cpp:69-93) plus the delta of delta_bylog (:103-113).
+//   M step: expect_j = f_j / N * (D_j + E),  D_j = sum_{c in j} n_c (a_c - e_c) / m_c,  E = sum_c n_c e_c / m_c
+//   delta : log m' - log m = log1p(m' / m - 1), with 1/m kept from the previous pass.
+// On the first pass of a fit S.yp is stale and the caller ignores the returned delta.
+__device__ __forceinline__ PassOut em_pass(Slots &S, int nslots, int lane, const Freq f, double inv_n)
+{
     double acc_d = 0.0, acc_e = 0.0, acc_delta = 0.0;
 #pragma unroll
     for (int k = 0; k < kMaxSlots; ++k) {
         if (k < nslots) {
-            const double m = fma(fb, S.d[k], F * S.e[k]);
-            const double r = S.n[k] / m;
-            acc_d = fma(r, S.d[k], acc_d);
+            const double m = fma(f.fb, S.a[k], f.g * S.e[k]);
+            const double y = fast_rcp(m);
+            const double r = S.n[k] * y;
+            acc_d = fma(r, S.a[k] - S.e[k], acc_d);
             acc_e = fma(r, S.e[k], acc_e);
-            const double lm = log(m);
-            acc_delta = fma(S.n[k], fabs(lm - S.lm[k]), acc_delta);
-            S.lm[k] = lm;
+            const double u = fma(m, S.yp[k], -1.0);
+            double dl;
+            if (__ballot(fabs(u) > kLog1pMaxU) == 0) dl = log1p_small(u);   // the common case, wave-uniform
+            else dl = log_pos(1.0 + u);
+            acc_delta = fma(S.n[k], fabs(dl), acc_delta);
+            S.yp[k] = y;
         }
     }
     const double drow = row_sum(acc_d);
-    const double etot = rows_total(row_sum(acc_e));
+    // E over lanes l, l+32 lands in the lower half, delta in the upper half; then rows, then row pairs
+    const DPair h = swap32(acc_e, acc_delta);
+    double z = row_sum(h.a + h.b);
+    const DPair w = swap16(z, z);
+    z = w.a + w.b;
+    const double etot = lane_value<0>(z);
     PassOut o;
-    o.ex[0] = f[0] * inv_n * (lane_value<0>(drow) + etot);
-    o.ex[1] = f[1] * inv_n * (lane_value<16>(drow) + etot);
-    o.ex[2] = f[2] * inv_n * (lane_value<32>(drow) + etot);
-    o.ex[3] = f[3] * inv_n * (lane_value<48>(drow) + etot);
-    o.delta = rows_total(row_sum(acc_delta));
+    o.delta = lane_value<32>(z);
+    o.ex_own = f.fb * inv_n * (drow + etot);
     return o;
 }
 
 // EM (src/Algorithm.cpp:115-130) followed by UpdateF's log-likelihood sum (src/BaseType.cpp:58-62).
-// f holds the initial frequencies; on return ex = expect_allele_prob of the last pass (one M step ahead
-// of the frequencies the returned log-likelihood was computed with, as in the reference).
-__device__ __forceinline__ double em_fit(Slots &S, int nslots, int row, double (&f)[4], double inv_n,
+// f0 = the lane's initial frequency.  Returns the log-likelihood of the last pass; ex = expect_allele_prob
+// of that pass (one M step ahead of the frequencies the log-likelihood belongs to, as in the reference).
+__device__ __forceinline__ double em_fit(Slots &S, int nslots, int lane, double f0, double inv_n,
                                          double (&ex)[4], int &passes)
 {
+    Freq f{f0, others_sum(f0, lane)};
     PassOut o;
     for (int it = 0;; ++it) {                  // pass 0 + at most kEmIters update passes
-        o = em_pass(S, nslots, row, f, inv_n);
+        o = em_pass(S, nslots, lane, f, inv_n);
         passes += 1;
         if (it > 0 && o.delta < kEmEpsilon) break;   // NaN never converges, as in the reference
         if (it == kEmIters) break;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) f[j] = o.ex[j];
+        f.fb = o.ex_own;
+        f.g = others_sum(o.ex_own, lane);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ex[j] = o.ex[j];
-    double ll = 0.0;
+    ex[0] = lane_value<0>(o.ex_own);
+    ex[1] = lane_value<16>(o.ex_own);
+    ex[2] = lane_value<32>(o.ex_own);
+    ex[3] = lane_value<48>(o.ex_own);
+    double ll = 0.0;                           // sum_c n_c log m_c = -sum_c n_c log(1/m_c)
 #pragma unroll
     for (int k = 0; k < kMaxSlots; ++k)
-        if (k < nslots) ll = fma(S.n[k], S.lm[k], ll);
+        if (k < nslots) ll = fma(-S.n[k], log_pos(S.yp[k]), ll);
     return rows_total(row_sum(ll));
 }
 
@@ -172,11 +198,11 @@ __device__ void lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
 #pragma unroll
     for (int k = 0; k < kMaxSlots; ++k) {
         const int idx = t + 16 * k;
-        S.n[k] = 0.0; S.d[k] = 0.0; S.e[k] = 1.0; S.lm[k] = 0.0;
+        S.n[k] = 0.0; S.a[k] = 1.0; S.e[k] = 1.0; S.yp[k] = 1.0;     // empty slot: m = fb + g > 0, weight 0
         if (k < nslots && idx < cnt_row) {
             const int q = s_q[row * 128 + idx];
             S.n[k] = (double)s_n[row * 128 + idx];
-            S.d[k] = lut->d[q];
+            S.a[k] = lut->a[q];
             S.e[k] = lut->e[q];
         }
     }
@@ -216,7 +242,7 @@ __device__ void lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
             f[j] = (depth_sum > 0 && ((setmask >> j) & 1u)) ? (double)depth[j] / (double)depth_sum : 0.0;
         const double freq_sum = ((f[0] + f[1]) + f[2]) + f[3];
         if (freq_sum == 0) return false;
-        loglik = em_fit(S, nslots, row, f, inv_n, ex, passes);
+        loglik = em_fit(S, nslots, lane, pick4(f, row), inv_n, ex, passes);
         fits += 1;
         return true;
     };
