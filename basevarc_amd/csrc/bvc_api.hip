@@ -21,13 +21,22 @@ struct bvc_ctx {
     QualLut *d_lut = nullptr;
     uint32_t *d_counts = nullptr;      // [sites][512] scratch between the two stages
     size_t counts_cap = 0;
+    // overlap mode: stage 2 of call i runs on `side` while stage 1 of call i+1 streams on `stream`
+    bool overlap = false;
+    hipStream_t side = nullptr;
+    uint32_t *d_counts_alt = nullptr;  // second histogram buffer (calls alternate)
+    size_t counts_alt_cap = 0;
+    int flip = 0;
+    hipEvent_t ev_hist_done[2] = {nullptr, nullptr};
+    hipEvent_t ev_em_done[2] = {nullptr, nullptr};
+    bool em_pending[2] = {false, false};
     uint32_t *d_grp_counts = nullptr;  // [sites][groups + 1][512] in group mode
     size_t grp_counts_cap = 0;
     char *d_stage = nullptr;           // staging for BVC_PTR_HOST calls
     size_t stage_cap = 0;
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;   // free events
-    struct Triple { hipEvent_t a, b, c; int64_t sites; };
+    struct Triple { hipEvent_t a, b, c, d; int64_t sites; };   // hist = a..b, EM = c..d
     std::vector<Triple> ev_pending;
     bvc_profile prof{};
     std::string err;
@@ -76,26 +85,62 @@ hipEvent_t take_event(bvc_ctx *ctx)
     return e;
 }
 
-// The two stages on device pointers.  comb/n_comb may be null.
+// Make the context's stream wait for every stage-2 launch still running on the side stream.
+int join_side(bvc_ctx *ctx)
+{
+    for (int b = 0; b < 2; ++b)
+        if (ctx->em_pending[b]) {
+            BVC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_em_done[b], 0));
+            ctx->em_pending[b] = false;
+        }
+    return BVC_OK;
+}
+
+// The two stages on device pointers.
 int run_dense_device(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                      const int8_t *bases, const int8_t *quals, const int8_t *ref_base, double min_af,
                      bvc_site_result *results)
 {
-    int rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_counts), &ctx->counts_cap,
-                    (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t));
+    const size_t cbytes = (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t);
+    const int buf = ctx->overlap ? ctx->flip : 0;
+    if (ctx->overlap) ctx->flip ^= 1;
+    uint32_t **counts_p = buf ? &ctx->d_counts_alt : &ctx->d_counts;
+    size_t *cap_p = buf ? &ctx->counts_alt_cap : &ctx->counts_cap;
+    if (cbytes > *cap_p) {                      // growing a buffer: nothing may still be reading it
+        int rcj = join_side(ctx);
+        if (rcj != BVC_OK) return rcj;
+    }
+    int rc = ensure(ctx, reinterpret_cast<void **>(counts_p), cap_p, cbytes);
     if (rc != BVC_OK) return rc;
+    uint32_t *counts = *counts_p;
     const int split = choose_hist_split(n_sites, n_samples, ctx->n_cu);
-    bvc_ctx::Triple t{nullptr, nullptr, nullptr, n_sites};
-    if (ctx->profiling) { t.a = take_event(ctx); t.b = take_event(ctx); t.c = take_event(ctx); }
-    if (split > 1)
-        BVC_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t), ctx->stream));
+    bvc_ctx::Triple t{nullptr, nullptr, nullptr, nullptr, n_sites};
+    if (ctx->profiling) { t.a = take_event(ctx); t.b = take_event(ctx); t.c = take_event(ctx); t.d = take_event(ctx); }
+
+    // stage 1 on the context's stream; the histogram buffer is free once the EM that read it has finished
+    if (ctx->overlap && ctx->em_pending[buf]) {
+        BVC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_em_done[buf], 0));
+        ctx->em_pending[buf] = false;
+    }
+    if (split > 1) BVC_HIP(ctx, hipMemsetAsync(counts, 0, cbytes, ctx->stream));
     if (t.a) BVC_HIP(ctx, hipEventRecord(t.a, ctx->stream));
-    BVC_HIP(ctx, launch_hist_dense(ctx->stream, n_sites, n_samples, row_stride, bases, quals, nullptr, 0,
-                                   ctx->d_counts, split));
+    BVC_HIP(ctx, launch_hist_dense(ctx->stream, n_sites, n_samples, row_stride, bases, quals, nullptr, 0, counts, split));
     if (t.b) BVC_HIP(ctx, hipEventRecord(t.b, ctx->stream));
-    BVC_HIP(ctx, launch_lrt(ctx->stream, n_sites, ctx->d_counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut,
-                            nullptr, nullptr, results));
-    if (t.c) { BVC_HIP(ctx, hipEventRecord(t.c, ctx->stream)); ctx->ev_pending.push_back(t); }
+
+    // stage 2: same stream, or the side stream behind an event
+    hipStream_t s2 = ctx->stream;
+    if (ctx->overlap) {
+        s2 = ctx->side;
+        BVC_HIP(ctx, hipEventRecord(ctx->ev_hist_done[buf], ctx->stream));
+        BVC_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_hist_done[buf], 0));
+    }
+    if (t.c) BVC_HIP(ctx, hipEventRecord(t.c, s2));
+    BVC_HIP(ctx, launch_lrt(s2, n_sites, counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut, nullptr, nullptr, results));
+    if (t.d) { BVC_HIP(ctx, hipEventRecord(t.d, s2)); ctx->ev_pending.push_back(t); }
+    if (ctx->overlap) {
+        BVC_HIP(ctx, hipEventRecord(ctx->ev_em_done[buf], s2));
+        ctx->em_pending[buf] = true;
+    }
     return BVC_OK;
 }
 
@@ -156,6 +201,11 @@ int bvc_create(bvc_ctx **out, int device)
         delete ctx;
         return BVC_ERR_ALLOC;
     }
+    bool ok = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess;
+    for (int b = 0; b < 2 && ok; ++b)
+        ok = hipEventCreateWithFlags(&ctx->ev_hist_done[b], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->ev_em_done[b], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); bvc_destroy(ctx); return BVC_ERR_DEVICE; }
     *out = ctx;
     return BVC_OK;
 }
@@ -165,7 +215,13 @@ void bvc_destroy(bvc_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto &t : ctx->ev_pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.c); }
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    for (int b = 0; b < 2; ++b) {
+        if (ctx->ev_hist_done[b]) (void)hipEventDestroy(ctx->ev_hist_done[b]);
+        if (ctx->ev_em_done[b]) (void)hipEventDestroy(ctx->ev_em_done[b]);
+    }
+    if (ctx->d_counts_alt) (void)hipFree(ctx->d_counts_alt);
+    for (auto &t : ctx->ev_pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.c); (void)hipEventDestroy(t.d); }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
@@ -180,6 +236,8 @@ int bvc_set_stream(bvc_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return BVC_ERR_ARG;
     BVC_HIP(ctx, hipSetDevice(ctx->device));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->side));
+    ctx->em_pending[0] = ctx->em_pending[1] = false;
     BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     return BVC_OK;
@@ -189,8 +247,27 @@ int bvc_synchronize(bvc_ctx *ctx)
 {
     if (!ctx) return BVC_ERR_ARG;
     BVC_HIP(ctx, hipSetDevice(ctx->device));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->side));
+    ctx->em_pending[0] = ctx->em_pending[1] = false;
     BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BVC_OK;
+}
+
+int bvc_set_overlap(bvc_ctx *ctx, int on)
+{
+    if (!ctx) return BVC_ERR_ARG;
+    BVC_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = join_side(ctx);
+    if (rc != BVC_OK) return rc;
+    ctx->overlap = on != 0;
+    return BVC_OK;
+}
+
+int bvc_join(bvc_ctx *ctx)
+{
+    if (!ctx) return BVC_ERR_ARG;
+    BVC_HIP(ctx, hipSetDevice(ctx->device));
+    return join_side(ctx);
 }
 
 int bvc_set_profiling(bvc_ctx *ctx, int on)
@@ -204,14 +281,15 @@ int bvc_get_profile(bvc_ctx *ctx, bvc_profile *out, int reset)
 {
     if (!ctx || !out) return BVC_ERR_ARG;
     BVC_HIP(ctx, hipSetDevice(ctx->device));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->side));
     BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (auto &t : ctx->ev_pending) {
         float ms1 = 0.f, ms2 = 0.f;
         BVC_HIP(ctx, hipEventElapsedTime(&ms1, t.a, t.b));
-        BVC_HIP(ctx, hipEventElapsedTime(&ms2, t.b, t.c));
+        BVC_HIP(ctx, hipEventElapsedTime(&ms2, t.c, t.d));
         ctx->prof.hist_ms += ms1; ctx->prof.em_ms += ms2;
         ctx->prof.hist_launches += 1; ctx->prof.em_launches += 1; ctx->prof.sites += t.sites;
-        ctx->ev_pool.push_back(t.a); ctx->ev_pool.push_back(t.b); ctx->ev_pool.push_back(t.c);
+        ctx->ev_pool.push_back(t.a); ctx->ev_pool.push_back(t.b); ctx->ev_pool.push_back(t.c); ctx->ev_pool.push_back(t.d);
     }
     ctx->ev_pending.clear();
     *out = ctx->prof;
@@ -253,6 +331,7 @@ int bvc_lrt_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_
         BVC_HIP(ctx, hipMemcpyAsync(d_q, quals + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
         BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base + s0, (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
         rc = run_dense_device(ctx, ns, n_samples, row_stride, d_b, d_q, d_r, min_af, d_res);
+        if (rc == BVC_OK) rc = join_side(ctx);
         if (rc != BVC_OK) return rc;
         BVC_HIP(ctx, hipMemcpyAsync(results + s0, d_res, (size_t)ns * sizeof(bvc_site_result),
                                     hipMemcpyDeviceToHost, ctx->stream));
@@ -342,6 +421,8 @@ int bvc_lrt_csr(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
     int rc = check_common(ctx, n_sites, offsets, ref_base, results, results);
     if (rc != BVC_OK) return rc;
     if (n_sites == 0) return BVC_OK;
+    rc = join_side(ctx);                        // this path shares d_counts with overlapped dense calls
+    if (rc != BVC_OK) return rc;
     rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_counts), &ctx->counts_cap,
                 (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t));
     if (rc != BVC_OK) return rc;
@@ -394,6 +475,8 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
     if (n_groups < 1 || n_groups > BVC_MAX_GROUPS) return fail(ctx, BVC_ERR_ARG, "n_groups must be 1..32");
     if (!group_of_sample || !grp_results) return fail(ctx, BVC_ERR_ARG, "null group pointer");
     if (n_sites == 0) return BVC_OK;
+    rc = join_side(ctx);                        // this path shares d_counts with overlapped dense calls
+    if (rc != BVC_OK) return rc;
     const int n_hist = n_groups + 1;
 
     auto run_device = [&](int64_t ns, const int8_t *b, const int8_t *q, const int8_t *r, const uint8_t *g,

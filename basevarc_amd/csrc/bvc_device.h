@@ -15,10 +15,12 @@ constexpr int kDppXor2 = 0x4E;     // quad_perm [2,3,0,1]
 constexpr int kDppHalfMirror = 0x141;
 constexpr int kDppMirror = 0x140;
 
+// All controls used here (quad_perm, row mirrors) read a valid lane for every lane, so the "old" operand
+// is dead: bound_ctrl = true lets the compiler leave it undefined instead of zero-initialising it.
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
 }
 
 template <int CTRL>
@@ -38,6 +40,19 @@ __device__ __forceinline__ double row_sum(double v)
     v += dpp_f64<kDppHalfMirror>(v);
     v += dpp_f64<kDppMirror>(v);
     return v;
+}
+
+// Two independent row sums, step by step side by side: one chain's DPP wait states are filled by the other.
+__device__ __forceinline__ void row_sum2(double &x, double &y)
+{
+    double tx = dpp_f64<kDppXor1>(x), ty = dpp_f64<kDppXor1>(y);
+    x += tx; y += ty;
+    tx = dpp_f64<kDppXor2>(x); ty = dpp_f64<kDppXor2>(y);
+    x += tx; y += ty;
+    tx = dpp_f64<kDppHalfMirror>(x); ty = dpp_f64<kDppHalfMirror>(y);
+    x += tx; y += ty;
+    tx = dpp_f64<kDppMirror>(x); ty = dpp_f64<kDppMirror>(y);
+    x += tx; y += ty;
 }
 
 __device__ __forceinline__ int row_sum(int v)

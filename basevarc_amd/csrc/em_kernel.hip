@@ -23,16 +23,19 @@
 namespace bvc {
 namespace {
 
-constexpr int kMaxSlots = 8;              // 128 quality values / 16 lanes per row
 constexpr double kLrtThreshold = 24.0;    // LRT_THRESHOLD, src/BaseType.h:9
 constexpr int kEmIters = 100;             // src/BaseType.cpp:46
 constexpr double kEmEpsilon = 0.001;      // src/BaseType.cpp:45
 
+// Register-resident classes of one lane.  NS (slots per lane) is a template parameter: the kernel is
+// instantiated for NS = 2, 4 and 8 and each site is handled by the smallest variant that holds it, so the
+// common case (<= 32 quality values per base) runs with a small register footprint and many waves per SIMD.
+template <int NS>
 struct Slots {
-    double n[kMaxSlots];    // class count (0 for an empty slot)
-    double a[kMaxSlots];    // 1 - eps : likelihood when the allele matches the class's base
-    double e[kMaxSlots];    // eps / 3 : likelihood when it does not
-    double yp[kMaxSlots];   // 1 / (class marginal) from the previous pass
+    double n[NS];    // class count (0 for an empty slot)
+    double a[NS];    // 1 - eps : likelihood when the allele matches the class's base
+    double e[NS];    // eps / 3 : likelihood when it does not
+    double yp[NS];   // 1 / (class marginal) from the previous pass
 };
 
 // k-subsets of positions 0..n-1 in lexicographic order (what combs_ yields), as 4-bit position masks
@@ -67,20 +70,11 @@ __device__ __forceinline__ int pick4(const int (&v)[4], int j)
 // Frequencies live per lane: fb = frequency of the lane's own base, g = sum of the other three.  The class
 // marginal is m = fb * a + g * e -- the reference's sum_j f_j * L_ij with the three equal terms grouped;
 // every term is non-negative, so nothing cancels (src/Algorithm.cpp:74-78).
+// g is taken as 1 - fb: the four frequencies sum to 1 after every M step (sum_j expect_j = (1/N) sum_i 1)
+// and at the start (depth ratios), up to a few ulp -- the same few ulp the reference's own f_j carry.
 struct Freq {
     double fb, g;
 };
-
-// Sum of the other three rows' values of a row-uniform x: two swap steps, additions only.
-__device__ __forceinline__ double others_sum(double x, int lane)
-{
-    const DPair p = swap16(x, x);                       // even rows: a = own, b = partner; odd rows: a = partner, b = own
-    const double partner = (lane & 16) ? p.a : p.b;
-    const double pair = p.a + p.b;
-    const DPair q = swap32(pair, pair);                 // lower half: a = own pair, b = other pair; upper: the reverse
-    const double other_pair = (lane & 32) ? q.a : q.b;
-    return partner + other_pair;
-}
 
 struct PassOut {
     double ex_own;          // expect_allele_prob of the lane's own base (uniform within the row)
@@ -91,29 +85,35 @@ struct PassOut {
 //   M step: expect_j = f_j / N * (D_j + E),  D_j = sum_{c in j} n_c (a_c - e_c) / m_c,  E = sum_c n_c e_c / m_c
 //   delta : log m' - log m = log1p(m' / m - 1), with 1/m kept from the previous pass.
 // On the first pass of a fit S.yp is stale and the caller ignores the returned delta.
-__device__ __forceinline__ PassOut em_pass(Slots &S, int nslots, int lane, const Freq f, double inv_n)
+// The NS slots are independent dependency chains with no branch between them, so they interleave.
+template <int NS>
+__device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double inv_n)
 {
     double acc_d = 0.0, acc_e = 0.0, acc_delta = 0.0;
+    double u[NS];
+    bool big = false;
 #pragma unroll
-    for (int k = 0; k < kMaxSlots; ++k) {
-        if (k < nslots) {
-            const double m = fma(f.fb, S.a[k], f.g * S.e[k]);
-            const double y = fast_rcp(m);
-            const double r = S.n[k] * y;
-            acc_d = fma(r, S.a[k] - S.e[k], acc_d);
-            acc_e = fma(r, S.e[k], acc_e);
-            const double u = fma(m, S.yp[k], -1.0);
-            double dl;
-            if (__ballot(fabs(u) > kLog1pMaxU) == 0) dl = log1p_small(u);   // the common case, wave-uniform
-            else dl = log_pos(1.0 + u);
-            acc_delta = fma(S.n[k], fabs(dl), acc_delta);
-            S.yp[k] = y;
-        }
+    for (int k = 0; k < NS; ++k) {
+        const double m = fma(f.fb, S.a[k], f.g * S.e[k]);
+        const double y = fast_rcp(m);
+        const double r = S.n[k] * y;
+        acc_d = fma(r, S.a[k] - S.e[k], acc_d);
+        acc_e = fma(r, S.e[k], acc_e);
+        u[k] = fma(m, S.yp[k], -1.0);
+        big |= fabs(u[k]) > kLog1pMaxU;
+        S.yp[k] = y;
     }
-    const double drow = row_sum(acc_d);
+    if (__ballot(big) == 0) {                               // the common case, wave-uniform
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc_delta = fma(S.n[k], fabs(log1p_small(u[k])), acc_delta);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc_delta = fma(S.n[k], fabs(log_pos(1.0 + u[k])), acc_delta);
+    }
     // E over lanes l, l+32 lands in the lower half, delta in the upper half; then rows, then row pairs
     const DPair h = swap32(acc_e, acc_delta);
-    double z = row_sum(h.a + h.b);
+    double drow = acc_d, z = h.a + h.b;
+    row_sum2(drow, z);
     const DPair w = swap16(z, z);
     z = w.a + w.b;
     const double etot = lane_value<0>(z);
@@ -126,18 +126,19 @@ __device__ __forceinline__ PassOut em_pass(Slots &S, int nslots, int lane, const
 // EM (src/Algorithm.cpp:115-130) followed by UpdateF's log-likelihood sum (src/BaseType.cpp:58-62).
 // f0 = the lane's initial frequency.  Returns the log-likelihood of the last pass; ex = expect_allele_prob
 // of that pass (one M step ahead of the frequencies the log-likelihood belongs to, as in the reference).
-__device__ __forceinline__ double em_fit(Slots &S, int nslots, int lane, double f0, double inv_n,
+template <int NS>
+__device__ __forceinline__ double em_fit(Slots<NS> &S, int lane, double f0, double inv_n,
                                          double (&ex)[4], int &passes)
 {
-    Freq f{f0, others_sum(f0, lane)};
+    Freq f{f0, 1.0 - f0};
     PassOut o;
     for (int it = 0;; ++it) {                  // pass 0 + at most kEmIters update passes
-        o = em_pass(S, nslots, lane, f, inv_n);
+        o = em_pass<NS>(S, f, inv_n);
         passes += 1;
         if (it > 0 && o.delta < kEmEpsilon) break;   // NaN never converges, as in the reference
         if (it == kEmIters) break;
         f.fb = o.ex_own;
-        f.g = others_sum(o.ex_own, lane);
+        f.g = 1.0 - o.ex_own;
     }
     ex[0] = lane_value<0>(o.ex_own);
     ex[1] = lane_value<16>(o.ex_own);
@@ -145,8 +146,7 @@ __device__ __forceinline__ double em_fit(Slots &S, int nslots, int lane, double 
     ex[3] = lane_value<48>(o.ex_own);
     double ll = 0.0;                           // sum_c n_c log m_c = -sum_c n_c log(1/m_c)
 #pragma unroll
-    for (int k = 0; k < kMaxSlots; ++k)
-        if (k < nslots) ll = fma(-S.n[k], log_pos(S.yp[k]), ll);
+    for (int k = 0; k < NS; ++k) ll = fma(-S.n[k], log_pos(S.yp[k]), ll);
     return rows_total(row_sum(ll));
 }
 
@@ -160,7 +160,9 @@ struct SiteOut {
 
 // The whole per-site computation for one wavefront.  `hist` points at 512 class counts.
 // comb_list: candidate bases packed 4 bits each in SetBase order; n_comb entries.
-__device__ void lrt_site(const uint32_t *__restrict__ hist, int ref, double min_af,
+// Returns false (and leaves `out` untouched) when the site needs a different NS variant.
+template <int NS>
+__device__ bool lrt_site(const uint32_t *__restrict__ hist, int ref, double min_af,
                          uint32_t comb_list, int n_comb, const QualLut *__restrict__ lut,
                          uint32_t *s_n, uint8_t *s_q, SiteOut &out)
 {
@@ -192,14 +194,16 @@ __device__ void lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
     int maxcnt = max(max(__builtin_amdgcn_readlane(cnt_row, 0), __builtin_amdgcn_readlane(cnt_row, 16)),
                      max(__builtin_amdgcn_readlane(cnt_row, 32), __builtin_amdgcn_readlane(cnt_row, 48)));
     const int nslots = (maxcnt + 15) >> 4;
+    // variant gate (wave-uniform): NS = 2 takes 0..2 slots, NS = 4 takes 3..4, NS = 8 takes 5..8
+    if (nslots > NS || (NS > 2 && nslots <= NS / 2)) return false;
     __syncthreads();                           // single-wave workgroup: orders the LDS writes above
 
-    Slots S;
+    Slots<NS> S;
 #pragma unroll
-    for (int k = 0; k < kMaxSlots; ++k) {
+    for (int k = 0; k < NS; ++k) {
         const int idx = t + 16 * k;
         S.n[k] = 0.0; S.a[k] = 1.0; S.e[k] = 1.0; S.yp[k] = 1.0;     // empty slot: m = fb + g > 0, weight 0
-        if (k < nslots && idx < cnt_row) {
+        if (idx < cnt_row) {
             const int q = s_q[row * 128 + idx];
             S.n[k] = (double)s_n[row * 128 + idx];
             S.a[k] = lut->a[q];
@@ -214,7 +218,7 @@ __device__ void lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
 #pragma unroll
     for (int j = 0; j < 4; ++j) out.depth[j] = depth[j];
     out.depth_total = depth_total;
-    if (total_i == 0) return;                                   // src/BaseType.cpp:75
+    if (total_i == 0) return true;                              // src/BaseType.cpp:75
     const double inv_n = 1.0 / depth_total;
 
     // candidate list: bases of base_comb whose count frequency >= min_af (:77-83)
@@ -224,7 +228,7 @@ __device__ void lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
         const int b = (comb_list >> (4 * c)) & 3;
         if ((double)pick4(depth, b) / depth_total >= min_af) { blist |= (uint32_t)b << (4 * n); ++n; }
     }
-    if (n == 0) return;                                          // :84
+    if (n == 0) return true;                                     // :84
 
     int passes = 0, fits = 0;
     double base_frq[4] = {0, 0, 0, 0};
@@ -242,7 +246,7 @@ __device__ void lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
             f[j] = (depth_sum > 0 && ((setmask >> j) & 1u)) ? (double)depth[j] / (double)depth_sum : 0.0;
         const double freq_sum = ((f[0] + f[1]) + f[2]) + f[3];
         if (freq_sum == 0) return false;
-        loglik = em_fit(S, nslots, lane, pick4(f, row), inv_n, ex, passes);
+        loglik = em_fit<NS>(S, lane, pick4(f, row), inv_n, ex, passes);
         fits += 1;
         return true;
     };
@@ -293,7 +297,7 @@ __device__ void lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
             break;
         }
     }
-    if (status == 1 && full_level) { out.status = 1; out.n_passes = passes; out.n_fits = fits; return; }
+    if (status == 1 && full_level) { out.status = 1; out.n_passes = passes; out.n_fits = fits; return true; }
 
     out.status = status;
     out.n_passes = passes;
@@ -333,6 +337,7 @@ __device__ void lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
         out.var_qual = vq;
         out.called = 1;
     }
+    return true;
 }
 
 __device__ __forceinline__ void store_result(bvc_site_result *dst, const SiteOut &o)
@@ -346,6 +351,7 @@ __device__ __forceinline__ void store_result(bvc_site_result *dst, const SiteOut
     *dst = r;
 }
 
+template <int NS>
 __global__ __launch_bounds__(64) void lrt_kernel(int64_t n_sites, const uint32_t *__restrict__ counts,
                                                  int64_t hist_stride, const int8_t *__restrict__ ref_base,
                                                  double min_af, const QualLut *__restrict__ lut,
@@ -365,11 +371,12 @@ __global__ __launch_bounds__(64) void lrt_kernel(int64_t n_sites, const uint32_t
         for (int c = 0; c < nc; ++c) list |= (uint32_t)(comb[site * 4 + c] & 3) << (4 * c);
     }
     SiteOut o;
-    lrt_site(counts + site * hist_stride, ref_base[site], min_af, list, nc, lut, s_n, s_q, o);
+    if (!lrt_site<NS>(counts + site * hist_stride, ref_base[site], min_af, list, nc, lut, s_n, s_q, o)) return;
     if ((threadIdx.x & 63) == 0) store_result(results + site, o);
 }
 
 // Caller's --group loop (src/BaseVarC.cpp:617-661): one wavefront per (site, group).
+template <int NS>
 __global__ __launch_bounds__(64) void lrt_groups_kernel(int64_t n_sites, int n_groups,
                                                         const uint32_t *__restrict__ grp_counts,
                                                         const int8_t *__restrict__ ref_base, double min_af,
@@ -391,10 +398,9 @@ __global__ __launch_bounds__(64) void lrt_groups_kernel(int64_t n_sites, int n_g
     for (int i = 0; i < 3; ++i)
         if (i < ov.n_alt) { list |= (uint32_t)(ov.alt_base[i] & 3) << (4 * nc); ++nc; }
     SiteOut o;
-    // Always run the histogram load (depths are reported for every group, :640); the LRT itself only when
-    // the overall call succeeded and the group has covered samples (:633-636, :641).
-    const double eff_min_af = min_af;
-    lrt_site(hist, ref, eff_min_af, list, ov.called ? nc : 0, lut, s_n, s_q, o);
+    // The histogram is always loaded (depths are reported for every group, :640); the LRT itself runs only
+    // when the overall call succeeded and the group has covered samples (:633-636, :641).
+    if (!lrt_site<NS>(hist, ref, min_af, list, ov.called ? nc : 0, lut, s_n, s_q, o)) return;
     if ((threadIdx.x & 63) == 0) {
         bvc_group_result r;
         for (int j = 0; j < 4; ++j) r.depth[j] = o.depth[j];
@@ -433,7 +439,12 @@ hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *count
                       const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results)
 {
     if (n_sites <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lrt_kernel, dim3((unsigned)n_sites), dim3(64), 0, stream, n_sites, counts, hist_stride,
+    // Every variant visits every site; a wave leaves at once when the site belongs to another variant.
+    hipLaunchKernelGGL(lrt_kernel<2>, dim3((unsigned)n_sites), dim3(64), 0, stream, n_sites, counts, hist_stride,
+                       ref_base, min_af, lut, comb, n_comb, results);
+    hipLaunchKernelGGL(lrt_kernel<4>, dim3((unsigned)n_sites), dim3(64), 0, stream, n_sites, counts, hist_stride,
+                       ref_base, min_af, lut, comb, n_comb, results);
+    hipLaunchKernelGGL(lrt_kernel<8>, dim3((unsigned)n_sites), dim3(64), 0, stream, n_sites, counts, hist_stride,
                        ref_base, min_af, lut, comb, n_comb, results);
     return hipGetLastError();
 }
@@ -443,8 +454,13 @@ hipError_t launch_lrt_groups(hipStream_t stream, int64_t n_sites, int n_groups, 
                              const bvc_site_result *overall, bvc_group_result *grp_results)
 {
     if (n_sites <= 0 || n_groups <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lrt_groups_kernel, dim3((unsigned)(n_sites * n_groups)), dim3(64), 0, stream, n_sites,
-                       n_groups, grp_counts, ref_base, min_af, lut, overall, grp_results);
+    const dim3 grid((unsigned)(n_sites * n_groups));
+    hipLaunchKernelGGL(lrt_groups_kernel<2>, grid, dim3(64), 0, stream, n_sites, n_groups, grp_counts, ref_base,
+                       min_af, lut, overall, grp_results);
+    hipLaunchKernelGGL(lrt_groups_kernel<4>, grid, dim3(64), 0, stream, n_sites, n_groups, grp_counts, ref_base,
+                       min_af, lut, overall, grp_results);
+    hipLaunchKernelGGL(lrt_groups_kernel<8>, grid, dim3(64), 0, stream, n_sites, n_groups, grp_counts, ref_base,
+                       min_af, lut, overall, grp_results);
     return hipGetLastError();
 }
 

@@ -47,7 +47,7 @@ assert GROUP_DTYPE.itemsize == C.sizeof(GroupResult) == 48
 
 EXPORTS = [
     "bvc_version", "bvc_device_count", "bvc_create", "bvc_destroy", "bvc_last_error", "bvc_set_stream",
-    "bvc_synchronize", "bvc_set_profiling", "bvc_get_profile", "bvc_lrt_dense", "bvc_lrt_dense_groups",
+    "bvc_synchronize", "bvc_set_overlap", "bvc_join", "bvc_set_profiling", "bvc_get_profile", "bvc_lrt_dense", "bvc_lrt_dense_groups",
     "bvc_lrt_csr", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense",
 ]
 
@@ -79,6 +79,8 @@ def load_library():
     L.bvc_last_error.restype = C.c_char_p; L.bvc_last_error.argtypes = [vp]
     L.bvc_set_stream.restype = C.c_int; L.bvc_set_stream.argtypes = [vp, vp]
     L.bvc_synchronize.restype = C.c_int; L.bvc_synchronize.argtypes = [vp]
+    L.bvc_set_overlap.restype = C.c_int; L.bvc_set_overlap.argtypes = [vp, C.c_int]
+    L.bvc_join.restype = C.c_int; L.bvc_join.argtypes = [vp]
     L.bvc_set_profiling.restype = C.c_int; L.bvc_set_profiling.argtypes = [vp, C.c_int]
     L.bvc_get_profile.restype = C.c_int; L.bvc_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
     L.bvc_lrt_dense.restype = C.c_int
@@ -149,6 +151,13 @@ class Context:
 
     def synchronize(self):
         self._check(self._L.bvc_synchronize(self._h))
+
+    def set_overlap(self, on=True):
+        """Run stage 2 of each device-pointer call under stage 1 of the next; results need join()/synchronize()."""
+        self._check(self._L.bvc_set_overlap(self._h, int(bool(on))))
+
+    def join(self):
+        self._check(self._L.bvc_join(self._h))
 
     def set_profiling(self, on=True):
         self._check(self._L.bvc_set_profiling(self._h, int(bool(on))))

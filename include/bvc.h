@@ -95,6 +95,15 @@ const char *bvc_last_error(const bvc_ctx *ctx);
 /* Run on the caller's HIP stream (hipStream_t passed as void*; NULL = the device's default stream). */
 int  bvc_set_stream(bvc_ctx *ctx, void *hip_stream);
 int  bvc_synchronize(bvc_ctx *ctx);
+/*
+ * Overlap mode (off by default).  With it on, bvc_lrt_dense on device pointers runs its second stage
+ * (EM/LRT, FP64-bound) on an internal side stream, so that it executes underneath the first stage
+ * (histogram, HBM-bound) of the NEXT call.  Results of a call are then complete only after bvc_join
+ * (makes the context's stream wait for all side work) or bvc_synchronize; the caller must keep the
+ * ref_base and results buffers of a call alive and untouched until then.
+ */
+int  bvc_set_overlap(bvc_ctx *ctx, int on);
+int  bvc_join(bvc_ctx *ctx);
 /* HIP-event timing of each kernel (adds two event records per launch). */
 int  bvc_set_profiling(bvc_ctx *ctx, int on);
 int  bvc_get_profile(bvc_ctx *ctx, bvc_profile *out, int reset);

@@ -120,6 +120,20 @@ def test_lrt_matches_oracle_random_sites(ctx, nind):
         assert_site_matches(got[s], orc.basetype_lrt(b, q, r, m), where=f"nind={nind} site={s}")
 
 
+@pytest.mark.parametrize("qlo,qhi,nind", [(1, 127, 3000), (0, 127, 3000), (20, 90, 40000), (2, 60, 800), (30, 33, 5000)])
+def test_lrt_wide_quality_ranges(ctx, qlo, qhi, nind):
+    """More than 32 / 64 distinct quality values per base: the NS = 4 and NS = 8 kernel variants."""
+    rng = np.random.default_rng(qhi * 1000 + nind)
+    sites = [random_site(rng, nind, af=af, second_af=af2, qlo=qlo, qhi=qhi)
+             for af, af2 in ((0.0, 0.0), (0.01, 0.0), (0.1, 0.0), (0.3, 0.1), (0.0, 0.0), (0.05, 0.0))]
+    B, Q, R = pad_rows(sites)
+    m = caller_min_af(nind)
+    got = ctx.lrt_dense(B, Q, R, m)
+    for s, (b, q, r) in enumerate(sites):
+        assert_site_matches(got[s], orc.basetype_lrt(b, q, r, m), where=f"q{qlo}-{qhi} nind={nind} site={s}",
+                            path_strict=(qlo > 0))
+
+
 def test_lrt_edge_cases(ctx):
     cases = [
         ([], [], 0),                                             # depth_total == 0
@@ -297,6 +311,39 @@ def test_config2_1e4_sites_by_1e4_samples(ctx):
         assert_site_matches(res[s], exp_f[j], where=f"config2 faithful site {s}", path_strict=False)
     called = int(res["called"].sum())
     assert 0.05 * ns < called < 0.5 * ns          # ~20 % polymorphic sites in the mixture
+
+
+def test_overlap_mode_gives_identical_records(ctx):
+    """Stage 2 on the side stream under the next call's stage 1 (bvc_set_overlap): same bytes out."""
+    import torch
+    from basevarc_amd.lib import SITE_DTYPE
+    ns, n = 300, 50000
+    m = caller_min_af(n)
+    tiles = []
+    for t in range(5):
+        b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+        q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+        r = torch.empty(ns, dtype=torch.int8, device="cuda")
+        ctx.synth_dense_device(7, 1000 * t, b, q, r)
+        tiles.append((b, q, r))
+    ctx.synchronize()
+    plain = []
+    for b, q, r in tiles:
+        out = ctx.lrt_dense_device(b, q, r, m)
+        ctx.synchronize()
+        plain.append(out.cpu().numpy().copy())
+    try:
+        ctx.set_overlap(True)
+        outs = [torch.zeros(ns * SITE_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in tiles]
+        for rep in range(3):
+            for (b, q, r), o in zip(tiles, outs):
+                ctx.lrt_dense_device(b, q, r, m, o)
+        ctx.join()
+        torch.cuda.current_stream().synchronize()
+        for o, p in zip(outs, plain):
+            assert np.array_equal(o.cpu().numpy(), p)
+    finally:
+        ctx.set_overlap(False)
 
 
 def test_full_size_sites_1e6_samples(ctx):
