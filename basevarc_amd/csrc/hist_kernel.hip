@@ -71,6 +71,9 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_kernel(
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [class][copy]
     const int tid = threadIdx.x;
     const uint32_t lane_off = (uint32_t)(tid & (kCopies - 1));
+    // This kernel is HBM-bound and may share the chip with the FP64-bound EM kernel of the previous tile
+    // (overlap mode): its few instructions go first so the memory pipeline never waits on the VALU.
+    __builtin_amdgcn_s_setprio(3);
 
     for (int i = tid * 4; i < kLdsWords; i += kHistThreads * 4)
         *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
