@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 CSV output (kernel trace, --stats, --pmc passes) into profiles/.
+
+usage: tools/pmc_summary.py <round tag> <dir with rocprofv3 output dirs> [n_samples sites_per_launch]
+
+HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+reports exactly half the bytes of a wide (16 B/lane) coalesced streaming read, so the read side is doubled
+for the streaming histogram kernel; WRITE_SIZE is taken as is.  Counters come from separate --pmc passes.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    for k in ("hist_dense_groups_kernel", "hist_dense_kernel", "hist_csr_kernel", "lrt_groups_kernel", "lrt_kernel<2>",
+              "lrt_kernel<4>", "lrt_kernel<8>", "synth_dense_kernel", "sum_groups_kernel"):
+        if k in name:
+            return k
+    return name.split("(")[0][:60]
+
+
+def counters(d):
+    out = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"])
+            out[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            out[k]["_dur_ns"].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    return out
+
+
+def main():
+    tag, base = sys.argv[1], sys.argv[2]
+    n_samples = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
+    sites = int(sys.argv[4]) if len(sys.argv) > 4 else 4000
+    lines = [f"# rocprofv3 PMC summary ({tag})", "",
+             "Per-dispatch averages; each counter group from its own `rocprofv3 --pmc ... --kernel-trace` pass.", ""]
+    summary = {}
+    for sub in sorted(glob.glob(os.path.join(base, "pmc_*"))):
+        if not os.path.isdir(sub):
+            continue
+        c = counters(sub)
+        lines += [f"## pass {os.path.basename(sub)}", "", "| kernel | dispatches | avg ms | counter | avg value |", "|---|---|---|---|---|"]
+        for k in sorted(c):
+            dur = c[k].pop("_dur_ns")
+            # skip warm-up dispatch of each kernel
+            for name, vals in sorted(c[k].items()):
+                v = vals[1:] if len(vals) > 2 else vals
+                dd = dur[1:] if len(dur) > 2 else dur
+                lines.append(f"| {k} | {len(vals)} | {sum(dd) / len(dd) / 1e6:.4f} | {name} | {sum(v) / len(v):.6g} |")
+                summary.setdefault(k, {})[name] = sum(v) / len(v)
+                summary[k]["ms_under_pmc_" + name] = sum(dd) / len(dd) / 1e6
+        lines.append("")
+    h = summary.get("hist_dense_kernel", {})
+    if "FETCH_SIZE" in h:
+        fetch = h["FETCH_SIZE"] * 1024 * 2          # gfx950: FETCH_SIZE counts 64 B per 128-B request
+        write = h.get("WRITE_SIZE", 0.0) * 1024
+        alg = 2.0 * n_samples * sites
+        t = {"kernel": "hist_dense_kernel", "n_samples": n_samples, "sites_per_launch": sites,
+             "fetch_size_kib_raw": h["FETCH_SIZE"], "write_size_kib_raw": h.get("WRITE_SIZE"),
+             "hbm_read_bytes_per_launch": fetch, "hbm_write_bytes_per_launch": write,
+             "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": alg,
+             "traffic_over_algorithmic": (fetch + write) / alg,
+             "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of 16 B/lane streams), WRITE_SIZE KiB x 1024",
+             "source": f"profiles/{tag}_pmc_summary.md"}
+        json.dump(t, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+        lines += ["## HBM traffic of hist_dense_kernel per launch", "",
+                  f"- FETCH_SIZE raw {h['FETCH_SIZE']:.1f} KiB -> read bytes (x1024 x2) = {fetch:.4g}",
+                  f"- WRITE_SIZE raw {h.get('WRITE_SIZE', 0):.1f} KiB -> write bytes = {write:.4g}",
+                  f"- algorithmic bytes (2 B x {sites} sites x {n_samples} samples) = {alg:.4g}",
+                  f"- traffic / algorithmic = {(fetch + write) / alg:.4f}", ""]
+    open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.md"), "w").write("\n".join(lines))
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
