@@ -94,3 +94,14 @@ def test_oracle_reproduces_golden_fixtures():
                 assert r[k] == e[k], (name, i, k)
             np.testing.assert_array_equal(np.array(r["af"]), np.array(e["af"]))
             assert (r["var_qual"] == e["var_qual"]) or (np.isnan(r["var_qual"]) and np.isnan(e["var_qual"]))
+
+
+def test_cpp_facade_compiles_against_the_abi(built_lib, tmp_path):
+    """include/bvc_basetype.hpp (the reference's BaseType interface in C++) builds with plain g++ -std=c++11,
+    as the reference does (configure.ac:33), and links against libbvc.so."""
+    import subprocess
+    exe = tmp_path / "facade_demo"
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "facade_demo.cpp"), "-L", os.path.dirname(built_lib),
+                           "-lbvc", "-Wl,-rpath," + os.path.dirname(built_lib), "-o", str(exe)])
+    assert exe.exists()

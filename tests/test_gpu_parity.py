@@ -215,6 +215,38 @@ def test_basetype_facade_reads_like_the_reference(ctx):
         gr.LRT()
 
 
+def test_cpp_facade_caller(tmp_path):
+    """A bt_f-style C++ caller built on include/bvc_basetype.hpp, run as its own process (system HIP runtime)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "basevarc_amd")
+    exe = tmp_path / "facade_demo"
+    subprocess.check_call(["g++", "-std=c++11", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "facade_demo.cpp"), "-L", libdir, "-lbvc",
+                           "-Wl,-rpath," + libdir, "-o", str(exe)])
+    rng = np.random.default_rng(77)
+    sites = [random_site(rng, n, af=af) for n, af in ((40, 0.2), (400, 0.05), (3000, 0.0), (3000, 0.3), (1, 0.0))]
+    text = "".join(f"{len(b)} {r} 0.001 " + " ".join(f"{x} {y}" for x, y in zip(b, q)) + "\n" for b, q, r in sites)
+    out = subprocess.run([str(exe)], input=text, capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert len(out) == len(sites)
+    for line, (b, q, r) in zip(out, sites):
+        e = orc.basetype_lrt(b, q, r, 0.001)
+        main, _, grp = line.partition("|")
+        f = main.split()
+        assert int(f[0]) == e["called"] and int(f[1]) == e["n_alt"]
+        for i in range(e["n_alt"]):
+            assert int(f[2 + 2 * i]) == e["alt_base"][i]
+            assert float(f[3 + 2 * i]) == pytest.approx(e["af"][i], abs=AF_ATOL)
+        k = 2 + 2 * e["n_alt"]
+        assert float(f[k]) == pytest.approx(e["var_qual"], rel=QUAL_RTOL, abs=1e-6)
+        assert [int(x) for x in f[k + 1:k + 5]] == e["depth"]
+        if e["called"] and len(b) // 2 > 0:
+            h = len(b) // 2
+            g = orc.basetype_lrt(b[:h], q[:h], r, 0.001, base_comb=[r] + e["alt_base"])
+            want = [(f"{g['af'][g['alt_base'].index(a)]:.6f}" if a in g["alt_base"] else "0") for a in e["alt_base"]]
+            assert grp.split() == want
+
+
 def test_csr_matches_dense(ctx):
     rng = np.random.default_rng(21)
     sites = [random_site(rng, int(n), af=0.05) for n in rng.integers(0, 900, 40)]
