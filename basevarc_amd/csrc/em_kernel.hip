@@ -17,6 +17,8 @@
 //                                                             E   = sum_c       n_c e_c / m_c
 //   stop rule     delta = sum_c n_c |log m_c' - log m_c| < 1e-3
 // FP64 throughout; no MFMA (nothing here is a dense contraction).
+#include <cstdlib>
+
 #include "bvc_device.h"
 #include "bvc_internal.h"
 
@@ -25,6 +27,10 @@ namespace {
 
 constexpr double kLrtThreshold = 24.0;    // LRT_THRESHOLD, src/BaseType.h:9
 constexpr int kEmIters = 100;             // src/BaseType.cpp:46
+// var_qual is >= 0 or NaN; this marks records whose chi-square tail is still to be evaluated.  The libm-style
+// log/exp/log10 of that step live in their own small kernel so that their constants and registers stay out
+// of the EM kernel (hoisted into VGPRs across the site loop they cost it half its occupancy).
+constexpr double kVarQualPending = -1.0;
 constexpr double kEmEpsilon = 0.001;      // src/BaseType.cpp:45
 
 // Register-resident classes of one lane.  NS (slots per lane) is a template parameter: the kernel is
@@ -35,6 +41,7 @@ struct Slots {
     double n[NS];    // class count (0 for an empty slot)
     double a[NS];    // 1 - eps : likelihood when the allele matches the class's base
     double e[NS];    // eps / 3 : likelihood when it does not
+    double d[NS];    // a - e
     double yp[NS];   // 1 / (class marginal) from the previous pass
 };
 
@@ -83,32 +90,58 @@ struct PassOut {
 
 // One E+M pass (singleEM, src/Algorithm.cpp:69-93) plus the delta of delta_bylog (:103-113).
 //   M step: expect_j = f_j / N * (D_j + E),  D_j = sum_{c in j} n_c (a_c - e_c) / m_c,  E = sum_c n_c e_c / m_c
-//   delta : log m' - log m = log1p(m' / m - 1), with 1/m kept from the previous pass.
-// On the first pass of a fit S.yp is stale and the caller ignores the returned delta.
+//   u     : m' / m - 1 = m' * yp - 1  with yp = 1/m kept from the previous pass
+//   1/m'  : yp / (1 + u) -> yp * (1 - u) refined by two Newton steps (no v_rcp_f64 on the common paths)
+//   delta : sum_c n_c |log m_c' - log m_c| = sum_c n_c |log1p(u_c)|, used ONLY in the test delta < 1e-3.
+// Every non-empty class has n_c >= 1, so one class with |u| >= 2^-9 already gives delta > 1.9e-3: the test
+// fails whatever the other terms are and no logarithm is evaluated in that pass (about half of all passes:
+// the long sub-linear tails of alleles whose frequency drifts to zero).  Three wave-uniform tiers:
+//   near (all |u| < 2^-9): two Newton steps, delta from the cubic log1p series (truncation 3e-12 relative)
+//   far  (some |u| in [2^-9, 2^-6]): two Newton steps, delta reported as "not converged"
+//   jump (some |u| > 2^-6, first passes of a fit): v_rcp_f64 + two Newton steps, "not converged"
+// Empty slots have a = e = 1, so m = 1 and u = 0 to an ulp: they never raise the tier.
 // The NS slots are independent dependency chains with no branch between them, so they interleave.
+constexpr double kFarU = 0.001953125;                       // 2^-9
+constexpr double kNotConverged = 1.0;                       // any value >= kEmEpsilon
+
 template <int NS>
 __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double inv_n)
 {
     double acc_d = 0.0, acc_e = 0.0, acc_delta = 0.0;
-    double u[NS];
-    bool big = false;
+    double m[NS], u[NS];
+    double umax = 0.0;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-        const double m = fma(f.fb, S.a[k], f.g * S.e[k]);
-        const double y = fast_rcp(m);
-        const double r = S.n[k] * y;
-        acc_d = fma(r, S.a[k] - S.e[k], acc_d);
-        acc_e = fma(r, S.e[k], acc_e);
-        u[k] = fma(m, S.yp[k], -1.0);
-        big |= fabs(u[k]) > kLog1pMaxU;
-        S.yp[k] = y;
+        m[k] = fma(f.fb, S.a[k], f.g * S.e[k]);
+        u[k] = fma(m[k], S.yp[k], -1.0);
+        umax = fmax(umax, fabs(u[k]));                      // fmax drops a NaN: NaN lanes take the near tier
     }
-    if (__ballot(big) == 0) {                               // the common case, wave-uniform
+    const bool far = __ballot(umax >= kFarU) != 0;
+    if (!far) {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) acc_delta = fma(S.n[k], fabs(log1p_small(u[k])), acc_delta);
+        for (int k = 0; k < NS; ++k) {
+            double p = fma(-0.25, u[k], 1.0 / 3.0);
+            p = fma(p, u[k], -0.5);
+            p = fma(p, u[k], 1.0);
+            acc_delta = fma(S.n[k], fabs(u[k] * p), acc_delta);
+        }
+    }
+    if (__ballot(umax > kLog1pMaxU) == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            double y = fma(-S.yp[k], u[k], S.yp[k]);
+            y = fma(y, fma(-m[k], y, 1.0), y);
+            S.yp[k] = fma(y, fma(-m[k], y, 1.0), y);
+        }
     } else {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) acc_delta = fma(S.n[k], fabs(log_pos(1.0 + u[k])), acc_delta);
+        for (int k = 0; k < NS; ++k) S.yp[k] = fast_rcp(m[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const double r = S.n[k] * S.yp[k];
+        acc_d = fma(r, S.d[k], acc_d);
+        acc_e = fma(r, S.e[k], acc_e);
     }
     // E over lanes l, l+32 lands in the lower half, delta in the upper half; then rows, then row pairs
     const DPair h = swap32(acc_e, acc_delta);
@@ -118,7 +151,7 @@ __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double in
     z = w.a + w.b;
     const double etot = lane_value<0>(z);
     PassOut o;
-    o.delta = lane_value<32>(z);
+    o.delta = far ? kNotConverged : lane_value<32>(z);
     o.ex_own = f.fb * inv_n * (drow + etot);
     return o;
 }
@@ -132,6 +165,10 @@ __device__ __forceinline__ double em_fit(Slots<NS> &S, int lane, double f0, doub
 {
     Freq f{f0, 1.0 - f0};
     PassOut o;
+    // every fit starts from yp = 1 (not from the previous fit's, which may hold NaNs): its first pass then
+    // has |u| = |m - 1| and takes the big tier, whose reciprocal does not depend on yp
+#pragma unroll
+    for (int k = 0; k < NS; ++k) S.yp[k] = 1.0;
     for (int it = 0;; ++it) {                  // pass 0 + at most kEmIters update passes
         o = em_pass<NS>(S, f, inv_n);
         passes += 1;
@@ -209,6 +246,7 @@ __device__ bool lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
             S.a[k] = lut->a[q];
             S.e[k] = lut->e[q];
         }
+        S.d[k] = S.a[k] - S.e[k];
     }
 
     // ---- BaseType::LRT ---------------------------------------------------------------------------
@@ -330,9 +368,7 @@ __device__ bool lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
         } else if (chi <= 0) {
             vq = 0.0;
         } else {
-            const double p = kf_gammaq_dev(0.5, chi / 2.0);      // chisf(chi, 1), src/Algorithm.cpp:3-7
-            vq = (p != 0.0) ? -10 * log10(p) : 10000.0;          // NaN != 0 -> NaN, like `if (chi_prob)`
-            if (vq == 0) vq = 0.0;
+            vq = kVarQualPending;                                // chisf(chi, 1): finished by var_qual_kernel
         }
         out.var_qual = vq;
         out.called = 1;
@@ -361,18 +397,22 @@ __global__ __launch_bounds__(64) void lrt_kernel(int64_t n_sites, const uint32_t
 {
     __shared__ uint32_t s_n[512];
     __shared__ uint8_t s_q[512];
-    const int64_t site = blockIdx.x;
-    if (site >= n_sites) return;
-    uint32_t list = 0x3210u;                                     // default base_comb, src/BaseType.h:79
-    int nc = 4;
-    if (comb) {
-        nc = min((int)n_comb[site], 4);
-        list = 0;
-        for (int c = 0; c < nc; ++c) list |= (uint32_t)(comb[site * 4 + c] & 3) << (4 * c);
+    // A bounded number of waves walks the sites: the launcher sizes the grid so that this FP64-bound kernel
+    // holds only a few wave slots per SIMD and the HBM-bound histogram kernel of the next tile, which runs
+    // at the same time in overlap mode, keeps its occupancy.
+    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
+        uint32_t list = 0x3210u;                                 // default base_comb, src/BaseType.h:79
+        int nc = 4;
+        if (comb) {
+            nc = min((int)n_comb[site], 4);
+            list = 0;
+            for (int c = 0; c < nc; ++c) list |= (uint32_t)(comb[site * 4 + c] & 3) << (4 * c);
+        }
+        SiteOut o;
+        const bool mine = lrt_site<NS>(counts + site * hist_stride, ref_base[site], min_af, list, nc, lut, s_n, s_q, o);
+        if (mine && (threadIdx.x & 63) == 0) store_result(results + site, o);
+        __syncthreads();                                         // s_n / s_q are reused by the next site
     }
-    SiteOut o;
-    if (!lrt_site<NS>(counts + site * hist_stride, ref_base[site], min_af, list, nc, lut, s_n, s_q, o)) return;
-    if ((threadIdx.x & 63) == 0) store_result(results + site, o);
 }
 
 // Caller's --group loop (src/BaseVarC.cpp:617-661): one wavefront per (site, group).
@@ -386,38 +426,53 @@ __global__ __launch_bounds__(64) void lrt_groups_kernel(int64_t n_sites, int n_g
 {
     __shared__ uint32_t s_n[512];
     __shared__ uint8_t s_q[512];
-    const int64_t site = blockIdx.x / n_groups;
-    const int g = (int)(blockIdx.x % n_groups);
-    if (site >= n_sites) return;
-    const uint32_t *hist = grp_counts + (site * (n_groups + 1) + g) * BVC_NCLASS;
-    const bvc_site_result ov = overall[site];
-    const int ref = ref_base[site];
-    uint32_t list = (uint32_t)(ref & 3);                         // base_comb = {ref} + alt_bases (:614-615)
-    int nc = 1;
+    const int64_t n_work = n_sites * n_groups;
+    for (int64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const int64_t site = w / n_groups;
+        const int g = (int)(w % n_groups);
+        const uint32_t *hist = grp_counts + (site * (n_groups + 1) + g) * BVC_NCLASS;
+        const bvc_site_result ov = overall[site];
+        const int ref = ref_base[site];
+        uint32_t list = (uint32_t)(ref & 3);                     // base_comb = {ref} + alt_bases (:614-615)
+        int nc = 1;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-        if (i < ov.n_alt) { list |= (uint32_t)(ov.alt_base[i] & 3) << (4 * nc); ++nc; }
-    SiteOut o;
-    // The histogram is always loaded (depths are reported for every group, :640); the LRT itself runs only
-    // when the overall call succeeded and the group has covered samples (:633-636, :641).
-    if (!lrt_site<NS>(hist, ref, min_af, list, ov.called ? nc : 0, lut, s_n, s_q, o)) return;
-    if ((threadIdx.x & 63) == 0) {
-        bvc_group_result r;
-        for (int j = 0; j < 4; ++j) r.depth[j] = o.depth[j];
-        for (int j = 0; j < 7; ++j) r.pad[j] = 0;
-        r.ran = (ov.called && o.depth_total > 0) ? 1 : 0;
+        for (int i = 0; i < 3; ++i)
+            if (i < ov.n_alt) { list |= (uint32_t)(ov.alt_base[i] & 3) << (4 * nc); ++nc; }
+        SiteOut o;
+        // The histogram is always loaded (depths are reported for every group, :640); the LRT itself runs only
+        // when the overall call succeeded and the group has covered samples (:633-636, :641).
+        const bool mine = lrt_site<NS>(hist, ref, min_af, list, ov.called ? nc : 0, lut, s_n, s_q, o);
+        if (mine && (threadIdx.x & 63) == 0) {
+            bvc_group_result r;
+            for (int j = 0; j < 4; ++j) r.depth[j] = o.depth[j];
+            for (int j = 0; j < 7; ++j) r.pad[j] = 0;
+            r.ran = (ov.called && o.depth_total > 0) ? 1 : 0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            double af = 0.0;                                     // literal 0 when the group lacks the ALT (:650)
-            if (r.ran && i < ov.n_alt) {
+            for (int i = 0; i < 3; ++i) {
+                double af = 0.0;                                 // literal 0 when the group lacks the ALT (:650)
+                if (r.ran && i < ov.n_alt) {
 #pragma unroll
-                for (int tt = 0; tt < 3; ++tt)
-                    if (tt < o.n_alt && o.alt_base[tt] == ov.alt_base[i]) af = o.af[tt];
+                    for (int tt = 0; tt < 3; ++tt)
+                        if (tt < o.n_alt && o.alt_base[tt] == ov.alt_base[i]) af = o.af[tt];
+                }
+                r.af[i] = af;
             }
-            r.af[i] = af;
+            grp_results[site * n_groups + g] = r;
         }
-        grp_results[site * n_groups + g] = r;
+        __syncthreads();
     }
+}
+
+// var_qual = -10 log10(chisf(chi, 1)) for the records lrt_kernel left pending (src/BaseType.cpp:127-133).
+__global__ void var_qual_kernel(int64_t n_sites, bvc_site_result *__restrict__ results)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sites) return;
+    if (!results[s].called || results[s].var_qual != kVarQualPending) return;
+    const double p = kf_gammaq_dev(0.5, results[s].chi / 2.0);   // chisf(chi, 1), src/Algorithm.cpp:3-7
+    double vq = (p != 0.0) ? -10 * log10(p) : 10000.0;           // NaN != 0 -> NaN, like `if (chi_prob)`
+    if (vq == 0) vq = 0.0;
+    results[s].var_qual = vq;
 }
 
 __global__ void sum_groups_kernel(int64_t total, int n_hist, const uint32_t *__restrict__ grp_counts,
@@ -434,18 +489,37 @@ __global__ void sum_groups_kernel(int64_t total, int n_hist, const uint32_t *__r
 
 }  // namespace
 
+// Waves the EM kernels keep on the chip: 8 per CU (2 per SIMD) by default; BVC_EM_WAVES_PER_CU overrides.
+static int64_t em_grid_cap()
+{
+    static int64_t cap = 0;
+    if (cap == 0) {
+        int per_cu = 8;
+        if (const char *e = getenv("BVC_EM_WAVES_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) per_cu = v; }
+        int dev = 0, n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t p;
+            if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) n_cu = p.multiProcessorCount;
+        }
+        cap = (int64_t)per_cu * n_cu;
+    }
+    return cap;
+}
+
 hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *counts, int64_t hist_stride,
                       const int8_t *ref_base, double min_af, const QualLut *lut,
                       const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results)
 {
     if (n_sites <= 0) return hipSuccess;
-    // Every variant visits every site; a wave leaves at once when the site belongs to another variant.
-    hipLaunchKernelGGL(lrt_kernel<2>, dim3((unsigned)n_sites), dim3(64), 0, stream, n_sites, counts, hist_stride,
+    // Every variant visits every site; a wave skips a site at once when it belongs to another variant.
+    const dim3 grid((unsigned)(n_sites < em_grid_cap() ? n_sites : em_grid_cap()));
+    hipLaunchKernelGGL(lrt_kernel<2>, grid, dim3(64), 0, stream, n_sites, counts, hist_stride,
                        ref_base, min_af, lut, comb, n_comb, results);
-    hipLaunchKernelGGL(lrt_kernel<4>, dim3((unsigned)n_sites), dim3(64), 0, stream, n_sites, counts, hist_stride,
+    hipLaunchKernelGGL(lrt_kernel<4>, grid, dim3(64), 0, stream, n_sites, counts, hist_stride,
                        ref_base, min_af, lut, comb, n_comb, results);
-    hipLaunchKernelGGL(lrt_kernel<8>, dim3((unsigned)n_sites), dim3(64), 0, stream, n_sites, counts, hist_stride,
+    hipLaunchKernelGGL(lrt_kernel<8>, grid, dim3(64), 0, stream, n_sites, counts, hist_stride,
                        ref_base, min_af, lut, comb, n_comb, results);
+    hipLaunchKernelGGL(var_qual_kernel, dim3((unsigned)((n_sites + 255) / 256)), dim3(256), 0, stream, n_sites, results);
     return hipGetLastError();
 }
 
@@ -454,7 +528,8 @@ hipError_t launch_lrt_groups(hipStream_t stream, int64_t n_sites, int n_groups, 
                              const bvc_site_result *overall, bvc_group_result *grp_results)
 {
     if (n_sites <= 0 || n_groups <= 0) return hipSuccess;
-    const dim3 grid((unsigned)(n_sites * n_groups));
+    const int64_t n_work = n_sites * n_groups;
+    const dim3 grid((unsigned)(n_work < em_grid_cap() ? n_work : em_grid_cap()));
     hipLaunchKernelGGL(lrt_groups_kernel<2>, grid, dim3(64), 0, stream, n_sites, n_groups, grp_counts, ref_base,
                        min_af, lut, overall, grp_results);
     hipLaunchKernelGGL(lrt_groups_kernel<4>, grid, dim3(64), 0, stream, n_sites, n_groups, grp_counts, ref_base,
