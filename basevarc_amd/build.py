@@ -27,6 +27,7 @@ def build(force=False, verbose=False):
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wextra", "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+    cmd[1:1] = os.environ.get("BVC_EXTRA_FLAGS", "").split()      # experiments: -DBVC_HIST_UNROLL=8 ...
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

@@ -16,10 +16,16 @@
 namespace bvc {
 namespace {
 
-constexpr int kHistThreads = 512;
+#ifndef BVC_HIST_THREADS
+#define BVC_HIST_THREADS 512
+#endif
+#ifndef BVC_HIST_UNROLL
+#define BVC_HIST_UNROLL 2
+#endif
+constexpr int kHistThreads = BVC_HIST_THREADS;
 constexpr int kCopies = 32;                         // one copy per LDS bank
 constexpr int kLdsWords = BVC_NCLASS * kCopies;     // 16384 words = 64 KiB
-constexpr int kUnroll = 4;                          // 16-byte loads in flight per lane and array
+constexpr int kUnroll = BVC_HIST_UNROLL;            // 16-byte loads in flight per lane and array
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 

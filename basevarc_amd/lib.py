@@ -239,6 +239,22 @@ class Context:
                                           _dev_ptr(ref_t), float(min_af), _dev_ptr(results_t), BVC_PTR_DEVICE))
         return results_t
 
+    def lrt_dense_groups_device(self, bases_t, quals_t, ref_t, min_af, group_t, n_groups, results_t=None,
+                                grp_results_t=None):
+        """Group mode on device tensors; group_t: uint8 [n_samples].  Returns (results_t, grp_results_t)."""
+        import torch
+        ns, n = bases_t.shape
+        stride = bases_t.stride(0)
+        assert bases_t.stride(1) == 1 and quals_t.stride(1) == 1 and quals_t.stride(0) == stride
+        if results_t is None:
+            results_t = torch.empty(ns * SITE_DTYPE.itemsize, dtype=torch.uint8, device=bases_t.device)
+        if grp_results_t is None:
+            grp_results_t = torch.empty(ns * n_groups * GROUP_DTYPE.itemsize, dtype=torch.uint8, device=bases_t.device)
+        self._check(self._L.bvc_lrt_dense_groups(self._h, ns, n, stride, _dev_ptr(bases_t), _dev_ptr(quals_t),
+                                                 _dev_ptr(ref_t), float(min_af), _dev_ptr(group_t), int(n_groups),
+                                                 _dev_ptr(results_t), _dev_ptr(grp_results_t), BVC_PTR_DEVICE))
+        return results_t, grp_results_t
+
     def hist_dense_device(self, bases_t, quals_t, counts_t=None):
         import torch
         ns, n = bases_t.shape

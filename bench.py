@@ -38,6 +38,8 @@ def parse():
     p.add_argument("--cpu-sites", type=int, default=-1, help="sites for the CPU baseline (-1: one per core, 0: skip)")
     p.add_argument("--no-verify", action="store_true", help="skip the post-run spot check against the oracle")
     p.add_argument("--no-overlap", action="store_true", help="run the two kernels of a step back to back on one stream")
+    p.add_argument("--groups", type=int, default=0, help="population groups (BASELINE configs[4]: 5); 0 = overall call only")
+    p.add_argument("--coverage", type=float, default=1.0, help="fraction of samples covered per site (sparse variant)")
     return p.parse_args()
 
 
@@ -87,15 +89,27 @@ def main():
         b = torch.empty((a.tile_sites, stride), dtype=torch.int8, device=dev)
         q = torch.empty((a.tile_sites, stride), dtype=torch.int8, device=dev)
         r = torch.empty(a.tile_sites, dtype=torch.int8, device=dev)
-        ctx.synth_dense_device(a.seed, site_base + t * a.tile_sites, b[:, :n], q[:, :n], r)
+        ctx.synth_dense_device(a.seed, site_base + t * a.tile_sites, b[:, :n], q[:, :n], r,
+                               cov_thr16=int(round(a.coverage * 65536)))
         tiles.append((b[:, :n], q[:, :n], r))
     results = [torch.empty(a.tile_sites * SITE_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(n_tiles)]
     torch.cuda.synchronize()
     log("dataset resident; warm-up")
 
+    group_t = grp_results = None
+    if a.groups > 0:
+        from basevarc_amd.lib import GROUP_DTYPE
+        gnp = (np.arange(n) % a.groups).astype(np.uint8)         # group = sample % k
+        group_t = torch.from_numpy(gnp).to(dev)
+        grp_results = [torch.empty(a.tile_sites * a.groups * GROUP_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+                       for _ in range(n_tiles)]
+
     def step(i):
         b, q, r = tiles[i % n_tiles]
-        ctx.lrt_dense_device(b, q, r, min_af, results[i % n_tiles])
+        if a.groups > 0:
+            ctx.lrt_dense_groups_device(b, q, r, min_af, group_t, a.groups, results[i % n_tiles], grp_results[i % n_tiles])
+        else:
+            ctx.lrt_dense_device(b, q, r, min_af, results[i % n_tiles])
 
     def barrier():
         ctx.join()                          # every step's results are complete before the clock is read
@@ -137,7 +151,8 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": f"synthetic pileup {a.total_sites} sites x {n} samples per GPU (BASELINE configs[2]), "
-                        f"dense coverage, Q10-40, 20% polymorphic; step = tile of {a.tile_sites} sites",
+                        f"{'dense coverage' if a.coverage >= 1 else f'coverage {a.coverage:g}'}, Q10-40, 20% polymorphic"
+                        f"{f', {a.groups} population groups' if a.groups else ''}; step = tile of {a.tile_sites} sites",
             "n_samples": n, "sites_per_step": a.tile_sites, "resident_tiles": n_tiles,
             "resident_GB_per_gpu": round(n_tiles * tile_bytes / 1e9, 1), "min_af": min_af,
             "sharding": f"sites x{world}, no collective", "seed": a.seed, "overlap": not a.no_overlap,
@@ -156,6 +171,8 @@ def main():
         out["called_fraction"] = float(last["called"].mean())
     if rank == 0 and not a.no_verify:
         out["verified"] = spot_check(ctx, tiles, results, min_af, a, np)
+        if a.groups > 0:
+            out["verified_groups"] = spot_check_groups(ctx, tiles, results, grp_results, group_t, min_af, a, np)
     if rank == 0 and world == 1 and a.cpu_sites != 0:
         out["cpu_baseline"] = cpu_baseline(tiles[0], min_af, a, np)
     if rank == 0:
@@ -196,6 +213,25 @@ def spot_check(ctx, tiles, results, min_af, a, np):
               and [int(g["alt_base"][k]) for k in range(g["n_alt"])] == e["alt_base"]
               and all(abs(float(g["af"][k]) - e["af"][k]) <= 1e-6 for k in range(e["n_alt"]))
               and abs(float(g["var_qual"]) - e["var_qual"]) <= 1e-6 * max(1.0, abs(e["var_qual"])))
+        bad += not ok
+    return {"sites_checked": int(len(pick)), "mismatches": int(bad)}
+
+
+def spot_check_groups(ctx, tiles, results, grp_results, group_t, min_af, a, np):
+    """8 sites of the last processed tile against the oracle's restatement of the caller's --group loop."""
+    from basevarc_amd.lib import GROUP_DTYPE
+    from oracle import orc
+    i = (a.steps - 1) % len(tiles)
+    b, q, r = tiles[i]
+    g = group_t.cpu().numpy()
+    gres = grp_results[i].cpu().numpy().view(GROUP_DTYPE).reshape(a.tile_sites, a.groups)
+    bad = 0
+    pick = np.linspace(0, a.tile_sites - 1, 8).astype(int)
+    for s in pick:
+        _, gd, ga, ran = orc.dense_site_groups(b[s].cpu().numpy(), q[s].cpu().numpy(), int(r[s].item()), min_af, g,
+                                               a.groups, use_hist=True)
+        ok = (np.array_equal(gres[s]["depth"], gd) and np.array_equal(gres[s]["ran"], ran)
+              and np.allclose(gres[s]["af"], ga, rtol=0, atol=1e-6))
         bad += not ok
     return {"sites_checked": int(len(pick)), "mismatches": int(bad)}
 
