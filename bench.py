@@ -60,12 +60,18 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # One rank per GPU.  (Rehearsal on a 1-GPU box: BVC_BENCH_BACKEND=gloo lets ranks share device 0.)
+    backend = os.environ.get("BVC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)          # RCCL; used for barrier + max only
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # RCCL; used for barrier + max only
+        else:
+            dist.init_process_group(backend)
 
     from basevarc_amd import Context
     from basevarc_amd.lib import SITE_DTYPE, results_from_tensor
@@ -73,14 +79,14 @@ def main():
     n = a.samples
     stride = (n + 15) // 16 * 16
     min_af = min(0.001, 100.0 / n)                               # src/BaseVarC.cpp:541-543
-    ctx = Context(local_rank, stream=torch.cuda.current_stream())
+    ctx = Context(dev_index, stream=torch.cuda.current_stream())
     ctx.set_overlap(not a.no_overlap)       # EM/LRT of step i runs under the histogram pass of step i+1
 
     # ---- resident dataset: as many tiles of the 1e5-site workload as fit (all 25 on a 288 GB MI355X)
     want_tiles = max(1, (a.total_sites + a.tile_sites - 1) // a.tile_sites)
     free_b, _ = torch.cuda.mem_get_info(dev)
     tile_bytes = 2 * a.tile_sites * stride
-    fit = int((free_b - (6 << 30)) // tile_bytes)
+    fit = int((free_b // (world if backend != "nccl" else 1) - (6 << 30)) // tile_bytes)
     n_tiles = max(1, min(want_tiles, fit))
     site_base = rank * a.total_sites                             # each rank owns its own site range
     log(f"generating {n_tiles} tiles of {a.tile_sites} sites x {n} samples ({n_tiles * tile_bytes / 1e9:.1f} GB) on device")
@@ -132,7 +138,7 @@ def main():
     prof = ctx.profile(reset=True)
     ctx.set_profiling(False)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
