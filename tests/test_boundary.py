@@ -82,9 +82,11 @@ def test_product_never_imports_the_oracle():
 def test_oracle_reproduces_golden_fixtures():
     from oracle import orc
     from tests.golden.golden_io import load_golden
-    for name in ("basetype_random.npz", "basetype_edge.npz"):
+    for name in ("basetype_random.npz", "basetype_edge.npz", "testdata_pileup.npz"):
         g = load_golden(name)
         for i, e in enumerate(g["expected"]):
+            if name == "testdata_pileup.npz" and i % 23 and not e["called"]:
+                continue                                    # every called site + a 1/23 sample of the rest
             b = g["bases"][g["offsets"][i]:g["offsets"][i + 1]]
             q = g["quals"][g["offsets"][i]:g["offsets"][i + 1]]
             if len(b) > 6000:

@@ -302,6 +302,23 @@ def test_golden_fixtures(ctx):
                 assert_site_matches(got[j], g["expected"][i], where=f"{name}[{i}]")
 
 
+def test_reference_test_data_pileup(ctx):
+    """BASELINE configs[0] at the BaseType boundary: every covered position of the reference's own test data
+    (test/test.sh:3 -- 100 BAMs, chr17:41197700-41276155, -q 20; 66,614 sites, depth 0..28), pileup columns
+    extracted by tests/golden/make_testdata_pileup.py.  north_star: "identical ref/alt calls and AF/LRT within
+    1e-6 on the test/ data"."""
+    from tests.golden.golden_io import load_golden
+    g = load_golden("testdata_pileup.npz")
+    n = len(g["ref"])
+    assert n == 66614
+    got = ctx.lrt_csr(g["offsets"], g["bases"], g["quals"], g["ref"], float(g["min_af"][0]))
+    called = 0
+    for i in range(n):
+        assert_site_matches(got[i], g["expected"][i], where=f"test data site {i}")
+        called += g["expected"][i]["called"]
+    assert called == int(got["called"].sum()) == 76
+
+
 # ------------------------------------------------------------------ synthetic generator + configs
 def test_device_generator_is_bit_identical_to_cpu(ctx):
     import torch
