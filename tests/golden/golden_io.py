@@ -36,7 +36,8 @@ def save_golden(name, sites, min_afs, expected):
 
 
 def load_golden(name):
-    z = np.load(os.path.join(HERE, name))
+    with np.load(os.path.join(HERE, name)) as zf:
+        z = {k: zf[k] for k in zf.files}            # decompress each array once, not per access
     n = len(z["ref"])
     exp = []
     for i in range(n):
