@@ -445,15 +445,16 @@ __global__ __launch_bounds__(64) void lrt_groups_kernel(int64_t n_sites, int n_g
         if (mine && (threadIdx.x & 63) == 0) {
             bvc_group_result r;
             for (int j = 0; j < 4; ++j) r.depth[j] = o.depth[j];
-            for (int j = 0; j < 7; ++j) r.pad[j] = 0;
+            for (int j = 0; j < 6; ++j) r.pad[j] = 0;
             r.ran = (ov.called && o.depth_total > 0) ? 1 : 0;
+            r.present = 0;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 double af = 0.0;                                 // literal 0 when the group lacks the ALT (:650)
                 if (r.ran && i < ov.n_alt) {
 #pragma unroll
                     for (int tt = 0; tt < 3; ++tt)
-                        if (tt < o.n_alt && o.alt_base[tt] == ov.alt_base[i]) af = o.af[tt];
+                        if (tt < o.n_alt && o.alt_base[tt] == ov.alt_base[i]) { af = o.af[tt]; r.present |= (uint8_t)(1u << i); }
                 }
                 r.af[i] = af;
             }

@@ -1,0 +1,283 @@
+#include "pileup.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "stats.h"
+
+namespace bvchost {
+
+static const char kBase2Char[6] = {'A', 'C', 'G', 'T', 'N', 'N'};   // src/BaseType.h:24 has four entries; see vcf_line
+static const char kStrand[2] = {'-', '+'};                          // src/BaseType.h:23
+static const double kMln10To10 = -0.23025850929940458;              // src/BaseType.h:10
+static const double kQualThreshold = 60;                            // src/BaseType.h:12
+
+std::string fmt_fixed(double v, int prec)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%.*f", prec, v);
+    return buf;
+}
+
+// ---- temp-batch pileup text ------------------------------------------------------------------------
+void format_pileup_token(const AlleleInfo *a, std::string &out)   // src/BaseVarC.cpp:513-520
+{
+    if (!a) { out += ". "; return; }
+    if (a->is_indel == 1) { out += a->indel; out += ' '; return; }
+    char buf[48];
+    std::snprintf(buf, sizeof buf, "%u,%u,%u,%u,%u ", (unsigned)a->base, (unsigned)a->mapq, (unsigned)a->qual,
+                  (unsigned)a->rpr, (unsigned)a->strand);
+    out += buf;
+}
+
+static inline int atoi_span(const char *&p, const char *end)   // atoi on a field: optional sign, digits
+{
+    int sign = 1, v = 0;
+    if (p < end && (*p == '-' || *p == '+')) { if (*p == '-') sign = -1; ++p; }
+    while (p < end && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); ++p; }
+    return sign * v;
+}
+
+// The reference keeps ONE AlleleInfo alive across tokens, lines and positions (src/BaseVarC.cpp:392, 407-440)
+// and an indel token only sets is_indel/indel, so an indel entry carries the base/mapq/qual/rpr/strand of
+// the last base token the thread parsed.  Those stale fields reach the strand counts of the CVG line and
+// the per-sample column of the VCF line, so the carry is part of the observable behaviour and is kept
+// (starting from zeros, where the reference starts from an uninitialised object).
+static thread_local AlleleInfo g_carry;
+
+void reset_parser_carry() { g_carry = AlleleInfo(); g_carry.base = 0; }
+
+int parse_pileup_line(const char *line, size_t len, int32_t j0, SiteColumn &site)
+{
+    const char *p = line, *end = line + len;
+    int32_t j = j0;
+    AlleleInfo &ai = g_carry;
+    while (p < end) {
+        while (p < end && *p == ' ') ++p;                       // strtok_r skips runs of delimiters
+        if (p >= end || *p == '\n') break;
+        const char *tok = p;
+        while (p < end && *p != ' ' && *p != '\n') ++p;
+        const char c = tok[0];
+        if (c != '+' && c != '-' && c != 'N' && c != '.') {
+            const char *q = tok;
+            ai.is_indel = 0;
+            int field[5] = {ai.base, ai.mapq, ai.qual, ai.rpr, ai.strand};
+            for (int i = 0; i < 5 && q < p; ++i) {              // missing fields keep the previous value
+                field[i] = atoi_span(q, p);
+                while (q < p && *q != ',') ++q;                 // atoi stops at the first non-digit
+                if (q < p) ++q;
+            }
+            ai.base = (uint8_t)(field[0] & 7);                  // bit-field widths, src/BamProcess.h:32-37
+            ai.mapq = (uint8_t)field[1];
+            ai.qual = (uint8_t)field[2];
+            ai.rpr = (uint8_t)field[3];
+            ai.strand = (uint8_t)(field[4] & 1);
+            if (ai.base != 4) {                                 // skip N base, :427
+                site.aiv.push_back(ai);
+                site.aiv.back().indel.clear();
+                site.sample.push_back(j);
+            }
+        } else if (c != '.') {
+            ai.is_indel = 1;
+            ai.indel.assign(tok, p - tok);
+            site.aiv.push_back(ai);
+            site.sample.push_back(j);
+        }
+        ++j;
+    }
+    return j - j0;
+}
+
+// ---- headers ---------------------------------------------------------------------------------------
+const char *const kCvgHeader =
+    "##fileformat=CVGv1.0\n"
+    "##Group information is the depth of A:C:G:T:Indel\n"
+    "#CHROM\tPOS\tREF\tDepth\tA\tC\tG\tT\tIndels\tFS\tSOR\tStrand_Coverage(REF_FWD,REF_REV,ALT_FWD,ALT_REV)";
+
+const char *const kVcfHeader =
+    "##fileformat=VCFv4.2\n"
+    "##FILTER=<ID=LowQual,Description=\"Low quality (QUAL < 60)\">\n"
+    "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
+    "##FORMAT=<ID=AB,Number=1,Type=String,Description=\"Allele Base\">\n"
+    "##FORMAT=<ID=SO,Number=1,Type=String,Description=\"Strand orientation of the mapping base. Marked as + or -\">\n"
+    "##FORMAT=<ID=BP,Number=1,Type=String,Description=\"Base Probability which calculate by base quality\">\n"
+    "##INFO=<ID=CM_AF,Number=A,Type=Float,Description=\"An ordered, comma delimited list of allele frequencies base on LRT algorithm\">\n"
+    "##INFO=<ID=CM_CAF,Number=A,Type=Float,Description=\"An ordered, comma delimited list of allele frequencies just base on read count\">\n"
+    "##INFO=<ID=CM_AC,Number=A,Type=Integer,Description=\"An ordered, comma delimited allele depth in CMDB\">\n"
+    "##INFO=<ID=CM_DP,Number=A,Type=Integer,Description=\"Total Depth\">\n"
+    "##INFO=<ID=SB_REF,Number=A,Type=Integer,Description=\"Read number support REF: Forward,Reverse\">\n"
+    "##INFO=<ID=SB_ALT,Number=A,Type=Integer,Description=\"Read number support ALT: Forward,Reverse\">\n"
+    "##INFO=<ID=FS,Number=1,Type=Float,Description=\"Phred-scaled p-value using Fisher's exact test to detect strand bias\">\n"
+    "##INFO=<ID=BaseQRankSum,Number=1,Type=Float,Description=\"Phred-score from Wilcoxon rank sum test of Alt Vs. Ref base qualities\">\n"
+    "##INFO=<ID=SOR,Number=1,Type=Float,Description=\"Symmetric Odds Ratio of 2x2 contingency table to detect strand bias\">\n"
+    "##INFO=<ID=MQRankSum,Number=1,Type=Float,Description=\"Phred-score From Wilcoxon rank sum test of Alt vs. Ref read mapping qualities\">\n"
+    "##INFO=<ID=ReadPosRankSum,Number=1,Type=Float,Description=\"Phred-score from Wilcoxon rank sum test of Alt vs. Ref read position bias\">\n"
+    "##INFO=<ID=QD,Number=1,Type=Float,Description=\"Variant Confidence Quality by Depth\">\n";
+
+std::string cvg_header(const Groups &g)                                   // src/BaseVarC.cpp:318, 366, 381
+{
+    std::string h = kCvgHeader;
+    for (auto const &n : g.names) h += "\t" + n;
+    h += "\n";
+    return h;
+}
+
+std::string vcf_header(const Groups &g, const std::string &reference, const std::vector<std::string> &sample_names)
+{
+    std::string h = kVcfHeader;                                            // src/BaseVarC.cpp:319, 364-380
+    for (auto const &n : g.names)
+        h += "##INFO=<ID=" + n + "_AF,Number=A,Type=Float,Description=\"Allele frequency in the " + n +
+             " populations calculated based on LRT.[0,1]\">\n";
+    if (FILE *f = std::fopen((reference + ".fai").c_str(), "r")) {
+        char contig[512], len[64], t1[64], t2[64], t3[64];
+        while (std::fscanf(f, "%511s %63s %63s %63s %63s", contig, len, t1, t2, t3) == 5)
+            h += std::string("##contig=<ID=") + contig + ",length=" + len + ">\n";
+        std::fclose(f);
+    }
+    h += "##reference=file://" + reference + "\n";
+    h += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t";
+    for (size_t i = 0; i < sample_names.size(); ++i) { if (i) h += "\t"; h += sample_names[i]; }
+    h += "\n";
+    return h;
+}
+
+// ---- CVG line: bt_f, src/BaseVarC.cpp:548-610 + group columns :617-663 ------------------------------------
+std::string cvg_line(const std::string &chr, int32_t pos, int8_t ref_base, const SiteColumn &site,
+                     const bvc_group_result *grp, int n_groups)
+{
+    int cnt[4] = {0, 0, 0, 0};
+    std::map<std::string, int> indel_m;    // the reference iterates a hash map here (:570-573): order by key instead
+    for (auto const &a : site.aiv) {
+        if (a.is_indel == 0) { if (a.base < 4) cnt[a.base] += 1; }
+        else indel_m[a.indel] += 1;
+    }
+    std::string indels = ".";
+    if (!indel_m.empty()) {
+        indels.clear();
+        for (auto const &kv : indel_m) indels += kv.first + "|" + std::to_string(kv.second) + ",";
+        indels.pop_back();
+    }
+    // sortidx: indices by descending count; std::sort on four elements is an insertion sort, ties keep order
+    int didx[4] = {0, 1, 2, 3};
+    std::stable_sort(didx, didx + 4, [&cnt](int a, int b) { return cnt[a] > cnt[b]; });
+    int alt_base = (didx[0] != ref_base) ? didx[0] : didx[1];
+    int ref_fwd = 0, ref_rev = 0, alt_fwd = 0, alt_rev = 0;
+    for (auto const &a : site.aiv) {                              // indel entries take part with carried fields
+        if (a.strand == 1) {
+            if (a.base == ref_base) ref_fwd += 1;
+            else if (a.base == alt_base) alt_fwd += 1;
+        } else {
+            if (a.base == ref_base) ref_rev += 1;
+            else if (a.base == alt_base) alt_rev += 1;
+        }
+    }
+    const double fs = bt_fisher_exact(ref_fwd, ref_rev, alt_fwd, alt_rev);
+    const double sor = (alt_fwd * ref_rev > 0) ? (double)(ref_fwd * alt_rev) / (ref_rev * alt_fwd) : 10000.0;
+    const int dep = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    char buf[256];
+    std::string out = chr + "\t" + std::to_string(pos) + "\t" + kBase2Char[ref_base & 3] + "\t";
+    std::snprintf(buf, sizeof buf, "%d\t%d\t%d\t%d\t%d\t", dep, cnt[0], cnt[1], cnt[2], cnt[3]);
+    out += buf;
+    out += indels + "\t" + fmt_fixed(fs, 3) + "\t" + fmt_fixed(sor, 3) + "\t";
+    std::snprintf(buf, sizeof buf, "%d,%d,%d,%d\t", ref_fwd, ref_rev, alt_fwd, alt_rev);
+    out += buf;
+    for (int g = 0; g < n_groups; ++g) {
+        std::snprintf(buf, sizeof buf, "%d:%d:%d:%d\t", grp[g].depth[0], grp[g].depth[1], grp[g].depth[2], grp[g].depth[3]);
+        out += buf;
+    }
+    out.pop_back();
+    out += "\n";
+    return out;
+}
+
+void group_af_info(const bvc_site_result &bt, const bvc_group_result *grp, const Groups &g,
+                   std::map<std::string, std::string> &info)          // src/BaseVarC.cpp:641-659
+{
+    for (size_t k = 0; k < g.names.size(); ++k) {
+        std::string af;
+        if (grp[k].ran) {
+            for (int i = 0; i < bt.n_alt; ++i) {
+                if (grp[k].present & (1u << i)) af += fmt_fixed(grp[k].af[i], 6) + ",";
+                else af += "0,";
+            }
+            if (!af.empty()) af.pop_back();
+        } else {
+            af = "0";
+        }
+        info.insert({g.names[k] + "_AF", af});
+    }
+}
+
+// ---- VCF line: WriteVcf, src/BaseType.cpp:141-234 ---------------------------------------------------------
+std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int32_t pos, int8_t ref_base,
+                     const SiteColumn &site, std::map<std::string, std::string> &info, int32_t n_samples)
+{
+    std::string alt_gt[8];                                        // genotype string per base code 0..7
+    bool has_gt[8] = {false, false, false, false, false, false, false, false};
+    auto is_alt = [&bt](int b) { for (int i = 0; i < bt.n_alt; ++i) if (bt.alt_base[i] == b) return true; return false; };
+    for (int i = 0; i < bt.n_alt; ++i) { alt_gt[bt.alt_base[i] & 7] = "./" + std::to_string(i + 1); has_gt[bt.alt_base[i] & 7] = true; }
+    int ref_fwd = 0, ref_rev = 0, alt_fwd = 0, alt_rev = 0;
+    std::vector<double> ref_quals, ref_mapqs, ref_rprs, alt_quals, alt_mapqs, alt_rprs;
+    std::string samgt;
+    size_t k = 0;
+    char buf[96];
+    for (int32_t i = 0; i < n_samples; ++i) {
+        if (k >= site.sample.size() || site.sample[k] != i) { samgt += "./.\t"; continue; }
+        const AlleleInfo &a = site.aiv[k++];
+        if (!has_gt[a.base]) { alt_gt[a.base] = "./."; has_gt[a.base] = true; }
+        const std::string &gt = (a.base == ref_base) ? std::string("0/.") : alt_gt[a.base];
+        // BASE2CHAR has four entries in the reference (src/BaseType.h:24); an indel entry carrying an N base
+        // would index past it there -- 'N' is printed here.
+        std::snprintf(buf, sizeof buf, ":%c:%c:%.6f\t", kBase2Char[a.base < 6 ? a.base : 5], kStrand[a.strand & 1],
+                      1 - std::exp(kMln10To10 * a.qual));
+        samgt += gt;
+        samgt += buf;
+        if (a.is_indel == 1 || a.base == 4) continue;
+        const bool alt = is_alt(a.base);
+        if (a.base == ref_base) { ref_quals.push_back(a.qual); ref_mapqs.push_back(a.mapq); ref_rprs.push_back(a.rpr); }
+        else if (alt) { alt_quals.push_back(a.qual); alt_mapqs.push_back(a.mapq); alt_rprs.push_back(a.rpr); }
+        if (a.strand == 1) { if (a.base == ref_base) ref_fwd += 1; else if (alt) alt_fwd += 1; }
+        else { if (a.base == ref_base) ref_rev += 1; else if (alt) alt_rev += 1; }
+    }
+    const double phred_mapq = RankSumTest(ref_mapqs, alt_mapqs);
+    const double phred_qual = RankSumTest(ref_quals, alt_quals);
+    const double phred_rpr = RankSumTest(ref_rprs, alt_rprs);
+    const double fs = bt_fisher_exact(ref_fwd, ref_rev, alt_fwd, alt_rev);
+    const double sor = (alt_fwd * ref_rev > 0) ? (double)(ref_fwd * alt_rev) / (ref_rev * alt_fwd) : 10000.0;
+    double ad_sum = 0;
+    std::string ac, af, caf, alt;
+    for (int i = 0; i < bt.n_alt; ++i) {
+        const int b = bt.alt_base[i];
+        ad_sum += bt.depth[b];
+        alt += kBase2Char[b & 3]; alt += ",";
+        ac += std::to_string(bt.depth[b]) + ",";
+        af += fmt_fixed(bt.af[i], 6) + ",";
+        caf += fmt_fixed(bt.depth[b] / bt.depth_total, 6) + ",";
+    }
+    alt.pop_back();
+    if (!samgt.empty()) samgt.pop_back();
+    ac.pop_back(); info.insert({"CM_AC", ac});
+    af.pop_back(); info.insert({"CM_AF", af});
+    caf.pop_back(); info.insert({"CM_CAF", caf});
+    info.insert({"QD", fmt_fixed(bt.var_qual / ad_sum, 3)});
+    info.insert({"CM_DP", fmt_fixed(bt.depth_total, 0)});
+    info.insert({"MQRankSum", fmt_fixed(phred_mapq, 3)});
+    info.insert({"ReadPosRankSum", fmt_fixed(phred_rpr, 3)});
+    info.insert({"BaseQRankSum", fmt_fixed(phred_qual, 3)});
+    info.insert({"FS", fmt_fixed(fs, 3)});
+    info.insert({"SOR", fmt_fixed(sor, 3)});
+    info.insert({"SB_REF", std::to_string(ref_fwd) + "," + std::to_string(ref_rev)});
+    info.insert({"SB_ALT", std::to_string(alt_fwd) + "," + std::to_string(alt_rev)});
+    const char *qt = (bt.var_qual > kQualThreshold) ? "." : "LowQual";
+    std::string out = chr + "\t" + std::to_string(pos) + "\t.\t" + kBase2Char[ref_base & 3] + "\t" + alt + "\t" +
+                      fmt_fixed(bt.var_qual, 2) + "\t" + qt + "\t";
+    for (auto const &kv : info) out += kv.first + "=" + kv.second + ";";
+    out.pop_back();
+    out += "\tGT:AB:SO:BP\t" + samgt + "\n";
+    return out;
+}
+
+}  // namespace bvchost

@@ -1,0 +1,75 @@
+// pileup.h -- host-side data structures and text formats either side of the basetype hot path.
+//
+// Counterparts in the reference (paths under /root/reference):
+//   AlleleInfo                      src/BamProcess.h:30-39
+//   temp-batch pileup text writer   bt_r, src/BaseVarC.cpp:509-527
+//   temp-batch pileup text parser   bt_s, src/BaseVarC.cpp:403-441
+//   CVG line                        bt_f, src/BaseVarC.cpp:548-610, 617-663
+//   VCF line                        WriteVcf, src/BaseType.cpp:141-234
+//   headers                         src/BaseVarC.cpp:65-88, 364-382
+#ifndef BVC_HOST_PILEUP_H
+#define BVC_HOST_PILEUP_H
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/bvc.h"
+
+namespace bvchost {
+
+struct AlleleInfo {                 // src/BamProcess.h:30-39
+    uint8_t base = 4;               // 0 A, 1 C, 2 G, 3 T, 4 N, 5 indel marker
+    uint8_t mapq = 0;
+    uint8_t qual = 0;
+    uint8_t rpr = 0;
+    uint8_t strand = 0;             // 0 '-', 1 '+'
+    uint8_t is_indel = 0;
+    std::string indel;
+};
+
+// One position: the entries of the samples that have data, in sample order (aiv), and which sample each
+// entry belongs to (the inverse of the reference's `idx` map, src/BaseVarC.cpp:428-429).
+struct SiteColumn {
+    int32_t pos = 0;
+    std::vector<AlleleInfo> aiv;
+    std::vector<int32_t> sample;
+    void clear() { aiv.clear(); sample.clear(); }
+};
+
+// Population groups: name-sorted (std::map order in the reference, src/BaseVarC.cpp:98, 358-362).
+struct Groups {
+    std::vector<std::string> names;
+    std::vector<uint8_t> of_sample;     // group index per sample, 255 = in no group
+    bool empty() const { return names.empty(); }
+};
+
+// ---- temp-batch pileup text (f1) -----------------------------------------------------------------------
+// One line per position; per sample one space-terminated token: "." | "base,mapq,qual,rpr,strand" | indel.
+void format_pileup_token(const AlleleInfo *a, std::string &out);           // a == nullptr -> ". "
+// Parses the tokens of one batch's line; sample indices start at j0.  Returns the number of tokens seen
+// (= samples in that batch).  N bases are dropped, indel tokens kept (src/BaseVarC.cpp:427-436).
+int parse_pileup_line(const char *line, size_t len, int32_t j0, SiteColumn &site);
+
+// ---- emission (f2) -------------------------------------------------------------------------------------
+extern const char *const kCvgHeader;
+extern const char *const kVcfHeader;
+std::string cvg_header(const Groups &g);
+std::string vcf_header(const Groups &g, const std::string &reference, const std::vector<std::string> &sample_names);
+
+struct CvgCounts { int na, nc, ng, nt; };
+// CVG line without the trailing newline handling of groups: pass grp (n_groups records) or nullptr.
+std::string cvg_line(const std::string &chr, int32_t pos, int8_t ref_base, const SiteColumn &site,
+                     const bvc_group_result *grp, int n_groups);
+// VCF line for a called site.  info carries the "<group>_AF" entries; the rest is filled here.
+std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int32_t pos, int8_t ref_base,
+                     const SiteColumn &site, std::map<std::string, std::string> &info, int32_t n_samples);
+// "<group>_AF" values from the group records (src/BaseVarC.cpp:646-658).
+void group_af_info(const bvc_site_result &bt, const bvc_group_result *grp, const Groups &g,
+                   std::map<std::string, std::string> &info);
+
+std::string fmt_fixed(double v, int prec);          // fmt's {:.Nf}
+
+}  // namespace bvchost
+#endif

@@ -28,7 +28,8 @@ class SiteResult(C.Structure):          # bvc_site_result, 120 bytes
 
 
 class GroupResult(C.Structure):         # bvc_group_result, 48 bytes
-    _fields_ = [("af", C.c_double * 3), ("depth", C.c_int32 * 4), ("ran", C.c_uint8), ("pad", C.c_uint8 * 7)]
+    _fields_ = [("af", C.c_double * 3), ("depth", C.c_int32 * 4), ("ran", C.c_uint8), ("present", C.c_uint8),
+                ("pad", C.c_uint8 * 6)]
 
 
 class Profile(C.Structure):
@@ -41,7 +42,7 @@ SITE_DTYPE = np.dtype([
     ("base_frq", "<f8", (4,)), ("depth", "<i4", (4,)), ("n_passes", "<i4"), ("alt_base", "i1", (3,)),
     ("n_alt", "u1"), ("called", "u1"), ("n_kept", "u1"), ("kept", "i1", (4,)), ("status", "u1"), ("n_fits", "u1"),
 ])
-GROUP_DTYPE = np.dtype([("af", "<f8", (3,)), ("depth", "<i4", (4,)), ("ran", "u1"), ("pad", "u1", (7,))])
+GROUP_DTYPE = np.dtype([("af", "<f8", (3,)), ("depth", "<i4", (4,)), ("ran", "u1"), ("present", "u1"), ("pad", "u1", (6,))])
 assert SITE_DTYPE.itemsize == C.sizeof(SiteResult) == 120
 assert GROUP_DTYPE.itemsize == C.sizeof(GroupResult) == 48
 

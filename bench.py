@@ -234,8 +234,8 @@ def spot_check_groups(ctx, tiles, results, grp_results, group_t, min_af, a, np):
     bad = 0
     pick = np.linspace(0, a.tile_sites - 1, 8).astype(int)
     for s in pick:
-        _, gd, ga, ran = orc.dense_site_groups(b[s].cpu().numpy(), q[s].cpu().numpy(), int(r[s].item()), min_af, g,
-                                               a.groups, use_hist=True)
+        _, gd, ga, ran, _ = orc.dense_site_groups(b[s].cpu().numpy(), q[s].cpu().numpy(), int(r[s].item()), min_af, g,
+                                                  a.groups, use_hist=True)
         ok = (np.array_equal(gres[s]["depth"], gd) and np.array_equal(gres[s]["ran"], ran)
               and np.allclose(gres[s]["af"], ga, rtol=0, atol=1e-6))
         bad += not ok

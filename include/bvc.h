@@ -74,7 +74,9 @@ typedef struct bvc_group_result {
     double  af[3];          /* <group>_AF for overall alt i: gr_bt.af_lrt[alt] or 0 when absent (:646-652) */
     int32_t depth[4];       /* na:nc:ng:nt of the group's covered samples (:640) */
     uint8_t ran;            /* 1 when the group's BaseType was built and LRT() run (:641-644) */
-    uint8_t pad[7];
+    uint8_t present;        /* bit i set: overall alt i is among the group's alt_bases (af_lrt.count(b), :647);
+                               a clear bit is the literal "0" of :650, not an estimated frequency of zero */
+    uint8_t pad[6];
 } bvc_group_result;
 
 typedef struct bvc_profile {

@@ -431,7 +431,7 @@ int orc_dense_site_groups(int64_t n_samples, const int8_t *bases_row, const int8
                           int8_t ref_base, double min_af,
                           const uint8_t *group_of_sample, int32_t n_groups, int use_hist,
                           orc_result *overall, int32_t *grp_depth, double *grp_af,
-                          int32_t *grp_ran)
+                          int32_t *grp_ran, int32_t *grp_present)
 {
     int8_t comb[4];
     int32_t n_comb, g;
@@ -453,6 +453,7 @@ int orc_dense_site_groups(int64_t n_samples, const int8_t *bases_row, const int8
         }
         for (i = 0; i < 3; ++i) grp_af[g * 3 + i] = 0.0;
         grp_ran[g] = 0;
+        grp_present[g] = 0;
         if (ok && depth > 0) {                             /* :633-636, :641 */
             orc_result gr;
             dense_site_subset(n_samples, bases_row, quals_row, group_of_sample, g, ref_base,
@@ -460,7 +461,10 @@ int orc_dense_site_groups(int64_t n_samples, const int8_t *bases_row, const int8
             grp_ran[g] = 1;
             for (i = 0; i < overall->n_alt && i < 3; ++i)  /* :646-652 */
                 for (t = 0; t < gr.n_alt; ++t)
-                    if (gr.alt_base[t] == overall->alt_base[i]) grp_af[g * 3 + i] = gr.af[t];
+                    if (gr.alt_base[t] == overall->alt_base[i]) {     /* gr_bt.af_lrt.count(b), :647 */
+                        grp_af[g * 3 + i] = gr.af[t];
+                        grp_present[g] |= 1 << i;
+                    }
         }
     }
     return ok;

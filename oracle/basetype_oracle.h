@@ -73,12 +73,13 @@ int orc_dense_batch(int64_t n_sites, int64_t n_samples, int64_t row_stride,
                     double min_af, int use_hist, int threads, orc_result *out);
 
 /* Caller's --group loop (src/BaseVarC.cpp:617-661) for one site.
- * grp_depth[g*4+b], grp_af[g*3+i] (af of overall alt i, 0 when absent), grp_has_af[g]. */
+ * grp_depth[g*4+b], grp_af[g*3+i] (af of overall alt i, 0 when absent), grp_ran[g],
+ * grp_present[g] bit i = overall alt i is among the group's alt bases. */
 int orc_dense_site_groups(int64_t n_samples, const int8_t *bases_row, const int8_t *quals_row,
                           int8_t ref_base, double min_af,
                           const uint8_t *group_of_sample, int32_t n_groups, int use_hist,
                           orc_result *overall, int32_t *grp_depth, double *grp_af,
-                          int32_t *grp_ran);
+                          int32_t *grp_ran, int32_t *grp_present);
 
 /* Counter-based synthetic pileup, integer-only, bit-identical to the device
  * generator in basevarc_amd/csrc. cov_thr16: sample covered iff r16 < cov_thr16 (65536 = dense). */

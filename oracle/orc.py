@@ -70,7 +70,7 @@ def lib():
                                       C.c_int, C.c_int, rp]
         L.orc_dense_site_groups.restype = C.c_int
         L.orc_dense_site_groups.argtypes = [C.c_int64, i8p, i8p, C.c_int8, C.c_double, u8p, C.c_int32,
-                                            C.c_int, rp, i32p, f64p, i32p]
+                                            C.c_int, rp, i32p, f64p, i32p, i32p]
         L.orc_synth_site.restype = None
         L.orc_synth_site.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_uint32, i8p, i8p, i8p]
         _lib = L
@@ -142,10 +142,11 @@ def dense_site_groups(bases_row, quals_row, ref_base, min_af, group_of_sample, n
     gd = np.zeros((n_groups, 4), dtype=np.int32)
     ga = np.zeros((n_groups, 3), dtype=np.float64)
     gr = np.zeros(n_groups, dtype=np.int32)
+    gp = np.zeros(n_groups, dtype=np.int32)
     lib().orc_dense_site_groups(len(b), _p(b, C.c_int8), _p(q, C.c_int8), int(ref_base), float(min_af),
                                 _p(g, C.c_uint8), int(n_groups), int(bool(use_hist)), C.byref(r),
-                                _p(gd, C.c_int32), _p(ga, C.c_double), _p(gr, C.c_int32))
-    return r.as_dict(), gd, ga, gr
+                                _p(gd, C.c_int32), _p(ga, C.c_double), _p(gr, C.c_int32), _p(gp, C.c_int32))
+    return r.as_dict(), gd, ga, gr, gp
 
 
 def synth_tile(seed, site0, n_sites, n_samples, cov_thr16=65536):

@@ -280,10 +280,11 @@ def test_group_mode_matches_callers_group_loop(ctx):
         m = caller_min_af(n)
         res, gres = ctx.lrt_dense_groups(B, Q, R, m, grp, k)
         for s, (b, q, r) in enumerate(sites):
-            o, gd, ga, ran = orc.dense_site_groups(b, q, r, m, grp, k)
+            o, gd, ga, ran, pres = orc.dense_site_groups(b, q, r, m, grp, k)
             assert_site_matches(res[s], o, where=f"groups overall n={n} site={s}")
             assert np.array_equal(gres[s]["depth"], gd), (n, s)
             assert np.array_equal(gres[s]["ran"], ran), (n, s)
+            assert np.array_equal(gres[s]["present"], pres), (n, s)
             np.testing.assert_allclose(gres[s]["af"], ga, rtol=0, atol=AF_ATOL, err_msg=f"n={n} site={s}")
 
 

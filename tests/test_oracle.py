@@ -159,12 +159,12 @@ def test_group_loop_literal_zero_when_group_lacks_alt():
     alt = (ref + 1) % 4
     b[(grp == 0) & (np.arange(n) < 200)] = alt          # ALT only in group 0
     grp[-10:] = 255                                      # ungrouped samples
-    o, gd, ga, ran = orc.dense_site_groups(b, q, ref, caller_min_af(n), grp, 3)
+    o, gd, ga, ran, _ = orc.dense_site_groups(b, q, ref, caller_min_af(n), grp, 3)
     assert o["called"] == 1 and o["alt_base"] == [alt]
     assert ran.tolist() == [1, 1, 1]
     assert ga[0, 0] > 0.2 and ga[1, 0] == 0.0 and ga[2, 0] == 0.0
     assert gd.sum() == n - 10
-    oh, gdh, gah, _ = orc.dense_site_groups(b, q, ref, caller_min_af(n), grp, 3, use_hist=True)
+    oh, gdh, gah, _, _ = orc.dense_site_groups(b, q, ref, caller_min_af(n), grp, 3, use_hist=True)
     assert np.array_equal(gd, gdh)
     np.testing.assert_allclose(ga, gah, atol=1e-12)
 
