@@ -34,5 +34,31 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST = os.path.join(HERE, "host")
+HOST_SOURCES = ["stats.cpp", "pileup.cpp", "bgzf.cpp", "bam.cpp"]
+HOST_LIB = os.path.join(HERE, "libbvchost.so")
+HOST_EXE = os.path.join(HERE, "BaseVarC")
+
+
+def build_host(force=False):
+    """g++ build of the host side (the reference's `BaseVarC basetype` command line and its text formats):
+    basevarc_amd/BaseVarC (links libbvc.so) and basevarc_amd/libbvchost.so (test hooks, no GPU code)."""
+    srcs = [os.path.join(HOST, f) for f in HOST_SOURCES + ["main.cpp", "capi.cpp"]]
+    hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
+    newest = max(os.path.getmtime(f) for f in srcs + hdrs)
+    inc = ["-I", os.path.join(HERE, "..", "include")]
+    flags = ["-std=c++11", "-O2", "-Wall", "-Wextra", "-fPIC", "-pthread"]
+    if force or not os.path.exists(HOST_LIB) or os.path.getmtime(HOST_LIB) < newest:
+        subprocess.check_call(["g++"] + flags + inc + ["-shared", "-o", HOST_LIB] +
+                              [os.path.join(HOST, f) for f in HOST_SOURCES + ["capi.cpp"]] + ["-lz"])
+    build()
+    if force or not os.path.exists(HOST_EXE) or os.path.getmtime(HOST_EXE) < max(newest, os.path.getmtime(LIB)):
+        subprocess.check_call(["g++"] + flags + inc + ["-o", HOST_EXE] +
+                              [os.path.join(HOST, f) for f in HOST_SOURCES + ["main.cpp"]] +
+                              ["-L", HERE, "-lbvc", "-lz", "-Wl,-rpath,$ORIGIN"])
+    return HOST_EXE, HOST_LIB
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_host(force=True))

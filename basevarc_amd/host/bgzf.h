@@ -1,0 +1,54 @@
+// bgzf.h -- minimal BGZF (blocked gzip) reader/writer on zlib.  The reference uses htslib's bgzf_* for its
+// temp-batch files and its .vcf.gz/.cvg.gz outputs (src/BaseVarC.cpp:10, 218-233, 320-330, 498-527);
+// htslib is absent from the reference tree, so the format is implemented from the SAM specification (4.1).
+#ifndef BVC_HOST_BGZF_H
+#define BVC_HOST_BGZF_H
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace bvchost {
+
+class BgzfWriter {
+ public:
+    explicit BgzfWriter(const std::string &path, int level = 6);
+    ~BgzfWriter();
+    bool ok() const { return fp_ != nullptr && !failed_; }
+    void write(const char *data, size_t n);
+    void write(const std::string &s) { write(s.data(), s.size()); }
+    bool close();                               // flushes and appends the EOF marker block
+ private:
+    void flush_block(size_t n);
+    FILE *fp_;
+    int level_;
+    bool failed_;
+    std::vector<unsigned char> buf_;
+};
+
+class BgzfReader {
+ public:
+    explicit BgzfReader(const std::string &path);
+    ~BgzfReader();
+    bool ok() const { return fp_ != nullptr; }
+    bool is_bgzf() const { return bgzf_; }
+    // one line without its terminator; false at end of file
+    bool getline(std::string &line);
+    size_t read(void *dst, size_t n);           // up to n bytes of the uncompressed stream
+    bool seek(uint64_t voffset);                // BGZF virtual offset: compressed block start << 16 | within-block
+    uint64_t tell() const { return (block_addr_ << 16) | (uint64_t)pos_; }
+    static bool has_eof_marker(const std::string &path);   // bgzf_check_EOF
+ private:
+    bool load_block();
+    FILE *fp_;
+    bool bgzf_;
+    uint64_t block_addr_;
+    uint64_t next_addr_;
+    std::vector<unsigned char> block_;
+    size_t pos_;
+    bool eof_;
+};
+
+}  // namespace bvchost
+#endif

@@ -1,0 +1,97 @@
+// capi.cpp -- C entry points of the host-side pieces, for tests and for callers in other languages.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pileup.h"
+#include "stats.h"
+
+using namespace bvchost;
+
+extern "C" {
+
+double bvchost_erfc(double x) { return kf_erfc(x); }
+double bvchost_normsf(double x) { return normsf(x); }
+double bvchost_fisher_phred(int n11, int n12, int n21, int n22) { return bt_fisher_exact(n11, n12, n21, n22); }
+double bvchost_fisher_two_sided(int n11, int n12, int n21, int n22)
+{
+    double l, r, t;
+    kt_fisher_exact(n11, n12, n21, n22, &l, &r, &t);
+    return t;
+}
+double bvchost_ranksum(const double *x, int n1, const double *y, int n2)
+{
+    std::vector<double> a(x, x + n1), b(y, y + n2);
+    return RankSumTest(a, b);
+}
+
+// Parses the concatenated batch lines of ONE position (lines separated by '\n') and formats the CVG line and, when
+// `bt` says called, the VCF line.  Returns the number of bytes needed; output is truncated to cap.
+static size_t copy_out(const std::string &s, char *out, size_t cap)
+{
+    if (out && cap) { const size_t n = s.size() < cap - 1 ? s.size() : cap - 1; std::memcpy(out, s.data(), n); out[n] = 0; }
+    return s.size() + 1;
+}
+
+void bvchost_reset_parser(void) { reset_parser_carry(); }
+
+// site handle API (tests): build a SiteColumn from batch lines, then ask for its pieces
+struct bvchost_site { SiteColumn col; };
+
+bvchost_site *bvchost_site_parse(const char *lines, int32_t pos)
+{
+    bvchost_site *s = new bvchost_site();
+    s->col.pos = pos;
+    int32_t j = 0;
+    const char *p = lines;
+    while (*p) {
+        const char *nl = std::strchr(p, '\n');
+        const size_t len = nl ? (size_t)(nl - p) : std::strlen(p);
+        j += parse_pileup_line(p, len, j, s->col);
+        p += len + (nl ? 1 : 0);
+    }
+    return s;
+}
+void bvchost_site_free(bvchost_site *s) { delete s; }
+int32_t bvchost_site_size(const bvchost_site *s) { return (int32_t)s->col.aiv.size(); }
+// fields: 0 base, 1 mapq, 2 qual, 3 rpr, 4 strand, 5 is_indel, 6 sample index
+int32_t bvchost_site_field(const bvchost_site *s, int32_t k, int field)
+{
+    const AlleleInfo &a = s->col.aiv[(size_t)k];
+    switch (field) {
+    case 0: return a.base; case 1: return a.mapq; case 2: return a.qual; case 3: return a.rpr;
+    case 4: return a.strand; case 5: return a.is_indel; default: return s->col.sample[(size_t)k];
+    }
+}
+size_t bvchost_cvg_line(const bvchost_site *s, const char *chr, int8_t ref_base, const bvc_group_result *grp, int n_groups,
+                        char *out, size_t cap)
+{
+    return copy_out(cvg_line(chr, s->col.pos, ref_base, s->col, grp, n_groups), out, cap);
+}
+size_t bvchost_vcf_line(const bvchost_site *s, const bvc_site_result *bt, const char *chr, int8_t ref_base, int32_t n_samples,
+                        const char *extra_info_keys, const char *extra_info_vals, char *out, size_t cap)
+{
+    std::map<std::string, std::string> info;
+    if (extra_info_keys && extra_info_vals) {                    // ';'-separated parallel lists
+        std::string k(extra_info_keys), v(extra_info_vals);
+        size_t a = 0, b = 0;
+        while (a < k.size()) {
+            const size_t ea = k.find(';', a), eb = v.find(';', b);
+            info.insert({k.substr(a, ea - a), v.substr(b, eb - b)});
+            if (ea == std::string::npos) break;
+            a = ea + 1; b = eb + 1;
+        }
+    }
+    return copy_out(vcf_line(*bt, chr, s->col.pos, ref_base, s->col, info, n_samples), out, cap);
+}
+size_t bvchost_format_token(int base, int mapq, int qual, int rpr, int strand, const char *indel, char *out, size_t cap)
+{
+    AlleleInfo a;
+    a.base = (uint8_t)base; a.mapq = (uint8_t)mapq; a.qual = (uint8_t)qual; a.rpr = (uint8_t)rpr; a.strand = (uint8_t)strand;
+    if (indel) { a.is_indel = 1; a.indel = indel; }
+    std::string s;
+    format_pileup_token(base < 0 ? nullptr : &a, s);
+    return copy_out(s, out, cap);
+}
+
+}  // extern "C"

@@ -1,0 +1,456 @@
+// main.cpp -- `BaseVarC basetype` on MI355X: the reference's command line, temp-batch files and outputs, with
+// the per-site BaseType work of a whole tile of positions handed to libbvc in one call.
+//
+// Counterparts in the reference (src/BaseVarC.cpp): main :151-174, runBaseType :176-314, bt_r :467-534,
+// bt_s :316-465, bt_f :536-669, parseOptions :797-827.  Same options and defaults, same file names
+// (<out>.vcf.gz, <out>.cvg.gz, <out>.tmp.thread.<t>/batch.<b>), same --load/--rerun/--keep_tmp behaviour.
+// Additive: --gpus <n> (devices to spread the threads over; default all), --tile <sites per device call>.
+#include <getopt.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <stdexcept>
+#include <thread>
+#include <tuple>
+#include <unordered_map>
+
+#include "bam.h"
+#include "bgzf.h"
+#include "pileup.h"
+
+using namespace bvchost;
+
+static const char *BASEVARC_USAGE_MESSAGE =
+    "Contact: Zilong Li [zimusen94@gmail.com]\n"
+    "Usage  : BaseVarC <command> [options]\n\n"
+    "Commands:\n"
+    "         basetype       Variants Caller\n"
+    "         popmatrix      Create population matrix\n"
+    "         concat         Concat popmatrix\n";
+
+static const char *BASETYPE_MESSAGE =
+    "Commands: BaseVarC basetype\n"
+    "Usage   : BaseVarC basetype [options]\n\n"
+    "Options :\n"
+    "  --input,      -i         BAM/CRAM file list, one file per row\n"
+    "  --output,     -o         Output file prefix\n"
+    "  --reference,  -r         Reference file\n"
+    "  --region,     -s         Samtools-like region <chr:start-end>\n"
+    "  --group,      -g         Population group information <SampleID Group>\n"
+    "  --mapq,       -q <INT>   Mapping quality >= INT [10]\n"
+    "  --thread,     -t <INT>   Number of threads\n"
+    "  --batch,      -b <INT>   Number of samples each batch\n"
+    "  --maf,        -a <FLOAT> Minimum allele count frequency [min(0.001, 100/N, maf)]\n"
+    "  --load,                  Load data only\n"
+    "  --rerun,                 Read previous loaded data and rerun\n"
+    "  --keep_tmp,              Don't remove tmp files when basetype finished\n"
+    "  --verbose,    -v         Set verbose output\n"
+    "  --gpus           <INT>   MI355X devices to use [all]\n"
+    "  --tile           <INT>   Positions per device call [4096]\n";
+
+namespace opt {
+static bool verbose = false, rerun = false, load = false, keep_tmp = false;
+static int mapq = 10, thread = 1, batch = 10, gpus = 0, tile = 4096;
+static double maf = 0.001;
+static std::string input, reference, posfile, group, region, output;
+}  // namespace opt
+
+static const char *shortopts = "hva:i:r:p:s:o:q:t:b:g:";
+static const struct option longopts[] = {
+    {"help", no_argument, NULL, 'h'},        {"verbose", no_argument, NULL, 'v'},
+    {"keep_tmp", no_argument, NULL, 6},      {"load", no_argument, NULL, 7},
+    {"rerun", no_argument, NULL, 8},         {"maf", required_argument, NULL, 'a'},
+    {"input", required_argument, NULL, 'i'}, {"reference", required_argument, NULL, 'r'},
+    {"posfile", required_argument, NULL, 'p'}, {"group", required_argument, NULL, 'g'},
+    {"region", required_argument, NULL, 's'}, {"output", required_argument, NULL, 'o'},
+    {"batch", required_argument, NULL, 'b'}, {"thread", required_argument, NULL, 't'},
+    {"mapq", required_argument, NULL, 'q'},  {"gpus", required_argument, NULL, 9},
+    {"tile", required_argument, NULL, 10},   {NULL, 0, NULL, 0}};
+
+static void parse_options(int argc, char **argv, const char *msg)          // src/BaseVarC.cpp:797-827
+{
+    bool die = false;
+    for (int c; (c = getopt_long(argc, argv, shortopts, longopts, NULL)) != -1;) {
+        std::istringstream arg(optarg != NULL ? optarg : "");
+        switch (c) {
+        case 'q': arg >> opt::mapq; break;
+        case 'b': arg >> opt::batch; break;
+        case 't': arg >> opt::thread; break;
+        case 'i': arg >> opt::input; break;
+        case 'r': arg >> opt::reference; break;
+        case 'p': arg >> opt::posfile; break;
+        case 's': arg >> opt::region; break;
+        case 'g': arg >> opt::group; break;
+        case 'o': arg >> opt::output; break;
+        case 'a': arg >> opt::maf; break;
+        case 8: opt::rerun = true; break;
+        case 7: opt::load = true; break;
+        case 6: opt::keep_tmp = true; break;
+        case 9: arg >> opt::gpus; break;
+        case 10: arg >> opt::tile; break;
+        case 'v': opt::verbose = true; break;
+        default: die = true;
+        }
+    }
+    if (die || opt::input.empty() || opt::output.empty()) {
+        std::cerr << msg;
+        std::exit(die ? EXIT_FAILURE : EXIT_SUCCESS);
+    }
+}
+
+static std::tuple<std::string, int32_t, int32_t> splitrg(std::string rg)   // src/BaseVarUtils.h:49-75
+{
+    if (rg.find(":") == std::string::npos || rg.find("-") == std::string::npos)
+        throw std::invalid_argument("region must be feed with samtools-like format, i.e. chr:start-end");
+    size_t p = rg.find(":");
+    std::string chr = rg.substr(0, p);
+    rg.erase(0, p + 1);
+    p = rg.find("-");
+    const int32_t s = std::stoi(rg.substr(0, p));
+    rg.erase(0, p + 1);
+    const int32_t e = std::stoi(rg) - 1;                                 // the reference's end - 1
+    return std::make_tuple(chr, s, e);
+}
+
+static bool file_exists(const std::string &f) { struct stat st; return ::stat(f.c_str(), &st) == 0; }
+
+static std::string tmp_name(int ithread, int ibatch)
+{
+    return opt::output + ".tmp.thread." + std::to_string(ithread) + "/batch." + std::to_string(ibatch);
+}
+
+// Per-thread window of positions (src/BaseVarC.cpp:399-403, 497, 523).  The reference's arithmetic can run a
+// non-last thread past the end when psize % thread is large; the range is clamped here.
+static void thread_window(size_t psize, int thread, int ithread, size_t &lo, size_t &hi)
+{
+    const size_t window = psize % thread + psize / thread;
+    lo = std::min(psize, (size_t)ithread * window);
+    hi = (ithread == thread - 1) ? psize : std::min(psize, (size_t)(ithread + 1) * window);
+}
+
+// ---- phase 1: BAM -> temp-batch pileup text (bt_r, src/BaseVarC.cpp:467-534) ------------------------------------
+static void bt_r(const std::vector<std::string> &bams, const std::vector<int32_t> &pv, const std::string &refseq,
+                 const std::string &chr, int32_t rg_s, int32_t rg_e, int nb, int bc, int ib, int thread)
+{
+    const size_t b0 = (size_t)ib * bc, b1 = (ib == nb - 1) ? bams.size() : (size_t)(ib + 1) * bc;
+    std::vector<PosAlleleMap> allele_mv;
+    std::string names;
+    for (size_t b = b0; b < b1; ++b) {
+        BamFile reader;
+        if (!reader.open(bams[b])) throw std::runtime_error("ERROR: can not open file " + bams[b]);
+        if (!reader.sorted())
+            throw std::runtime_error("ERROR: BAM file does not appear to be sorted (no SO:coordinate) found in header.\n       Sorted BAMs are required.");
+        const std::string sm = reader.sample_name();
+        PosAlleleMap m;
+        std::vector<BamRecord> rv;
+        const int rid = reader.ref_index(chr);
+        // region padded by 1000 on both sides (gr.Pad(1000), src/BamProcess.cpp:290); [beg, end) 0-based
+        if (rid < 0 || !reader.fetch(rid, std::max(0, rg_s - 1 - 1000), rg_e + 1000, opt::mapq, rv) || rv.empty())
+            std::cerr << "warning: " << sm << " region " << opt::region << " is empty." << std::endl;
+        else
+            find_snp_at_pos(rv, rg_s, refseq, pv, m);
+        allele_mv.push_back(std::move(m));
+        names += sm + '\t';
+    }
+    names += "\n";
+    std::vector<BgzfWriter *> fpv;
+    for (int i = 0; i < thread; ++i) {
+        BgzfWriter *fp = new BgzfWriter(tmp_name(i, ib));
+        if (!fp->ok()) throw std::runtime_error("ERROR: fail to write " + tmp_name(i, ib));
+        fp->write(names);
+        fpv.push_back(fp);
+    }
+    const size_t psize = pv.size();
+    const size_t window = psize % thread + psize / thread;
+    std::string out;
+    for (size_t i = 0, j = 0; i < psize; ++i) {
+        const int32_t p = pv[i];
+        out.clear();
+        for (auto const &m : allele_mv) {
+            auto it = m.find(p);
+            format_pileup_token(it == m.end() ? nullptr : &it->second, out);
+        }
+        out += "\n";
+        if (i == (j + 1) * window && j + 1 < (size_t)thread) ++j;
+        fpv[j]->write(out);
+    }
+    for (auto fp : fpv) {
+        if (!fp->close()) std::cerr << "warning: file cannot be closed" << std::endl;
+        delete fp;
+    }
+}
+
+// ---- phase 2: temp-batch text -> tiles -> libbvc -> CVG/VCF (successor of bt_s + bt_f) ------------------------
+struct TileRunner {
+    bvc_ctx *ctx = nullptr;
+    const Groups *groups = nullptr;
+    std::string chr;
+    int32_t n_samples = 0;
+    double min_af = 0;
+    BgzfWriter *fvcf = nullptr, *fcvg = nullptr;
+    std::vector<SiteColumn> sites;
+    std::vector<int8_t> refs;
+
+    void flush()
+    {
+        const int64_t ns = (int64_t)sites.size();
+        if (ns == 0) return;
+        std::vector<bvc_site_result> res((size_t)ns);
+        std::vector<bvc_group_result> gres;
+        const int ng = groups ? (int)groups->names.size() : 0;
+        int rc;
+        if (ng == 0) {
+            // ragged form: exactly the vectors bt_f builds (src/BaseVarC.cpp:550-559)
+            std::vector<int64_t> offsets(1, 0);
+            std::vector<int8_t> bases, quals;
+            for (auto const &s : sites) {
+                for (auto const &a : s.aiv)
+                    if (a.is_indel == 0) { bases.push_back((int8_t)a.base); quals.push_back((int8_t)a.qual); }
+                offsets.push_back((int64_t)bases.size());
+            }
+            static const int8_t none = 0;
+            rc = bvc_lrt_csr(ctx, ns, offsets.data(), bases.empty() ? &none : bases.data(), quals.empty() ? &none : quals.data(),
+                             refs.data(), min_af, res.data(), BVC_PTR_HOST);
+        } else {
+            // dense [site][sample] tile with -1 for "no observation"; group of each sample is shared by all sites
+            const int64_t stride = ((int64_t)n_samples + 15) / 16 * 16;
+            std::vector<int8_t> bases((size_t)(ns * stride), (int8_t)-1), quals((size_t)(ns * stride), (int8_t)0);
+            for (int64_t s = 0; s < ns; ++s)
+                for (size_t k = 0; k < sites[s].aiv.size(); ++k) {
+                    const AlleleInfo &a = sites[s].aiv[k];
+                    if (a.is_indel == 0) {
+                        bases[(size_t)(s * stride + sites[s].sample[k])] = (int8_t)a.base;
+                        quals[(size_t)(s * stride + sites[s].sample[k])] = (int8_t)a.qual;
+                    }
+                }
+            gres.resize((size_t)(ns * ng));
+            rc = bvc_lrt_dense_groups(ctx, ns, n_samples, stride, bases.data(), quals.data(), refs.data(), min_af,
+                                      groups->of_sample.data(), ng, res.data(), gres.data(), BVC_PTR_HOST);
+        }
+        if (rc != BVC_OK) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(ctx));
+        for (int64_t s = 0; s < ns; ++s) {
+            const bvc_group_result *g = ng ? &gres[(size_t)(s * ng)] : nullptr;
+            fcvg->write(cvg_line(chr, sites[s].pos, refs[s], sites[s], g, ng));
+            if (res[s].called) {
+                std::map<std::string, std::string> info;
+                if (ng) group_af_info(res[s], g, *groups, info);
+                fvcf->write(vcf_line(res[s], chr, sites[s].pos, refs[s], sites[s], info, n_samples));
+            }
+        }
+        sites.clear();
+        refs.clear();
+    }
+};
+
+static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32_t> &pv, const std::string &refseq,
+                 const std::string &chr, int32_t rg_s, int32_t N, int thread, int ithread, int device)
+{
+    BgzfWriter fpv(opt::output + "." + std::to_string(ithread) + ".vcf.gz");
+    BgzfWriter fpc(opt::output + "." + std::to_string(ithread) + ".cvg.gz");
+    std::vector<BgzfReader *> fpiv;
+    for (auto const &f : ftmp_v) fpiv.push_back(new BgzfReader(f));
+    std::string sams, line;
+    for (auto fp : fpiv)
+        if (fp->getline(line)) sams += line;
+    if (!sams.empty()) sams.pop_back();                                 // names are tab-terminated
+    std::vector<std::string> names;
+    { std::istringstream iss(sams); std::string id; while (std::getline(iss, id, '\t')) names.push_back(id); }
+    // population groups (src/BaseVarC.cpp:335-369): name-sorted, a sample not listed belongs to no group
+    Groups groups;
+    if (!opt::group.empty()) {
+        std::ifstream ifg(opt::group);
+        std::unordered_map<std::string, std::string> popg_m;
+        std::string id, grp;
+        while (ifg >> id >> grp) popg_m.insert({id, grp});
+        std::map<std::string, std::vector<int>> popg_idx;
+        for (size_t i = 0; i < names.size(); ++i) {
+            auto it = popg_m.find(names[i]);
+            if (it != popg_m.end()) popg_idx[it->second].push_back((int)i);
+        }
+        if (popg_idx.size() > BVC_MAX_GROUPS) throw std::runtime_error("ERROR: more than 32 population groups");
+        groups.of_sample.assign((size_t)N, 255);
+        for (auto const &kv : popg_idx) {
+            for (int i : kv.second) groups.of_sample[(size_t)i] = (uint8_t)groups.names.size();
+            groups.names.push_back(kv.first);
+        }
+    }
+    if (ithread == 0) {
+        fpc.write(cvg_header(groups));
+        fpv.write(vcf_header(groups, opt::reference, names));
+    }
+    std::cerr << "begin to load data and run basetype" << std::endl;
+    TileRunner tr;
+    if (bvc_create(&tr.ctx, device) != BVC_OK) throw std::runtime_error("ERROR: no usable gfx950 device for libbvc");
+    tr.groups = groups.empty() ? nullptr : &groups;
+    tr.chr = chr;
+    tr.n_samples = N;
+    double min_af = 100.0 / N;                                          // src/BaseVarC.cpp:541-543
+    if (min_af > 0.001) min_af = 0.001;
+    if (opt::maf < min_af) min_af = opt::maf;
+    tr.min_af = min_af;
+    tr.fvcf = &fpv;
+    tr.fcvg = &fpc;
+    int64_t tile = opt::tile > 0 ? opt::tile : 4096;
+    if (!groups.empty()) tile = std::max<int64_t>(1, std::min<int64_t>(tile, ((int64_t)256 << 20) / std::max(1, N)));
+    reset_parser_carry();
+    size_t lo, hi;
+    thread_window(pv.size(), thread, ithread, lo, hi);
+    int32_t count = 0;
+    SiteColumn site;
+    for (size_t ip = lo; ip < hi; ++ip) {
+        const int32_t p = pv[ip];
+        site.clear();
+        site.pos = p;
+        int32_t j = 0;
+        for (auto fp : fpiv)
+            if (fp->getline(line)) j += parse_pileup_line(line.data(), line.size(), j, site);
+        if (!site.aiv.empty()) {
+            const char rc = refseq[(size_t)(p - rg_s)];
+            const int8_t ref_base = rc == 'A' ? 0 : rc == 'C' ? 1 : rc == 'G' ? 2 : rc == 'T' ? 3 : -1;
+            tr.sites.push_back(site);
+            tr.refs.push_back(ref_base);
+            if ((int64_t)tr.sites.size() >= tile) tr.flush();
+            if (!(++count % 1000)) std::cerr << "basetype completed " << count << " sites -- thread" << ithread << std::endl;
+        }
+    }
+    tr.flush();
+    bvc_destroy(tr.ctx);
+    if (!fpv.close()) std::cerr << "warning: file cannot be closed" << std::endl;
+    if (!fpc.close()) std::cerr << "warning: file cannot be closed" << std::endl;
+    for (auto fp : fpiv) delete fp;
+    if (!opt::keep_tmp)
+        for (auto const &f : ftmp_v) std::remove(f.c_str());
+}
+
+template <class F>
+static void run_pool(int n_tasks, int n_threads, F fn)
+{
+    std::atomic<int> next(0);
+    std::mutex mu;
+    std::string err;
+    std::vector<std::thread> ws;
+    for (int t = 0; t < std::max(1, std::min(n_threads, n_tasks)); ++t)
+        ws.emplace_back([&]() {
+            for (int i; (i = next++) < n_tasks;) {
+                try { fn(i); } catch (const std::exception &e) { std::lock_guard<std::mutex> g(mu); if (err.empty()) err = e.what(); }
+            }
+        });
+    for (auto &w : ws) w.join();
+    if (!err.empty()) throw std::runtime_error(err);
+}
+
+static void run_basetype(int argc, char **argv)                          // src/BaseVarC.cpp:176-314
+{
+    parse_options(argc, argv, BASETYPE_MESSAGE);
+    if (opt::reference.empty()) throw std::invalid_argument("reference must be feed");
+    time_t tim = time(0);
+    const clock_t ctb = clock();
+    std::cout << "basetype start -- " << ctime(&tim);
+    std::vector<std::string> bams;
+    { std::ifstream ibam(opt::input); std::string l; while (std::getline(ibam, l)) bams.push_back(l); }
+    const int32_t N = (int32_t)bams.size();
+    if (N == 0) throw std::invalid_argument("empty input list");
+    std::string chr;
+    int32_t rg_s, rg_e;
+    const int32_t buf = 1000;
+    std::tie(chr, rg_s, rg_e) = splitrg(opt::region);
+    std::string refseq, err;
+    if (!fetch_reference(opt::reference, chr, rg_s, rg_e + buf, refseq, err)) throw std::runtime_error(err);
+    std::vector<int32_t> pv;
+    for (size_t i = 0; i + buf < refseq.length(); ++i) {
+        const char c = refseq[i];
+        if (c == 'A' || c == 'C' || c == 'G' || c == 'T') pv.push_back((int32_t)i + rg_s);
+    }
+    const int thread = std::max(1, opt::thread);
+    for (int i = 0; i < thread; ++i) {
+        const std::string d = opt::output + ".tmp.thread." + std::to_string(i);
+        if (::mkdir(d.c_str(), 0777) != 0 && !file_exists(d)) throw std::runtime_error("ERROR: fail to run mkdir");
+    }
+    const int bc = std::max(1, opt::batch);
+    const int nb = 1 + (N - 1) / bc;
+    std::vector<std::vector<std::string>> ftmp_vv((size_t)thread);
+    int ngz = 0, bk = nb - 1;
+    for (int j = 0; j < nb; ++j) {
+        int k = 0;
+        for (int i = 0; i < thread; ++i) {
+            const std::string f = tmp_name(i, j);
+            ftmp_vv[(size_t)i].push_back(f);
+            if (file_exists(f)) {
+                if (BgzfReader(f).is_bgzf()) { if (BgzfReader::has_eof_marker(f)) { k += 1; ngz += 1; } }
+                else std::cerr << "warning: " << f << " is not bgziped" << std::endl;
+            }
+        }
+        if (k != thread) bk = bk > j ? j : bk;
+    }
+    int first_batch = 0;
+    bool extract = true;
+    if (opt::rerun && ngz > 0) { extract = ngz != thread * nb; first_batch = bk; }
+    if (extract) {
+        std::cerr << "begin to extract reads from bam" << std::endl;
+        run_pool(nb - first_batch, thread, [&](int t) { bt_r(bams, pv, refseq, chr, rg_s, rg_e, nb, bc, first_batch + t, thread); });
+    }
+    time_t tim1 = time(0);
+    std::cout << "basetype loading done -- " << ctime(&tim1);
+    if (opt::load) std::exit(EXIT_SUCCESS);
+    int gpus = bvc_device_count();
+    if (gpus <= 0) throw std::runtime_error("ERROR: no gfx950 device (libbvc has no CPU fallback)");
+    if (opt::gpus > 0 && opt::gpus < gpus) gpus = opt::gpus;
+    {
+        std::vector<std::thread> workers;
+        std::mutex mu;
+        std::string werr;
+        for (int i = 0; i < thread; ++i)
+            workers.emplace_back([&, i]() {
+                try { bt_s(ftmp_vv[(size_t)i], pv, refseq, chr, rg_s, N, thread, i, i % gpus); }
+                catch (const std::exception &e) { std::lock_guard<std::mutex> g(mu); if (werr.empty()) werr = e.what(); }
+            });
+        // merge the per-thread sub-files in thread (= position) order (src/BaseVarC.cpp:268-296)
+        BgzfWriter fov(opt::output + ".vcf.gz"), foc(opt::output + ".cvg.gz");
+        std::string line;
+        for (int i = 0; i < thread; ++i) {
+            workers[(size_t)i].join();
+            if (!werr.empty()) throw std::runtime_error(werr);
+            const std::string subvcf = opt::output + "." + std::to_string(i) + ".vcf.gz";
+            const std::string subcvg = opt::output + "." + std::to_string(i) + ".cvg.gz";
+            { BgzfReader fiv(subvcf); while (fiv.getline(line)) { line += '\n'; fov.write(line); } }
+            { BgzfReader fic(subcvg); while (fic.getline(line)) { line += '\n'; foc.write(line); } }
+            std::remove(subvcf.c_str());
+            std::remove(subcvg.c_str());
+        }
+        std::cout << "merge subfiles done" << std::endl;
+        if (!fov.close()) std::cerr << "warning: file cannot be closed" << std::endl;
+        if (!foc.close()) std::cerr << "warning: file cannot be closed" << std::endl;
+    }
+    for (int i = 0; i < thread; ++i) ::rmdir((opt::output + ".tmp.thread." + std::to_string(i)).c_str());
+    time_t tim2 = time(0);
+    std::cout << "basetype computing done -- " << ctime(&tim2);
+    std::cout << "basetype elapsed cpu secs : " << double(clock() - ctb) / CLOCKS_PER_SEC << std::endl;
+    std::cout << "basetype done" << std::endl;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc <= 1) { std::cerr << BASEVARC_USAGE_MESSAGE; return 0; }
+    const std::string command(argv[1]);
+    try {
+        if (command == "basetype") run_basetype(argc - 1, argv + 1);
+        else if (command == "popmatrix" || command == "concat") {
+            std::cerr << "BaseVarC " << command << " is not part of the MI355X build (only the basetype path is)" << std::endl;
+            return 1;
+        } else { std::cerr << BASEVARC_USAGE_MESSAGE; return 0; }
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

@@ -17,6 +17,9 @@ static const double kQualThreshold = 60;                            // src/BaseT
 
 std::string fmt_fixed(double v, int prec)
 {
+    // fmt prints a NaN as "nan" or "-nan" by its sign bit, which for 0/0 is an accident of code generation;
+    // a NaN is printed as "nan" here.
+    if (std::isnan(v)) return "nan";
     char buf[64];
     std::snprintf(buf, sizeof buf, "%.*f", prec, v);
     return buf;

@@ -51,6 +51,8 @@ void format_pileup_token(const AlleleInfo *a, std::string &out);           // a 
 // Parses the tokens of one batch's line; sample indices start at j0.  Returns the number of tokens seen
 // (= samples in that batch).  N bases are dropped, indel tokens kept (src/BaseVarC.cpp:427-436).
 int parse_pileup_line(const char *line, size_t len, int32_t j0, SiteColumn &site);
+// The parser carries one AlleleInfo across calls within a thread, as bt_s does; call this at thread start.
+void reset_parser_carry();
 
 // ---- emission (f2) -------------------------------------------------------------------------------------
 extern const char *const kCvgHeader;
