@@ -118,7 +118,9 @@ def get_offset(r, pos):                    # src/BamProcess.cpp:232-261
     return offset
 
 
-def find_snp_at_pos(rv, pv):               # src/BamProcess.cpp:4-94; returns {pos: (base, qual) | 'indel'}
+def find_snp_at_pos(rv, pv, refseq=None, rg_s=0):
+    """src/BamProcess.cpp:4-94.  Returns {pos: AlleleInfo dict}; indel entries have is_indel = 1 and, when the
+    region's reference string is given, the indel token the reference would write."""
     out = {}
     if not rv:
         return out
@@ -155,23 +157,27 @@ def find_snp_at_pos(rv, pv):               # src/BamProcess.cpp:4-94; returns {p
                     break
             assert sk is not None
             op = c[sk][0]
-            indel = 0
+            indel, indel_str = 0, ""
+            strand = 0 if (r["flag"] & 0x10 or r["flag"] & 0x20) else 1
             if sx == pos and sk + 1 < len(c):
                 op2, l2 = c[sk + 1]
                 if op2 == "D":
                     indel = -l2
+                    indel_str = "-" + (refseq[pos - rg_s + 1:pos - rg_s + 1 + l2] if refseq is not None else "")
                 elif op2 == "I":
                     indel = l2
+                    indel_str = "+" + r["seq"][sy:sy + l2]
                 elif op2 == "P" and sk + 2 < len(c):
                     # the reference re-reads c[sk] in this loop (src/BamProcess.cpp:60-62), so l3 stays 0
                     # unless c[sk] itself is an insertion, which cannot be the operation containing pos
                     indel = 0
             if indel != 0:
-                out.setdefault(pos, "indel")
+                out.setdefault(pos, dict(base=5, mapq=0, qual=r["mapq"], rpr=0, strand=strand, is_indel=1, indel=indel_str))
                 break
             if op not in "DN":
                 o = get_offset(r, pos)
-                out.setdefault(pos, (BASE_CODE.get(r["seq"][o], 4), r["qual"][o]))
+                out.setdefault(pos, dict(base=BASE_CODE.get(r["seq"][o], 4), mapq=r["mapq"], qual=r["qual"][o], rpr=(o + 1) & 255,
+                                         strand=strand, is_indel=0, indel=""))
                 break
             elif j < last:
                 j += 1
@@ -229,39 +235,56 @@ def md_ref_bases(r, into):
             qpos += l
 
 
-def main():
-    from oracle import orc
-    from tests.golden.golden_io import save_golden
-    chrom, start, end = REGION
+def load_samples(root, bam_list, region=REGION, mapq=MAPQ):
+    """Reads every BAM of the list: (names, per-sample filtered record lists, reference bases known from MD tags)."""
+    chrom, start, end = region
     rg_s, rg_e = start, end - 1                               # splitrg quirk, src/BaseVarUtils.h:71
-    pv = list(range(rg_s, rg_e + 1))
-    bams = [l.strip() for l in open(os.path.join(REF_ROOT, "bam.list")) if l.strip()]
-    per_sample, ref_at, names = [], {}, []
+    bams = [l.strip() for l in open(bam_list) if l.strip()]
+    rvs, ref_at, names = [], {}, []
     for b in bams:
-        header, recs = read_bam(os.path.join(REF_ROOT, b))
+        header, recs = read_bam(os.path.join(root, b))
         assert "SO:coord" in header
         names.append(sample_name(header))
         rv = [r for r in recs if r["ref"] == chrom and not (r["flag"] & 0x4) and r["cigar"]
               and end_pos(r) > rg_s - 1000 - 1 and r["pos"] < rg_e + 1000
-              and not (r["flag"] & 0x400) and r["mapq"] >= MAPQ]
+              and not (r["flag"] & 0x400) and r["mapq"] >= mapq]
         for r in rv:
             md_ref_bases(r, ref_at)
-        per_sample.append(find_snp_at_pos(rv, pv))
-    n_samples = len(bams)
+        rvs.append(rv)
+    return names, rvs, ref_at
+
+
+def region_reference(ref_at, rg_s, rg_e, buf=1000):
+    """The string RefReader::GetTargetBase would return for [rg_s, rg_e + buf], with N where no read tells."""
+    return "".join(ref_at.get(p, "N") if ref_at.get(p, "N") in BASE_CODE else "N" for p in range(rg_s, rg_e + buf + 1))
+
+
+def main():
+    from oracle import orc
+    from tests.golden.golden_io import save_golden
+    chrom, start, end = REGION
+    rg_s, rg_e = start, end - 1
+    pv = list(range(rg_s, rg_e + 1))
+    names, rvs, ref_at = load_samples(REF_ROOT, os.path.join(REF_ROOT, "bam.list"))
+    per_sample = [find_snp_at_pos(rv, pv) for rv in rvs]
+    refseq = region_reference(ref_at, rg_s, rg_e)
+    with open(os.path.join(os.path.dirname(__file__), "testdata", "chr17_41197700_region.txt"), "w") as f:
+        f.write(f"chr17 {rg_s} 81195210\n{refseq}\n")       # contig, 1-based start, contig length / bases
+    n_samples = len(names)
     min_af = min(100.0 / n_samples, 0.001)                   # src/BaseVarC.cpp:541-543 with default --maf
     sites, mafs, positions = [], [], []
     skipped_ref = 0
     for pos in pv:
         entries = [m[pos] for m in per_sample if pos in m]
-        entries = [e for e in entries if e == "indel" or e[0] != 4]      # N bases dropped (:427)
+        entries = [e for e in entries if e["is_indel"] or e["base"] != 4]   # N bases dropped (:427)
         if not entries:
             continue                                                     # `if (!aiv.empty())`, :442
         rb = ref_at.get(pos)
         if rb not in BASE_CODE:
             skipped_ref += 1
             continue
-        obs = [e for e in entries if e != "indel"]
-        sites.append((np.array([e[0] for e in obs], dtype=np.int8), np.array([e[1] for e in obs], dtype=np.int8),
+        obs = [e for e in entries if not e["is_indel"]]
+        sites.append((np.array([e["base"] for e in obs], dtype=np.int8), np.array([e["qual"] for e in obs], dtype=np.int8),
                       BASE_CODE[rb]))
         mafs.append(min_af)
         positions.append(pos)

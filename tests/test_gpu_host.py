@@ -1,0 +1,49 @@
+"""GPU end-to-end test of the host program: `BaseVarC basetype` (basevarc_amd/BaseVarC, C++ over libbvc) on the
+reference's own test data, with the reference's own command line (test/test.sh:3), against the Python pipeline
+(tests/hostref.py: pileup restatement + CPU oracle + emit restatement).  BASELINE configs[0] at file level."""
+import gzip
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("thread", [1, 4])
+def test_basetype_command_on_reference_test_data(tmp_path, thread):
+    from basevarc_amd import build as b
+    from tests import hostref
+    exe, _ = b.build_host()
+    fa = hostref.write_fasta(str(tmp_path / "chr17.fa"))
+    lst = hostref.write_bam_list(str(tmp_path / "bam.list"))
+    out = str(tmp_path / "test.out")
+    r = subprocess.run([exe, "basetype", "--rerun", "-q", "20", "-t", str(thread), "-b", "10", "-i", lst, "-s",
+                        hostref.REGION, "-r", fa, "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "basetype done" in r.stdout
+    pipe = hostref.Pipeline(mapq=20, batch=10, thread=thread)
+    vcf_body, cvg_body = pipe.outputs()
+    vcf_head, cvg_head = hostref.headers(fa, pipe.names)
+    got_vcf = gzip.decompress(open(out + ".vcf.gz", "rb").read()).decode()
+    got_cvg = gzip.decompress(open(out + ".cvg.gz", "rb").read()).decode()
+    assert got_cvg.count("\n") == 66614 + 3                      # every covered position + 3 header lines
+    assert got_cvg == cvg_head + cvg_body
+    want_vcf = vcf_head + vcf_body
+    assert got_vcf.split("\n")[:20] == want_vcf.split("\n")[:20]
+    gl, wl = got_vcf.split("\n"), want_vcf.split("\n")
+    assert len(gl) == len(wl) and sum(1 for l in gl if l and l[0] != "#") == 76
+    for g, w in zip(gl, wl):
+        if g == w:
+            continue
+        # device and host libm may differ in the last printed digit of a float field: compare numerically
+        gf, wf = g.split("\t"), w.split("\t")
+        assert gf[:5] == wf[:5] and gf[6] == wf[6] and gf[8:] == wf[8:], (g[:200], w[:200])
+        assert abs(float(gf[5]) - float(wf[5])) <= 0.011
+        for a, c in zip(gf[7].split(";"), wf[7].split(";")):
+            ka, va = a.split("="); kc, vc = c.split("=")
+            assert ka == kc
+            for x, y in zip(va.split(","), vc.split(",")):
+                assert x == y or abs(float(x) - float(y)) <= 2e-6 * max(1.0, abs(float(y))) + 1.1e-3, (ka, x, y)
+    # temp files and directories are gone (no --keep_tmp), sub-files merged
+    import os
+    assert not os.path.exists(out + ".tmp.thread.0") and not os.path.exists(out + ".0.vcf.gz")

@@ -159,3 +159,28 @@ def test_cvg_and_vcf_lines_match_the_python_restatement(H):
             assert buf.value.decode() == eo.vcf_line(e, "chr17", 4242 + it, ref, aiv, sample, n, extra)
         H.bvchost_site_free(s)
     assert n_vcf > 10
+
+
+# ----------------------------------------------------------------------------- phase 1 end to end (no GPU needed)
+@pytest.mark.parametrize("thread,batch", [(1, 10), (4, 10), (3, 37)])
+def test_load_phase_writes_the_temp_batch_files_of_the_test_data(tmp_path, thread, batch):
+    """`BaseVarC basetype --load` on the reference's test BAMs (test/test.sh:3): BGZF/BAM decoding, read
+    filters, the first-usable-read pileup rule and the temp-batch text, against the Python restatement."""
+    import gzip
+    import subprocess
+    from basevarc_amd import build as b
+    from tests import hostref
+    exe, _ = b.build_host()
+    fa = hostref.write_fasta(str(tmp_path / "chr17.fa"))
+    lst = hostref.write_bam_list(str(tmp_path / "bam.list"))
+    out = str(tmp_path / "test.out")
+    subprocess.run([exe, "basetype", "--load", "-q", "20", "-t", str(thread), "-b", str(batch), "-i", lst, "-s",
+                    hostref.REGION, "-r", fa, "-o", out], check=True, capture_output=True)
+    pipe = hostref.Pipeline(mapq=20, batch=batch, thread=thread)
+    want = pipe.batch_files()
+    assert len(want) == thread * (1 + (pipe.n - 1) // batch)
+    for (t, ib), text in want.items():
+        f = f"{out}.tmp.thread.{t}/batch.{ib}"
+        raw = open(f, "rb").read()
+        assert raw[:4] == b"\x1f\x8b\x08\x04" and raw[12:14] == b"BC" and raw[-28:-12] == raw[-28:][:16]   # BGZF + EOF block
+        assert gzip.decompress(raw).decode() == text, (t, ib)
