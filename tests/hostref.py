@@ -88,9 +88,14 @@ class Pipeline:
                 out[(t, ib)] = "".join(lines)
         return out
 
-    def outputs(self):
-        """(vcf_text, cvg_text) of the merged outputs, headers included (no population groups)."""
+    def outputs(self, group_of=None):
+        """(vcf_text, cvg_text) bodies of the merged outputs.  group_of: {sample name: group name} or None."""
+        import numpy as np
         from oracle import orc
+        gnames, gidx = [], None
+        if group_of:
+            gnames = sorted(set(group_of[n] for n in self.names if n in group_of))
+            gidx = np.array([gnames.index(group_of[n]) if n in group_of else 255 for n in self.names], dtype=np.uint8)
         files = self.batch_files()
         nb = 1 + (self.n - 1) // self.batch
         vcf, cvg = [], []
@@ -104,19 +109,38 @@ class Pipeline:
                 if not aiv:
                     continue
                 ref = "ACGT".index(self.refseq[p - self.rg_s])
-                cvg.append(eo.cvg_line(self.chr, p, ref, aiv))
                 b = [a["base"] for a in aiv if not a["is_indel"]]
                 q = [a["qual"] for a in aiv if not a["is_indel"]]
                 e = orc.basetype_lrt(b, q, ref, self.min_af)
+                gd, info = None, {}
+                if gnames:
+                    db = np.full(self.n, -1, dtype=np.int8)
+                    dq = np.zeros(self.n, dtype=np.int8)
+                    for a, j in zip(aiv, sample):
+                        if not a["is_indel"]:
+                            db[j], dq[j] = a["base"], a["qual"]
+                    _, gdep, gaf, ran, pres = orc.dense_site_groups(db, dq, ref, self.min_af, gidx, len(gnames))
+                    gd = gdep.tolist()
+                    for g, name in enumerate(gnames):            # src/BaseVarC.cpp:646-659
+                        if ran[g]:
+                            info[name + "_AF"] = ",".join(eo.fx(gaf[g][i], 6) if pres[g] >> i & 1 else "0"
+                                                          for i in range(e["n_alt"]))
+                        else:
+                            info[name + "_AF"] = "0"
+                cvg.append(eo.cvg_line(self.chr, p, ref, aiv, gd))
                 if e["called"]:
-                    vcf.append(eo.vcf_line(e, self.chr, p, ref, aiv, sample, self.n))
+                    vcf.append(eo.vcf_line(e, self.chr, p, ref, aiv, sample, self.n, info))
         return "".join(vcf), "".join(cvg)
 
 
-def headers(reference_path, names):
+def headers(reference_path, names, group_names=()):
     contig, _, length, _ = region_fixture()
     # CVG_HEADER / VCF_HEADER, src/BaseVarC.cpp:65-88; assembled as bt_s does (:364-382)
     from tests.hostref_headers import CVG_HEADER, VCF_HEADER
-    vh = VCF_HEADER + f"##contig=<ID={contig},length={length}>\n" + f"##reference=file://{reference_path}\n"
+    vh = VCF_HEADER
+    for g in group_names:
+        vh += (f"##INFO=<ID={g}_AF,Number=A,Type=Float,Description=\"Allele frequency in the {g} populations "
+               "calculated based on LRT.[0,1]\">\n")
+    vh += f"##contig=<ID={contig},length={length}>\n" + f"##reference=file://{reference_path}\n"
     vh += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n"
-    return vh, CVG_HEADER + "\n"
+    return vh, CVG_HEADER + "".join("\t" + g for g in group_names) + "\n"

@@ -9,21 +9,28 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("thread", [1, 4])
-def test_basetype_command_on_reference_test_data(tmp_path, thread):
+@pytest.mark.parametrize("thread,grouped", [(1, False), (4, False), (2, True)])
+def test_basetype_command_on_reference_test_data(tmp_path, thread, grouped):
     from basevarc_amd import build as b
     from tests import hostref
     exe, _ = b.build_host()
     fa = hostref.write_fasta(str(tmp_path / "chr17.fa"))
     lst = hostref.write_bam_list(str(tmp_path / "bam.list"))
     out = str(tmp_path / "test.out")
-    r = subprocess.run([exe, "basetype", "--rerun", "-q", "20", "-t", str(thread), "-b", "10", "-i", lst, "-s",
-                        hostref.REGION, "-r", fa, "-o", out], capture_output=True, text=True)
+    pipe = hostref.Pipeline(mapq=20, batch=10, thread=thread)
+    cmd = [exe, "basetype", "--rerun", "-q", "20", "-t", str(thread), "-b", "10", "-i", lst, "-s", hostref.REGION,
+           "-r", fa, "-o", out]
+    group_of = None
+    if grouped:                                                   # --group <SampleID Group>; 7 samples left ungrouped
+        group_of = {n: ["EAS", "AFR", "EUR"][i % 3] for i, n in enumerate(pipe.names) if i % 14 != 5}
+        gf = tmp_path / "groups.txt"
+        gf.write_text("".join(f"{k} {v}\n" for k, v in group_of.items()))
+        cmd += ["-g", str(gf)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "basetype done" in r.stdout
-    pipe = hostref.Pipeline(mapq=20, batch=10, thread=thread)
-    vcf_body, cvg_body = pipe.outputs()
-    vcf_head, cvg_head = hostref.headers(fa, pipe.names)
+    vcf_body, cvg_body = pipe.outputs(group_of)
+    vcf_head, cvg_head = hostref.headers(fa, pipe.names, sorted(set(group_of.values())) if grouped else ())
     got_vcf = gzip.decompress(open(out + ".vcf.gz", "rb").read()).decode()
     got_cvg = gzip.decompress(open(out + ".cvg.gz", "rb").read()).decode()
     assert got_cvg.count("\n") == 66614 + 3                      # every covered position + 3 header lines
