@@ -214,6 +214,21 @@ void group_af_info(const bvc_site_result &bt, const bvc_group_result *grp, const
     }
 }
 
+// The BP sub-field depends only on the 8-bit quality: 256 strings, formatted once.
+static const std::string &bp_field(uint8_t qual)
+{
+    static const std::vector<std::string> table = [] {
+        std::vector<std::string> t(256);
+        char b[32];
+        for (int q = 0; q < 256; ++q) {
+            std::snprintf(b, sizeof b, ":%.6f\t", 1 - std::exp(kMln10To10 * q));
+            t[(size_t)q] = b;
+        }
+        return t;
+    }();
+    return table[qual];
+}
+
 // ---- VCF line: WriteVcf, src/BaseType.cpp:141-234 ---------------------------------------------------------
 std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int32_t pos, int8_t ref_base,
                      const SiteColumn &site, std::map<std::string, std::string> &info, int32_t n_samples)
@@ -226,7 +241,6 @@ std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int32_t 
     std::vector<double> ref_quals, ref_mapqs, ref_rprs, alt_quals, alt_mapqs, alt_rprs;
     std::string samgt;
     size_t k = 0;
-    char buf[96];
     for (int32_t i = 0; i < n_samples; ++i) {
         if (k >= site.sample.size() || site.sample[k] != i) { samgt += "./.\t"; continue; }
         const AlleleInfo &a = site.aiv[k++];
@@ -234,10 +248,12 @@ std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int32_t 
         const std::string &gt = (a.base == ref_base) ? std::string("0/.") : alt_gt[a.base];
         // BASE2CHAR has four entries in the reference (src/BaseType.h:24); an indel entry carrying an N base
         // would index past it there -- 'N' is printed here.
-        std::snprintf(buf, sizeof buf, ":%c:%c:%.6f\t", kBase2Char[a.base < 6 ? a.base : 5], kStrand[a.strand & 1],
-                      1 - std::exp(kMln10To10 * a.qual));
         samgt += gt;
-        samgt += buf;
+        samgt += ':';
+        samgt += kBase2Char[a.base < 6 ? a.base : 5];
+        samgt += ':';
+        samgt += kStrand[a.strand & 1];
+        samgt += bp_field(a.qual);                          // ":<1 - 10^(-qual/10) as {:.6f}>\t"
         if (a.is_indel == 1 || a.base == 4) continue;
         const bool alt = is_alt(a.base);
         if (a.base == ref_base) { ref_quals.push_back(a.qual); ref_mapqs.push_back(a.mapq); ref_rprs.push_back(a.rpr); }
