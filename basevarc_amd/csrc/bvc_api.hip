@@ -32,6 +32,8 @@ struct bvc_ctx {
     bool em_pending[2] = {false, false};
     uint32_t *d_grp_counts = nullptr;  // [sites][groups + 1][512] in group mode
     size_t grp_counts_cap = 0;
+    uint32_t *d_grp_counts_alt = nullptr;
+    size_t grp_counts_alt_cap = 0;
     char *d_stage = nullptr;           // staging for BVC_PTR_HOST calls
     size_t stage_cap = 0;
     bool profiling = false;
@@ -226,6 +228,7 @@ void bvc_destroy(bvc_ctx *ctx)
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
     if (ctx->d_grp_counts) (void)hipFree(ctx->d_grp_counts);
+    if (ctx->d_grp_counts_alt) (void)hipFree(ctx->d_grp_counts_alt);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     delete ctx;
 }
@@ -475,22 +478,42 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
     if (n_groups < 1 || n_groups > BVC_MAX_GROUPS) return fail(ctx, BVC_ERR_ARG, "n_groups must be 1..32");
     if (!group_of_sample || !grp_results) return fail(ctx, BVC_ERR_ARG, "null group pointer");
     if (n_sites == 0) return BVC_OK;
-    rc = join_side(ctx);                        // this path shares d_counts with overlapped dense calls
-    if (rc != BVC_OK) return rc;
     const int n_hist = n_groups + 1;
 
+    // Same two-stage structure as the plain dense call: stage 1 (one pass, n_groups + 1 histograms per site) on the
+    // context's stream; stage 2 (sum, overall LRT, per-group LRT) on the side stream in overlap mode.
     auto run_device = [&](int64_t ns, const int8_t *b, const int8_t *q, const int8_t *r, const uint8_t *g,
                           bvc_site_result *res, bvc_group_result *gres) -> int {
-        int rc2 = ensure(ctx, reinterpret_cast<void **>(&ctx->d_counts), &ctx->counts_cap,
-                         (size_t)ns * BVC_NCLASS * sizeof(uint32_t));
+        const int buf = ctx->overlap ? ctx->flip : 0;
+        if (ctx->overlap) ctx->flip ^= 1;
+        uint32_t **cp = buf ? &ctx->d_counts_alt : &ctx->d_counts;
+        size_t *ccap = buf ? &ctx->counts_alt_cap : &ctx->counts_cap;
+        uint32_t **gp = buf ? &ctx->d_grp_counts_alt : &ctx->d_grp_counts;
+        size_t *gcap = buf ? &ctx->grp_counts_alt_cap : &ctx->grp_counts_cap;
+        const size_t cbytes = (size_t)ns * BVC_NCLASS * sizeof(uint32_t), gbytes = cbytes * (size_t)n_hist;
+        if (cbytes > *ccap || gbytes > *gcap) { int rj = join_side(ctx); if (rj != BVC_OK) return rj; }
+        int rc2 = ensure(ctx, reinterpret_cast<void **>(cp), ccap, cbytes);
         if (rc2 != BVC_OK) return rc2;
-        rc2 = ensure(ctx, reinterpret_cast<void **>(&ctx->d_grp_counts), &ctx->grp_counts_cap,
-                     (size_t)ns * n_hist * BVC_NCLASS * sizeof(uint32_t));
+        rc2 = ensure(ctx, reinterpret_cast<void **>(gp), gcap, gbytes);
         if (rc2 != BVC_OK) return rc2;
-        BVC_HIP(ctx, launch_hist_dense(ctx->stream, ns, n_samples, row_stride, b, q, g, n_groups, ctx->d_grp_counts, 1));
-        BVC_HIP(ctx, launch_sum_groups(ctx->stream, ns, n_hist, ctx->d_grp_counts, ctx->d_counts));
-        BVC_HIP(ctx, launch_lrt(ctx->stream, ns, ctx->d_counts, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res));
-        BVC_HIP(ctx, launch_lrt_groups(ctx->stream, ns, n_groups, ctx->d_grp_counts, r, min_af, ctx->d_lut, res, gres));
+        if (ctx->overlap && ctx->em_pending[buf]) {
+            BVC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_em_done[buf], 0));
+            ctx->em_pending[buf] = false;
+        }
+        BVC_HIP(ctx, launch_hist_dense(ctx->stream, ns, n_samples, row_stride, b, q, g, n_groups, *gp, 1));
+        hipStream_t s2 = ctx->stream;
+        if (ctx->overlap) {
+            s2 = ctx->side;
+            BVC_HIP(ctx, hipEventRecord(ctx->ev_hist_done[buf], ctx->stream));
+            BVC_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_hist_done[buf], 0));
+        }
+        BVC_HIP(ctx, launch_sum_groups(s2, ns, n_hist, *gp, *cp));
+        BVC_HIP(ctx, launch_lrt(s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res));
+        BVC_HIP(ctx, launch_lrt_groups(s2, ns, n_groups, *gp, r, min_af, ctx->d_lut, res, gres));
+        if (ctx->overlap) {
+            BVC_HIP(ctx, hipEventRecord(ctx->ev_em_done[buf], s2));
+            ctx->em_pending[buf] = true;
+        }
         return BVC_OK;
     };
 
@@ -522,6 +545,7 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
         BVC_HIP(ctx, hipMemcpyAsync(d_q, quals + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
         BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base + s0, (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
         rc = run_device(ns, d_b, d_q, d_r, d_g, d_res, d_gres);
+        if (rc == BVC_OK) rc = join_side(ctx);
         if (rc != BVC_OK) return rc;
         BVC_HIP(ctx, hipMemcpyAsync(results + s0, d_res, (size_t)ns * sizeof(bvc_site_result), hipMemcpyDeviceToHost,
                                     ctx->stream));

@@ -7,6 +7,17 @@
 
 namespace bvc {
 
+// Per-device one-time setup flags (function attributes, constant tables).  A process may drive several
+// devices from several threads (the host program does: thread i -> device i mod gpus), so "done once" is
+// tracked per device and the setup itself is idempotent.
+constexpr int kMaxDevices = 64;
+inline int current_device_slot()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+    return d;
+}
+
 // Base-quality -> likelihood table, built on the HOST with the same libm exp() the CPU path uses
 // (src/BaseType.cpp:13,15) and uploaded once per context:
 //   a[q] = 1 - eps   likelihood of the observed base given the matching allele

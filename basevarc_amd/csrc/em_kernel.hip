@@ -17,6 +17,7 @@
 //                                                             E   = sum_c       n_c e_c / m_c
 //   stop rule     delta = sum_c n_c |log m_c' - log m_c| < 1e-3
 // FP64 throughout; no MFMA (nothing here is a dense contraction).
+#include <atomic>
 #include <cstdlib>
 
 #include "bvc_device.h"
@@ -493,8 +494,10 @@ __global__ void sum_groups_kernel(int64_t total, int n_hist, const uint32_t *__r
 // Waves the EM kernels keep on the chip: 8 per CU (2 per SIMD) by default; BVC_EM_WAVES_PER_CU overrides.
 static int64_t em_grid_cap()
 {
-    static int64_t cap = 0;
-    if (cap == 0) {
+    static std::atomic<int64_t> cap_dev[kMaxDevices];
+    std::atomic<int64_t> &cap = cap_dev[current_device_slot()];
+    int64_t c = cap.load();
+    if (c == 0) {
         int per_cu = 8;
         if (const char *e = getenv("BVC_EM_WAVES_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) per_cu = v; }
         int dev = 0, n_cu = 256;
@@ -502,9 +505,10 @@ static int64_t em_grid_cap()
             hipDeviceProp_t p;
             if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) n_cu = p.multiProcessorCount;
         }
-        cap = (int64_t)per_cu * n_cu;
+        c = (int64_t)per_cu * n_cu;
+        cap.store(c);
     }
-    return cap;
+    return c;
 }
 
 hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *counts, int64_t hist_stride,

@@ -10,6 +10,8 @@
 // The LDS histogram is replicated kCopies times with copy = lane % kCopies, laid out [class][copy], so the
 // bank of an update is lane % 32 whatever the data are: the heavily skewed keys of real pileups (>90 %
 // reference base, a handful of quality values) cannot cause bank or same-address conflicts.
+#include <atomic>
+
 #include "bvc_device.h"
 #include "bvc_internal.h"
 
@@ -188,17 +190,24 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
             const u32x4 *bv = reinterpret_cast<const u32x4 *>(brow);
             const u32x4 *qv = reinterpret_cast<const u32x4 *>(qrow);
             const u32x4 *gv = reinterpret_cast<const u32x4 *>(group_of_sample);
-            for (int64_t c = tid; c < n16; c += kHistThreads) {
-                const u32x4 b = __builtin_nontemporal_load(&bv[c]);
-                const u32x4 q = __builtin_nontemporal_load(&qv[c]);
-                const u32x4 g = gv[c];
+            auto count16 = [&](const u32x4 b, const u32x4 q, const u32x4 g) {
                 const uint32_t bw[4] = {b.x, b.y, b.z, b.w}, qw[4] = {q.x, q.y, q.z, q.w}, gw[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
                 for (int w = 0; w < 4; ++w)
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         add((bw[w] >> (8 * k)) & 0xFFu, (qw[w] >> (8 * k)) & 0xFFu, (gw[w] >> (8 * k)) & 0xFFu);
+            };
+            int64_t c = tid;
+            for (; c + kHistThreads < n16; c += 2 * kHistThreads) {        // two 16-byte loads per array in flight
+                const u32x4 b0 = __builtin_nontemporal_load(&bv[c]), b1 = __builtin_nontemporal_load(&bv[c + kHistThreads]);
+                const u32x4 q0 = __builtin_nontemporal_load(&qv[c]), q1 = __builtin_nontemporal_load(&qv[c + kHistThreads]);
+                const u32x4 g0 = gv[c], g1 = gv[c + kHistThreads];
+                count16(b0, q0, g0);
+                count16(b1, q1, g1);
             }
+            for (; c < n16; c += kHistThreads)
+                count16(__builtin_nontemporal_load(&bv[c]), __builtin_nontemporal_load(&qv[c]), gv[c]);
         }
         for (int64_t i = (n16 << 4) + tid; i < n_samples; i += kHistThreads)
             add((uint8_t)brow[i], (uint8_t)qrow[i], group_of_sample[i]);
@@ -268,8 +277,9 @@ hipError_t launch_hist_dense(hipStream_t stream, int64_t n_sites, int64_t n_samp
                              int n_groups, uint32_t *counts, int split)
 {
     if (n_sites <= 0) return hipSuccess;
-    static bool attr_done[2] = {false, false};
-    static bool gattr_done[2] = {false, false};
+    static std::atomic<bool> attr_done_dev[kMaxDevices][2], gattr_done_dev[kMaxDevices][2];
+    std::atomic<bool> *attr_done = attr_done_dev[current_device_slot()];
+    std::atomic<bool> *gattr_done = gattr_done_dev[current_device_slot()];
     const bool aligned = ((reinterpret_cast<uintptr_t>(bases) | reinterpret_cast<uintptr_t>(quals)) & 15u) == 0 &&
                          (row_stride & 15) == 0;
     const size_t lds = (size_t)kLdsWords * sizeof(uint32_t);
@@ -308,7 +318,8 @@ hipError_t launch_hist_csr(hipStream_t stream, int64_t n_sites, const int64_t *o
                            const int8_t *bases, const int8_t *quals, uint32_t *counts)
 {
     if (n_sites <= 0) return hipSuccess;
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done_dev[kMaxDevices];
+    std::atomic<bool> &attr_done = attr_done_dev[current_device_slot()];
     const size_t lds = (size_t)kLdsWords * sizeof(uint32_t);
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(hist_csr_kernel),

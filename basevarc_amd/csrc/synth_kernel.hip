@@ -2,6 +2,8 @@
 // Integer arithmetic only, so any site can be regenerated bit for bit on the CPU by the test oracle
 // without ever storing or moving the tile.  Not part of the reference: it exists because the
 // benchmark configs (1e5 sites x 1e6 samples = 200 GB) can only be produced where they are consumed.
+#include <atomic>
+
 #include "bvc_internal.h"
 #include "synth_tables.inc"
 
@@ -100,7 +102,8 @@ hipError_t launch_synth_dense(hipStream_t stream, uint64_t seed, int64_t site0, 
                               int8_t *bases, int8_t *quals, int8_t *ref_base)
 {
     if (n_sites <= 0 || n_samples < 0) return hipSuccess;
-    static bool tables_done = false;
+    static std::atomic<bool> tables_done_dev[kMaxDevices];       // __constant__ symbols are per device
+    std::atomic<bool> &tables_done = tables_done_dev[current_device_slot()];
     if (!tables_done) {
         hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_af_thr), SYNTH_AF_THR, sizeof(SYNTH_AF_THR));
         if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_err_thr), SYNTH_ERR_THR, sizeof(SYNTH_ERR_THR));
