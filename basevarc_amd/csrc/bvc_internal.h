@@ -43,11 +43,11 @@ hipError_t launch_hist_csr(hipStream_t stream, int64_t n_sites, const int64_t *o
 //   {ref}+alt_bases define the candidates and whose `called` gates the run (group mode).
 hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *counts, int64_t hist_stride,
                       const int8_t *ref_base, double min_af, const QualLut *lut,
-                      const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results);
+                      const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results, bool shared = false);
 
 hipError_t launch_lrt_groups(hipStream_t stream, int64_t n_sites, int n_groups, const uint32_t *grp_counts,
                              const int8_t *ref_base, double min_af, const QualLut *lut,
-                             const bvc_site_result *overall, bvc_group_result *grp_results);
+                             const bvc_site_result *overall, bvc_group_result *grp_results, bool shared = false);
 
 // Sum the per-group histograms (+ the "no group" one) into the overall histogram of each site.
 hipError_t launch_sum_groups(hipStream_t stream, int64_t n_sites, int n_hist, const uint32_t *grp_counts,

@@ -491,33 +491,37 @@ __global__ void sum_groups_kernel(int64_t total, int n_hist, const uint32_t *__r
 
 }  // namespace
 
-// Waves the EM kernels keep on the chip: 8 per CU (2 per SIMD) by default; BVC_EM_WAVES_PER_CU overrides.
-static int64_t em_grid_cap()
+// Waves the EM kernels keep on the chip.  `shared` = the launch runs underneath a streaming histogram kernel
+// (overlap mode with long rows): 8 per CU (2 per SIMD) leaves that kernel its wave slots and registers.
+// Otherwise the kernel has the chip to itself for most of its life and takes 24 per CU.
+// BVC_EM_WAVES_PER_CU overrides both.
+static int64_t em_grid_cap(bool shared)
 {
-    static std::atomic<int64_t> cap_dev[kMaxDevices];
-    std::atomic<int64_t> &cap = cap_dev[current_device_slot()];
-    int64_t c = cap.load();
-    if (c == 0) {
-        int per_cu = 8;
-        if (const char *e = getenv("BVC_EM_WAVES_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) per_cu = v; }
-        int dev = 0, n_cu = 256;
+    static std::atomic<int> n_cu_dev[kMaxDevices];
+    std::atomic<int> &n_cu_a = n_cu_dev[current_device_slot()];
+    int n_cu = n_cu_a.load();
+    if (n_cu == 0) {
+        n_cu = 256;
+        int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess) {
             hipDeviceProp_t p;
             if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) n_cu = p.multiProcessorCount;
         }
-        c = (int64_t)per_cu * n_cu;
-        cap.store(c);
+        n_cu_a.store(n_cu);
     }
-    return c;
+    int per_cu = shared ? 8 : 24;
+    if (const char *e = getenv("BVC_EM_WAVES_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) per_cu = v; }
+    return (int64_t)per_cu * n_cu;
 }
 
 hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *counts, int64_t hist_stride,
                       const int8_t *ref_base, double min_af, const QualLut *lut,
-                      const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results)
+                      const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results, bool shared)
 {
     if (n_sites <= 0) return hipSuccess;
+    const int64_t cap = em_grid_cap(shared);
     // Every variant visits every site; a wave skips a site at once when it belongs to another variant.
-    const dim3 grid((unsigned)(n_sites < em_grid_cap() ? n_sites : em_grid_cap()));
+    const dim3 grid((unsigned)(n_sites < cap ? n_sites : cap));
     hipLaunchKernelGGL(lrt_kernel<2>, grid, dim3(64), 0, stream, n_sites, counts, hist_stride,
                        ref_base, min_af, lut, comb, n_comb, results);
     hipLaunchKernelGGL(lrt_kernel<4>, grid, dim3(64), 0, stream, n_sites, counts, hist_stride,
@@ -530,11 +534,12 @@ hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *count
 
 hipError_t launch_lrt_groups(hipStream_t stream, int64_t n_sites, int n_groups, const uint32_t *grp_counts,
                              const int8_t *ref_base, double min_af, const QualLut *lut,
-                             const bvc_site_result *overall, bvc_group_result *grp_results)
+                             const bvc_site_result *overall, bvc_group_result *grp_results, bool shared)
 {
     if (n_sites <= 0 || n_groups <= 0) return hipSuccess;
+    const int64_t cap = em_grid_cap(shared);
     const int64_t n_work = n_sites * n_groups;
-    const dim3 grid((unsigned)(n_work < em_grid_cap() ? n_work : em_grid_cap()));
+    const dim3 grid((unsigned)(n_work < cap ? n_work : cap));
     hipLaunchKernelGGL(lrt_groups_kernel<2>, grid, dim3(64), 0, stream, n_sites, n_groups, grp_counts, ref_base,
                        min_af, lut, overall, grp_results);
     hipLaunchKernelGGL(lrt_groups_kernel<4>, grid, dim3(64), 0, stream, n_sites, n_groups, grp_counts, ref_base,
