@@ -560,6 +560,25 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
     return BVC_OK;
 }
 
+int bvc_stream_read_ms(bvc_ctx *ctx, const void *device_ptr, int64_t bytes, int repeats, double *ms_per_pass)
+{
+    if (!ctx || !device_ptr || !ms_per_pass || bytes < 16 || repeats < 1) return ctx ? fail(ctx, BVC_ERR_ARG, "bad argument") : BVC_ERR_ARG;
+    BVC_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_counts), &ctx->counts_cap, 256);
+    if (rc != BVC_OK) return rc;
+    hipEvent_t a = take_event(ctx), b = take_event(ctx);
+    BVC_HIP(ctx, launch_stream_read(ctx->stream, device_ptr, bytes, ctx->d_counts));        // warm-up
+    BVC_HIP(ctx, hipEventRecord(a, ctx->stream));
+    for (int i = 0; i < repeats; ++i) BVC_HIP(ctx, launch_stream_read(ctx->stream, device_ptr, bytes, ctx->d_counts));
+    BVC_HIP(ctx, hipEventRecord(b, ctx->stream));
+    BVC_HIP(ctx, hipEventSynchronize(b));
+    float ms = 0.f;
+    BVC_HIP(ctx, hipEventElapsedTime(&ms, a, b));
+    ctx->ev_pool.push_back(a); ctx->ev_pool.push_back(b);
+    *ms_per_pass = (double)ms / repeats;
+    return BVC_OK;
+}
+
 int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites, int64_t n_samples,
                     int64_t row_stride, uint32_t cov_thr16, int8_t *bases, int8_t *quals, int8_t *ref_base)
 {

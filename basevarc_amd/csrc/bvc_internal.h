@@ -34,6 +34,8 @@ hipError_t launch_hist_dense(hipStream_t stream, int64_t n_sites, int64_t n_samp
 // Number of sample-range splits per site launch_hist_dense should use for this shape (1 = none).
 int choose_hist_split(int64_t n_sites, int64_t n_samples, int n_cu);
 
+hipError_t launch_stream_read(hipStream_t stream, const void *src, int64_t bytes, uint32_t *sink);
+
 hipError_t launch_hist_csr(hipStream_t stream, int64_t n_sites, const int64_t *offsets,
                            const int8_t *bases, const int8_t *quals, uint32_t *counts);
 

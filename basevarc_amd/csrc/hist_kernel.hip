@@ -256,6 +256,32 @@ __global__ __launch_bounds__(kHistThreads) void hist_csr_kernel(
     }
 }
 
+// Plain streaming read, 16 B per lane, nothing else: the empirical HBM read ceiling the histogram kernel is
+// compared with next to the 8 TB/s spec figure.  The XOR keeps the loads alive.
+__global__ __launch_bounds__(512) void stream_read_kernel(const u32x4 *__restrict__ src, int64_t n16, uint32_t *__restrict__ sink)
+{
+    uint32_t acc = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + stride < n16; i += 2 * stride) {
+        const u32x4 a = __builtin_nontemporal_load(&src[i]), b = __builtin_nontemporal_load(&src[i + stride]);
+        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w;
+    }
+    for (; i < n16; i += stride) { const u32x4 a = __builtin_nontemporal_load(&src[i]); acc ^= a.x ^ a.y ^ a.z ^ a.w; }
+    if (acc == 0x9E3779B9u) sink[0] = acc;       // practically never: the store only makes the result observable
+}
+
+}  // namespace
+
+hipError_t launch_stream_read(hipStream_t stream, const void *src, int64_t bytes, uint32_t *sink)
+{
+    const int64_t n16 = bytes / 16;
+    if (n16 <= 0) return hipSuccess;
+    hipLaunchKernelGGL(stream_read_kernel, dim3(4096), dim3(512), 0, stream, reinterpret_cast<const u32x4 *>(src), n16, sink);
+    return hipGetLastError();
+}
+
+namespace {
 }  // namespace
 
 int choose_hist_split(int64_t n_sites, int64_t n_samples, int n_cu)

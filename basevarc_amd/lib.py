@@ -49,7 +49,7 @@ assert GROUP_DTYPE.itemsize == C.sizeof(GroupResult) == 48
 EXPORTS = [
     "bvc_version", "bvc_device_count", "bvc_create", "bvc_destroy", "bvc_last_error", "bvc_set_stream",
     "bvc_synchronize", "bvc_set_overlap", "bvc_join", "bvc_set_profiling", "bvc_get_profile", "bvc_lrt_dense", "bvc_lrt_dense_groups",
-    "bvc_lrt_csr", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense",
+    "bvc_lrt_csr", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense", "bvc_stream_read_ms",
 ]
 
 _lib = None
@@ -96,6 +96,8 @@ def load_library():
     L.bvc_lrt_hist.argtypes = [vp, i64, vp, vp, dbl, vp, vp, vp, u32]
     L.bvc_synth_dense.restype = C.c_int
     L.bvc_synth_dense.argtypes = [vp, C.c_uint64, i64, i64, i64, i64, u32, vp, vp, vp]
+    L.bvc_stream_read_ms.restype = C.c_int
+    L.bvc_stream_read_ms.argtypes = [vp, vp, i64, C.c_int, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -269,6 +271,17 @@ class Context:
         ns, n = bases_t.shape
         self._check(self._L.bvc_synth_dense(self._h, int(seed), int(site0), ns, n, bases_t.stride(0), int(cov_thr16),
                                             _dev_ptr(bases_t), _dev_ptr(quals_t), _dev_ptr(ref_t)))
+
+
+def _stream_read_gbs(self, tensor, repeats=5):
+    """Empirical HBM read bandwidth (GB/s): a plain 16 B/lane streaming read of `tensor` (device, contiguous)."""
+    ms = C.c_double()
+    nbytes = tensor.numel() * tensor.element_size()
+    self._check(self._L.bvc_stream_read_ms(self._h, _dev_ptr(tensor), nbytes, int(repeats), C.byref(ms)))
+    return nbytes / (ms.value * 1e-3) / 1e9
+
+
+Context.stream_read_gbs = _stream_read_gbs
 
 
 def results_from_tensor(results_t):

@@ -123,6 +123,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # empirical read ceiling: the same 8 GB tile through a plain 16 B/lane streaming kernel
+    empirical_gbs = ctx.stream_read_gbs(tiles[0][0].as_strided((a.tile_sites, stride), (stride, 1)))
     for i in range(a.warmup):
         step(n_tiles - 1 - (i % n_tiles))
     barrier()
@@ -167,6 +169,7 @@ def main():
             "bound": "hbm", "kernel": "hist_dense_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a, n),
             "avg_launch_ms": hist_ms, "algorithmic_bytes_per_launch": alg_bytes,
+            "empirical_stream_read_GBs": empirical_gbs, "frac_of_empirical": achieved / empirical_gbs if empirical_gbs else None,
         },
         "kernels_ms_per_step": {"hist_dense_kernel": hist_ms, "lrt_kernel": em_ms},
     }

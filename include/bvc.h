@@ -159,6 +159,11 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
                     int64_t row_stride, uint32_t cov_thr16, int8_t *bases, int8_t *quals,
                     int8_t *ref_base);
 
+/* ---- measurement aid ------------------------------------------------------------------------------- */
+/* Streams `bytes` of device memory once with 16-byte loads per lane and nothing else; HIP-event time in ms.
+ * The empirical HBM read ceiling to hold next to the spec peak when judging the histogram kernel. */
+int bvc_stream_read_ms(bvc_ctx *ctx, const void *device_ptr, int64_t bytes, int repeats, double *ms_per_pass);
+
 #ifdef __cplusplus
 }
 #endif
