@@ -40,9 +40,8 @@ constexpr double kEmEpsilon = 0.001;      // src/BaseType.cpp:45
 template <int NS>
 struct Slots {
     double n[NS];    // class count (0 for an empty slot)
-    double a[NS];    // 1 - eps : likelihood when the allele matches the class's base
-    double e[NS];    // eps / 3 : likelihood when it does not
-    double d[NS];    // a - e
+    double e[NS];    // eps / 3 : likelihood of the observed base given a non-matching allele
+    double d[NS];    // (1 - eps) - eps / 3 : matching minus non-matching likelihood
     double yp[NS];   // 1 / (class marginal) from the previous pass
 };
 
@@ -75,13 +74,15 @@ __device__ __forceinline__ int pick4(const int (&v)[4], int j)
     return j == 0 ? v[0] : (j == 1 ? v[1] : (j == 2 ? v[2] : v[3]));
 }
 
-// Frequencies live per lane: fb = frequency of the lane's own base, g = sum of the other three.  The class
-// marginal is m = fb * a + g * e -- the reference's sum_j f_j * L_ij with the three equal terms grouped;
-// every term is non-negative, so nothing cancels (src/Algorithm.cpp:74-78).
-// g is taken as 1 - fb: the four frequencies sum to 1 after every M step (sum_j expect_j = (1/N) sum_i 1)
-// and at the start (depth ratios), up to a few ulp -- the same few ulp the reference's own f_j carry.
+// Frequencies live per lane: fb = frequency of the lane's own base.  The class marginal is the reference's
+// sum_j f_j * L_ij (src/Algorithm.cpp:74-78) with the three equal terms grouped and the other three
+// frequencies taken as 1 - fb (the four sum to 1 after every M step, sum_j expect_j = (1/N) sum_i 1, and at
+// the start, up to the few ulp the reference's own f_j carry):
+//     m = fb * a + (1 - fb) * e = fb * (a - e) + e = fma(fb, d, e)
+// One rounding of the exact value; for a = 0 (Q = 0) d = -e exactly and m = e * (1 - fb) comes out with full
+// relative accuracy, including m = 0 when fb = 1 -- the case the reference leaves unguarded (:81-82).
 struct Freq {
-    double fb, g;
+    double fb;
 };
 
 struct PassOut {
@@ -100,7 +101,7 @@ struct PassOut {
 //   near (all |u| < 2^-9): two Newton steps, delta from the cubic log1p series (truncation 3e-12 relative)
 //   far  (some |u| in [2^-9, 2^-6]): two Newton steps, delta reported as "not converged"
 //   jump (some |u| > 2^-6, first passes of a fit): v_rcp_f64 + two Newton steps, "not converged"
-// Empty slots have a = e = 1, so m = 1 and u = 0 to an ulp: they never raise the tier.
+// Empty slots have d = 0, e = 1, so m = 1 and u = 0 to an ulp: they never raise the tier.
 // The NS slots are independent dependency chains with no branch between them, so they interleave.
 constexpr double kFarU = 0.001953125;                       // 2^-9
 constexpr double kNotConverged = 1.0;                       // any value >= kEmEpsilon
@@ -113,7 +114,7 @@ __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double in
     double umax = 0.0;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-        m[k] = fma(f.fb, S.a[k], f.g * S.e[k]);
+        m[k] = fma(f.fb, S.d[k], S.e[k]);
         u[k] = fma(m[k], S.yp[k], -1.0);
         umax = fmax(umax, fabs(u[k]));                      // fmax drops a NaN: NaN lanes take the near tier
     }
@@ -164,7 +165,7 @@ template <int NS>
 __device__ __forceinline__ double em_fit(Slots<NS> &S, int lane, double f0, double inv_n,
                                          double (&ex)[4], int &passes)
 {
-    Freq f{f0, 1.0 - f0};
+    Freq f{f0};
     PassOut o;
     // every fit starts from yp = 1 (not from the previous fit's, which may hold NaNs): its first pass then
     // has |u| = |m - 1| and takes the big tier, whose reciprocal does not depend on yp
@@ -176,7 +177,6 @@ __device__ __forceinline__ double em_fit(Slots<NS> &S, int lane, double f0, doub
         if (it > 0 && o.delta < kEmEpsilon) break;   // NaN never converges, as in the reference
         if (it == kEmIters) break;
         f.fb = o.ex_own;
-        f.g = 1.0 - o.ex_own;
     }
     ex[0] = lane_value<0>(o.ex_own);
     ex[1] = lane_value<16>(o.ex_own);
@@ -240,14 +240,13 @@ __device__ bool lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const int idx = t + 16 * k;
-        S.n[k] = 0.0; S.a[k] = 1.0; S.e[k] = 1.0; S.yp[k] = 1.0;     // empty slot: m = fb + g > 0, weight 0
+        S.n[k] = 0.0; S.d[k] = 0.0; S.e[k] = 1.0; S.yp[k] = 1.0;     // empty slot: m = 1, u = 0, weight 0
         if (idx < cnt_row) {
             const int q = s_q[row * 128 + idx];
             S.n[k] = (double)s_n[row * 128 + idx];
-            S.a[k] = lut->a[q];
             S.e[k] = lut->e[q];
+            S.d[k] = lut->a[q] - S.e[k];
         }
-        S.d[k] = S.a[k] - S.e[k];
     }
 
     // ---- BaseType::LRT ---------------------------------------------------------------------------
