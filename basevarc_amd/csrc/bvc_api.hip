@@ -560,6 +560,14 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
     return BVC_OK;
 }
 
+int bvc_set_tuning(const char *key, int value)
+{
+    if (!key) return BVC_ERR_ARG;
+    if (std::strcmp(key, "em_rows") == 0 && value >= -1 && value <= 1) { set_em_tuning(value, -1); return BVC_OK; }
+    if (std::strcmp(key, "em_waves_per_cu") == 0 && value >= 0 && value <= 32) { set_em_tuning(-2, value); return BVC_OK; }
+    return BVC_ERR_ARG;
+}
+
 int bvc_stream_read_ms(bvc_ctx *ctx, const void *device_ptr, int64_t bytes, int repeats, double *ms_per_pass)
 {
     if (!ctx || !device_ptr || !ms_per_pass || bytes < 16 || repeats < 1) return ctx ? fail(ctx, BVC_ERR_ARG, "bad argument") : BVC_ERR_ARG;

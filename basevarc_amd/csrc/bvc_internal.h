@@ -47,6 +47,9 @@ hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *count
                       const int8_t *ref_base, double min_af, const QualLut *lut,
                       const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results, bool shared = false);
 
+// rows_mode: -1 auto, 0 one site per wave, 1 four sites per wave; waves_per_cu: 0 = default policy
+void set_em_tuning(int rows_mode, int waves_per_cu);
+
 hipError_t launch_lrt_groups(hipStream_t stream, int64_t n_sites, int n_groups, const uint32_t *grp_counts,
                              const int8_t *ref_base, double min_af, const QualLut *lut,
                              const bvc_site_result *overall, bvc_group_result *grp_results, bool shared = false);

@@ -49,7 +49,7 @@ assert GROUP_DTYPE.itemsize == C.sizeof(GroupResult) == 48
 EXPORTS = [
     "bvc_version", "bvc_device_count", "bvc_create", "bvc_destroy", "bvc_last_error", "bvc_set_stream",
     "bvc_synchronize", "bvc_set_overlap", "bvc_join", "bvc_set_profiling", "bvc_get_profile", "bvc_lrt_dense", "bvc_lrt_dense_groups",
-    "bvc_lrt_csr", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense", "bvc_stream_read_ms",
+    "bvc_lrt_csr", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense", "bvc_stream_read_ms", "bvc_set_tuning",
 ]
 
 _lib = None
@@ -96,6 +96,7 @@ def load_library():
     L.bvc_lrt_hist.argtypes = [vp, i64, vp, vp, dbl, vp, vp, vp, u32]
     L.bvc_synth_dense.restype = C.c_int
     L.bvc_synth_dense.argtypes = [vp, C.c_uint64, i64, i64, i64, i64, u32, vp, vp, vp]
+    L.bvc_set_tuning.restype = C.c_int; L.bvc_set_tuning.argtypes = [C.c_char_p, C.c_int]
     L.bvc_stream_read_ms.restype = C.c_int
     L.bvc_stream_read_ms.argtypes = [vp, vp, i64, C.c_int, C.POINTER(C.c_double)]
     _lib = L
@@ -282,6 +283,12 @@ def _stream_read_gbs(self, tensor, repeats=5):
 
 
 Context.stream_read_gbs = _stream_read_gbs
+
+
+def set_tuning(key, value):
+    """Process-wide kernel tuning knob (include/bvc.h: "em_rows", "em_waves_per_cu"); results do not depend on it."""
+    if load_library().bvc_set_tuning(key.encode(), int(value)) != 0:
+        raise BvcError(f"bvc_set_tuning({key!r}, {value}) rejected")
 
 
 def results_from_tensor(results_t):

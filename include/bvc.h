@@ -159,6 +159,11 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
                     int64_t row_stride, uint32_t cov_thr16, int8_t *bases, int8_t *quals,
                     int8_t *ref_base);
 
+/* ---- tuning (process-wide; additive, no counterpart in the reference) ------------------------------- */
+/* key "em_rows": -1 pick by tile size (default), 0 one site per wavefront, 1 four sites per wavefront;
+ * key "em_waves_per_cu": 0 default policy, 1..32 resident EM wavefronts per CU.  Results do not depend on them. */
+int bvc_set_tuning(const char *key, int value);
+
 /* ---- measurement aid ------------------------------------------------------------------------------- */
 /* Streams `bytes` of device memory once with 16-byte loads per lane and nothing else; HIP-event time in ms.
  * The empirical HBM read ceiling to hold next to the spec peak when judging the histogram kernel. */

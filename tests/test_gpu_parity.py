@@ -363,6 +363,36 @@ def test_config2_1e4_sites_by_1e4_samples(ctx):
     assert 0.05 * ns < called < 0.5 * ns          # ~20 % polymorphic sites in the mixture
 
 
+@pytest.mark.parametrize("rows", [0, 1])
+def test_both_em_layouts_match_the_oracle(ctx, rows):
+    """One site per wavefront and four sites per wavefront (rows) are two layouts of the same arithmetic."""
+    import torch
+    from basevarc_amd.lib import results_from_tensor, set_tuning
+    try:
+        set_tuning("em_rows", rows)
+        for n, ns in ((3000, 401), (40000, 97)):
+            m = caller_min_af(n)
+            b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+            q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+            r = torch.empty(ns, dtype=torch.int8, device="cuda")
+            ctx.synth_dense_device(9, 777, b, q, r)
+            res = results_from_tensor(ctx.lrt_dense_device(b, q, r, m))
+            exp, _ = orc.dense_batch(b.cpu().numpy(), q.cpu().numpy(), r.cpu().numpy(), m, use_hist=True)
+            for s in range(ns):
+                assert_site_matches(res[s], exp[s], where=f"rows={rows} n={n} site={s}", path_strict=False)
+        rng = np.random.default_rng(rows)
+        sites = [random_site(rng, nind, af=af, second_af=af2, qlo=qlo, qhi=qhi)
+                 for nind in (1, 7, 60, 900) for af, af2 in ((0.0, 0.0), (0.05, 0.0), (0.3, 0.1))
+                 for qlo, qhi in ((2, 41), (0, 127), (30, 33))]
+        B, Q, R = pad_rows(sites)
+        got = ctx.lrt_dense(B, Q, R, 0.001)
+        for s, (bb, qq, rr) in enumerate(sites):
+            assert_site_matches(got[s], orc.basetype_lrt(bb, qq, rr, 0.001), where=f"rows={rows} mixed site {s}",
+                                path_strict=False)
+    finally:
+        set_tuning("em_rows", -1)
+
+
 def test_overlap_mode_gives_identical_records(ctx):
     """Stage 2 on the side stream under the next call's stage 1 (bvc_set_overlap): same bytes out."""
     import torch
