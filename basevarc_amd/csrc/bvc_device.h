@@ -6,7 +6,6 @@
 namespace bvc {
 
 constexpr int kWave = 64;          // CDNA wavefront
-constexpr int kRow = 16;           // DPP row: one base's classes live on one row of 16 lanes
 
 // ---- cross-lane movement -------------------------------------------------------------------------
 // DPP controls (ISA: quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141)
@@ -64,15 +63,6 @@ __device__ __forceinline__ int row_sum(int v)
     return v;
 }
 
-__device__ __forceinline__ int row_max(int v)
-{
-    v = max(v, dpp_i32<kDppXor1>(v));
-    v = max(v, dpp_i32<kDppXor2>(v));
-    v = max(v, dpp_i32<kDppHalfMirror>(v));
-    v = max(v, dpp_i32<kDppMirror>(v));
-    return v;
-}
-
 // Value held by `lane` (compile-time), broadcast through SGPRs: wave-uniform by construction.
 template <int LANE>
 __device__ __forceinline__ double lane_value(double v)
@@ -86,13 +76,6 @@ __device__ __forceinline__ double lane_value(double v)
 __device__ __forceinline__ double rows_total(double v)
 {
     return ((lane_value<0>(v) + lane_value<16>(v)) + lane_value<32>(v)) + lane_value<48>(v);
-}
-
-__device__ __forceinline__ double uniform(double v)
-{
-    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
 }
 
 // ---- gfx950 cross-row exchange ---------------------------------------------------------------------
@@ -132,20 +115,9 @@ __device__ __forceinline__ double fast_rcp(double x)
     return y;
 }
 
-// log1p(u) for |u| <= 2^-6 by its Taylor series to u^8 (truncation < 5e-16 relative).
-constexpr double kLog1pMaxU = 0.015625;
-__device__ __forceinline__ double log1p_small(double u)
-{
-    double p = -1.0 / 8.0;
-    p = fma(p, u, 1.0 / 7.0);
-    p = fma(p, u, -1.0 / 6.0);
-    p = fma(p, u, 1.0 / 5.0);
-    p = fma(p, u, -1.0 / 4.0);
-    p = fma(p, u, 1.0 / 3.0);
-    p = fma(p, u, -1.0 / 2.0);
-    p = fma(p, u, 1.0);
-    return u * p;
-}
+// Above this relative change of a class marginal the reciprocal is taken from v_rcp_f64 instead of a Newton
+// update of the previous one (em_kernel.hip).
+constexpr double kLog1pMaxU = 0.015625;   // 2^-6
 
 // Natural log of a positive finite double (about 2 ulp): frexp, then 2*atanh((m-1)/(m+1)) on
 // m in [sqrt(1/2), sqrt(2)).  0 -> -inf, NaN -> NaN.

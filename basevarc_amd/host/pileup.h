@@ -60,7 +60,6 @@ extern const char *const kVcfHeader;
 std::string cvg_header(const Groups &g);
 std::string vcf_header(const Groups &g, const std::string &reference, const std::vector<std::string> &sample_names);
 
-struct CvgCounts { int na, nc, ng, nt; };
 // CVG line without the trailing newline handling of groups: pass grp (n_groups records) or nullptr.
 std::string cvg_line(const std::string &chr, int32_t pos, int8_t ref_base, const SiteColumn &site,
                      const bvc_group_result *grp, int n_groups);
