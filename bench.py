@@ -36,7 +36,7 @@ def parse():
     p.add_argument("--tile-sites", type=int, default=4000, help="sites per step")
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--cpu-sites", type=int, default=-1, help="sites for the CPU baseline (-1: one per core, 0: skip)")
-    p.add_argument("--no-verify", action="store_true", help="skip the post-run spot check against the oracle")
+    p.add_argument("--no-verify", action="store_true", help="CPU leg: time the baseline only, skip the wider check")
     p.add_argument("--no-overlap", action="store_true", help="run the two kernels of a step back to back on one stream")
     p.add_argument("--groups", type=int, default=0, help="population groups (BASELINE configs[4]: 5); 0 = overall call only")
     p.add_argument("--coverage", type=float, default=1.0, help="fraction of samples covered per site (sparse variant)")
@@ -178,12 +178,18 @@ def main():
         last = results_from_tensor(results[(a.steps - 1) % n_tiles])
         out["em_passes_per_site"] = float(last["n_passes"].mean())
         out["called_fraction"] = float(last["called"].mean())
-    if rank == 0 and not a.no_verify:
-        out["verified"] = spot_check(ctx, tiles, results, min_af, a, np)
-        if a.groups > 0:
-            out["verified_groups"] = spot_check_groups(ctx, tiles, results, grp_results, group_t, min_af, a, np)
     if rank == 0 and world == 1 and a.cpu_sites != 0:
-        out["cpu_baseline"] = cpu_baseline(tiles[0], min_af, a, np)
+        # CPU leg (the only place the oracle is used here): the reference path's CPU port timed on a bounded sample
+        # of the same workload, and -- since its answers are at hand -- checked against the GPU records of those
+        # sites and of a wider sample through the oracle's histogram form.
+        step(0)
+        ctx.synchronize()
+        out["cpu_baseline"] = cpu_baseline(tiles[0], min_af, a, np, results_from_tensor(results[0]))
+        if not a.no_verify:
+            out["cpu_baseline"]["gpu_check_hist_form"] = spot_check(ctx, tiles, results, min_af, a, np)
+            if a.groups > 0:
+                out["cpu_baseline"]["gpu_check_groups"] = spot_check_groups(ctx, tiles, results, grp_results, group_t,
+                                                                            min_af, a, np)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -206,10 +212,10 @@ def pmc_traffic(a, n):
 
 
 def spot_check(ctx, tiles, results, min_af, a, np):
-    """After the timed region: 64 sites of the last processed tile against the oracle's histogram form."""
+    """Part of the CPU leg, after the timed region: 64 sites of tile 0 against the oracle's histogram form."""
     from basevarc_amd.lib import results_from_tensor
     from oracle import orc
-    i = (a.steps - 1) % len(tiles)
+    i = 0                                                    # tile 0 was just recomputed by the CPU leg
     b, q, r = tiles[i]
     res = results_from_tensor(results[i])
     pick = np.linspace(0, a.tile_sites - 1, 64).astype(int)
@@ -230,7 +236,7 @@ def spot_check_groups(ctx, tiles, results, grp_results, group_t, min_af, a, np):
     """8 sites of the last processed tile against the oracle's restatement of the caller's --group loop."""
     from basevarc_amd.lib import GROUP_DTYPE
     from oracle import orc
-    i = (a.steps - 1) % len(tiles)
+    i = 0
     b, q, r = tiles[i]
     g = group_t.cpu().numpy()
     gres = grp_results[i].cpu().numpy().view(GROUP_DTYPE).reshape(a.tile_sites, a.groups)
@@ -245,9 +251,10 @@ def spot_check_groups(ctx, tiles, results, grp_results, group_t, min_af, a, np):
     return {"sites_checked": int(len(pick)), "mismatches": int(bad)}
 
 
-def cpu_baseline(tile, min_af, a, np):
+def cpu_baseline(tile, min_af, a, np, gpu_records):
     """The faithful per-sample CPU port (oracle/basetype_oracle.c) on a bounded sample of the same
-    workload: one site per host thread (about 20 s each at N = 1e6)."""
+    workload: one site per host thread (about 10-20 s each at N = 1e6); its answers are compared with
+    the GPU records of the same sites."""
     from oracle import orc
     cores = os.cpu_count() or 1
     try:
@@ -260,11 +267,21 @@ def cpu_baseline(tile, min_af, a, np):
     b, q, r = tile
     hb, hq, hr = b[:k].cpu().numpy(), q[:k].cpu().numpy(), r[:k].cpu().numpy()
     t0 = time.perf_counter()
-    _, used = orc.dense_batch(hb, hq, hr, min_af, use_hist=False, threads=min(cores, k))
+    exp, used = orc.dense_batch(hb, hq, hr, min_af, use_hist=False, threads=min(cores, k))
     dt = time.perf_counter() - t0
+    bad = 0
+    for s, e in enumerate(exp):
+        g = gpu_records[s]
+        floor = 1e-6 + 2e-10 * abs(e["lr_alt"])             # drift of the per-sample sum
+        ok = (int(g["called"]) == e["called"] and [int(x) for x in g["depth"]] == e["depth"]
+              and [int(g["alt_base"][i]) for i in range(g["n_alt"])] == e["alt_base"]
+              and all(abs(float(g["af"][i]) - e["af"][i]) <= 1e-6 for i in range(e["n_alt"]))
+              and abs(float(g["var_qual"]) - e["var_qual"]) <= max(floor, 1e-6 * abs(e["var_qual"])))
+        bad += not ok
     return {"value": k / dt, "unit": "sites/s", "cores": int(used), "kind": "port",
             "sample": f"first {k} sites of tile 0 at N={a.samples}, one site per thread, faithful per-sample "
-                      f"restatement of BaseType ctor+LRT+EM (oracle/basetype_oracle.c), {dt:.1f} s"}
+                      f"restatement of BaseType ctor+LRT+EM (oracle/basetype_oracle.c), {dt:.1f} s",
+            "gpu_check_same_sites": {"sites": k, "mismatches": int(bad)}}
 
 
 if __name__ == "__main__":

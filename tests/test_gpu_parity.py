@@ -194,6 +194,31 @@ def test_set_base_and_min_af_filter(ctx):
             assert_site_matches(got[j], exps[i][0], where=f"setbase {i}")
 
 
+def test_min_af_zero_follows_the_reference_quirks(ctx):
+    """--maf 0: zero-depth bases pass the filter, UpdateF skips zero-coverage subsets while
+    `bc` keeps them (the index shift of src/BaseType.cpp:54 vs :104), and a candidate list without any coverage
+    makes the reference index an empty vector -- reported as status = 1, no call."""
+    rng = np.random.default_rng(41)
+    cases = []
+    for _ in range(40):
+        nind = int(rng.choice([6, 40, 500]))
+        b, q, ref = random_site(rng, nind, af=float(rng.choice([0.0, 0.1, 0.4])), qlo=20, qhi=40)
+        present = sorted(set(int(x) for x in b))
+        k = int(rng.integers(1, 5))
+        comb = [int(x) for x in rng.permutation(4)[:k]]
+        cases.append((b, q, ref, comb))
+    cases.append((np.array([3, 3, 3], dtype=np.int8), np.array([30, 30, 30], dtype=np.int8), 0, [0, 1]))   # no coverage at all
+    counts = np.array([orc.dense_hist(b, q) for b, q, _, _ in cases])
+    combs = np.array([c + [0] * (4 - len(c)) for _, _, _, c in cases], dtype=np.int8)
+    got = ctx.lrt_hist(counts, [r for _, _, r, _ in cases], 0.0, combs, [len(c) for _, _, _, c in cases])
+    n_status = 0
+    for s, (b, q, r, comb) in enumerate(cases):
+        e = orc.basetype_lrt(b, q, r, 0.0, base_comb=comb)
+        assert_site_matches(got[s], e, where=f"maf0 case {s} comb={comb}", path_strict=False)
+        n_status += e["status"]
+    assert n_status >= 1 and int(got[-1]["status"]) == 1 and int(got[-1]["called"]) == 0
+
+
 def test_basetype_facade_reads_like_the_reference(ctx):
     from basevarc_amd import BaseType
     rng = np.random.default_rng(2)
