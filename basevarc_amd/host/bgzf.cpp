@@ -60,6 +60,34 @@ void BgzfWriter::write(const char *data, size_t n)
     }
 }
 
+bool BgzfWriter::append_file(const std::string &path)
+{
+    if (!fp_) return false;
+    flush_block(buf_.size());
+    FILE *in = std::fopen(path.c_str(), "rb");
+    if (!in) return false;
+    std::fseek(in, 0, SEEK_END);
+    long size = std::ftell(in);
+    std::fseek(in, 0, SEEK_SET);
+    if (size >= 28) {                           // drop the trailing EOF marker when present
+        unsigned char tail[28];
+        std::fseek(in, size - 28, SEEK_SET);
+        if (std::fread(tail, 1, 28, in) == 28 && std::memcmp(tail, kEofMarker, 28) == 0) size -= 28;
+        std::fseek(in, 0, SEEK_SET);
+    }
+    std::vector<unsigned char> chunk(1 << 20);
+    bool good = true;
+    while (size > 0 && good) {
+        const size_t want = size < (long)chunk.size() ? (size_t)size : chunk.size();
+        const size_t got = std::fread(chunk.data(), 1, want, in);
+        if (got == 0) { good = false; break; }
+        if (std::fwrite(chunk.data(), 1, got, fp_) != got) { failed_ = true; good = false; }
+        size -= (long)got;
+    }
+    std::fclose(in);
+    return good;
+}
+
 bool BgzfWriter::close()
 {
     if (!fp_) return false;

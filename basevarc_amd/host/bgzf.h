@@ -19,6 +19,9 @@ class BgzfWriter {
     void write(const char *data, size_t n);
     void write(const std::string &s) { write(s.data(), s.size()); }
     bool close();                               // flushes and appends the EOF marker block
+    // Appends a finished BGZF file block for block (its EOF marker dropped): BGZF blocks are independent gzip
+    // members, so concatenating files is concatenating their blocks -- no inflate/deflate round trip.
+    bool append_file(const std::string &path);
  private:
     void flush_block(size_t n);
     FILE *fp_;

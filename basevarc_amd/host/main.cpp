@@ -416,14 +416,14 @@ static void run_basetype(int argc, char **argv)                          // src/
             });
         // merge the per-thread sub-files in thread (= position) order (src/BaseVarC.cpp:268-296)
         BgzfWriter fov(opt::output + ".vcf.gz"), foc(opt::output + ".cvg.gz");
-        std::string line;
         for (int i = 0; i < thread; ++i) {
             workers[(size_t)i].join();
             if (!werr.empty()) throw std::runtime_error(werr);
             const std::string subvcf = opt::output + "." + std::to_string(i) + ".vcf.gz";
             const std::string subcvg = opt::output + "." + std::to_string(i) + ".cvg.gz";
-            { BgzfReader fiv(subvcf); while (fiv.getline(line)) { line += '\n'; fov.write(line); } }
-            { BgzfReader fic(subcvg); while (fic.getline(line)) { line += '\n'; foc.write(line); } }
+            // the reference re-reads and re-compresses the sub-files line by line (src/BaseVarC.cpp:279-290); BGZF
+            // files concatenate block for block, which yields the same uncompressed stream
+            if (!fov.append_file(subvcf) || !foc.append_file(subcvg)) throw std::runtime_error("ERROR: fail to write");
             std::remove(subvcf.c_str());
             std::remove(subcvg.c_str());
         }
