@@ -840,7 +840,8 @@ hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *count
     // quarter the reduction work per site but need four times the sites to fill the chip: measured on MI355X
     // at N = 1e6, 0.83 vs 0.60 ms for a 4,000-site tile and 1.68 vs 1.95 ms for 16,000 sites.
     const int mode = g_em_rows_mode.load();
-    const bool rows = mode < 0 ? n_sites >= 12288 : mode != 0;
+    // (not underneath a streaming histogram kernel: its 248 registers per lane would take that kernel's occupancy)
+    const bool rows = mode < 0 ? (!shared && n_sites >= 12288) : mode != 0;
     if (rows) {
         // four sites per wave: a quarter of the waves hold the same number of sites in flight
         const int64_t want = (n_sites + 3) / 4;
