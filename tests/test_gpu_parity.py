@@ -455,7 +455,7 @@ def test_full_size_sites_1e6_samples(ctx):
     """configs[2] shape (N = 1e6 samples per site): exact histogram, and the LRT against the oracle."""
     import torch
     from basevarc_amd.lib import results_from_tensor
-    ns, n = 24, 1_000_000
+    ns, n = 256, 1_000_000
     m = caller_min_af(n)
     b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
     q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
@@ -464,12 +464,16 @@ def test_full_size_sites_1e6_samples(ctx):
     counts = ctx.hist_dense_device(b, q).cpu().numpy().view(np.uint32)
     res = results_from_tensor(ctx.lrt_dense_device(b, q, r, m))
     hb, hq, hr = b.cpu().numpy(), q.cpu().numpy(), r.cpu().numpy()
+    assert (counts.sum(axis=1) == n).all()             # checksum of every histogram = sample count
     for s in range(ns):
-        key = hb[s].astype(np.int64) * 128 + hq[s]
-        assert np.array_equal(counts[s], np.bincount(key, minlength=512).astype(np.uint32)), s
-        assert counts[s].sum() == n                    # checksum of the histogram = sample count
+        if s < 32:                                     # independent recount with numpy on a subset (slow in Python)
+            key = hb[s].astype(np.int64) * 128 + hq[s]
+            assert np.array_equal(counts[s], np.bincount(key, minlength=512).astype(np.uint32)), s
+        assert np.array_equal(counts[s], orc.dense_hist(hb[s], hq[s])), s
         assert_site_matches(res[s], orc.hist_lrt(counts[s], hr[s], m), where=f"1e6 hist-oracle site {s}",
                             path_strict=False)
+    same_path = np.mean([int(res[s]["n_passes"]) == orc.hist_lrt(counts[s], hr[s], m)["n_passes"] for s in range(ns)])
+    assert same_path > 0.97, same_path
     # faithful per-sample oracle on 4 sites (about 20 s each, run in parallel on the host cores)
     exp_f, _ = orc.dense_batch(hb[:4], hq[:4], hr[:4], m, use_hist=False)
     for s in range(4):
