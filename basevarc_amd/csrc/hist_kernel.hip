@@ -281,9 +281,6 @@ hipError_t launch_stream_read(hipStream_t stream, const void *src, int64_t bytes
     return hipGetLastError();
 }
 
-namespace {
-}  // namespace
-
 int choose_hist_split(int64_t n_sites, int64_t n_samples, int n_cu)
 {
     // Two 512-thread workgroups fit a CU (2 x 64 KiB LDS).  With fewer sites than that, cut each site's
