@@ -85,6 +85,9 @@ struct Freq {
     double fb;
 };
 
+constexpr int kDppRor8 = 0x128;                 // row_ror:8
+template <int L> constexpr int dpp_newbcast() { return 0x150 + L; }   // row_newbcast:L (lane L of each row)
+
 struct PassOut {
     double ex_own;          // expect_allele_prob of the lane's own base (uniform within the row)
     double delta;           // sum_c n_c |log m_c' - log m_c| (wave-uniform)
@@ -107,7 +110,7 @@ constexpr double kFarU = 0.001953125;                       // 2^-9
 constexpr double kNotConverged = 1.0;                       // any value >= kEmEpsilon
 
 template <int NS>
-__device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double inv_n)
+__device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double inv_n, int lane)
 {
     double acc_d = 0.0, acc_e = 0.0, acc_delta = 0.0;
     double m[NS], u[NS];
@@ -145,15 +148,22 @@ __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double in
         acc_d = fma(r, S.d[k], acc_d);
         acc_e = fma(r, S.e[k], acc_e);
     }
-    // E over lanes l, l+32 lands in the lower half, delta in the upper half; then rows, then row pairs
+    // Three sums in one 16-lane reduction.  swap32 folds the wave's halves: z = E over lanes (l, l+32) in the
+    // lower half, delta in the upper half.  Within each row, lanes 0-7 then reduce D and lanes 8-15 reduce z
+    // (one exchange across the row's halves, three butterfly steps); swap16 adds the row pairs.
     const DPair h = swap32(acc_e, acc_delta);
-    double drow = acc_d, z = h.a + h.b;
-    row_sum2(drow, z);
-    const DPair w = swap16(z, z);
-    z = w.a + w.b;
-    const double etot = lane_value<0>(z);
+    const double z = h.a + h.b;
+    const bool hi = (lane & 8) != 0;
+    double v = (hi ? z : acc_d) + dpp_f64<kDppRor8>(hi ? acc_d : z);
+    v += dpp_f64<kDppXor1>(v);
+    v += dpp_f64<kDppXor2>(v);
+    v += dpp_f64<kDppHalfMirror>(v);
+    const double drow = dpp_f64<dpp_newbcast<0>()>(v);          // lanes 0-7 of the row: D of the row's base
+    const DPair w = swap16(v, v);
+    const double t = w.a + w.b;                                  // lanes 8-15: rows 0,1 -> E, rows 2,3 -> delta
+    const double etot = lane_value<8>(t);
     PassOut o;
-    o.delta = far ? kNotConverged : lane_value<32>(z);
+    o.delta = far ? kNotConverged : lane_value<40>(t);
     o.ex_own = f.fb * inv_n * (drow + etot);
     return o;
 }
@@ -172,7 +182,7 @@ __device__ __forceinline__ double em_fit(Slots<NS> &S, int lane, double f0, doub
 #pragma unroll
     for (int k = 0; k < NS; ++k) S.yp[k] = 1.0;
     for (int it = 0;; ++it) {                  // pass 0 + at most kEmIters update passes
-        o = em_pass<NS>(S, f, inv_n);
+        o = em_pass<NS>(S, f, inv_n, lane);
         passes += 1;
         if (it > 0 && o.delta < kEmEpsilon) break;   // NaN never converges, as in the reference
         if (it == kEmIters) break;
@@ -425,8 +435,6 @@ __global__ __launch_bounds__(64) void lrt_kernel(int64_t n_sites, const uint32_t
 // the short transition code (log-likelihood, subset bookkeeping, result) runs with the other rows masked.
 // =====================================================================================================
 constexpr int kRowSlots = 8;
-constexpr int kDppRor8 = 0x128;                 // row_ror:8
-template <int L> constexpr int dpp_newbcast() { return 0x150 + L; }   // row_newbcast:L (lane L of each row)
 
 template <int NSL>
 __device__ __forceinline__ void rows_pass(const double (&sn)[kRowSlots], const double (&sd)[kRowSlots],
