@@ -19,21 +19,21 @@ struct bvc_ctx {
     int n_cu = 256;
     hipStream_t stream = nullptr;
     QualLut *d_lut = nullptr;
-    uint32_t *d_counts = nullptr;      // [sites][512] scratch between the two stages
-    size_t counts_cap = 0;
+    // [sites][512] scratch between the two stages.  Overlap mode cycles through kRing buffers: with three, the
+    // histogram pass of call i+1 waits only for the EM of call i-2 (long finished), never for the one running
+    // beside it, so both streams run back to back.
+    static constexpr int kRing = 3;
+    uint32_t *d_cnt[kRing] = {nullptr, nullptr, nullptr};
+    size_t cnt_cap[kRing] = {0, 0, 0};
     // overlap mode: stage 2 of call i runs on `side` while stage 1 of call i+1 streams on `stream`
     bool overlap = false;
     hipStream_t side = nullptr;
-    uint32_t *d_counts_alt = nullptr;  // second histogram buffer (calls alternate)
-    size_t counts_alt_cap = 0;
     int flip = 0;
-    hipEvent_t ev_hist_done[2] = {nullptr, nullptr};
-    hipEvent_t ev_em_done[2] = {nullptr, nullptr};
-    bool em_pending[2] = {false, false};
-    uint32_t *d_grp_counts = nullptr;  // [sites][groups + 1][512] in group mode
-    size_t grp_counts_cap = 0;
-    uint32_t *d_grp_counts_alt = nullptr;
-    size_t grp_counts_alt_cap = 0;
+    hipEvent_t ev_hist_done[kRing] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_em_done[kRing] = {nullptr, nullptr, nullptr};
+    bool em_pending[kRing] = {false, false, false};
+    uint32_t *d_grp[kRing] = {nullptr, nullptr, nullptr};   // [sites][groups + 1][512] in group mode
+    size_t grp_cap[kRing] = {0, 0, 0};
     char *d_stage = nullptr;           // staging for BVC_PTR_HOST calls
     size_t stage_cap = 0;
     bool profiling = false;
@@ -90,7 +90,7 @@ hipEvent_t take_event(bvc_ctx *ctx)
 // Make the context's stream wait for every stage-2 launch still running on the side stream.
 int join_side(bvc_ctx *ctx)
 {
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < bvc_ctx::kRing; ++b)
         if (ctx->em_pending[b]) {
             BVC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_em_done[b], 0));
             ctx->em_pending[b] = false;
@@ -105,9 +105,9 @@ int run_dense_device(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t r
 {
     const size_t cbytes = (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t);
     const int buf = ctx->overlap ? ctx->flip : 0;
-    if (ctx->overlap) ctx->flip ^= 1;
-    uint32_t **counts_p = buf ? &ctx->d_counts_alt : &ctx->d_counts;
-    size_t *cap_p = buf ? &ctx->counts_alt_cap : &ctx->counts_cap;
+    if (ctx->overlap) ctx->flip = (ctx->flip + 1) % bvc_ctx::kRing;
+    uint32_t **counts_p = &ctx->d_cnt[buf];
+    size_t *cap_p = &ctx->cnt_cap[buf];
     if (cbytes > *cap_p) {                      // growing a buffer: nothing may still be reading it
         int rcj = join_side(ctx);
         if (rcj != BVC_OK) return rcj;
@@ -207,7 +207,7 @@ int bvc_create(bvc_ctx **out, int device)
         return BVC_ERR_ALLOC;
     }
     bool ok = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess;
-    for (int b = 0; b < 2 && ok; ++b)
+    for (int b = 0; b < bvc_ctx::kRing && ok; ++b)
         ok = hipEventCreateWithFlags(&ctx->ev_hist_done[b], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&ctx->ev_em_done[b], hipEventDisableTiming) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); bvc_destroy(ctx); return BVC_ERR_DEVICE; }
@@ -221,17 +221,15 @@ void bvc_destroy(bvc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < bvc_ctx::kRing; ++b) {
         if (ctx->ev_hist_done[b]) (void)hipEventDestroy(ctx->ev_hist_done[b]);
         if (ctx->ev_em_done[b]) (void)hipEventDestroy(ctx->ev_em_done[b]);
+        if (ctx->d_cnt[b]) (void)hipFree(ctx->d_cnt[b]);
+        if (ctx->d_grp[b]) (void)hipFree(ctx->d_grp[b]);
     }
-    if (ctx->d_counts_alt) (void)hipFree(ctx->d_counts_alt);
     for (auto &t : ctx->ev_pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.c); (void)hipEventDestroy(t.d); }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
-    if (ctx->d_counts) (void)hipFree(ctx->d_counts);
-    if (ctx->d_grp_counts) (void)hipFree(ctx->d_grp_counts);
-    if (ctx->d_grp_counts_alt) (void)hipFree(ctx->d_grp_counts_alt);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     delete ctx;
 }
@@ -243,7 +241,7 @@ int bvc_set_stream(bvc_ctx *ctx, void *hip_stream)
     if (!ctx) return BVC_ERR_ARG;
     BVC_HIP(ctx, hipSetDevice(ctx->device));
     BVC_HIP(ctx, hipStreamSynchronize(ctx->side));
-    ctx->em_pending[0] = ctx->em_pending[1] = false;
+    for (bool &p : ctx->em_pending) p = false;
     BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     return BVC_OK;
@@ -254,7 +252,7 @@ int bvc_synchronize(bvc_ctx *ctx)
     if (!ctx) return BVC_ERR_ARG;
     BVC_HIP(ctx, hipSetDevice(ctx->device));
     BVC_HIP(ctx, hipStreamSynchronize(ctx->side));
-    ctx->em_pending[0] = ctx->em_pending[1] = false;
+    for (bool &p : ctx->em_pending) p = false;
     BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BVC_OK;
 }
@@ -427,15 +425,15 @@ int bvc_lrt_csr(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
     int rc = check_common(ctx, n_sites, offsets, ref_base, results, results);
     if (rc != BVC_OK) return rc;
     if (n_sites == 0) return BVC_OK;
-    rc = join_side(ctx);                        // this path shares d_counts with overlapped dense calls
+    rc = join_side(ctx);                        // this path shares d_cnt[0] with overlapped dense calls
     if (rc != BVC_OK) return rc;
-    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_counts), &ctx->counts_cap,
+    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_cnt[0]), &ctx->cnt_cap[0],
                 (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t));
     if (rc != BVC_OK) return rc;
     if (flags & BVC_PTR_DEVICE) {
         if (!bases || !quals) return fail(ctx, BVC_ERR_ARG, "null data pointer");
-        BVC_HIP(ctx, launch_hist_csr(ctx->stream, n_sites, offsets, bases, quals, ctx->d_counts));
-        BVC_HIP(ctx, launch_lrt(ctx->stream, n_sites, ctx->d_counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut,
+        BVC_HIP(ctx, launch_hist_csr(ctx->stream, n_sites, offsets, bases, quals, ctx->d_cnt[0]));
+        BVC_HIP(ctx, launch_lrt(ctx->stream, n_sites, ctx->d_cnt[0], BVC_NCLASS, ref_base, min_af, ctx->d_lut,
                                 nullptr, nullptr, results));
         return BVC_OK;
     }
@@ -461,8 +459,8 @@ int bvc_lrt_csr(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
         BVC_HIP(ctx, hipMemcpyAsync(d_q, quals, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
     }
     BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
-    BVC_HIP(ctx, launch_hist_csr(ctx->stream, n_sites, d_o, d_b, d_q, ctx->d_counts));
-    BVC_HIP(ctx, launch_lrt(ctx->stream, n_sites, ctx->d_counts, BVC_NCLASS, d_r, min_af, ctx->d_lut, nullptr,
+    BVC_HIP(ctx, launch_hist_csr(ctx->stream, n_sites, d_o, d_b, d_q, ctx->d_cnt[0]));
+    BVC_HIP(ctx, launch_lrt(ctx->stream, n_sites, ctx->d_cnt[0], BVC_NCLASS, d_r, min_af, ctx->d_lut, nullptr,
                             nullptr, d_res));
     BVC_HIP(ctx, hipMemcpyAsync(results, d_res, (size_t)n_sites * sizeof(bvc_site_result), hipMemcpyDeviceToHost,
                                 ctx->stream));
@@ -488,11 +486,11 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
     auto run_device = [&](int64_t ns, const int8_t *b, const int8_t *q, const int8_t *r, const uint8_t *g,
                           bvc_site_result *res, bvc_group_result *gres) -> int {
         const int buf = ctx->overlap ? ctx->flip : 0;
-        if (ctx->overlap) ctx->flip ^= 1;
-        uint32_t **cp = buf ? &ctx->d_counts_alt : &ctx->d_counts;
-        size_t *ccap = buf ? &ctx->counts_alt_cap : &ctx->counts_cap;
-        uint32_t **gp = buf ? &ctx->d_grp_counts_alt : &ctx->d_grp_counts;
-        size_t *gcap = buf ? &ctx->grp_counts_alt_cap : &ctx->grp_counts_cap;
+        if (ctx->overlap) ctx->flip = (ctx->flip + 1) % bvc_ctx::kRing;
+        uint32_t **cp = &ctx->d_cnt[buf];
+        size_t *ccap = &ctx->cnt_cap[buf];
+        uint32_t **gp = &ctx->d_grp[buf];
+        size_t *gcap = &ctx->grp_cap[buf];
         const size_t cbytes = (size_t)ns * BVC_NCLASS * sizeof(uint32_t), gbytes = cbytes * (size_t)n_hist;
         if (cbytes > *ccap || gbytes > *gcap) { int rj = join_side(ctx); if (rj != BVC_OK) return rj; }
         int rc2 = ensure(ctx, reinterpret_cast<void **>(cp), ccap, cbytes);
@@ -572,12 +570,12 @@ int bvc_stream_read_ms(bvc_ctx *ctx, const void *device_ptr, int64_t bytes, int 
 {
     if (!ctx || !device_ptr || !ms_per_pass || bytes < 16 || repeats < 1) return ctx ? fail(ctx, BVC_ERR_ARG, "bad argument") : BVC_ERR_ARG;
     BVC_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_counts), &ctx->counts_cap, 256);
+    int rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_cnt[0]), &ctx->cnt_cap[0], 256);
     if (rc != BVC_OK) return rc;
     hipEvent_t a = take_event(ctx), b = take_event(ctx);
-    BVC_HIP(ctx, launch_stream_read(ctx->stream, device_ptr, bytes, ctx->d_counts));        // warm-up
+    BVC_HIP(ctx, launch_stream_read(ctx->stream, device_ptr, bytes, ctx->d_cnt[0]));        // warm-up
     BVC_HIP(ctx, hipEventRecord(a, ctx->stream));
-    for (int i = 0; i < repeats; ++i) BVC_HIP(ctx, launch_stream_read(ctx->stream, device_ptr, bytes, ctx->d_counts));
+    for (int i = 0; i < repeats; ++i) BVC_HIP(ctx, launch_stream_read(ctx->stream, device_ptr, bytes, ctx->d_cnt[0]));
     BVC_HIP(ctx, hipEventRecord(b, ctx->stream));
     BVC_HIP(ctx, hipEventSynchronize(b));
     float ms = 0.f;

@@ -814,7 +814,7 @@ void set_em_tuning(int rows_mode, int waves_per_cu)
 }
 
 // Waves the EM kernels keep on the chip.  `shared` = the launch runs underneath a streaming histogram kernel
-// (overlap mode with long rows): 8 per CU (2 per SIMD) leaves that kernel its wave slots and registers.
+// (overlap mode with long rows): 10 per CU (swept 4..24 on MI355X at N = 1e6) leaves that kernel its wave slots and registers.
 // Otherwise the kernel has the chip to itself for most of its life and takes 24 per CU.
 // BVC_EM_WAVES_PER_CU / bvc_set_tuning override both.
 static int64_t em_grid_cap(bool shared)
@@ -831,7 +831,7 @@ static int64_t em_grid_cap(bool shared)
         }
         n_cu_a.store(n_cu);
     }
-    int per_cu = shared ? 8 : 24;
+    int per_cu = shared ? 10 : 24;
     if (g_em_waves_per_cu.load() > 0) per_cu = g_em_waves_per_cu.load();
     return (int64_t)per_cu * n_cu;
 }
