@@ -206,10 +206,25 @@ struct SiteOut {
     int alt_base[3], n_alt, called, n_kept, kept[4], status;
 };
 
+// Orders a wavefront's LDS accesses around a point (its scratch is private to the wave; the workgroup's other
+// waves work on other sites and are never waited for).
+template <int WPB>
+__device__ __forceinline__ void wave_lds_sync()
+{
+    if (WPB == 1) {
+        __syncthreads();                       // single-wave workgroup: no s_barrier is emitted, and the compiler
+                                               // keeps the site loop's register footprint at 76 VGPRs
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
 // The whole per-site computation for one wavefront.  `hist` points at 512 class counts.
 // comb_list: candidate bases packed 4 bits each in SetBase order; n_comb entries.
 // Returns false (and leaves `out` untouched) when the site needs a different NS variant.
-template <int NS>
+template <int NS, int WPB>
 __device__ bool lrt_site(const uint32_t *__restrict__ hist, int ref, double min_af,
                          uint32_t comb_list, int n_comb, const QualLut *__restrict__ lut,
                          uint32_t *s_n, uint8_t *s_q, SiteOut &out)
@@ -244,7 +259,7 @@ __device__ bool lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
     const int nslots = (maxcnt + 15) >> 4;
     // variant gate (wave-uniform): NS = 2 takes 0..2 slots, NS = 4 takes 3..4, NS = 8 takes 5..8
     if (nslots > NS || (NS > 2 && nslots <= NS / 2)) return false;
-    __syncthreads();                           // single-wave workgroup: orders the LDS writes above
+    wave_lds_sync<WPB>();                      // the wave's own LDS writes above, read back below
 
     Slots<NS> S;
 #pragma unroll
@@ -397,20 +412,28 @@ __device__ __forceinline__ void store_result(bvc_site_result *dst, const SiteOut
     *dst = r;
 }
 
-template <int NS>
-__global__ __launch_bounds__(64) void lrt_kernel(int64_t n_sites, const uint32_t *__restrict__ counts,
+// Workgroups of WPB independent wavefronts.  WPB = 4 when the kernel has the chip to itself: the dispatcher
+// spreads a workgroup's waves over the CU's four SIMDs, which keeps the SIMDs evenly loaded (single-wave
+// workgroups are placed unevenly, and this latency-bound kernel runs at the pace of its most crowded SIMD:
+// 0.57 -> 0.48 ms per 4000 sites).  WPB = 1 underneath the histogram kernel, whose 64 KiB workgroups are
+// placed more easily around small single-wave ones (measured: 4-wave workgroups cost that kernel 5 %).
+template <int NS, int WPB>
+__global__ __launch_bounds__(64 * WPB) void lrt_kernel(int64_t n_sites, const uint32_t *__restrict__ counts,
                                                  int64_t hist_stride, const int8_t *__restrict__ ref_base,
                                                  double min_af, const QualLut *__restrict__ lut,
                                                  const int8_t *__restrict__ comb,
                                                  const uint8_t *__restrict__ n_comb,
                                                  bvc_site_result *__restrict__ results)
 {
-    __shared__ uint32_t s_n[512];
-    __shared__ uint8_t s_q[512];
+    __shared__ uint32_t s_n_all[WPB][512];
+    __shared__ uint8_t s_q_all[WPB][512];
+    const int wave = WPB == 1 ? 0 : (int)(threadIdx.x >> 6);
+    uint32_t *s_n = s_n_all[wave];
+    uint8_t *s_q = s_q_all[wave];
     // A bounded number of waves walks the sites: the launcher sizes the grid so that this FP64-bound kernel
     // holds only a few wave slots per SIMD and the HBM-bound histogram kernel of the next tile, which runs
     // at the same time in overlap mode, keeps its occupancy.
-    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
+    for (int64_t site = (int64_t)blockIdx.x * WPB + wave; site < n_sites; site += (int64_t)gridDim.x * WPB) {
         uint32_t list = 0x3210u;                                 // default base_comb, src/BaseType.h:79
         int nc = 4;
         if (comb) {
@@ -419,9 +442,9 @@ __global__ __launch_bounds__(64) void lrt_kernel(int64_t n_sites, const uint32_t
             for (int c = 0; c < nc; ++c) list |= (uint32_t)(comb[site * 4 + c] & 3) << (4 * c);
         }
         SiteOut o;
-        const bool mine = lrt_site<NS>(counts + site * hist_stride, ref_base[site], min_af, list, nc, lut, s_n, s_q, o);
+        const bool mine = lrt_site<NS, WPB>(counts + site * hist_stride, ref_base[site], min_af, list, nc, lut, s_n, s_q, o);
         if (mine && (threadIdx.x & 63) == 0) store_result(results + site, o);
-        __syncthreads();                                         // s_n / s_q are reused by the next site
+        wave_lds_sync<WPB>();                                    // s_n / s_q are reused by the next site
     }
 }
 
@@ -729,18 +752,21 @@ __global__ __launch_bounds__(64) void lrt_rows_kernel(int64_t n_sites, const uin
 }
 
 // Caller's --group loop (src/BaseVarC.cpp:617-661): one wavefront per (site, group).
-template <int NS>
-__global__ __launch_bounds__(64) void lrt_groups_kernel(int64_t n_sites, int n_groups,
+template <int NS, int WPB>
+__global__ __launch_bounds__(64 * WPB) void lrt_groups_kernel(int64_t n_sites, int n_groups,
                                                         const uint32_t *__restrict__ grp_counts,
                                                         const int8_t *__restrict__ ref_base, double min_af,
                                                         const QualLut *__restrict__ lut,
                                                         const bvc_site_result *__restrict__ overall,
                                                         bvc_group_result *__restrict__ grp_results)
 {
-    __shared__ uint32_t s_n[512];
-    __shared__ uint8_t s_q[512];
+    __shared__ uint32_t s_n_all[WPB][512];
+    __shared__ uint8_t s_q_all[WPB][512];
+    const int wave = WPB == 1 ? 0 : (int)(threadIdx.x >> 6);
+    uint32_t *s_n = s_n_all[wave];
+    uint8_t *s_q = s_q_all[wave];
     const int64_t n_work = n_sites * n_groups;
-    for (int64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+    for (int64_t w = (int64_t)blockIdx.x * WPB + wave; w < n_work; w += (int64_t)gridDim.x * WPB) {
         const int64_t site = w / n_groups;
         const int g = (int)(w % n_groups);
         const uint32_t *hist = grp_counts + (site * (n_groups + 1) + g) * BVC_NCLASS;
@@ -754,7 +780,7 @@ __global__ __launch_bounds__(64) void lrt_groups_kernel(int64_t n_sites, int n_g
         SiteOut o;
         // The histogram is always loaded (depths are reported for every group, :640); the LRT itself runs only
         // when the overall call succeeded and the group has covered samples (:633-636, :641).
-        const bool mine = lrt_site<NS>(hist, ref, min_af, list, ov.called ? nc : 0, lut, s_n, s_q, o);
+        const bool mine = lrt_site<NS, WPB>(hist, ref, min_af, list, ov.called ? nc : 0, lut, s_n, s_q, o);
         if (mine && (threadIdx.x & 63) == 0) {
             bvc_group_result r;
             for (int j = 0; j < 4; ++j) r.depth[j] = o.depth[j];
@@ -773,7 +799,7 @@ __global__ __launch_bounds__(64) void lrt_groups_kernel(int64_t n_sites, int n_g
             }
             grp_results[site * n_groups + g] = r;
         }
-        __syncthreads();
+        wave_lds_sync<WPB>();
     }
 }
 
@@ -817,6 +843,8 @@ void set_em_tuning(int rows_mode, int waves_per_cu)
 // (overlap mode with long rows): 10 per CU (swept 4..24 on MI355X at N = 1e6) leaves that kernel its wave slots and registers.
 // Otherwise the kernel has the chip to itself for most of its life and takes 24 per CU.
 // BVC_EM_WAVES_PER_CU / bvc_set_tuning override both.
+constexpr int64_t kRowsMinSites = 12288;
+
 static int64_t em_grid_cap(bool shared)
 {
     static std::atomic<int> n_cu_dev[kMaxDevices];
@@ -836,36 +864,60 @@ static int64_t em_grid_cap(bool shared)
     return (int64_t)per_cu * n_cu;
 }
 
+template <int WPB>
+static void launch_lrt_variants(hipStream_t stream, int64_t want_waves, bool skip2, int64_t n_sites,
+                                const uint32_t *counts, int64_t hist_stride, const int8_t *ref_base, double min_af,
+                                const QualLut *lut, const int8_t *comb, const uint8_t *n_comb,
+                                bvc_site_result *results)
+{
+    // Every variant visits every site; a wave skips a site at once when it belongs to another variant.
+    const dim3 grid((unsigned)((want_waves + WPB - 1) / WPB)), block(64 * WPB);
+    if (!skip2)
+        hipLaunchKernelGGL((lrt_kernel<2, WPB>), grid, block, 0, stream, n_sites, counts, hist_stride, ref_base,
+                           min_af, lut, comb, n_comb, results);
+    hipLaunchKernelGGL((lrt_kernel<4, WPB>), grid, block, 0, stream, n_sites, counts, hist_stride, ref_base, min_af,
+                       lut, comb, n_comb, results);
+    hipLaunchKernelGGL((lrt_kernel<8, WPB>), grid, block, 0, stream, n_sites, counts, hist_stride, ref_base, min_af,
+                       lut, comb, n_comb, results);
+}
+
 hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *counts, int64_t hist_stride,
                       const int8_t *ref_base, double min_af, const QualLut *lut,
                       const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results, bool shared)
 {
     if (n_sites <= 0) return hipSuccess;
     const int64_t cap = em_grid_cap(shared);
-    // Every variant visits every site; a wave skips a site at once when it belongs to another variant.
-    const dim3 grid((unsigned)(n_sites < cap ? n_sites : cap));
+    const int64_t want_waves = n_sites < cap ? n_sites : cap;
     // Layout of the common (<= 32 classes per base) sites: one site per wave, or four (rows).  Four per wave
-    // quarter the reduction work per site but need four times the sites to fill the chip: measured on MI355X
-    // at N = 1e6, 0.83 vs 0.60 ms for a 4,000-site tile and 1.68 vs 1.95 ms for 16,000 sites.
+    // quarter the reduction work per site but need four times the sites to fill the chip.
     const int mode = g_em_rows_mode.load();
     // (not underneath a streaming histogram kernel: its 248 registers per lane would take that kernel's occupancy)
-    const bool rows = mode < 0 ? (!shared && n_sites >= 12288) : mode != 0;
+    const bool rows = mode < 0 ? (!shared && n_sites >= kRowsMinSites) : mode != 0;
     if (rows) {
         // four sites per wave: a quarter of the waves hold the same number of sites in flight
         const int64_t want = (n_sites + 3) / 4;
         const dim3 rgrid((unsigned)(want < cap ? want : cap));
         hipLaunchKernelGGL(lrt_rows_kernel, rgrid, dim3(64), 0, stream, n_sites, counts, hist_stride,
                            ref_base, min_af, lut, comb, n_comb, results);
-    } else {
-        hipLaunchKernelGGL(lrt_kernel<2>, grid, dim3(64), 0, stream, n_sites, counts, hist_stride,
-                           ref_base, min_af, lut, comb, n_comb, results);
     }
-    hipLaunchKernelGGL(lrt_kernel<4>, grid, dim3(64), 0, stream, n_sites, counts, hist_stride,
-                       ref_base, min_af, lut, comb, n_comb, results);
-    hipLaunchKernelGGL(lrt_kernel<8>, grid, dim3(64), 0, stream, n_sites, counts, hist_stride,
-                       ref_base, min_af, lut, comb, n_comb, results);
+    if (shared) launch_lrt_variants<1>(stream, want_waves, rows, n_sites, counts, hist_stride, ref_base, min_af, lut, comb, n_comb, results);
+    else launch_lrt_variants<4>(stream, want_waves, rows, n_sites, counts, hist_stride, ref_base, min_af, lut, comb, n_comb, results);
     hipLaunchKernelGGL(var_qual_kernel, dim3((unsigned)((n_sites + 255) / 256)), dim3(256), 0, stream, n_sites, results);
     return hipGetLastError();
+}
+
+template <int WPB>
+static void launch_group_variants(hipStream_t stream, int64_t want_waves, int64_t n_sites, int n_groups,
+                                  const uint32_t *grp_counts, const int8_t *ref_base, double min_af,
+                                  const QualLut *lut, const bvc_site_result *overall, bvc_group_result *grp_results)
+{
+    const dim3 grid((unsigned)((want_waves + WPB - 1) / WPB)), block(64 * WPB);
+    hipLaunchKernelGGL((lrt_groups_kernel<2, WPB>), grid, block, 0, stream, n_sites, n_groups, grp_counts, ref_base,
+                       min_af, lut, overall, grp_results);
+    hipLaunchKernelGGL((lrt_groups_kernel<4, WPB>), grid, block, 0, stream, n_sites, n_groups, grp_counts, ref_base,
+                       min_af, lut, overall, grp_results);
+    hipLaunchKernelGGL((lrt_groups_kernel<8, WPB>), grid, block, 0, stream, n_sites, n_groups, grp_counts, ref_base,
+                       min_af, lut, overall, grp_results);
 }
 
 hipError_t launch_lrt_groups(hipStream_t stream, int64_t n_sites, int n_groups, const uint32_t *grp_counts,
@@ -875,13 +927,9 @@ hipError_t launch_lrt_groups(hipStream_t stream, int64_t n_sites, int n_groups, 
     if (n_sites <= 0 || n_groups <= 0) return hipSuccess;
     const int64_t cap = em_grid_cap(shared);
     const int64_t n_work = n_sites * n_groups;
-    const dim3 grid((unsigned)(n_work < cap ? n_work : cap));
-    hipLaunchKernelGGL(lrt_groups_kernel<2>, grid, dim3(64), 0, stream, n_sites, n_groups, grp_counts, ref_base,
-                       min_af, lut, overall, grp_results);
-    hipLaunchKernelGGL(lrt_groups_kernel<4>, grid, dim3(64), 0, stream, n_sites, n_groups, grp_counts, ref_base,
-                       min_af, lut, overall, grp_results);
-    hipLaunchKernelGGL(lrt_groups_kernel<8>, grid, dim3(64), 0, stream, n_sites, n_groups, grp_counts, ref_base,
-                       min_af, lut, overall, grp_results);
+    const int64_t want_waves = n_work < cap ? n_work : cap;
+    if (shared) launch_group_variants<1>(stream, want_waves, n_sites, n_groups, grp_counts, ref_base, min_af, lut, overall, grp_results);
+    else launch_group_variants<4>(stream, want_waves, n_sites, n_groups, grp_counts, ref_base, min_af, lut, overall, grp_results);
     return hipGetLastError();
 }
 
