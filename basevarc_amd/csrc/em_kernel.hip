@@ -412,11 +412,12 @@ __device__ __forceinline__ void store_result(bvc_site_result *dst, const SiteOut
     *dst = r;
 }
 
-// Workgroups of WPB independent wavefronts.  WPB = 4 when the kernel has the chip to itself: the dispatcher
-// spreads a workgroup's waves over the CU's four SIMDs, which keeps the SIMDs evenly loaded (single-wave
-// workgroups are placed unevenly, and this latency-bound kernel runs at the pace of its most crowded SIMD:
-// 0.57 -> 0.48 ms per 4000 sites).  WPB = 1 underneath the histogram kernel, whose 64 KiB workgroups are
-// placed more easily around small single-wave ones (measured: 4-wave workgroups cost that kernel 5 %).
+// Workgroups of WPB independent wavefronts (4 by default): the dispatcher spreads a workgroup's waves over the
+// CU's four SIMDs, which keeps the SIMDs evenly loaded.  Single-wave workgroups (WPB = 1, kept for A/B runs:
+// BVC_EM_WPB) are placed unevenly, and this latency-bound kernel runs at the pace of its most crowded SIMD:
+// 0.57 -> 0.48 ms per 4000 sites alone, 1.25 -> 1.19 ms underneath the histogram kernel at 8 waves per CU.
+// The wave index is made scalar (readfirstlane): the site state then lives in SGPRs and branches stay scalar;
+// derived from threadIdx directly it is "divergent" to the compiler and the kernel needs 116 instead of 76 VGPRs.
 template <int NS, int WPB>
 __global__ __launch_bounds__(64 * WPB) void lrt_kernel(int64_t n_sites, const uint32_t *__restrict__ counts,
                                                  int64_t hist_stride, const int8_t *__restrict__ ref_base,
@@ -427,13 +428,14 @@ __global__ __launch_bounds__(64 * WPB) void lrt_kernel(int64_t n_sites, const ui
 {
     __shared__ uint32_t s_n_all[WPB][512];
     __shared__ uint8_t s_q_all[WPB][512];
-    const int wave = WPB == 1 ? 0 : (int)(threadIdx.x >> 6);
-    uint32_t *s_n = s_n_all[wave];
-    uint8_t *s_q = s_q_all[wave];
+    // wave-uniform by construction: tell the compiler, so that the site state stays in scalar registers
+    const int wave = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // A bounded number of waves walks the sites: the launcher sizes the grid so that this FP64-bound kernel
     // holds only a few wave slots per SIMD and the HBM-bound histogram kernel of the next tile, which runs
     // at the same time in overlap mode, keeps its occupancy.
     for (int64_t site = (int64_t)blockIdx.x * WPB + wave; site < n_sites; site += (int64_t)gridDim.x * WPB) {
+        uint32_t *s_n = s_n_all[wave];
+        uint8_t *s_q = s_q_all[wave];
         uint32_t list = 0x3210u;                                 // default base_comb, src/BaseType.h:79
         int nc = 4;
         if (comb) {
@@ -762,7 +764,8 @@ __global__ __launch_bounds__(64 * WPB) void lrt_groups_kernel(int64_t n_sites, i
 {
     __shared__ uint32_t s_n_all[WPB][512];
     __shared__ uint8_t s_q_all[WPB][512];
-    const int wave = WPB == 1 ? 0 : (int)(threadIdx.x >> 6);
+    // wave-uniform by construction: tell the compiler, so that the site state stays in scalar registers
+    const int wave = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *s_n = s_n_all[wave];
     uint8_t *s_q = s_q_all[wave];
     const int64_t n_work = n_sites * n_groups;
@@ -833,6 +836,9 @@ __global__ void sum_groups_kernel(int64_t total, int n_hist, const uint32_t *__r
 static std::atomic<int> g_em_rows_mode{[] { const char *e = getenv("BVC_EM_ROWS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }()};
 static std::atomic<int> g_em_waves_per_cu{[] { const char *e = getenv("BVC_EM_WAVES_PER_CU"); const int v = e ? atoi(e) : 0; return (v > 0 && v <= 32) ? v : 0; }()};
 
+// waves per EM workgroup: 0 = default (4), 1 or 4 forced (BVC_EM_WPB; experiments only)
+static std::atomic<int> g_em_wpb{[] { const char *e = getenv("BVC_EM_WPB"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 4) ? v : 0; }()};
+
 void set_em_tuning(int rows_mode, int waves_per_cu)
 {
     if (rows_mode >= -1 && rows_mode <= 1) g_em_rows_mode.store(rows_mode);
@@ -840,7 +846,7 @@ void set_em_tuning(int rows_mode, int waves_per_cu)
 }
 
 // Waves the EM kernels keep on the chip.  `shared` = the launch runs underneath a streaming histogram kernel
-// (overlap mode with long rows): 10 per CU (swept 4..24 on MI355X at N = 1e6) leaves that kernel its wave slots and registers.
+// (overlap mode with long rows): 8 per CU = two 4-wave workgroups (swept 4..24 on MI355X at N = 1e6) leaves that kernel its wave slots and registers.
 // Otherwise the kernel has the chip to itself for most of its life and takes 24 per CU.
 // BVC_EM_WAVES_PER_CU / bvc_set_tuning override both.
 constexpr int64_t kRowsMinSites = 12288;
@@ -859,7 +865,7 @@ static int64_t em_grid_cap(bool shared)
         }
         n_cu_a.store(n_cu);
     }
-    int per_cu = shared ? 10 : 24;
+    int per_cu = shared ? 8 : 24;
     if (g_em_waves_per_cu.load() > 0) per_cu = g_em_waves_per_cu.load();
     return (int64_t)per_cu * n_cu;
 }
@@ -900,7 +906,8 @@ hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *count
         hipLaunchKernelGGL(lrt_rows_kernel, rgrid, dim3(64), 0, stream, n_sites, counts, hist_stride,
                            ref_base, min_af, lut, comb, n_comb, results);
     }
-    if (shared) launch_lrt_variants<1>(stream, want_waves, rows, n_sites, counts, hist_stride, ref_base, min_af, lut, comb, n_comb, results);
+    const int wpb = g_em_wpb.load() ? g_em_wpb.load() : 4;
+    if (wpb == 1) launch_lrt_variants<1>(stream, want_waves, rows, n_sites, counts, hist_stride, ref_base, min_af, lut, comb, n_comb, results);
     else launch_lrt_variants<4>(stream, want_waves, rows, n_sites, counts, hist_stride, ref_base, min_af, lut, comb, n_comb, results);
     hipLaunchKernelGGL(var_qual_kernel, dim3((unsigned)((n_sites + 255) / 256)), dim3(256), 0, stream, n_sites, results);
     return hipGetLastError();
@@ -928,7 +935,8 @@ hipError_t launch_lrt_groups(hipStream_t stream, int64_t n_sites, int n_groups, 
     const int64_t cap = em_grid_cap(shared);
     const int64_t n_work = n_sites * n_groups;
     const int64_t want_waves = n_work < cap ? n_work : cap;
-    if (shared) launch_group_variants<1>(stream, want_waves, n_sites, n_groups, grp_counts, ref_base, min_af, lut, overall, grp_results);
+    const int wpb = g_em_wpb.load() ? g_em_wpb.load() : 4;
+    if (wpb == 1) launch_group_variants<1>(stream, want_waves, n_sites, n_groups, grp_counts, ref_base, min_af, lut, overall, grp_results);
     else launch_group_variants<4>(stream, want_waves, n_sites, n_groups, grp_counts, ref_base, min_af, lut, overall, grp_results);
     return hipGetLastError();
 }

@@ -40,6 +40,7 @@ def parse():
     p.add_argument("--no-overlap", action="store_true", help="run the two kernels of a step back to back on one stream")
     p.add_argument("--groups", type=int, default=0, help="population groups (BASELINE configs[4]: 5); 0 = overall call only")
     p.add_argument("--coverage", type=float, default=1.0, help="fraction of samples covered per site (sparse variant)")
+    p.add_argument("--profile-every", type=int, default=1, help="time the kernels of every K-th step with HIP events (1 = every step)")
     return p.parse_args()
 
 
@@ -134,6 +135,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
+        if a.profile_every > 1:
+            ctx.set_profiling(i % a.profile_every == 0)
         step(i)
     barrier()
     dt = time.perf_counter() - t0
