@@ -140,7 +140,7 @@ int run_dense_device(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t r
     // underneath a long streaming pass the EM kernel keeps to a few wave slots; with short rows it is the longer
     // kernel and takes the chip
     const bool shared = ctx->overlap && n_samples >= 200000;
-    BVC_HIP(ctx, launch_lrt(s2, n_sites, counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut, nullptr, nullptr, results, shared));
+    BVC_HIP(ctx, launch_lrt(s2, n_sites, counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut, nullptr, nullptr, results, shared, n_samples));
     if (t.d) { BVC_HIP(ctx, hipEventRecord(t.d, s2)); ctx->ev_pending.push_back(t); }
     if (ctx->overlap) {
         BVC_HIP(ctx, hipEventRecord(ctx->ev_em_done[buf], s2));
@@ -510,7 +510,7 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
         }
         BVC_HIP(ctx, launch_sum_groups(s2, ns, n_hist, *gp, *cp));
         const bool shared = ctx->overlap && n_samples >= 200000;
-        BVC_HIP(ctx, launch_lrt(s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared));
+        BVC_HIP(ctx, launch_lrt(s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared, n_samples));
         BVC_HIP(ctx, launch_lrt_groups(s2, ns, n_groups, *gp, r, min_af, ctx->d_lut, res, gres, shared));
         if (ctx->overlap) {
             BVC_HIP(ctx, hipEventRecord(ctx->ev_em_done[buf], s2));

@@ -849,7 +849,7 @@ void set_em_tuning(int rows_mode, int waves_per_cu)
 // (overlap mode with long rows): 8 per CU = two 4-wave workgroups (swept 4..24 on MI355X at N = 1e6) leaves that kernel its wave slots and registers.
 // Otherwise the kernel has the chip to itself for most of its life and takes 24 per CU.
 // BVC_EM_WAVES_PER_CU / bvc_set_tuning override both.
-constexpr int64_t kRowsMinSites = 12288;
+constexpr int64_t kRowsMinSites = 12288, kRowsMinDepth = 200000;
 
 static int64_t em_grid_cap(bool shared)
 {
@@ -889,7 +889,8 @@ static void launch_lrt_variants(hipStream_t stream, int64_t want_waves, bool ski
 
 hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *counts, int64_t hist_stride,
                       const int8_t *ref_base, double min_af, const QualLut *lut,
-                      const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results, bool shared)
+                      const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results, bool shared,
+                      int64_t depth_hint)
 {
     if (n_sites <= 0) return hipSuccess;
     const int64_t cap = em_grid_cap(shared);
@@ -898,7 +899,10 @@ hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *count
     // quarter the reduction work per site but need four times the sites to fill the chip.
     const int mode = g_em_rows_mode.load();
     // (not underneath a streaming histogram kernel: its 248 registers per lane would take that kernel's occupancy)
-    const bool rows = mode < 0 ? (!shared && n_sites >= kRowsMinSites) : mode != 0;
+    // Measured on MI355X (serial mode): N = 1e6, 16,000 / 32,000 sites: 1.63 vs 1.78 ms and 3.22 vs 3.58 ms in favour
+    // of rows; N = 1e4, 40,000 sites: 2.87 vs 2.58 ms against (fits are short there and the rows' masked transitions
+    // weigh more); 4,000 sites at any depth: against.
+    const bool rows = mode < 0 ? (!shared && n_sites >= kRowsMinSites && depth_hint >= kRowsMinDepth) : mode != 0;
     if (rows) {
         // four sites per wave: a quarter of the waves hold the same number of sites in flight
         const int64_t want = (n_sites + 3) / 4;
