@@ -93,38 +93,47 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_kernel(
         const int part = (int)(w % split);
         const int8_t *brow = bases + site * row_stride;
         const int8_t *qrow = quals + site * row_stride;
-        // sample range of this part, in 16-sample chunks; the last part also takes the ragged tail
+        // The parts of a site take its 16-sample chunks round robin in blocks of kUnroll * kHistThreads chunks
+        // (16 KiB per array), so the workgroups that share a row sweep it together: on MI355X a few wide
+        // sweeping windows read HBM faster than one narrow stream per workgroup (tools/micro/read_bw.hip).
+        // The last part also takes the ragged tail.
         const int64_t n16 = n_samples >> 4;
-        const int64_t c0 = n16 * part / split, c1 = n16 * (part + 1) / split;
+        constexpr int64_t kBlockChunks = (int64_t)kUnroll * kHistThreads;
 
         if (ALIGNED) {
             const u32x4 *bv = reinterpret_cast<const u32x4 *>(brow);
             const u32x4 *qv = reinterpret_cast<const u32x4 *>(qrow);
-            int64_t c = c0 + tid;
-            // main loop: kUnroll independent 16-byte loads per array in flight, then the LDS updates
-            for (; c + (int64_t)(kUnroll - 1) * kHistThreads < c1; c += (int64_t)kUnroll * kHistThreads) {
-                u32x4 b[kUnroll], q[kUnroll];
+            for (int64_t cb = (int64_t)part * kBlockChunks; cb < n16; cb += (int64_t)split * kBlockChunks) {
+                const int64_t c = cb + tid;
+                if (cb + kBlockChunks <= n16) {
+                    // kUnroll independent 16-byte loads per array in flight, then the LDS updates
+                    u32x4 b[kUnroll], q[kUnroll];
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
-                    b[u] = __builtin_nontemporal_load(&bv[c + (int64_t)u * kHistThreads]);
-                    q[u] = __builtin_nontemporal_load(&qv[c + (int64_t)u * kHistThreads]);
+                    for (int u = 0; u < kUnroll; ++u) {
+                        b[u] = __builtin_nontemporal_load(&bv[c + (int64_t)u * kHistThreads]);
+                        q[u] = __builtin_nontemporal_load(&qv[c + (int64_t)u * kHistThreads]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kUnroll; ++u) count_chunk(hist, b[u], q[u], lane_off);
+                } else {
+                    for (int64_t ct = c; ct < n16; ct += kHistThreads) {
+                        const u32x4 b = __builtin_nontemporal_load(&bv[ct]);
+                        const u32x4 q = __builtin_nontemporal_load(&qv[ct]);
+                        // not every lane of the wave is here: per-sample test, no wave-wide vote
+                        count_word_checked(hist, b.x, q.x, lane_off); count_word_checked(hist, b.y, q.y, lane_off);
+                        count_word_checked(hist, b.z, q.z, lane_off); count_word_checked(hist, b.w, q.w, lane_off);
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < kUnroll; ++u) count_chunk(hist, b[u], q[u], lane_off);
-            }
-            for (; c < c1; c += kHistThreads) {
-                const u32x4 b = __builtin_nontemporal_load(&bv[c]);
-                const u32x4 q = __builtin_nontemporal_load(&qv[c]);
-                // not every lane of the wave is here: per-sample test, no wave-wide vote
-                count_word_checked(hist, b.x, q.x, lane_off); count_word_checked(hist, b.y, q.y, lane_off);
-                count_word_checked(hist, b.z, q.z, lane_off); count_word_checked(hist, b.w, q.w, lane_off);
             }
         } else {
-            for (int64_t i = c0 * 16 + tid; i < c1 * 16; i += kHistThreads) {
-                const uint32_t b = (uint8_t)brow[i], q = (uint8_t)qrow[i];
-                if (b < 4u && q < 128u)
-                    __hip_atomic_fetch_add(&hist[((b << 7) | q) * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int64_t cb = (int64_t)part * kBlockChunks; cb < n16; cb += (int64_t)split * kBlockChunks) {
+                const int64_t i1 = (cb + kBlockChunks < n16 ? cb + kBlockChunks : n16) * 16;
+                for (int64_t i = cb * 16 + tid; i < i1; i += kHistThreads) {
+                    const uint32_t b = (uint8_t)brow[i], q = (uint8_t)qrow[i];
+                    if (b < 4u && q < 128u)
+                        __hip_atomic_fetch_add(&hist[((b << 7) | q) * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
         if (part == split - 1) {
@@ -283,6 +292,8 @@ hipError_t launch_stream_read(hipStream_t stream, const void *src, int64_t bytes
 
 int choose_hist_split(int64_t n_sites, int64_t n_samples, int n_cu)
 {
+    static const int forced = [] { const char *e = getenv("BVC_HIST_SPLIT"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : 0; }();
+    if (forced) return forced;
     // Two 512-thread workgroups fit a CU (2 x 64 KiB LDS).  With fewer sites than that, cut each site's
     // sample range so the whole chip streams; parts are merged with global atomics on 512 words.
     const int64_t want = (int64_t)n_cu * 4;
