@@ -16,6 +16,7 @@
 #include <ctime>
 #include <fstream>
 #include <iostream>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -191,7 +192,14 @@ static void bt_r(const std::vector<std::string> &bams, const std::vector<int32_t
 }
 
 // ---- phase 2: temp-batch text -> tiles -> libbvc -> CVG/VCF (successor of bt_s + bt_f) ------------------------
+// BVC_HOST_PROFILE=1: where a phase-2 thread spends its time (seconds), printed when the thread ends
+struct StageClock {
+    double read = 0, parse = 0, pack = 0, gpu = 0, cvg = 0, vcf = 0, write = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+
 struct TileRunner {
+    StageClock clk;
     bvc_ctx *ctx = nullptr;
     const Groups *groups = nullptr;
     std::string chr;
@@ -209,6 +217,7 @@ struct TileRunner {
         std::vector<bvc_group_result> gres;
         const int ng = groups ? (int)groups->names.size() : 0;
         int rc;
+        double t0 = StageClock::now(), t1;
         if (ng == 0) {
             // ragged form: exactly the vectors bt_f builds (src/BaseVarC.cpp:550-559)
             std::vector<int64_t> offsets(1, 0);
@@ -219,6 +228,7 @@ struct TileRunner {
                 offsets.push_back((int64_t)bases.size());
             }
             static const int8_t none = 0;
+            t1 = StageClock::now(); clk.pack += t1 - t0; t0 = t1;
             rc = bvc_lrt_csr(ctx, ns, offsets.data(), bases.empty() ? &none : bases.data(), quals.empty() ? &none : quals.data(),
                              refs.data(), min_af, res.data(), BVC_PTR_HOST);
         } else {
@@ -234,17 +244,25 @@ struct TileRunner {
                     }
                 }
             gres.resize((size_t)(ns * ng));
+            t1 = StageClock::now(); clk.pack += t1 - t0; t0 = t1;
             rc = bvc_lrt_dense_groups(ctx, ns, n_samples, stride, bases.data(), quals.data(), refs.data(), min_af,
                                       groups->of_sample.data(), ng, res.data(), gres.data(), BVC_PTR_HOST);
         }
         if (rc != BVC_OK) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(ctx));
+        t1 = StageClock::now(); clk.gpu += t1 - t0; t0 = t1;
         for (int64_t s = 0; s < ns; ++s) {
             const bvc_group_result *g = ng ? &gres[(size_t)(s * ng)] : nullptr;
-            fcvg->write(cvg_line(chr, sites[s].pos, refs[s], sites[s], g, ng));
+            const std::string cl = cvg_line(chr, sites[s].pos, refs[s], sites[s], g, ng);
+            t1 = StageClock::now(); clk.cvg += t1 - t0; t0 = t1;
+            fcvg->write(cl);
+            t1 = StageClock::now(); clk.write += t1 - t0; t0 = t1;
             if (res[s].called) {
                 std::map<std::string, std::string> info;
                 if (ng) group_af_info(res[s], g, *groups, info);
-                fvcf->write(vcf_line(res[s], chr, sites[s].pos, refs[s], sites[s], info, n_samples));
+                const std::string vl = vcf_line(res[s], chr, sites[s].pos, refs[s], sites[s], info, n_samples);
+                t1 = StageClock::now(); clk.vcf += t1 - t0; t0 = t1;
+                fvcf->write(vl);
+                t1 = StageClock::now(); clk.write += t1 - t0; t0 = t1;
             }
         }
         sites.clear();
@@ -312,8 +330,14 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
         site.clear();
         site.pos = p;
         int32_t j = 0;
-        for (auto fp : fpiv)
-            if (fp->getline(line)) j += parse_pileup_line(line.data(), line.size(), j, site);
+        for (auto fp : fpiv) {
+            double t0 = StageClock::now();
+            const bool got = fp->getline(line);
+            double t1 = StageClock::now();
+            tr.clk.read += t1 - t0;
+            if (got) j += parse_pileup_line(line.data(), line.size(), j, site);
+            tr.clk.parse += StageClock::now() - t1;
+        }
         if (!site.aiv.empty()) {
             const char rc = refseq[(size_t)(p - rg_s)];
             const int8_t ref_base = rc == 'A' ? 0 : rc == 'C' ? 1 : rc == 'G' ? 2 : rc == 'T' ? 3 : -1;
@@ -324,6 +348,12 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
         }
     }
     tr.flush();
+    if (getenv("BVC_HOST_PROFILE")) {
+        const StageClock &c = tr.clk;
+        std::cerr << "[profile] thread " << ithread << ": read+inflate " << c.read << " s, parse " << c.parse << " s, pack "
+                  << c.pack << " s, libbvc " << c.gpu << " s, cvg lines " << c.cvg << " s, vcf lines " << c.vcf
+                  << " s, compress+write " << c.write << " s" << std::endl;
+    }
     bvc_destroy(tr.ctx);
     if (!fpv.close()) std::cerr << "warning: file cannot be closed" << std::endl;
     if (!fpc.close()) std::cerr << "warning: file cannot be closed" << std::endl;

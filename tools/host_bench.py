@@ -59,9 +59,13 @@ def main():
             os.remove(raw)
     t0 = time.perf_counter()
     r = subprocess.run([exe, "basetype", "--rerun", "-t", str(thread), "-b", str(batch), "-i", os.path.join(d, "bam.list"),
-                        "-s", f"chrS:{start}-{start + npos}", "-r", fa, "-o", out], capture_output=True, text=True)
+                        "-s", f"chrS:{start}-{start + npos}", "-r", fa, "-o", out], capture_output=True, text=True,
+                       env=dict(os.environ, BVC_HOST_PROFILE="1"))
     dt = time.perf_counter() - t0
     assert r.returncode == 0, r.stderr[-2000:]
+    for l in r.stderr.splitlines():
+        if l.startswith("[profile]"):
+            print(l)
     n_cvg = gzip.decompress(open(out + ".cvg.gz", "rb").read()).count(b"\n") - 3
     n_vcf = sum(1 for l in gzip.decompress(open(out + ".vcf.gz", "rb").read()).split(b"\n") if l and not l.startswith(b"#"))
     print({"n_samples": n, "positions": npos, "threads": thread, "text_MB": total / 1e6, "seconds": dt,

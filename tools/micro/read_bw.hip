@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <algorithm>
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -73,18 +74,19 @@ __global__ void coop_kernel(const u32x4 *__restrict__ a, const u32x4 *__restrict
 }
 
 template <typename F>
-static double best_ms(F launch, int reps = 5)
+static double best_ms(F launch, int reps = 21)       // median of `reps` timed launches
 {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     launch(); hipDeviceSynchronize();
-    double best = 1e30;
+    std::vector<float> t;
     for (int r = 0; r < reps; ++r) {
         hipEventRecord(a); launch(); hipEventRecord(b); hipEventSynchronize(b);
         float ms = 0; hipEventElapsedTime(&ms, a, b);
-        if (ms < best) best = ms;
+        t.push_back(ms);
     }
-    return best;
+    std::sort(t.begin(), t.end());
+    return t[t.size() / 2];
 }
 
 int main()
