@@ -101,13 +101,19 @@ struct PassOut {
 // Every non-empty class has n_c >= 1, so one class with |u| >= 2^-9 already gives delta > 1.9e-3: the test
 // fails whatever the other terms are and no logarithm is evaluated in that pass (about half of all passes:
 // the long sub-linear tails of alleles whose frequency drifts to zero).  Three wave-uniform tiers:
-//   near (all |u| < 2^-9): two Newton steps, delta from the cubic log1p series (truncation 3e-12 relative)
+//   near (all |u| < 2^-9): two Newton steps; delta is bracketed by A = sum_c n_c |u_c|, since |log1p(u)| lies
+//        within |u| (1 -+ 2^-9) there: A outside [eps / (1 + 2^-8), eps / (1 - 2^-8)) decides the test at one FMA
+//        per class; inside that window (a few passes per fit at most) delta is evaluated from the cubic log1p
+//        series (truncation 3e-12 relative) with a reduction of its own
 //   far  (some |u| in [2^-9, 2^-6]): two Newton steps, delta reported as "not converged"
 //   jump (some |u| > 2^-6, first passes of a fit): v_rcp_f64 + two Newton steps, "not converged"
 // Empty slots have d = 0, e = 1, so m = 1 and u = 0 to an ulp: they never raise the tier.
 // The NS slots are independent dependency chains with no branch between them, so they interleave.
 constexpr double kFarU = 0.001953125;                       // 2^-9
 constexpr double kNotConverged = 1.0;                       // any value >= kEmEpsilon
+constexpr double kConverged = 0.0;                          // any value < kEmEpsilon
+constexpr double kDeltaSureBelow = kEmEpsilon / (1.0 + 0.00390625);   // A below this: delta < eps for certain
+constexpr double kDeltaSureAbove = kEmEpsilon / (1.0 - 0.00390625);   // A at or above this: delta >= eps for certain
 
 template <int NS>
 __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double inv_n, int lane)
@@ -124,12 +130,7 @@ __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double in
     const bool far = __ballot(umax >= kFarU) != 0;
     if (!far) {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            double p = fma(-0.25, u[k], 1.0 / 3.0);
-            p = fma(p, u[k], -0.5);
-            p = fma(p, u[k], 1.0);
-            acc_delta = fma(S.n[k], fabs(u[k] * p), acc_delta);
-        }
+        for (int k = 0; k < NS; ++k) acc_delta = fma(S.n[k], fabs(u[k]), acc_delta);
     }
     if (__ballot(umax > kLog1pMaxU) == 0) {
 #pragma unroll
@@ -163,7 +164,22 @@ __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double in
     const double t = w.a + w.b;                                  // lanes 8-15: rows 0,1 -> E, rows 2,3 -> delta
     const double etot = lane_value<8>(t);
     PassOut o;
-    o.delta = far ? kNotConverged : lane_value<40>(t);
+    o.delta = kNotConverged;
+    if (!far) {
+        const double a_tot = lane_value<40>(t);                  // wave-uniform; NaN falls through to "not converged"
+        if (a_tot < kDeltaSureBelow) o.delta = kConverged;
+        else if (a_tot < kDeltaSureAbove) {                      // rare: the bracket straddles eps
+            double ex = 0.0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                double p = fma(-0.25, u[k], 1.0 / 3.0);
+                p = fma(p, u[k], -0.5);
+                p = fma(p, u[k], 1.0);
+                ex = fma(S.n[k], fabs(u[k] * p), ex);
+            }
+            o.delta = rows_total(row_sum(ex));
+        }
+    }
     o.ex_own = f.fb * inv_n * (drow + etot);
     return o;
 }
@@ -181,11 +197,18 @@ __device__ __forceinline__ double em_fit(Slots<NS> &S, int lane, double f0, doub
     // has |u| = |m - 1| and takes the big tier, whose reciprocal does not depend on yp
 #pragma unroll
     for (int k = 0; k < NS; ++k) S.yp[k] = 1.0;
-    for (int it = 0;; ++it) {                  // pass 0 + at most kEmIters update passes
+    // pass 0 + at most kEmIters update passes; two passes per trip so that 1/m can alternate between two register
+    // sets instead of being copied back every pass
+    for (int it = 0;; it += 2) {
         o = em_pass<NS>(S, f, inv_n, lane);
         passes += 1;
         if (it > 0 && o.delta < kEmEpsilon) break;   // NaN never converges, as in the reference
         if (it == kEmIters) break;
+        f.fb = o.ex_own;
+        o = em_pass<NS>(S, f, inv_n, lane);
+        passes += 1;
+        if (o.delta < kEmEpsilon) break;
+        if (it + 1 == kEmIters) break;
         f.fb = o.ex_own;
     }
     ex[0] = lane_value<0>(o.ex_own);
