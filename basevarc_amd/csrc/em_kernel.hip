@@ -90,56 +90,56 @@ template <int L> constexpr int dpp_newbcast() { return 0x150 + L; }   // row_new
 
 struct PassOut {
     double ex_own;          // expect_allele_prob of the lane's own base (uniform within the row)
-    double delta;           // sum_c n_c |log m_c' - log m_c| (wave-uniform)
+    bool converged;         // delta = sum_c n_c |log m_c' - log m_c| < 1e-3 (wave-uniform)
 };
 
-// One E+M pass (singleEM, src/Algorithm.cpp:69-93) plus the delta of delta_bylog (:103-113).
+// One E+M pass (singleEM, src/Algorithm.cpp:69-93) plus the convergence test on delta_bylog's delta (:103-113).
 //   M step: expect_j = f_j / N * (D_j + E),  D_j = sum_{c in j} n_c (a_c - e_c) / m_c,  E = sum_c n_c e_c / m_c
 //   u     : m' / m - 1 = m' * yp - 1  with yp = 1/m kept from the previous pass
-//   1/m'  : yp / (1 + u) -> yp * (1 - u) refined by two Newton steps (no v_rcp_f64 on the common paths)
-//   delta : sum_c n_c |log m_c' - log m_c| = sum_c n_c |log1p(u_c)|, used ONLY in the test delta < 1e-3.
-// Every non-empty class has n_c >= 1, so one class with |u| >= 2^-9 already gives delta > 1.9e-3: the test
-// fails whatever the other terms are and no logarithm is evaluated in that pass (about half of all passes:
-// the long sub-linear tails of alleles whose frequency drifts to zero).  Three wave-uniform tiers:
-//   near (all |u| < 2^-9): two Newton steps; delta is bracketed by A = sum_c n_c |u_c|, since |log1p(u)| lies
-//        within |u| (1 -+ 2^-9) there: A outside [eps / (1 + 2^-8), eps / (1 - 2^-8)) decides the test at one FMA
-//        per class; inside that window (a few passes per fit at most) delta is evaluated from the cubic log1p
-//        series (truncation 3e-12 relative) with a reduction of its own
-//   far  (some |u| in [2^-9, 2^-6]): two Newton steps, delta reported as "not converged"
-//   jump (some |u| > 2^-6, first passes of a fit): v_rcp_f64 + two Newton steps, "not converged"
-// Empty slots have d = 0, e = 1, so m = 1 and u = 0 to an ulp: they never raise the tier.
+//   1/m'  : yp / (1 + u) -> yp * (1 - u) refined by two Newton steps; v_rcp_f64 + two Newton steps only when some
+//           |u| > 2^-6 (the first passes of a fit)
+//   delta : sum_c n_c |log1p(u_c)| is used ONLY in the test delta < eps = 1e-3, so it is bracketed instead of
+//           evaluated: with A = sum_c n_c |u_c| (one FMA per class),
+//             A >= eps / (1 - 2^-8): not converged.  Either some |u| >= 2^-9, and that class alone (n_c >= 1) gives
+//                  delta > 1.9e-3; or every |u| < 2^-9, where |log1p(u)| >= |u| (1 - 2^-9), so delta >= eps.
+//             A <  eps / (1 + 2^-8): every n_c |u_c| < eps, so every |u| < 2^-9, |log1p(u)| <= |u| (1 + 2^-9) and
+//                  delta < eps: converged.
+//             in between (a few passes per fit at most): delta itself, log1p as a cubic (truncation 3e-12 relative),
+//                  with a reduction of its own.
+//           A is a sum of non-negative doubles (or NaN), so both comparisons are unsigned compares of its high
+//           word, done on the scalar unit; NaN and +inf compare high: "NaN never converges", as in the reference.
+// Empty slots have d = 0, e = 1, so m = 1 and u = 0 to an ulp: they add nothing.
 // The NS slots are independent dependency chains with no branch between them, so they interleave.
-constexpr double kFarU = 0.001953125;                       // 2^-9
-constexpr double kNotConverged = 1.0;                       // any value >= kEmEpsilon
-constexpr double kConverged = 0.0;                          // any value < kEmEpsilon
-constexpr double kDeltaSureBelow = kEmEpsilon / (1.0 + 0.00390625);   // A below this: delta < eps for certain
-constexpr double kDeltaSureAbove = kEmEpsilon / (1.0 - 0.00390625);   // A at or above this: delta >= eps for certain
+constexpr uint32_t hi_word(double x) { return (uint32_t)(__builtin_bit_cast(uint64_t, x) >> 32); }
+constexpr uint32_t kSureBelowHi = hi_word(kEmEpsilon / (1.0 + 0.00390625));        // hi(A) <  this: converged
+constexpr uint32_t kSureAboveHi = hi_word(kEmEpsilon / (1.0 - 0.00390625)) + 1u;   // hi(A) >= this: not converged
 
 template <int NS>
 __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double inv_n, int lane)
 {
-    double acc_d = 0.0, acc_e = 0.0, acc_delta = 0.0;
+    double acc_d = 0.0, acc_e = 0.0, acc_a;
     double m[NS], u[NS];
     double umax = 0.0;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         m[k] = fma(f.fb, S.d[k], S.e[k]);
         u[k] = fma(m[k], S.yp[k], -1.0);
-        umax = fmax(umax, fabs(u[k]));                      // fmax drops a NaN: NaN lanes take the near tier
+        umax = fmax(umax, fabs(u[k]));
+        // acc_a += n |u| in one instruction (the compiler materialises |u| with two extra moves otherwise)
+        if (k == 0) asm("v_mul_f64 %0, %1, |%2|" : "=v"(acc_a) : "v"(S.n[k]), "v"(u[k]));
+        else asm("v_fma_f64 %0, %1, |%2|, %0" : "+v"(acc_a) : "v"(S.n[k]), "v"(u[k]));
     }
-    const bool far = __ballot(umax >= kFarU) != 0;
-    if (!far) {
+    // The Newton path runs unconditionally and the rare jump passes redo 1/m afterwards: the vote on |u| is then
+    // long decided when its branch comes, instead of stalling the wave between u and the Newton steps.
+    const bool jump = __ballot(umax > kLog1pMaxU) != 0;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) acc_delta = fma(S.n[k], fabs(u[k]), acc_delta);
+    for (int k = 0; k < NS; ++k) {
+        double y = fma(-S.yp[k], u[k], S.yp[k]);
+        y = fma(y, fma(-m[k], y, 1.0), y);
+        S.yp[k] = fma(y, fma(-m[k], y, 1.0), y);
+        asm volatile("" : "+v"(S.yp[k]));                       // keeps these steps ahead of the branch below
     }
-    if (__ballot(umax > kLog1pMaxU) == 0) {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            double y = fma(-S.yp[k], u[k], S.yp[k]);
-            y = fma(y, fma(-m[k], y, 1.0), y);
-            S.yp[k] = fma(y, fma(-m[k], y, 1.0), y);
-        }
-    } else {
+    if (jump) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) S.yp[k] = fast_rcp(m[k]);
     }
@@ -150,9 +150,9 @@ __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double in
         acc_e = fma(r, S.e[k], acc_e);
     }
     // Three sums in one 16-lane reduction.  swap32 folds the wave's halves: z = E over lanes (l, l+32) in the
-    // lower half, delta in the upper half.  Within each row, lanes 0-7 then reduce D and lanes 8-15 reduce z
+    // lower half, A in the upper half.  Within each row, lanes 0-7 then reduce D and lanes 8-15 reduce z
     // (one exchange across the row's halves, three butterfly steps); swap16 adds the row pairs.
-    const DPair h = swap32(acc_e, acc_delta);
+    const DPair h = swap32(acc_e, acc_a);
     const double z = h.a + h.b;
     const bool hi = (lane & 8) != 0;
     double v = (hi ? z : acc_d) + dpp_f64<kDppRor8>(hi ? acc_d : z);
@@ -161,24 +161,21 @@ __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double in
     v += dpp_f64<kDppHalfMirror>(v);
     const double drow = dpp_f64<dpp_newbcast<0>()>(v);          // lanes 0-7 of the row: D of the row's base
     const DPair w = swap16(v, v);
-    const double t = w.a + w.b;                                  // lanes 8-15: rows 0,1 -> E, rows 2,3 -> delta
+    const double t = w.a + w.b;                                  // lanes 8-15: rows 0,1 -> E, rows 2,3 -> A
     const double etot = lane_value<8>(t);
+    const uint32_t a_hi = (uint32_t)__builtin_amdgcn_readlane(__double2hiint(t), 40);
     PassOut o;
-    o.delta = kNotConverged;
-    if (!far) {
-        const double a_tot = lane_value<40>(t);                  // wave-uniform; NaN falls through to "not converged"
-        if (a_tot < kDeltaSureBelow) o.delta = kConverged;
-        else if (a_tot < kDeltaSureAbove) {                      // rare: the bracket straddles eps
-            double ex = 0.0;
+    o.converged = a_hi < kSureBelowHi;
+    if (a_hi >= kSureBelowHi && a_hi < kSureAboveHi) {           // rare: the bracket straddles eps
+        double ex = 0.0;
 #pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                double p = fma(-0.25, u[k], 1.0 / 3.0);
-                p = fma(p, u[k], -0.5);
-                p = fma(p, u[k], 1.0);
-                ex = fma(S.n[k], fabs(u[k] * p), ex);
-            }
-            o.delta = rows_total(row_sum(ex));
+        for (int k = 0; k < NS; ++k) {
+            double p = fma(-0.25, u[k], 1.0 / 3.0);
+            p = fma(p, u[k], -0.5);
+            p = fma(p, u[k], 1.0);
+            ex = fma(S.n[k], fabs(u[k] * p), ex);
         }
+        o.converged = rows_total(row_sum(ex)) < kEmEpsilon;
     }
     o.ex_own = f.fb * inv_n * (drow + etot);
     return o;
@@ -202,12 +199,12 @@ __device__ __forceinline__ double em_fit(Slots<NS> &S, int lane, double f0, doub
     for (int it = 0;; it += 2) {
         o = em_pass<NS>(S, f, inv_n, lane);
         passes += 1;
-        if (it > 0 && o.delta < kEmEpsilon) break;   // NaN never converges, as in the reference
+        if (it > 0 && o.converged) break;
         if (it == kEmIters) break;
         f.fb = o.ex_own;
         o = em_pass<NS>(S, f, inv_n, lane);
         passes += 1;
-        if (o.delta < kEmEpsilon) break;
+        if (o.converged) break;
         if (it + 1 == kEmIters) break;
         f.fb = o.ex_own;
     }
@@ -483,6 +480,8 @@ __global__ __launch_bounds__(64 * WPB) void lrt_kernel(int64_t n_sites, const ui
 // the short transition code (log-likelihood, subset bookkeeping, result) runs with the other rows masked.
 // =====================================================================================================
 constexpr int kRowSlots = 8;
+constexpr double kFarU = 0.001953125;      // 2^-9: a row with a class at or above it cannot have converged
+constexpr double kNotConverged = 1.0;      // any value >= kEmEpsilon
 
 template <int NSL>
 __device__ __forceinline__ void rows_pass(const double (&sn)[kRowSlots], const double (&sd)[kRowSlots],
