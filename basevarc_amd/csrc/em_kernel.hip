@@ -854,7 +854,7 @@ __global__ void sum_groups_kernel(int64_t total, int n_hist, const uint32_t *__r
 
 }  // namespace
 
-// -1: pick by tile size, 0: one site per wave, 1: four sites per wave (BVC_EM_ROWS or bvc_set_tuning)
+// -1 (default) and 0: one site per wave; 1: four sites per wave for the <= 32-class sites (BVC_EM_ROWS or bvc_set_tuning)
 static std::atomic<int> g_em_rows_mode{[] { const char *e = getenv("BVC_EM_ROWS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }()};
 static std::atomic<int> g_em_waves_per_cu{[] { const char *e = getenv("BVC_EM_WAVES_PER_CU"); const int v = e ? atoi(e) : 0; return (v > 0 && v <= 32) ? v : 0; }()};
 
@@ -871,7 +871,6 @@ void set_em_tuning(int rows_mode, int waves_per_cu)
 // (overlap mode with long rows): 8 per CU = two 4-wave workgroups (swept 4..24 on MI355X at N = 1e6) leaves that kernel its wave slots and registers.
 // Otherwise the kernel has the chip to itself for most of its life and takes 24 per CU.
 // BVC_EM_WAVES_PER_CU / bvc_set_tuning override both.
-constexpr int64_t kRowsMinSites = 12288, kRowsMinDepth = 200000;
 
 static int64_t em_grid_cap(bool shared)
 {
@@ -917,14 +916,14 @@ hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *count
     if (n_sites <= 0) return hipSuccess;
     const int64_t cap = em_grid_cap(shared);
     const int64_t want_waves = n_sites < cap ? n_sites : cap;
-    // Layout of the common (<= 32 classes per base) sites: one site per wave, or four (rows).  Four per wave
-    // quarter the reduction work per site but need four times the sites to fill the chip.
-    const int mode = g_em_rows_mode.load();
-    // (not underneath a streaming histogram kernel: its 248 registers per lane would take that kernel's occupancy)
-    // Measured on MI355X (serial mode): N = 1e6, 16,000 / 32,000 sites: 1.63 vs 1.78 ms and 3.22 vs 3.58 ms in favour
-    // of rows; N = 1e4, 40,000 sites: 2.87 vs 2.58 ms against (fits are short there and the rows' masked transitions
-    // weigh more); 4,000 sites at any depth: against.
-    const bool rows = mode < 0 ? (!shared && n_sites >= kRowsMinSites && depth_hint >= kRowsMinDepth) : mode != 0;
+    // Layout of the common (<= 32 classes per base) sites: one site per wave, or four (rows).  Four per wave quarter
+    // the reduction work per site but need four times the sites to fill the chip and 248 registers per lane.  The
+    // rows layout was the faster one for deep tiles of >= 12,288 sites until the site-per-wave kernel got its even
+    // SIMD load and its shorter pass; measured since (MI355X, serial mode, N = 1e6): 16,000 sites 1.66 vs 1.69 ms,
+    // 32,000 sites 3.33 vs 3.31 ms, and N = 1e4, 40,000 sites 2.58 vs 2.87 ms -- so it is used only on request
+    // (bvc_set_tuning("em_rows", 1) / BVC_EM_ROWS=1) and stays as the A/B alternative.
+    (void)depth_hint;
+    const bool rows = g_em_rows_mode.load() > 0;
     if (rows) {
         // four sites per wave: a quarter of the waves hold the same number of sites in flight
         const int64_t want = (n_sites + 3) / 4;

@@ -160,7 +160,7 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
                     int8_t *ref_base);
 
 /* ---- tuning (process-wide; additive, no counterpart in the reference) ------------------------------- */
-/* key "em_rows": -1 pick by tile size (default), 0 one site per wavefront, 1 four sites per wavefront;
+/* key "em_rows": -1 default (= 0), 0 one site per wavefront, 1 four sites per wavefront (A/B alternative);
  * key "em_waves_per_cu": 0 default policy, 1..32 resident EM wavefronts per CU.  Results do not depend on them. */
 int bvc_set_tuning(const char *key, int value);
 
