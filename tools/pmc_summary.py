@@ -9,6 +9,7 @@ for the streaming histogram kernel; WRITE_SIZE is taken as is.  Counters come fr
 """
 import csv
 import glob
+import re
 import json
 import os
 import sys
@@ -18,20 +19,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    for k in ("hist_dense_groups_kernel", "hist_dense_kernel", "hist_csr_kernel", "lrt_groups_kernel", "lrt_kernel<2>",
-              "lrt_kernel<4>", "lrt_kernel<8>", "synth_dense_kernel", "sum_groups_kernel"):
+    m = re.search(r"(lrt_groups_kernel|lrt_kernel)<(\d+)", name)
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    for k in ("hist_dense_groups_kernel", "hist_dense_kernel", "hist_csr_kernel", "lrt_rows_kernel", "var_qual_kernel",
+              "synth_dense_kernel", "sum_groups_kernel", "stream_read_kernel"):
         if k in name:
             return k
     return name.split("(")[0][:60]
 
 
 def counters(d):
+    """Counters of the NEWEST run under d (gpurun merges every call's files into the same directory)."""
     out = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        for row in csv.DictReader(open(f)):
-            k = short(row["Kernel_Name"])
-            out[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-            out[k]["_dur_ns"].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        return out
+    f = max(files, key=os.path.getmtime)
+    for row in csv.DictReader(open(f)):
+        k = short(row["Kernel_Name"])
+        out[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        out[k]["_dur_ns"].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     return out
 
 
