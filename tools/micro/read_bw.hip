@@ -73,6 +73,75 @@ __global__ void coop_kernel(const u32x4 *__restrict__ a, const u32x4 *__restrict
     if (acc == 0x9E3779B9u) sink[0] = acc;
 }
 
+// The histogram kernel's real constraints on the cooperative shape: 64 KiB of LDS per workgroup (two per CU),
+// zeroed before and folded after every (row, part) item.  DYNAMIC: persistent workgroups take items in order
+// from a global counter and issue the first loads of the next item before folding the current one.
+template <bool DYNAMIC>
+__global__ __launch_bounds__(512) void coop_lds_kernel(const u32x4 *__restrict__ a, const u32x4 *__restrict__ b, int64_t row16,
+                                                       int64_t n_rows, int S, uint32_t *sink, unsigned int *counter)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ unsigned int s_item;
+    const int tid = threadIdx.x;
+    const int64_t n_items = n_rows * S;
+    uint32_t acc = 0;
+    for (int i = tid * 4; i < 16384; i += 512 * 4) *reinterpret_cast<u32x4 *>(&lds[i]) = u32x4{0, 0, 0, 0};
+    int64_t item;
+    if (DYNAMIC) {
+        if (tid == 0) s_item = atomicAdd(counter, 1u);
+        __syncthreads();
+        item = s_item;
+    } else {
+        item = blockIdx.x;
+    }
+    const int64_t chunk = 512;                                   // 16-byte units per block step (u1)
+    // first loads of the first item
+    u32x4 va = u32x4{0, 0, 0, 0}, vb = va;
+    int64_t r = 0, c = 0; int part = 0;
+    if (item < n_items) {
+        r = item / S; part = (int)(item % S); c = (int64_t)part * chunk + tid;
+        if (c < row16) { va = __builtin_nontemporal_load(&a[r * row16 + c]); vb = __builtin_nontemporal_load(&b[r * row16 + c]); }
+    }
+    while (item < n_items) {
+        const u32x4 *pa = a + r * row16, *pb = b + r * row16;
+        // stream the item: software-pipelined, the next block's loads are issued before the current one is used
+        for (;;) {
+            const int64_t cn = c + (int64_t)S * chunk;
+            u32x4 na = u32x4{0, 0, 0, 0}, nb = na;
+            const bool more = (cn - tid) < row16;                // block-uniform
+            if (more && cn < row16) { na = __builtin_nontemporal_load(&pa[cn]); nb = __builtin_nontemporal_load(&pb[cn]); }
+            acc ^= va.x ^ va.y ^ va.z ^ va.w ^ vb.x ^ vb.y ^ vb.z ^ vb.w;
+            if (!more) break;
+            va = na; vb = nb; c = cn;
+        }
+        int64_t next = n_items;
+        if (DYNAMIC) {
+            __syncthreads();
+            if (tid == 0) s_item = atomicAdd(counter, 1u);
+            __syncthreads();
+            next = s_item;
+            if (next < n_items) {                                 // prefetch the next item's first block before the fold
+                r = next / S; part = (int)(next % S); c = (int64_t)part * chunk + tid;
+                va = u32x4{0, 0, 0, 0}; vb = va;
+                if (c < row16) { va = __builtin_nontemporal_load(&a[r * row16 + c]); vb = __builtin_nontemporal_load(&b[r * row16 + c]); }
+            }
+        }
+        __syncthreads();
+        // fold: every thread sums the 32 copies of one class and clears them
+        uint32_t sum = 0;
+        for (int v = 0; v < 32; v += 4) {
+            const int cc = (v + 4 * (tid & 7)) & 31;
+            u32x4 *p = reinterpret_cast<u32x4 *>(&lds[tid * 32 + cc]);
+            const u32x4 x = *p; sum += x.x + x.y + x.z + x.w;
+            *p = u32x4{0, 0, 0, 0};
+        }
+        if (sum) atomicAdd(&sink[1 + (tid & 7)], sum);
+        __syncthreads();
+        item = next;
+    }
+    if (acc == 0x9E3779B9u) sink[0] = acc;
+}
+
 template <typename F>
 static double best_ms(F launch, int reps = 21)       // median of `reps` timed launches
 {
@@ -123,6 +192,18 @@ int main()
         report(name, (int)n_rows * S, 512, best_ms([&] { hipLaunchKernelGGL((coop_kernel<2>), dim3((unsigned)(n_rows * S)), dim3(512), 0, 0, pa, pb, row16, n_rows, S, sink); }));
         snprintf(name, sizeof name, "coop S=%d u1 (2 arrays)", S);
         report(name, (int)n_rows * S, 512, best_ms([&] { hipLaunchKernelGGL((coop_kernel<1>), dim3((unsigned)(n_rows * S)), dim3(512), 0, 0, pa, pb, row16, n_rows, S, sink); }));
+    }
+    {
+        unsigned int *counter; hipMalloc(&counter, 4);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(coop_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(coop_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        for (int S : {1, 2, 4, 8, 16, 32}) {
+            char name[64];
+            snprintf(name, sizeof name, "coop+LDS fold S=%d, 1 item/WG", S);
+            report(name, (int)n_rows * S, 512, best_ms([&] { hipLaunchKernelGGL((coop_lds_kernel<false>), dim3((unsigned)(n_rows * S)), dim3(512), 65536, 0, pa, pb, row16, n_rows, S, sink, counter); }));
+            snprintf(name, sizeof name, "coop+LDS fold S=%d, dynamic", S);
+            report(name, 512, 512, best_ms([&] { hipMemsetAsync(counter, 0, 4, 0); hipLaunchKernelGGL((coop_lds_kernel<true>), dim3(512), dim3(512), 65536, 0, pa, pb, row16, n_rows, S, sink, counter); }));
+        }
     }
     report("row-per-block u2 plain", 4000, 512, best_ms([&] { hipLaunchKernelGGL((row_kernel<2, false>), dim3(4000), dim3(512), 0, 0, pa, pb, row16, n_rows, sink); }));
     return 0;
