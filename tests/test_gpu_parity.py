@@ -451,6 +451,39 @@ def test_overlap_mode_gives_identical_records(ctx):
         ctx.set_overlap(False)
 
 
+def test_overlap_ring_with_growing_tiles_and_long_rows(ctx):
+    """Overlap mode with rows long enough for the capped EM grid, and calls of growing size: the three ring
+    buffers are re-allocated while other calls are in flight; every call still returns its plain-mode bytes."""
+    import torch
+    from basevarc_amd.lib import SITE_DTYPE
+    n = 200_000
+    m = caller_min_af(n)
+    sizes = [48, 200, 96, 400, 16, 640, 320]
+    tiles = []
+    for t, ns in enumerate(sizes):
+        b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+        q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+        r = torch.empty(ns, dtype=torch.int8, device="cuda")
+        ctx.synth_dense_device(9, 5000 * t, b, q, r)
+        tiles.append((b, q, r))
+    ctx.synchronize()
+    plain = []
+    for b, q, r in tiles:
+        out = ctx.lrt_dense_device(b, q, r, m)
+        ctx.synchronize()
+        plain.append(out.cpu().numpy().copy())
+    from basevarc_amd import Context
+    with Context(0) as fresh:                      # fresh context: its scratch starts empty and has to grow
+        fresh.set_overlap(True)
+        outs = [torch.zeros(b.shape[0] * SITE_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for b, _, _ in tiles]
+        for (b, q, r), o in zip(tiles, outs):
+            fresh.lrt_dense_device(b, q, r, m, o)
+        fresh.join()
+        fresh.synchronize()
+        for o, p in zip(outs, plain):
+            assert np.array_equal(o.cpu().numpy(), p)
+
+
 def test_full_size_sites_1e6_samples(ctx):
     """configs[2] shape (N = 1e6 samples per site): exact histogram, and the LRT against the oracle."""
     import torch
