@@ -501,17 +501,23 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
             BVC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_em_done[buf], 0));
             ctx->em_pending[buf] = false;
         }
+        bvc_ctx::Triple t{nullptr, nullptr, nullptr, nullptr, ns};
+        if (ctx->profiling) { t.a = take_event(ctx); t.b = take_event(ctx); t.c = take_event(ctx); t.d = take_event(ctx); }
+        if (t.a) BVC_HIP(ctx, hipEventRecord(t.a, ctx->stream));
         BVC_HIP(ctx, launch_hist_dense(ctx->stream, ns, n_samples, row_stride, b, q, g, n_groups, *gp, 1));
+        if (t.b) BVC_HIP(ctx, hipEventRecord(t.b, ctx->stream));
         hipStream_t s2 = ctx->stream;
         if (ctx->overlap) {
             s2 = ctx->side;
             BVC_HIP(ctx, hipEventRecord(ctx->ev_hist_done[buf], ctx->stream));
             BVC_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_hist_done[buf], 0));
         }
+        if (t.c) BVC_HIP(ctx, hipEventRecord(t.c, s2));
         BVC_HIP(ctx, launch_sum_groups(s2, ns, n_hist, *gp, *cp));
         const bool shared = ctx->overlap && n_samples >= 200000;
         BVC_HIP(ctx, launch_lrt(s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared, n_samples));
         BVC_HIP(ctx, launch_lrt_groups(s2, ns, n_groups, *gp, r, min_af, ctx->d_lut, res, gres, shared));
+        if (t.d) { BVC_HIP(ctx, hipEventRecord(t.d, s2)); ctx->ev_pending.push_back(t); }
         if (ctx->overlap) {
             BVC_HIP(ctx, hipEventRecord(ctx->ev_em_done[buf], s2));
             ctx->em_pending[buf] = true;

@@ -169,12 +169,14 @@ def main():
             "sharding": f"sites x{world}, no collective", "seed": a.seed, "overlap": not a.no_overlap,
         },
         "roofline": {
-            "bound": "hbm", "kernel": "hist_dense_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": "hist_dense_groups_kernel" if a.groups > 0 else "hist_dense_kernel",
+            "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a, n),
             "avg_launch_ms": hist_ms, "algorithmic_bytes_per_launch": alg_bytes,
             "empirical_stream_read_GBs": empirical_gbs, "frac_of_empirical": achieved / empirical_gbs if empirical_gbs else None,
         },
-        "kernels_ms_per_step": {"hist_dense_kernel": hist_ms, "lrt_kernel": em_ms},
+        "kernels_ms_per_step": {("hist_dense_groups_kernel" if a.groups > 0 else "hist_dense_kernel"): hist_ms,
+                                ("sum_groups + lrt + lrt_groups kernels" if a.groups > 0 else "lrt_kernel"): em_ms},
     }
 
     if rank == 0:
@@ -207,7 +209,7 @@ def pmc_traffic(a, n):
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(p))
-        if d.get("n_samples") == n and d.get("sites_per_launch") == a.tile_sites:
+        if d.get("n_samples") == n and d.get("sites_per_launch") == a.tile_sites and a.groups == 0 and a.coverage >= 1:
             return d.get("hbm_bytes_per_launch")
     except Exception:
         pass
