@@ -34,6 +34,7 @@ struct bvc_ctx {
     bool em_pending[kRing] = {false, false, false};
     uint32_t *d_grp[kRing] = {nullptr, nullptr, nullptr};   // [sites][groups + 1][512] in group mode
     size_t grp_cap[kRing] = {0, 0, 0};
+    int64_t *d_grp_scratch = nullptr;  // group mode: "samples ordered by group" flag + column bounds (hist_kernel.hip)
     char *d_stage = nullptr;           // staging for BVC_PTR_HOST calls
     size_t stage_cap = 0;
     bool profiling = false;
@@ -206,7 +207,8 @@ int bvc_create(bvc_ctx **out, int device)
         delete ctx;
         return BVC_ERR_ALLOC;
     }
-    bool ok = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&ctx->d_grp_scratch), (BVC_MAX_GROUPS + 4) * sizeof(int64_t)) == hipSuccess;
     for (int b = 0; b < bvc_ctx::kRing && ok; ++b)
         ok = hipEventCreateWithFlags(&ctx->ev_hist_done[b], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&ctx->ev_em_done[b], hipEventDisableTiming) == hipSuccess;
@@ -230,6 +232,7 @@ void bvc_destroy(bvc_ctx *ctx)
     for (auto &t : ctx->ev_pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.c); (void)hipEventDestroy(t.d); }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
+    if (ctx->d_grp_scratch) (void)hipFree(ctx->d_grp_scratch);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     delete ctx;
 }
@@ -504,7 +507,7 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
         bvc_ctx::Triple t{nullptr, nullptr, nullptr, nullptr, ns};
         if (ctx->profiling) { t.a = take_event(ctx); t.b = take_event(ctx); t.c = take_event(ctx); t.d = take_event(ctx); }
         if (t.a) BVC_HIP(ctx, hipEventRecord(t.a, ctx->stream));
-        BVC_HIP(ctx, launch_hist_dense(ctx->stream, ns, n_samples, row_stride, b, q, g, n_groups, *gp, 1));
+        BVC_HIP(ctx, launch_hist_dense(ctx->stream, ns, n_samples, row_stride, b, q, g, n_groups, *gp, 1, ctx->d_grp_scratch));
         if (t.b) BVC_HIP(ctx, hipEventRecord(t.b, ctx->stream));
         hipStream_t s2 = ctx->stream;
         if (ctx->overlap) {

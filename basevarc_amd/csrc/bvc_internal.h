@@ -30,7 +30,9 @@ struct QualLut {
 // Stage 1: dense pileup rows -> per-site class counts.  counts must be zeroed by the caller when split > 1.
 hipError_t launch_hist_dense(hipStream_t stream, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                              const int8_t *bases, const int8_t *quals, const uint8_t *group_of_sample,
-                             int n_groups, uint32_t *counts, int split);
+                             int n_groups, uint32_t *counts, int split, int64_t *group_scratch = nullptr);
+// group_scratch: BVC_MAX_GROUPS + 4 int64 of device memory; when given, calls whose samples are ordered by group
+// take the column-range kernel (decided on the device).
 // Number of sample-range splits per site launch_hist_dense should use for this shape (1 = none).
 int choose_hist_split(int64_t n_sites, int64_t n_samples, int n_cu);
 

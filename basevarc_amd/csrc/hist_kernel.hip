@@ -173,9 +173,10 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
     int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *__restrict__ bases,
     const int8_t *__restrict__ quals, const uint8_t *__restrict__ group_of_sample, int n_groups, int log2c,
-    uint32_t *__restrict__ grp_counts)
+    uint32_t *__restrict__ grp_counts, const int64_t *__restrict__ bounds)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    if (bounds && bounds[0] == 0) return;        // samples are ordered by group: hist_dense_ranges_kernel has the call
     const int tid = threadIdx.x;
     const int n_hist = n_groups + 1;
     const int words = (n_hist * BVC_NCLASS) << log2c;
@@ -233,7 +234,106 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
     }
 }
 
+// Group mode, samples ordered by group (every group a contiguous run of columns, ungrouped samples last): the
+// histogram of (site, group) is then the plain histogram of a column range, so the pass keeps the dense kernel's
+// 32 conflict-free LDS copies and its wave-wide fast path, and needs no per-sample group byte.
+// scratch[0] = 0 when group_of_sample is non-decreasing after clamping to n_groups, scratch[1 + h] = first sample of
+// histogram h, scratch[1 + n_hist] = n_samples (scratch is zeroed before the launch).
+__global__ void group_bounds_kernel(const uint8_t *__restrict__ group_of_sample, int64_t n_samples, int n_groups,
+                                    int64_t *__restrict__ scratch)
+{
+    const int n_hist = n_groups + 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += (int64_t)gridDim.x * blockDim.x) {
+        const int h = min((int)group_of_sample[i], n_groups);
+        if (i == 0)
+            for (int t = 0; t <= h; ++t) scratch[1 + t] = 0;
+        if (i == n_samples - 1) {
+            for (int t = h + 1; t <= n_hist; ++t) scratch[1 + t] = n_samples;
+        } else {
+            const int hn = min((int)group_of_sample[i + 1], n_groups);
+            if (hn < h) scratch[0] = 1;                          // not ordered: the general kernel takes the call
+            for (int t = h + 1; t <= hn; ++t) scratch[1 + t] = i + 1;
+        }
+    }
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(kHistThreads) void hist_dense_ranges_kernel(
+    int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *__restrict__ bases,
+    const int8_t *__restrict__ quals, int n_hist, const int64_t *__restrict__ scratch, uint32_t *__restrict__ grp_counts)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [class][copy]
+    (void)n_samples;
+    if (scratch[0] != 0) return;
+    const int tid = threadIdx.x;
+    const uint32_t lane_off = (uint32_t)(tid & (kCopies - 1));
+    __builtin_amdgcn_s_setprio(3);
+    for (int i = tid * 4; i < kLdsWords; i += kHistThreads * 4)
+        *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    auto scalar = [&](const int8_t *brow, const int8_t *qrow, int64_t i0, int64_t i1) {
+        for (int64_t i = i0 + tid; i < i1; i += kHistThreads) {
+            const uint32_t b = (uint8_t)brow[i], q = (uint8_t)qrow[i];
+            if (b < 4u && q < 128u)
+                __hip_atomic_fetch_add(&hist[((b << 7) | q) * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    const int64_t n_work = n_sites * n_hist;
+    for (int64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const int64_t site = w / n_hist;
+        const int h = (int)(w % n_hist);
+        const int8_t *brow = bases + site * row_stride;
+        const int8_t *qrow = quals + site * row_stride;
+        const int64_t s0 = scratch[1 + h], s1 = scratch[2 + h];
+        // [s0, s1) = unaligned head, whole 16-sample chunks [c0, c1), unaligned tail
+        const int64_t c0 = (s0 + 15) >> 4, c1 = s1 >> 4;
+        if (ALIGNED && c0 < c1) {
+            scalar(brow, qrow, s0, c0 << 4);
+            const u32x4 *bv = reinterpret_cast<const u32x4 *>(brow);
+            const u32x4 *qv = reinterpret_cast<const u32x4 *>(qrow);
+            constexpr int64_t kBlockChunks = (int64_t)kUnroll * kHistThreads;
+            int64_t cb = c0;
+            for (; cb + kBlockChunks <= c1; cb += kBlockChunks) {
+                u32x4 b[kUnroll], q[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    b[u] = __builtin_nontemporal_load(&bv[cb + tid + (int64_t)u * kHistThreads]);
+                    q[u] = __builtin_nontemporal_load(&qv[cb + tid + (int64_t)u * kHistThreads]);
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) count_chunk(hist, b[u], q[u], lane_off);
+            }
+            for (int64_t ct = cb + tid; ct < c1; ct += kHistThreads) {
+                const u32x4 b = __builtin_nontemporal_load(&bv[ct]);
+                const u32x4 q = __builtin_nontemporal_load(&qv[ct]);
+                count_word_checked(hist, b.x, q.x, lane_off); count_word_checked(hist, b.y, q.y, lane_off);
+                count_word_checked(hist, b.z, q.z, lane_off); count_word_checked(hist, b.w, q.w, lane_off);
+            }
+            scalar(brow, qrow, c1 << 4, s1);
+        } else {
+            scalar(brow, qrow, s0, s1);
+        }
+        __syncthreads();
+        for (int key = tid; key < BVC_NCLASS; key += kHistThreads) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int v = 0; v < kCopies; v += 4) {
+                const int cc = (v + 4 * (key & 7)) & (kCopies - 1);
+                u32x4 *p = reinterpret_cast<u32x4 *>(&hist[key * kCopies + cc]);
+                const u32x4 x = *p;
+                sum += x.x + x.y + x.z + x.w;
+                *p = u32x4{0u, 0u, 0u, 0u};
+            }
+            grp_counts[w * BVC_NCLASS + key] = sum;
+        }
+        __syncthreads();
+    }
+}
+
 // Ragged pileup: site s owns elements offsets[s] .. offsets[s+1]).  Byte loads (rows start anywhere).
+
 __global__ __launch_bounds__(kHistThreads) void hist_csr_kernel(
     int64_t n_sites, const int64_t *__restrict__ offsets, const int8_t *__restrict__ bases,
     const int8_t *__restrict__ quals, uint32_t *__restrict__ counts)
@@ -308,12 +408,13 @@ int choose_hist_split(int64_t n_sites, int64_t n_samples, int n_cu)
 
 hipError_t launch_hist_dense(hipStream_t stream, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                              const int8_t *bases, const int8_t *quals, const uint8_t *group_of_sample,
-                             int n_groups, uint32_t *counts, int split)
+                             int n_groups, uint32_t *counts, int split, int64_t *group_scratch)
 {
     if (n_sites <= 0) return hipSuccess;
-    static std::atomic<bool> attr_done_dev[kMaxDevices][2], gattr_done_dev[kMaxDevices][2];
+    static std::atomic<bool> attr_done_dev[kMaxDevices][2], gattr_done_dev[kMaxDevices][2], rattr_done_dev[kMaxDevices][2];
     std::atomic<bool> *attr_done = attr_done_dev[current_device_slot()];
     std::atomic<bool> *gattr_done = gattr_done_dev[current_device_slot()];
+    std::atomic<bool> *rattr_done = rattr_done_dev[current_device_slot()];
     const bool aligned = ((reinterpret_cast<uintptr_t>(bases) | reinterpret_cast<uintptr_t>(quals)) & 15u) == 0 &&
                          (row_stride & 15) == 0;
     const size_t lds = (size_t)kLdsWords * sizeof(uint32_t);
@@ -330,8 +431,31 @@ hipError_t launch_hist_dense(hipStream_t stream, int64_t n_sites, int64_t n_samp
         }
         const size_t glds = ((size_t)(n_groups + 1) * BVC_NCLASS << log2c) * sizeof(uint32_t);
         const int64_t ggrid = n_sites < 4096 ? n_sites : 4096;
+        const bool try_ranges = group_scratch != nullptr && n_samples > 0;
+        if (try_ranges) {
+            // Decided on the device, without a host round trip: the bounds kernel marks whether the samples are
+            // ordered by group; the range kernel and the general kernel are both launched and the one whose turn
+            // it is not returns at once.
+            const int n_hist = n_groups + 1;
+            auto rk = aligned ? hist_dense_ranges_kernel<true> : hist_dense_ranges_kernel<false>;
+            if (!rattr_done[aligned]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rk),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                rattr_done[aligned] = true;
+            }
+            hipError_t e = hipMemsetAsync(group_scratch, 0, (size_t)(BVC_MAX_GROUPS + 4) * sizeof(int64_t), stream);
+            if (e != hipSuccess) return e;
+            const int64_t bgrid = (n_samples + 255) / 256;
+            hipLaunchKernelGGL(group_bounds_kernel, dim3((unsigned)(bgrid < 1024 ? bgrid : 1024)), dim3(256), 0, stream,
+                               group_of_sample, n_samples, n_groups, group_scratch);
+            const int64_t n_work = n_sites * n_hist;
+            hipLaunchKernelGGL(rk, dim3((unsigned)(n_work < 4096 ? n_work : 4096)), dim3(kHistThreads), lds, stream,
+                               n_sites, n_samples, row_stride, bases, quals, n_hist, group_scratch, counts);
+        }
         hipLaunchKernelGGL(gk, dim3((unsigned)ggrid), dim3(kHistThreads), glds, stream, n_sites, n_samples,
-                           row_stride, bases, quals, group_of_sample, n_groups, log2c, counts);
+                           row_stride, bases, quals, group_of_sample, n_groups, log2c, counts,
+                           try_ranges ? group_scratch : nullptr);
         return hipGetLastError();
     }
     auto kern = aligned ? hist_dense_kernel<true> : hist_dense_kernel<false>;

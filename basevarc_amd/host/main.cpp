@@ -232,21 +232,23 @@ struct TileRunner {
             rc = bvc_lrt_csr(ctx, ns, offsets.data(), bases.empty() ? &none : bases.data(), quals.empty() ? &none : quals.data(),
                              refs.data(), min_af, res.data(), BVC_PTR_HOST);
         } else {
-            // dense [site][sample] tile with -1 for "no observation"; group of each sample is shared by all sites
+            // dense [site][column] tile with -1 for "no observation"; columns are the samples ordered by group
+            // (Groups::order_columns), the group of each column is shared by all sites
             const int64_t stride = ((int64_t)n_samples + 15) / 16 * 16;
             std::vector<int8_t> bases((size_t)(ns * stride), (int8_t)-1), quals((size_t)(ns * stride), (int8_t)0);
             for (int64_t s = 0; s < ns; ++s)
                 for (size_t k = 0; k < sites[s].aiv.size(); ++k) {
                     const AlleleInfo &a = sites[s].aiv[k];
                     if (a.is_indel == 0) {
-                        bases[(size_t)(s * stride + sites[s].sample[k])] = (int8_t)a.base;
-                        quals[(size_t)(s * stride + sites[s].sample[k])] = (int8_t)a.qual;
+                        const int64_t col = groups->column_of[(size_t)sites[s].sample[k]];
+                        bases[(size_t)(s * stride + col)] = (int8_t)a.base;
+                        quals[(size_t)(s * stride + col)] = (int8_t)a.qual;
                     }
                 }
             gres.resize((size_t)(ns * ng));
             t1 = StageClock::now(); clk.pack += t1 - t0; t0 = t1;
             rc = bvc_lrt_dense_groups(ctx, ns, n_samples, stride, bases.data(), quals.data(), refs.data(), min_af,
-                                      groups->of_sample.data(), ng, res.data(), gres.data(), BVC_PTR_HOST);
+                                      groups->of_column.data(), ng, res.data(), gres.data(), BVC_PTR_HOST);
         }
         if (rc != BVC_OK) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(ctx));
         t1 = StageClock::now(); clk.gpu += t1 - t0; t0 = t1;
@@ -301,6 +303,7 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
             for (int i : kv.second) groups.of_sample[(size_t)i] = (uint8_t)groups.names.size();
             groups.names.push_back(kv.first);
         }
+        groups.order_columns();
     }
     if (ithread == 0) {
         fpc.write(cvg_header(groups));

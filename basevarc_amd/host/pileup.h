@@ -12,6 +12,7 @@
 
 #include <cstdint>
 #include <map>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -42,6 +43,20 @@ struct SiteColumn {
 struct Groups {
     std::vector<std::string> names;
     std::vector<uint8_t> of_sample;     // group index per sample, 255 = in no group
+    // Column order of the dense tiles handed to libbvc: samples ordered by group (ungrouped last), so that every
+    // group is a contiguous run of columns and the library's column-range histogram kernel takes the call.
+    std::vector<int32_t> column_of;     // sample -> column
+    std::vector<uint8_t> of_column;     // group index per column (non-decreasing, 255 last)
+    void order_columns()
+    {
+        const size_t n = of_sample.size();
+        std::vector<int32_t> order(n);
+        for (size_t i = 0; i < n; ++i) order[i] = (int32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return of_sample[(size_t)x] < of_sample[(size_t)y]; });
+        column_of.assign(n, 0);
+        of_column.assign(n, 255);
+        for (size_t c = 0; c < n; ++c) { column_of[(size_t)order[c]] = (int32_t)c; of_column[c] = of_sample[(size_t)order[c]]; }
+    }
     bool empty() const { return names.empty(); }
 };
 

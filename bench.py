@@ -39,6 +39,8 @@ def parse():
     p.add_argument("--no-verify", action="store_true", help="CPU leg: time the baseline only, skip the wider check")
     p.add_argument("--no-overlap", action="store_true", help="run the two kernels of a step back to back on one stream")
     p.add_argument("--groups", type=int, default=0, help="population groups (BASELINE configs[4]: 5); 0 = overall call only")
+    p.add_argument("--group-layout", choices=("interleaved", "ordered"), default="interleaved",
+                   help="group of sample i: i %% k (SURVEY 8d) or contiguous runs of columns (takes the column-range kernel)")
     p.add_argument("--coverage", type=float, default=1.0, help="fraction of samples covered per site (sparse variant)")
     p.add_argument("--profile-every", type=int, default=1, help="time the kernels of every K-th step with HIP events (1 = every step)")
     return p.parse_args()
@@ -106,7 +108,10 @@ def main():
     group_t = grp_results = None
     if a.groups > 0:
         from basevarc_amd.lib import GROUP_DTYPE
-        gnp = (np.arange(n) % a.groups).astype(np.uint8)         # group = sample % k
+        if a.group_layout == "ordered":
+            gnp = (np.arange(n) * a.groups // n).astype(np.uint8)    # the same k equal groups as contiguous column runs
+        else:
+            gnp = (np.arange(n) % a.groups).astype(np.uint8)         # group = sample % k
         group_t = torch.from_numpy(gnp).to(dev)
         grp_results = [torch.empty(a.tile_sites * a.groups * GROUP_DTYPE.itemsize, dtype=torch.uint8, device=dev)
                        for _ in range(n_tiles)]
@@ -163,19 +168,19 @@ def main():
         "config": {
             "workload": f"synthetic pileup {a.total_sites} sites x {n} samples per GPU (BASELINE configs[2]), "
                         f"{'dense coverage' if a.coverage >= 1 else f'coverage {a.coverage:g}'}, Q10-40, 20% polymorphic"
-                        f"{f', {a.groups} population groups' if a.groups else ''}; step = tile of {a.tile_sites} sites",
+                        f"{f', {a.groups} population groups ({a.group_layout})' if a.groups else ''}; step = tile of {a.tile_sites} sites",
             "n_samples": n, "sites_per_step": a.tile_sites, "resident_tiles": n_tiles,
             "resident_GB_per_gpu": round(n_tiles * tile_bytes / 1e9, 1), "min_af": min_af,
             "sharding": f"sites x{world}, no collective", "seed": a.seed, "overlap": not a.no_overlap,
         },
         "roofline": {
-            "bound": "hbm", "kernel": "hist_dense_groups_kernel" if a.groups > 0 else "hist_dense_kernel",
+            "bound": "hbm", "kernel": ("hist_dense_ranges_kernel" if a.group_layout == "ordered" else "hist_dense_groups_kernel") if a.groups > 0 else "hist_dense_kernel",
             "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a, n),
             "avg_launch_ms": hist_ms, "algorithmic_bytes_per_launch": alg_bytes,
             "empirical_stream_read_GBs": empirical_gbs, "frac_of_empirical": achieved / empirical_gbs if empirical_gbs else None,
         },
-        "kernels_ms_per_step": {("hist_dense_groups_kernel" if a.groups > 0 else "hist_dense_kernel"): hist_ms,
+        "kernels_ms_per_step": {(("hist_dense_ranges_kernel" if a.group_layout == "ordered" else "hist_dense_groups_kernel") if a.groups > 0 else "hist_dense_kernel"): hist_ms,
                                 ("sum_groups + lrt + lrt_groups kernels" if a.groups > 0 else "lrt_kernel"): em_ms},
     }
 

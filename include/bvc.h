@@ -128,6 +128,8 @@ int bvc_lrt_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_
  * gr.SetBase({ref} + alt_bases); gr.LRT()  (src/BaseVarC.cpp:617-661).
  * group_of_sample[i] >= n_groups means "in no group" (src/BaseVarC.cpp:352-356).
  * grp_results is [n_sites][n_groups].
+ * Any column order gives the same records; when group_of_sample is non-decreasing (each group a contiguous run
+ * of columns, ungrouped samples last) the call takes a faster histogram kernel.
  */
 int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                          const int8_t *bases, const int8_t *quals, const int8_t *ref_base,

@@ -313,6 +313,48 @@ def test_group_mode_matches_callers_group_loop(ctx):
             np.testing.assert_allclose(gres[s]["af"], ga, rtol=0, atol=AF_ATOL, err_msg=f"n={n} site={s}")
 
 
+def test_group_mode_samples_ordered_by_group(ctx):
+    """Samples ordered by group take the column-range histogram kernel (decided on the device): the records must
+    equal, byte for byte, those of the same columns in shuffled order (general kernel), and match the oracle.
+    Covers empty groups, ungrouped samples last, ranges that start and end off the 16-byte grid, one-sample runs."""
+    rng = np.random.default_rng(34)
+    cases = [(5000, 5, [0.3, 0.2, 0.2, 0.1, 0.1, 0.1]),        # (n, k, fractions of groups 0..k-1 and ungrouped)
+             (40000 + 7, 5, [0.2, 0.0, 0.4, 0.2, 0.2, 0.0]),   # group 1 empty, nobody ungrouped
+             (48000, 5, [0.31, 0.17, 0.23, 0.09, 0.11, 0.09]),  # 16-byte aligned rows: vector body + ragged edges
+             (16 * 4096 + 16, 2, [0.5, 0.5, 0.0]),
+             (3000, 1, [0.9, 0.1]),
+             (2100, 32, [1 / 33.0] * 33),
+             (700, 3, [0.0, 0.0, 0.0, 1.0]),                    # everybody ungrouped
+             (64, 4, [0.25, 0.25, 0.25, 0.25, 0.0])]
+    for n, k, frac in cases:
+        counts = np.floor(np.array(frac) * n).astype(int)
+        counts[int(np.argmax(counts))] += n - counts.sum()
+        labels = np.concatenate([np.full(c, (g if g < k else 255), dtype=np.uint8) for g, c in enumerate(counts)])
+        assert labels.size == n and np.all(np.diff(np.minimum(labels, k).astype(int)) >= 0)
+        ns = 10
+        sites = []
+        for s in range(ns):
+            b, q, r = random_site(rng, n, af=[0.0, 0.02, 0.3][s % 3], second_af=0.05 if s % 4 == 0 else 0.0)
+            if s == 5:
+                b[rng.random(n) < 0.5] = -1
+            sites.append((b, q, r))
+        B, Q, R = pad_rows(sites)
+        m = caller_min_af(n)
+        res, gres = ctx.lrt_dense_groups(B, Q, R, m, labels, k)
+        perm = rng.permutation(n)                               # same columns, shuffled: the general kernel
+        Bp, Qp = B.copy(), Q.copy()
+        Bp[:, :n], Qp[:, :n] = B[:, perm], Q[:, perm]
+        res_p, gres_p = ctx.lrt_dense_groups(Bp, Qp, R, m, labels[perm], k)
+        assert np.array_equal(gres["depth"], gres_p["depth"]) and np.array_equal(res["depth"], res_p["depth"])
+        assert res.tobytes() == res_p.tobytes() and gres.tobytes() == gres_p.tobytes(), (n, k)
+        for s, (b, q, r) in enumerate(sites):
+            o, gd, ga, ran, pres = orc.dense_site_groups(b, q, r, m, labels, k)
+            assert_site_matches(res[s], o, where=f"ordered groups n={n} site={s}")
+            assert np.array_equal(gres[s]["depth"], gd), (n, s)
+            assert np.array_equal(gres[s]["ran"], ran) and np.array_equal(gres[s]["present"], pres), (n, s)
+            np.testing.assert_allclose(gres[s]["af"], ga, rtol=0, atol=AF_ATOL, err_msg=f"n={n} site={s}")
+
+
 # ------------------------------------------------------------------ golden fixtures (tests/golden)
 def test_golden_fixtures(ctx):
     from tests.golden.golden_io import load_golden
