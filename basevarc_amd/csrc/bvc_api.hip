@@ -518,7 +518,7 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
         if (t.c) BVC_HIP(ctx, hipEventRecord(t.c, s2));
         BVC_HIP(ctx, launch_sum_groups(s2, ns, n_hist, *gp, *cp));
         const bool shared = ctx->overlap && n_samples >= 200000;
-        BVC_HIP(ctx, launch_lrt(s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared, n_samples));
+        BVC_HIP(ctx, launch_lrt(s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared, n_samples, 12 /* = kGroupSharedWavesPerCu, em_kernel.hip */));
         BVC_HIP(ctx, launch_lrt_groups(s2, ns, n_groups, *gp, r, min_af, ctx->d_lut, res, gres, shared));
         if (t.d) { BVC_HIP(ctx, hipEventRecord(t.d, s2)); ctx->ev_pending.push_back(t); }
         if (ctx->overlap) {

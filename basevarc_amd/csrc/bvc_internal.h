@@ -48,7 +48,8 @@ hipError_t launch_hist_csr(hipStream_t stream, int64_t n_sites, const int64_t *o
 hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *counts, int64_t hist_stride,
                       const int8_t *ref_base, double min_af, const QualLut *lut,
                       const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results, bool shared = false,
-                      int64_t depth_hint = 0);   // samples per site when the caller knows it (layout choice only)
+                      int64_t depth_hint = 0,    // samples per site when the caller knows it (layout choice only)
+                      int shared_waves_per_cu = 0);   // 0 = default cap when shared
 
 // rows_mode: -1 auto, 0 one site per wave, 1 four sites per wave; waves_per_cu: 0 = default policy
 void set_em_tuning(int rows_mode, int waves_per_cu);

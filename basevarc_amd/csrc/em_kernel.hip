@@ -872,7 +872,11 @@ void set_em_tuning(int rows_mode, int waves_per_cu)
 // Otherwise the kernel has the chip to itself for most of its life and takes 24 per CU.
 // BVC_EM_WAVES_PER_CU / bvc_set_tuning override both.
 
-static int64_t em_grid_cap(bool shared)
+// Group mode's stage 2 (sum, overall LRT, per-group LRT) is a third longer and its histogram pass slower than the
+// plain call's: 12 waves per CU balance the two streams there (swept 4..32 on MI355X, k = 5, N = 1e6).
+constexpr int kGroupSharedWavesPerCu = 12;
+
+static int64_t em_grid_cap(bool shared, int shared_waves_per_cu = 0)
 {
     static std::atomic<int> n_cu_dev[kMaxDevices];
     std::atomic<int> &n_cu_a = n_cu_dev[current_device_slot()];
@@ -886,7 +890,7 @@ static int64_t em_grid_cap(bool shared)
         }
         n_cu_a.store(n_cu);
     }
-    int per_cu = shared ? 8 : 24;
+    int per_cu = shared ? (shared_waves_per_cu > 0 ? shared_waves_per_cu : 8) : 24;
     if (g_em_waves_per_cu.load() > 0) per_cu = g_em_waves_per_cu.load();
     return (int64_t)per_cu * n_cu;
 }
@@ -911,10 +915,10 @@ static void launch_lrt_variants(hipStream_t stream, int64_t want_waves, bool ski
 hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *counts, int64_t hist_stride,
                       const int8_t *ref_base, double min_af, const QualLut *lut,
                       const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results, bool shared,
-                      int64_t depth_hint)
+                      int64_t depth_hint, int shared_waves_per_cu)
 {
     if (n_sites <= 0) return hipSuccess;
-    const int64_t cap = em_grid_cap(shared);
+    const int64_t cap = em_grid_cap(shared, shared_waves_per_cu);
     const int64_t want_waves = n_sites < cap ? n_sites : cap;
     // Layout of the common (<= 32 classes per base) sites: one site per wave, or four (rows).  Four per wave quarter
     // the reduction work per site but need four times the sites to fill the chip and 248 registers per lane.  The
@@ -957,7 +961,7 @@ hipError_t launch_lrt_groups(hipStream_t stream, int64_t n_sites, int n_groups, 
                              const bvc_site_result *overall, bvc_group_result *grp_results, bool shared)
 {
     if (n_sites <= 0 || n_groups <= 0) return hipSuccess;
-    const int64_t cap = em_grid_cap(shared);
+    const int64_t cap = em_grid_cap(shared, kGroupSharedWavesPerCu);
     const int64_t n_work = n_sites * n_groups;
     const int64_t want_waves = n_work < cap ? n_work : cap;
     const int wpb = g_em_wpb.load() ? g_em_wpb.load() : 4;

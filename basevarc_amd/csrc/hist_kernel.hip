@@ -177,6 +177,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     if (bounds && bounds[0] == 0) return;        // samples are ordered by group: hist_dense_ranges_kernel has the call
+    __builtin_amdgcn_s_setprio(3);               // as in hist_dense_kernel: ahead of the EM kernels it shares the chip with
     const int tid = threadIdx.x;
     const int n_hist = n_groups + 1;
     const int words = (n_hist * BVC_NCLASS) << log2c;
