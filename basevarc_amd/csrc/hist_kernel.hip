@@ -169,12 +169,15 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_kernel(
 // site (the last one collects samples that belong to no group, :352-356).  LDS holds [hist][class][copy]
 // with as many copies as fit 64 KiB (copies = 1 << log2c); fewer copies than banks means some conflicts,
 // which the spread of keys over groups softens.
-template <bool ALIGNED>
+// LOG2C >= 0: the number of copies is a compile-time constant (the address is then five VALU instructions per
+// sample); LOG2C < 0: taken from the argument.
+template <bool ALIGNED, int LOG2C>
 __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
     int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *__restrict__ bases,
-    const int8_t *__restrict__ quals, const uint8_t *__restrict__ group_of_sample, int n_groups, int log2c,
+    const int8_t *__restrict__ quals, const uint8_t *__restrict__ group_of_sample, int n_groups, int log2c_arg,
     uint32_t *__restrict__ grp_counts, const int64_t *__restrict__ bounds)
 {
+    const int log2c = LOG2C >= 0 ? LOG2C : log2c_arg;
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     if (bounds && bounds[0] == 0) return;        // samples are ordered by group: hist_dense_ranges_kernel has the call
     __builtin_amdgcn_s_setprio(3);               // as in hist_dense_kernel: ahead of the EM kernels it shares the chip with
@@ -185,12 +188,13 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
     for (int i = tid; i < words; i += kHistThreads) hist[i] = 0;
     __syncthreads();
 
+    auto add_valid = [&](uint32_t b, uint32_t q, uint32_t g) {
+        const uint32_t h = g < (uint32_t)n_groups ? g : (uint32_t)n_groups;
+        __hip_atomic_fetch_add(&hist[((h << (9 + log2c)) | (b << (7 + log2c)) | (q << log2c)) + lane_off], 1u,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     auto add = [&](uint32_t b, uint32_t q, uint32_t g) {
-        if (b < 4u && q < 128u) {
-            const uint32_t h = g < (uint32_t)n_groups ? g : (uint32_t)n_groups;
-            __hip_atomic_fetch_add(&hist[(((h << 9) | (b << 7) | q) << log2c) + lane_off], 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        if (b < 4u && q < 128u) add_valid(b, q, g);
     };
 
     for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
@@ -201,13 +205,23 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
             const u32x4 *bv = reinterpret_cast<const u32x4 *>(brow);
             const u32x4 *qv = reinterpret_cast<const u32x4 *>(qrow);
             const u32x4 *gv = reinterpret_cast<const u32x4 *>(group_of_sample);
+            // the common case (every sample of the wave covered) skips the per-sample test, as in count_chunk
             auto count16 = [&](const u32x4 b, const u32x4 q, const u32x4 g) {
                 const uint32_t bw[4] = {b.x, b.y, b.z, b.w}, qw[4] = {q.x, q.y, q.z, q.w}, gw[4] = {g.x, g.y, g.z, g.w};
+                const uint32_t bad = ((b.x | b.y | b.z | b.w) & 0xFCFCFCFCu) | ((q.x | q.y | q.z | q.w) & 0x80808080u);
+                if (__ballot(bad != 0) == 0) {
 #pragma unroll
-                for (int w = 0; w < 4; ++w)
+                    for (int w = 0; w < 4; ++w)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        add((bw[w] >> (8 * k)) & 0xFFu, (qw[w] >> (8 * k)) & 0xFFu, (gw[w] >> (8 * k)) & 0xFFu);
+                        for (int k = 0; k < 4; ++k)
+                            add_valid((bw[w] >> (8 * k)) & 0xFFu, (qw[w] >> (8 * k)) & 0xFFu, (gw[w] >> (8 * k)) & 0xFFu);
+                } else {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            add((bw[w] >> (8 * k)) & 0xFFu, (qw[w] >> (8 * k)) & 0xFFu, (gw[w] >> (8 * k)) & 0xFFu);
+                }
             };
             int64_t c = tid;
             for (; c + kHistThreads < n16; c += 2 * kHistThreads) {        // two 16-byte loads per array in flight
@@ -412,7 +426,7 @@ hipError_t launch_hist_dense(hipStream_t stream, int64_t n_sites, int64_t n_samp
                              int n_groups, uint32_t *counts, int split, int64_t *group_scratch)
 {
     if (n_sites <= 0) return hipSuccess;
-    static std::atomic<bool> attr_done_dev[kMaxDevices][2], gattr_done_dev[kMaxDevices][2], rattr_done_dev[kMaxDevices][2];
+    static std::atomic<bool> attr_done_dev[kMaxDevices][2], gattr_done_dev[kMaxDevices][7], rattr_done_dev[kMaxDevices][2];
     std::atomic<bool> *attr_done = attr_done_dev[current_device_slot()];
     std::atomic<bool> *gattr_done = gattr_done_dev[current_device_slot()];
     std::atomic<bool> *rattr_done = rattr_done_dev[current_device_slot()];
@@ -423,12 +437,18 @@ hipError_t launch_hist_dense(hipStream_t stream, int64_t n_sites, int64_t n_samp
         const bool galigned = aligned && (reinterpret_cast<uintptr_t>(group_of_sample) & 15u) == 0;
         int log2c = 0;
         while (log2c < 5 && (size_t)(n_groups + 1) * BVC_NCLASS * (2u << log2c) <= (size_t)kLdsWords) ++log2c;
-        auto gk = galigned ? hist_dense_groups_kernel<true> : hist_dense_groups_kernel<false>;
-        if (!gattr_done[galigned]) {
+        using GroupKernel = void (*)(int64_t, int64_t, int64_t, const int8_t *, const int8_t *, const uint8_t *, int, int,
+                                     uint32_t *, const int64_t *);
+        static const GroupKernel aligned_kernels[6] = {
+            hist_dense_groups_kernel<true, 0>, hist_dense_groups_kernel<true, 1>, hist_dense_groups_kernel<true, 2>,
+            hist_dense_groups_kernel<true, 3>, hist_dense_groups_kernel<true, 4>, hist_dense_groups_kernel<true, 5>};
+        GroupKernel gk = galigned ? aligned_kernels[log2c] : hist_dense_groups_kernel<false, -1>;
+        const int gslot = galigned ? 1 + log2c : 0;
+        if (!gattr_done[gslot]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gk),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)lds);
             if (e != hipSuccess) return e;
-            gattr_done[galigned] = true;
+            gattr_done[gslot] = true;
         }
         const size_t glds = ((size_t)(n_groups + 1) * BVC_NCLASS << log2c) * sizeof(uint32_t);
         const int64_t ggrid = n_sites < 4096 ? n_sites : 4096;
