@@ -308,7 +308,8 @@ int bvc_lrt_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_
                   const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
                   double min_af, bvc_site_result *results, uint32_t flags)
 {
-    int rc = check_common(ctx, n_sites, bases, quals, ref_base, results);
+    // rows of zero samples carry no data: their pointers may be null
+    int rc = check_common(ctx, n_sites, n_samples ? bases : ref_base, n_samples ? quals : ref_base, ref_base, results);
     if (rc != BVC_OK) return rc;
     if (n_samples < 0 || row_stride < n_samples) return fail(ctx, BVC_ERR_ARG, "need 0 <= n_samples <= row_stride");
     if (n_sites == 0) return BVC_OK;
@@ -333,9 +334,9 @@ int bvc_lrt_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_
     for (int64_t s0 = 0; s0 < n_sites; s0 += chunk) {
         const int64_t ns = (n_sites - s0 < chunk) ? n_sites - s0 : chunk;
         // the last row may be shorter than row_stride in the caller's allocation: copy exactly what is addressed
-        const size_t bytes = (size_t)(ns - 1) * (size_t)row_stride + (size_t)n_samples;
-        BVC_HIP(ctx, hipMemcpyAsync(d_b, bases + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
-        BVC_HIP(ctx, hipMemcpyAsync(d_q, quals + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
+        const size_t bytes = n_samples ? (size_t)(ns - 1) * (size_t)row_stride + (size_t)n_samples : 0;
+        if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_b, bases + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_q, quals + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
         BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base + s0, (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
         rc = run_dense_device(ctx, ns, n_samples, row_stride, d_b, d_q, d_r, min_af, d_res);
         if (rc == BVC_OK) rc = join_side(ctx);
@@ -350,7 +351,8 @@ int bvc_lrt_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_
 int bvc_hist_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                    const int8_t *bases, const int8_t *quals, uint32_t *counts, uint32_t flags)
 {
-    int rc = check_common(ctx, n_sites, bases, quals, counts, counts);
+    int rc = check_common(ctx, n_sites, n_samples ? (const void *)bases : (const void *)counts,
+                          n_samples ? (const void *)quals : (const void *)counts, counts, counts);
     if (rc != BVC_OK) return rc;
     if (n_samples < 0 || row_stride < n_samples) return fail(ctx, BVC_ERR_ARG, "need 0 <= n_samples <= row_stride");
     if (n_sites == 0) return BVC_OK;
@@ -361,15 +363,15 @@ int bvc_hist_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row
         BVC_HIP(ctx, launch_hist_dense(ctx->stream, n_sites, n_samples, row_stride, bases, quals, nullptr, 0, counts, split));
         return BVC_OK;
     }
-    const size_t bytes = (size_t)(n_sites - 1) * (size_t)row_stride + (size_t)n_samples;
+    const size_t bytes = n_samples ? (size_t)(n_sites - 1) * (size_t)row_stride + (size_t)n_samples : 0;
     const size_t arr_al = (bytes + 255) & ~(size_t)255;
     rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage), &ctx->stage_cap, 2 * arr_al + cbytes + 256);
     if (rc != BVC_OK) return rc;
     int8_t *d_b = reinterpret_cast<int8_t *>(ctx->d_stage);
     int8_t *d_q = d_b + arr_al;
     uint32_t *d_c = reinterpret_cast<uint32_t *>(d_q + arr_al);
-    BVC_HIP(ctx, hipMemcpyAsync(d_b, bases, bytes, hipMemcpyHostToDevice, ctx->stream));
-    BVC_HIP(ctx, hipMemcpyAsync(d_q, quals, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_b, bases, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_q, quals, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (split > 1) BVC_HIP(ctx, hipMemsetAsync(d_c, 0, cbytes, ctx->stream));
     BVC_HIP(ctx, launch_hist_dense(ctx->stream, n_sites, n_samples, row_stride, d_b, d_q, nullptr, 0, d_c, split));
     BVC_HIP(ctx, hipMemcpyAsync(counts, d_c, cbytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -476,7 +478,8 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
                          double min_af, const uint8_t *group_of_sample, int32_t n_groups,
                          bvc_site_result *results, bvc_group_result *grp_results, uint32_t flags)
 {
-    int rc = check_common(ctx, n_sites, bases, quals, ref_base, results);
+    // rows of zero samples carry no data: their pointers may be null
+    int rc = check_common(ctx, n_sites, n_samples ? bases : ref_base, n_samples ? quals : ref_base, ref_base, results);
     if (rc != BVC_OK) return rc;
     if (n_samples < 0 || row_stride < n_samples) return fail(ctx, BVC_ERR_ARG, "need 0 <= n_samples <= row_stride");
     if (n_groups < 1 || n_groups > BVC_MAX_GROUPS) return fail(ctx, BVC_ERR_ARG, "n_groups must be 1..32");
@@ -551,9 +554,9 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
     BVC_HIP(ctx, hipMemcpyAsync(d_g, group_of_sample, (size_t)n_samples, hipMemcpyHostToDevice, ctx->stream));
     for (int64_t s0 = 0; s0 < n_sites; s0 += chunk) {
         const int64_t ns = (n_sites - s0 < chunk) ? n_sites - s0 : chunk;
-        const size_t bytes = (size_t)(ns - 1) * (size_t)row_stride + (size_t)n_samples;
-        BVC_HIP(ctx, hipMemcpyAsync(d_b, bases + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
-        BVC_HIP(ctx, hipMemcpyAsync(d_q, quals + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
+        const size_t bytes = n_samples ? (size_t)(ns - 1) * (size_t)row_stride + (size_t)n_samples : 0;
+        if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_b, bases + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_q, quals + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
         BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base + s0, (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
         rc = run_device(ns, d_b, d_q, d_r, d_g, d_res, d_gres);
         if (rc == BVC_OK) rc = join_side(ctx);

@@ -355,6 +355,58 @@ def test_group_mode_samples_ordered_by_group(ctx):
             np.testing.assert_allclose(gres[s]["af"], ga, rtol=0, atol=AF_ATOL, err_msg=f"n={n} site={s}")
 
 
+def test_random_shapes_strides_and_offsets_on_device(ctx):
+    """Seeded fuzz over the device-pointer entry points: random site and sample counts, row strides wider than the
+    row, rows that start off the 16-byte grid (tensor views at odd offsets), random coverage, junk in the padding.
+    Class counts against numpy, records against the oracle's histogram form."""
+    import torch
+    from basevarc_amd.lib import results_from_tensor
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        ns = int(rng.integers(1, 40))
+        n = int(rng.choice([0, 1, 7, 15, 16, 17, 100, 1023, 1024, 1025, 4099, int(rng.integers(2, 30000))]))
+        pad = int(rng.choice([0, 0, 1, 5, 16, 48]))
+        off = int(rng.choice([0, 0, 3, 16, 21]))
+        stride = n + pad
+        bh = rng.integers(0, 4, (ns, stride)).astype(np.int8)
+        qh = rng.integers(0, 60, (ns, stride)).astype(np.int8)
+        cov = float(rng.choice([1.0, 1.0, 0.5, 0.05]))
+        bh[rng.random((ns, stride)) > cov] = -1                   # uncovered samples
+        if stride > n:
+            bh[:, n:] = rng.integers(-128, 127, (ns, stride - n))  # junk in the padding must never be read as data
+            qh[:, n:] = rng.integers(-128, 127, (ns, stride - n))
+        rh = rng.integers(0, 4, ns).astype(np.int8)
+        flat_b = torch.zeros(off + ns * stride + 64, dtype=torch.int8, device="cuda")
+        flat_q = torch.zeros_like(flat_b)
+        flat_b[off:off + ns * stride] = torch.from_numpy(bh.reshape(-1)).cuda()
+        flat_q[off:off + ns * stride] = torch.from_numpy(qh.reshape(-1)).cuda()
+        bt = flat_b[off:off + ns * stride].view(ns, stride)[:, :n] if n else flat_b[off:off + ns * stride].view(ns, stride)[:, :0]
+        qt = flat_q[off:off + ns * stride].view(ns, stride)[:, :n] if n else flat_q[off:off + ns * stride].view(ns, stride)[:, :0]
+        rt = torch.from_numpy(rh).cuda()
+        m = caller_min_af(max(n, 1))
+        counts = ctx.hist_dense_device(bt, qt).cpu().numpy().view(np.uint32)
+        res = results_from_tensor(ctx.lrt_dense_device(bt, qt, rt, m))
+        ctx.synchronize()
+        for s in range(ns):
+            b, q = bh[s, :n], qh[s, :n]
+            ok = (b >= 0) & (b < 4) & (q >= 0)
+            exp = np.bincount(b[ok].astype(np.int64) * 128 + q[ok], minlength=512).astype(np.uint32)
+            assert np.array_equal(counts[s], exp), (case, s, ns, n, pad, off)
+            assert_site_matches(res[s], orc.hist_lrt(exp, int(rh[s]), m), where=f"fuzz case {case} site {s} n={n}")
+
+
+def test_zero_samples_is_a_no_call_not_an_error(ctx):
+    """Sites with no sample at all (empty vectors into BaseType): depth 0, no call, through host and CSR entry points."""
+    B = np.zeros((3, 0), dtype=np.int8)
+    R = np.array([0, 1, 2], dtype=np.int8)
+    for res in (ctx.lrt_dense(B, B.copy(), R, 0.001),
+                ctx.lrt_csr(np.zeros(4, dtype=np.int64), np.zeros(0, dtype=np.int8), np.zeros(0, dtype=np.int8), R, 0.001)):
+        assert res["called"].tolist() == [0, 0, 0] and res["depth_total"].tolist() == [0.0, 0.0, 0.0]
+        assert (res["depth"] == 0).all() and (res["n_alt"] == 0).all()
+    res, gres = ctx.lrt_dense_groups(B, B.copy(), R, 0.001, np.zeros(0, dtype=np.uint8), 2)
+    assert res["called"].tolist() == [0, 0, 0] and (gres["depth"] == 0).all() and (gres["ran"] == 0).all()
+
+
 # ------------------------------------------------------------------ golden fixtures (tests/golden)
 def test_golden_fixtures(ctx):
     from tests.golden.golden_io import load_golden
