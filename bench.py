@@ -37,6 +37,8 @@ def parse():
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--cpu-sites", type=int, default=-1, help="sites for the CPU baseline (-1: one per core, 0: skip)")
     p.add_argument("--no-verify", action="store_true", help="CPU leg: time the baseline only, skip the wider check")
+    p.add_argument("--verify-all", action="store_true",
+                   help="after the run, check EVERY resident site against the oracle's histogram form (about a minute)")
     p.add_argument("--no-overlap", action="store_true", help="run the two kernels of a step back to back on one stream")
     p.add_argument("--groups", type=int, default=0, help="population groups (BASELINE configs[4]: 5); 0 = overall call only")
     p.add_argument("--group-layout", choices=("interleaved", "ordered"), default="interleaved",
@@ -200,6 +202,8 @@ def main():
             if a.groups > 0:
                 out["cpu_baseline"]["gpu_check_groups"] = spot_check_groups(ctx, tiles, results, grp_results, group_t,
                                                                             min_af, a, np)
+    if rank == 0 and world == 1 and a.verify_all:
+        out["verify_all"] = verify_all(ctx, tiles, results, step, min_af, a, np)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -240,6 +244,42 @@ def spot_check(ctx, tiles, results, min_af, a, np):
               and abs(float(g["var_qual"]) - e["var_qual"]) <= 1e-6 * max(1.0, abs(e["var_qual"])))
         bad += not ok
     return {"sites_checked": int(len(pick)), "mismatches": int(bad)}
+
+
+def verify_all(ctx, tiles, results, step, min_af, a, np):
+    """every site of the resident dataset against the CPU histogram path (oracle, OpenMP over
+    sites): tile by tile, device -> host, one C call per tile."""
+    from basevarc_amd.lib import results_from_tensor
+    from oracle import orc
+    t0 = time.perf_counter()
+    for i in range(len(tiles)):
+        step(i)                                              # results[i] <- tile i, whatever the timed loop left there
+    ctx.join()
+    ctx.synchronize()
+    bad = called = sites = 0
+    worst_af = worst_q = 0.0
+    for i, (b, q, r) in enumerate(tiles):
+        exp, _ = orc.dense_batch(b.cpu().numpy(), q.cpu().numpy(), r.cpu().numpy(), min_af, use_hist=True, threads=16)
+        res = results_from_tensor(results[i])
+        for s, e in enumerate(exp):
+            g = res[s]
+            ok = (int(g["called"]) == e["called"] and [int(x) for x in g["depth"]] == e["depth"]
+                  and [int(g["alt_base"][k]) for k in range(g["n_alt"])] == e["alt_base"])
+            if ok:
+                for k in range(e["n_alt"]):
+                    d = abs(float(g["af"][k]) - e["af"][k])
+                    worst_af = max(worst_af, d)
+                    ok = ok and d <= 1e-6
+                dq = abs(float(g["var_qual"]) - e["var_qual"]) / max(1.0, abs(e["var_qual"]))
+                worst_q = max(worst_q, dq)
+                ok = ok and dq <= 1e-6
+            bad += not ok
+            called += e["called"]
+        sites += len(exp)
+        log(f"verify-all: tile {i + 1}/{len(tiles)}, {sites} sites, {bad} mismatches")
+    return {"sites_checked": int(sites), "called": int(called), "mismatches": int(bad), "max_abs_af_diff": worst_af,
+            "max_rel_var_qual_diff": worst_q, "against": "oracle histogram form (CPU, 16 threads)",
+            "seconds": time.perf_counter() - t0}
 
 
 def spot_check_groups(ctx, tiles, results, grp_results, group_t, min_af, a, np):
