@@ -204,6 +204,8 @@ def main():
                                                                             min_af, a, np)
     if rank == 0 and world == 1 and a.verify_all:
         out["verify_all"] = verify_all(ctx, tiles, results, step, min_af, a, np)
+        if a.groups > 0:
+            out["verify_all"]["groups_tile0"] = verify_groups_tile(ctx, tiles, results, grp_results, group_t, step, min_af, a, np)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -280,6 +282,35 @@ def verify_all(ctx, tiles, results, step, min_af, a, np):
     return {"sites_checked": int(sites), "called": int(called), "mismatches": int(bad), "max_abs_af_diff": worst_af,
             "max_rel_var_qual_diff": worst_q, "against": "oracle histogram form (CPU, 16 threads)",
             "seconds": time.perf_counter() - t0}
+
+
+def verify_groups_tile(ctx, tiles, results, grp_results, group_t, step, min_af, a, np):
+    """every site of tile 0 against the oracle's restatement of the caller's --group loop
+    (histogram form): per-group depths, which groups ran, per-group AF."""
+    from basevarc_amd.lib import GROUP_DTYPE
+    from oracle import orc
+    t0 = time.perf_counter()
+    step(0)
+    ctx.join()
+    ctx.synchronize()
+    b, q, r = tiles[0]
+    hb, hq, hr = b.cpu().numpy(), q.cpu().numpy(), r.cpu().numpy()
+    g = group_t.cpu().numpy()
+    gres = grp_results[0].cpu().numpy().view(GROUP_DTYPE).reshape(a.tile_sites, a.groups)
+    bad = ran_total = 0
+    worst = 0.0
+    for s in range(a.tile_sites):
+        _, gd, ga, ran, pres = orc.dense_site_groups(hb[s], hq[s], int(hr[s]), min_af, g, a.groups, use_hist=True)
+        d = float(np.max(np.abs(gres[s]["af"] - ga))) if ga.size else 0.0
+        worst = max(worst, d)
+        ok = (np.array_equal(gres[s]["depth"], gd) and np.array_equal(gres[s]["ran"], ran)
+              and np.array_equal(gres[s]["present"], pres) and d <= 1e-6)
+        bad += not ok
+        ran_total += int(np.sum(ran))
+        if (s + 1) % 1000 == 0:
+            log(f"verify groups: {s + 1}/{a.tile_sites} sites, {bad} mismatches")
+    return {"sites_checked": int(a.tile_sites), "group_runs": int(ran_total), "mismatches": int(bad),
+            "max_abs_group_af_diff": worst, "seconds": time.perf_counter() - t0}
 
 
 def spot_check_groups(ctx, tiles, results, grp_results, group_t, min_af, a, np):
