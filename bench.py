@@ -44,7 +44,9 @@ def parse():
     p.add_argument("--group-layout", choices=("interleaved", "ordered"), default="interleaved",
                    help="group of sample i: i %% k (SURVEY 8d) or contiguous runs of columns (takes the column-range kernel)")
     p.add_argument("--coverage", type=float, default=1.0, help="fraction of samples covered per site (sparse variant)")
-    p.add_argument("--profile-every", type=int, default=1, help="time the kernels of every K-th step with HIP events (1 = every step)")
+    p.add_argument("--profile-every", type=int, default=4,
+                   help="time the kernels of every K-th step of the timed region with HIP events (four timing events per "
+                        "step cost 10-20 us of stream time; 1 = every step)")
     return p.parse_args()
 
 
@@ -179,7 +181,7 @@ def main():
             "bound": "hbm", "kernel": ("hist_dense_ranges_kernel" if a.group_layout == "ordered" else "hist_dense_groups_kernel") if a.groups > 0 else "hist_dense_kernel",
             "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a, n),
-            "avg_launch_ms": hist_ms, "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_launch_ms": hist_ms, "launches_timed": int(prof["hist_launches"]), "algorithmic_bytes_per_launch": alg_bytes,
             "empirical_stream_read_GBs": empirical_gbs, "frac_of_empirical": achieved / empirical_gbs if empirical_gbs else None,
         },
         "kernels_ms_per_step": {(("hist_dense_ranges_kernel" if a.group_layout == "ordered" else "hist_dense_groups_kernel") if a.groups > 0 else "hist_dense_kernel"): hist_ms,
