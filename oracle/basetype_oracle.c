@@ -13,6 +13,12 @@
  *   caller's group loop     /root/reference/src/BaseVarC.cpp:617-661
  * The per-sample path keeps the reference's operation order (sums run j = 0..3 then i = 0..n-1,
  * a fresh zeroed 4*n scratch per E/M pass) so that it is also a fair CPU timing baseline.
+ *
+ * ORC_MODE_COMPENSATED is NOT the reference's arithmetic: the same per-sample loops with the three
+ * sums that run over all samples (M-step sums, delta, log-likelihood) accumulated in long double
+ * (64-bit significand on x86-64), i.e. without the drift a double accumulator picks up over 1e6
+ * nearly equal addends.  It exists to separate "the reference's own rounding drift" from "a
+ * difference in the algorithm" when the GPU path is compared at N = 1e6.
  */
 #include "basetype_oracle.h"
 
@@ -95,6 +101,7 @@ typedef struct site_model {
     int32_t depth[4];
     double depth_total;
     int32_t n_fits, n_passes;
+    int compensated;      /* 0: the reference's double accumulators; 1: long double (see header) */
 } site_model;
 
 /* One E+M pass: src/Algorithm.cpp:69-93.  marginal[] and expect[] arrive zeroed. */
@@ -114,7 +121,12 @@ static void em_pass(site_model *sm, const double *freq, double *marginal, double
         for (j = 0; j < ORC_NTYPE; ++j) post[(size_t)j * n + i] = lik[j] / marginal[i];
     }
     for (j = 0; j < ORC_NTYPE; ++j) {
-        if (sm->w) {
+        if (sm->compensated) {
+            long double acc = expect[j];
+            if (sm->w) { for (i = 0; i < n; ++i) acc += (long double)sm->w[i] * post[(size_t)j * n + i]; }
+            else { for (i = 0; i < n; ++i) acc += post[(size_t)j * n + i]; }
+            expect[j] = (double)acc;
+        } else if (sm->w) {
             for (i = 0; i < n; ++i) expect[j] += sm->w[i] * post[(size_t)j * n + i];
         } else {
             for (i = 0; i < n; ++i) expect[j] += post[(size_t)j * n + i];
@@ -136,14 +148,17 @@ static void em_fit(site_model *sm, double *freq, double *marginal, double *expec
     em_pass(sm, freq, marginal, expect);
     for (it = 0; it < iter_num; ++it) {
         double delta = 0.0;
+        long double delta_c = 0.0L;
         for (j = 0; j < ORC_NTYPE; ++j) { freq[j] = expect[j]; expect[j] = 0.0; }
         em_pass(sm, freq, next, expect);
         for (i = 0; i < n; ++i) {
             double d = fabs(log(next[i]) - log(marginal[i]));
-            delta += sm->w ? sm->w[i] * d : d;
+            if (sm->compensated) delta_c += sm->w ? (long double)sm->w[i] * d : (long double)d;
+            else delta += sm->w ? sm->w[i] * d : d;
             marginal[i] = next[i];
             next[i] = 0.0;
         }
+        if (sm->compensated) delta = (double)delta_c;
         if (delta < epsilon) break;
     }
     free(next);
@@ -191,6 +206,7 @@ static void update_f(site_model *sm, const int8_t *bases, int n, int k, fit_set 
     for (c = 0; c < fs->n_comb; ++c) {
         double freq[ORC_NTYPE] = { 0, 0, 0, 0 }, expect[ORC_NTYPE] = { 0, 0, 0, 0 };
         double freq_sum = 0.0, loglik = 0.0;
+        long double loglik_c = 0.0L;
         int32_t depth_sum = 0;
         for (t = 0; t < k; ++t) depth_sum += sm->depth[fs->comb[c][t]];
         if (depth_sum > 0)
@@ -201,9 +217,11 @@ static void update_f(site_model *sm, const int8_t *bases, int n, int k, fit_set 
         em_fit(sm, freq, marginal, expect, 100, 0.001);   /* src/BaseType.cpp:45-46,56 */
         for (i = 0; i < sm->n; ++i) {
             double lm = log(marginal[i]);
-            loglik += sm->w ? sm->w[i] * lm : lm;
+            if (sm->compensated) loglik_c += sm->w ? (long double)sm->w[i] * lm : (long double)lm;
+            else loglik += sm->w ? sm->w[i] * lm : lm;
             marginal[i] = 0.0;
         }
+        if (sm->compensated) loglik = (double)loglik_c;
         fs->lr[fs->n_fit] = loglik;
         for (j = 0; j < ORC_NTYPE; ++j) fs->bp[fs->n_fit][j] = expect[j];
         fs->n_fit++;
@@ -305,6 +323,13 @@ int orc_basetype_lrt(int32_t nind, const int8_t *bases, const int8_t *quals,
                      int8_t ref_base, double min_af,
                      const int8_t *base_comb, int32_t n_comb, orc_result *out)
 {
+    return orc_basetype_lrt_mode(nind, bases, quals, ref_base, min_af, base_comb, n_comb, 0, out);
+}
+
+int orc_basetype_lrt_mode(int32_t nind, const int8_t *bases, const int8_t *quals,
+                          int8_t ref_base, double min_af,
+                          const int8_t *base_comb, int32_t n_comb, int mode, orc_result *out)
+{
     site_model sm;
     double *L = (double *)malloc(sizeof(double) * ORC_NTYPE * (size_t)(nind > 0 ? nind : 1));
     int32_t i;
@@ -321,6 +346,7 @@ int orc_basetype_lrt(int32_t nind, const int8_t *bases, const int8_t *quals,
     }
     for (j = 0; j < 4; ++j) sm.depth_total += sm.depth[j];
     sm.n = nind; sm.L = L; sm.w = NULL; sm.nsample = nind;
+    sm.compensated = (mode & ORC_MODE_COMPENSATED) != 0;
     rc = lrt_on_model(&sm, ref_base, min_af, base_comb, n_comb, out);
     free(L);
     return rc;
@@ -329,6 +355,12 @@ int orc_basetype_lrt(int32_t nind, const int8_t *bases, const int8_t *quals,
 /* Histogram form: each non-empty (base, qual) class is one weighted row. */
 int orc_hist_lrt(const uint32_t *counts512, int8_t ref_base, double min_af,
                  const int8_t *base_comb, int32_t n_comb, orc_result *out)
+{
+    return orc_hist_lrt_mode(counts512, ref_base, min_af, base_comb, n_comb, 0, out);
+}
+
+int orc_hist_lrt_mode(const uint32_t *counts512, int8_t ref_base, double min_af,
+                      const int8_t *base_comb, int32_t n_comb, int mode, orc_result *out)
 {
     site_model sm;
     double L[512 * 4], w[512];
@@ -350,6 +382,7 @@ int orc_hist_lrt(const uint32_t *counts512, int8_t ref_base, double min_af,
         }
     for (j = 0; j < 4; ++j) sm.depth_total += sm.depth[j];
     sm.n = n; sm.L = L; sm.w = w; sm.nsample = (double)(int32_t)total;
+    sm.compensated = (mode & ORC_MODE_COMPENSATED) != 0;
     rc = lrt_on_model(&sm, ref_base, min_af, base_comb, n_comb, out);
     return rc;
 }
@@ -376,12 +409,12 @@ void orc_dense_hist(int64_t n_samples, const int8_t *bases_row, const int8_t *qu
 static int dense_site_subset(int64_t n_samples, const int8_t *bases_row, const int8_t *quals_row,
                              const uint8_t *group_of_sample, int32_t group,
                              int8_t ref_base, double min_af, const int8_t *base_comb,
-                             int32_t n_comb, int use_hist, orc_result *out)
+                             int32_t n_comb, int mode, orc_result *out)
 {
-    if (use_hist) {
+    if (mode & ORC_MODE_HIST) {
         uint32_t counts[512];
         orc_dense_hist(n_samples, bases_row, quals_row, group_of_sample, group, counts);
-        return orc_hist_lrt(counts, ref_base, min_af, base_comb, n_comb, out);
+        return orc_hist_lrt_mode(counts, ref_base, min_af, base_comb, n_comb, mode, out);
     } else {
         int8_t *b = (int8_t *)malloc((size_t)(n_samples > 0 ? n_samples : 1));
         int8_t *q = (int8_t *)malloc((size_t)(n_samples > 0 ? n_samples : 1));
@@ -393,7 +426,7 @@ static int dense_site_subset(int64_t n_samples, const int8_t *bases_row, const i
             if (group_of_sample && group >= 0 && group_of_sample[i] != (uint8_t)group) continue;
             b[n] = bases_row[i]; q[n] = quals_row[i]; n++;
         }
-        rc = orc_basetype_lrt(n, b, q, ref_base, min_af, base_comb, n_comb, out);
+        rc = orc_basetype_lrt_mode(n, b, q, ref_base, min_af, base_comb, n_comb, mode, out);
         free(b); free(q);
         return rc;
     }

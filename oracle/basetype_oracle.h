@@ -28,6 +28,11 @@ extern "C" {
 #define ORC_LRT_THRESHOLD 24.0            /* src/BaseType.h:9  */
 #define ORC_MLN10TO10 -0.23025850929940458 /* src/BaseType.h:10 */
 
+/* `mode` / `use_hist` arguments below are a bit set (0 = the faithful per-sample path): */
+#define ORC_MODE_HIST        1   /* EM on the (base, qual) count histogram instead of per-sample rows */
+#define ORC_MODE_COMPENSATED 2   /* NOT the reference's arithmetic: the sums over samples (M step, delta,
+                                    log-likelihood) in long double, to expose the reference's own drift */
+
 /* What BaseType exposes after LRT() (src/BaseType.h:70-74) plus diagnostics. */
 typedef struct orc_result {
     int32_t called;        /* return value of BaseType::LRT() */
@@ -57,10 +62,17 @@ int orc_basetype_lrt(int32_t nind, const int8_t *bases, const int8_t *quals,
                      int8_t ref_base, double min_af,
                      const int8_t *base_comb, int32_t n_comb, orc_result *out);
 
+int orc_basetype_lrt_mode(int32_t nind, const int8_t *bases, const int8_t *quals,
+                          int8_t ref_base, double min_af,
+                          const int8_t *base_comb, int32_t n_comb, int mode, orc_result *out);
+
 /* Same control flow, EM run on a (base, qual) count histogram: counts[b*128+q].
  * Derived checker for full-size inputs; validated against orc_basetype_lrt in tests. */
 int orc_hist_lrt(const uint32_t *counts512, int8_t ref_base, double min_af,
                  const int8_t *base_comb, int32_t n_comb, orc_result *out);
+
+int orc_hist_lrt_mode(const uint32_t *counts512, int8_t ref_base, double min_af,
+                      const int8_t *base_comb, int32_t n_comb, int mode, orc_result *out);
 
 /* Dense tile helpers: row = site, uncovered sample = base byte outside 0..3 or qual < 0. */
 int orc_dense_site(int64_t n_samples, const int8_t *bases_row, const int8_t *quals_row,

@@ -59,8 +59,12 @@ def lib():
         L.orc_chisf.restype = C.c_double; L.orc_chisf.argtypes = [C.c_double, C.c_double]
         L.orc_basetype_lrt.restype = C.c_int
         L.orc_basetype_lrt.argtypes = [C.c_int32, i8p, i8p, C.c_int8, C.c_double, i8p, C.c_int32, rp]
+        L.orc_basetype_lrt_mode.restype = C.c_int
+        L.orc_basetype_lrt_mode.argtypes = [C.c_int32, i8p, i8p, C.c_int8, C.c_double, i8p, C.c_int32, C.c_int, rp]
         L.orc_hist_lrt.restype = C.c_int
         L.orc_hist_lrt.argtypes = [u32p, C.c_int8, C.c_double, i8p, C.c_int32, rp]
+        L.orc_hist_lrt_mode.restype = C.c_int
+        L.orc_hist_lrt_mode.argtypes = [u32p, C.c_int8, C.c_double, i8p, C.c_int32, C.c_int, rp]
         L.orc_dense_site.restype = C.c_int
         L.orc_dense_site.argtypes = [C.c_int64, i8p, i8p, C.c_int8, C.c_double, rp]
         L.orc_dense_hist.restype = None
@@ -92,23 +96,33 @@ def chisf(x, k=1.0):
     return lib().orc_chisf(float(x), float(k))
 
 
-def basetype_lrt(bases, quals, ref_base, min_af, base_comb=None):
-    """BaseType(bases, quals, ref, min_af) [+ SetBase(base_comb)] + LRT() -- faithful per-sample path."""
+MODE_HIST = 1          # ORC_MODE_HIST
+MODE_COMPENSATED = 2   # ORC_MODE_COMPENSATED: long-double sums over samples -- NOT the reference's arithmetic
+
+
+def _mode(use_hist, compensated):
+    return (MODE_HIST if use_hist else 0) | (MODE_COMPENSATED if compensated else 0)
+
+
+def basetype_lrt(bases, quals, ref_base, min_af, base_comb=None, compensated=False):
+    """BaseType(bases, quals, ref, min_af) [+ SetBase(base_comb)] + LRT() -- faithful per-sample path.
+    compensated=True keeps the loops but accumulates the sums over samples in long double (oracle header)."""
     b = np.ascontiguousarray(bases, dtype=np.int8)
     q = np.ascontiguousarray(quals, dtype=np.int8)
     cb, nc = _comb(base_comb)
     r = OrcResult()
-    lib().orc_basetype_lrt(len(b), _p(b, C.c_int8), _p(q, C.c_int8), int(ref_base), float(min_af),
-                           _p(cb, C.c_int8) if cb is not None else None, nc, C.byref(r))
+    lib().orc_basetype_lrt_mode(len(b), _p(b, C.c_int8), _p(q, C.c_int8), int(ref_base), float(min_af),
+                                _p(cb, C.c_int8) if cb is not None else None, nc, _mode(False, compensated),
+                                C.byref(r))
     return r.as_dict()
 
 
-def hist_lrt(counts512, ref_base, min_af, base_comb=None):
+def hist_lrt(counts512, ref_base, min_af, base_comb=None, compensated=False):
     c = np.ascontiguousarray(counts512, dtype=np.uint32).reshape(512)
     cb, nc = _comb(base_comb)
     r = OrcResult()
-    lib().orc_hist_lrt(_p(c, C.c_uint32), int(ref_base), float(min_af),
-                       _p(cb, C.c_int8) if cb is not None else None, nc, C.byref(r))
+    lib().orc_hist_lrt_mode(_p(c, C.c_uint32), int(ref_base), float(min_af),
+                            _p(cb, C.c_int8) if cb is not None else None, nc, _mode(True, compensated), C.byref(r))
     return r.as_dict()
 
 
@@ -122,7 +136,7 @@ def dense_hist(bases_row, quals_row, group_of_sample=None, group=-1):
     return out
 
 
-def dense_batch(bases, quals, ref_base, min_af, use_hist=False, threads=0):
+def dense_batch(bases, quals, ref_base, min_af, use_hist=False, threads=0, compensated=False):
     """bases/quals: int8 [n_sites, n_samples] (C-contiguous).  Returns (list of dicts, threads used)."""
     b = np.ascontiguousarray(bases, dtype=np.int8)
     q = np.ascontiguousarray(quals, dtype=np.int8)
@@ -130,11 +144,12 @@ def dense_batch(bases, quals, ref_base, min_af, use_hist=False, threads=0):
     ns, n = b.shape
     res = (OrcResult * ns)()
     used = lib().orc_dense_batch(ns, n, n, _p(b, C.c_int8), _p(q, C.c_int8), _p(r, C.c_int8),
-                                 float(min_af), int(bool(use_hist)), int(threads), res)
+                                 float(min_af), _mode(use_hist, compensated), int(threads), res)
     return [x.as_dict() for x in res], used
 
 
-def dense_site_groups(bases_row, quals_row, ref_base, min_af, group_of_sample, n_groups, use_hist=False):
+def dense_site_groups(bases_row, quals_row, ref_base, min_af, group_of_sample, n_groups, use_hist=False,
+                      compensated=False):
     b = np.ascontiguousarray(bases_row, dtype=np.int8)
     q = np.ascontiguousarray(quals_row, dtype=np.int8)
     g = np.ascontiguousarray(group_of_sample, dtype=np.uint8)
@@ -144,7 +159,7 @@ def dense_site_groups(bases_row, quals_row, ref_base, min_af, group_of_sample, n
     gr = np.zeros(n_groups, dtype=np.int32)
     gp = np.zeros(n_groups, dtype=np.int32)
     lib().orc_dense_site_groups(len(b), _p(b, C.c_int8), _p(q, C.c_int8), int(ref_base), float(min_af),
-                                _p(g, C.c_uint8), int(n_groups), int(bool(use_hist)), C.byref(r),
+                                _p(g, C.c_uint8), int(n_groups), _mode(use_hist, compensated), C.byref(r),
                                 _p(gd, C.c_int32), _p(ga, C.c_double), _p(gr, C.c_int32), _p(gp, C.c_int32))
     return r.as_dict(), gd, ga, gr, gp
 

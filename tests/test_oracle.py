@@ -194,3 +194,32 @@ def test_synth_site_mixture():
         b, _, r = orc.synth_tile(1, s, 1, 4000)
         poly += (b[0] != r[0]).mean() > 0.05
     assert 5 <= poly <= 60          # 20 % polymorphic, AF log-uniform: a minority shows AF > ~4 %
+
+
+def test_compensated_sums_expose_the_drift_of_the_per_sample_sum():
+    """the reference adds N per-sample logs one by one in a double; that sum drifts with N
+    while the histogram sum of <= 512 terms does not.  ORC_MODE_COMPENSATED keeps the per-sample loops but
+    accumulates in long double: it must land on the histogram form (to rounding of the final doubles), and the
+    faithful form's distance from both must be the same number -- i.e. the drift is a property of the reference's
+    accumulator, not of regrouping equal terms."""
+    n = 200_000
+    b, q, r = orc.synth_tile(1, 0, 3, n)
+    m = caller_min_af(n)
+    for s in range(3):
+        cnt = orc.dense_hist(b[s], q[s])
+        f = orc.basetype_lrt(b[s], q[s], r[s], m)
+        c = orc.basetype_lrt(b[s], q[s], r[s], m, compensated=True)
+        h = orc.hist_lrt(cnt, r[s], m)
+        hc = orc.hist_lrt(cnt, r[s], m, compensated=True)
+        ulp_ll = abs(f["lr_alt"]) * 2.0 ** -52
+        assert (f["n_fits"], f["n_passes"]) == (c["n_fits"], c["n_passes"]) == (h["n_fits"], h["n_passes"])
+        # compensated per-sample == histogram form up to a few ulp of the log-likelihoods chi is a difference of
+        assert abs(c["chi"] - h["chi"]) <= 128 * ulp_ll, (c["chi"], h["chi"])
+        assert abs(hc["chi"] - h["chi"]) <= 128 * ulp_ll      # <= 512 class terms, each rounded once
+        assert abs(hc["chi"] - c["chi"]) <= 128 * ulp_ll
+        # the faithful sum is farther from both than they are from each other, and within the N*u*|loglik| bound
+        drift = abs(f["chi"] - c["chi"])
+        assert drift <= 2 * n * 2.0 ** -53 * abs(f["lr_alt"])
+        assert abs(abs(f["chi"] - h["chi"]) - drift) <= 128 * ulp_ll
+        assert drift > 1000 * ulp_ll                        # ... and it is far above the rounding of one sum
+        np.testing.assert_allclose(c["af"], h["af"], rtol=0, atol=1e-13)
