@@ -6,7 +6,7 @@ Python host side: a ctypes binding (`lib`) and a mirror of the reference's BaseT
 every compute call raises.
 """
 from .lib import BvcError, Context, SiteResult, GroupResult, load_library, library_path  # noqa: F401
-from .basetype import BaseType, BaseTypeBatch, caller_min_af  # noqa: F401
+from .basetype import BaseType, caller_min_af  # noqa: F401
 
 __all__ = ["BvcError", "Context", "SiteResult", "GroupResult", "load_library", "library_path",
-           "BaseType", "BaseTypeBatch", "caller_min_af"]
+           "BaseType", "caller_min_af"]

@@ -3,7 +3,8 @@
 `BaseType(bases, quals, ref, min_af)`, `SetBase(v)`, `LRT()` and the public fields `var_qual`,
 `depth_total`, `alt_bases`, `depth`, `af_lrt` have the reference's names and meaning, so a test written
 against the reference class reads the same here.  One object = one site = one library call, which is the
-slow way to use a GPU: `BaseTypeBatch` is the form bt_f's successor should use (one call per tile).
+slow way to use a GPU: a `basevarc_amd.Context` takes a whole tile of sites per call (`lrt_dense`, `lrt_csr`,
+`lrt_dense_groups`), which is the form bt_f's successor uses.
 The C++ counterpart for the reference's own callers is include/bvc_basetype.hpp.
 """
 import numpy as np
@@ -58,13 +59,10 @@ class BaseType:
         if self._done:
             raise RuntimeError("LRT() is single-shot, as in the reference (it consumes the per-sample vectors)")
         self._done = True
-        n = len(self._bases)
-        b = self._bases.reshape(1, n) if n else np.full((1, 1), -1, dtype=np.int8)
-        q = self._quals.reshape(1, n) if n else np.zeros((1, 1), dtype=np.int8)
-        counts = self._ctx.hist_dense(b, q)
         comb = np.zeros((1, 4), dtype=np.int8)
         comb[0, :len(self._comb)] = self._comb
-        rec = self._ctx.lrt_hist(counts, [self._ref], self._min_af, comb, [len(self._comb)])[0]
+        rec = self._ctx.lrt_csr([0, len(self._bases)], self._bases, self._quals, [self._ref], self._min_af,
+                                base_comb=comb, n_comb=[len(self._comb)])[0]
         self.record = rec
         self.var_qual = float(rec["var_qual"])
         self.depth_total = float(rec["depth_total"])
@@ -74,20 +72,4 @@ class BaseType:
         return bool(rec["called"])
 
 
-class BaseTypeBatch:
-    """A tile of sites through the batched ABI: the form the hot path is meant to be driven in."""
-
-    def __init__(self, ctx=None):
-        self._ctx = ctx or default_context()
-
-    def lrt_dense(self, bases, quals, ref_base, min_af):
-        return self._ctx.lrt_dense(bases, quals, ref_base, min_af)
-
-    def lrt_dense_groups(self, bases, quals, ref_base, min_af, group_of_sample, n_groups):
-        return self._ctx.lrt_dense_groups(bases, quals, ref_base, min_af, group_of_sample, n_groups)
-
-    def lrt_csr(self, offsets, bases, quals, ref_base, min_af):
-        return self._ctx.lrt_csr(offsets, bases, quals, ref_base, min_af)
-
-
-__all__ = ["BaseType", "BaseTypeBatch", "caller_min_af", "default_context", "NCLASS"]
+__all__ = ["BaseType", "caller_min_af", "default_context", "NCLASS"]

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -16,7 +17,6 @@ using namespace bvc;
 
 struct bvc_ctx {
     int device = -1;
-    int n_cu = 256;
     hipStream_t stream = nullptr;
     QualLut *d_lut = nullptr;
     // [sites][512] scratch between the two stages.  Overlap mode cycles through kRing buffers: with three, the
@@ -34,9 +34,15 @@ struct bvc_ctx {
     bool em_pending[kRing] = {false, false, false};
     uint32_t *d_grp[kRing] = {nullptr, nullptr, nullptr};   // [sites][groups + 1][512] in group mode
     size_t grp_cap[kRing] = {0, 0, 0};
+    uint32_t *d_sink = nullptr;        // 256-byte sink of the streaming-read measurement kernel (private to it)
     int64_t *d_grp_scratch = nullptr;  // group mode: "samples ordered by group" flag + column bounds (hist_kernel.hip)
-    char *d_stage = nullptr;           // staging for BVC_PTR_HOST calls
-    size_t stage_cap = 0;
+    // staging for BVC_PTR_HOST calls: two sets, so that the upload of chunk i+1 (copy stream) runs under the kernels
+    // of chunk i
+    char *d_stage[2] = {nullptr, nullptr};
+    size_t stage_cap[2] = {0, 0};
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_upload[2] = {nullptr, nullptr};
+    LaunchState ls;                    // launch policy + one-time kernel setup of this context
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;   // free events
     struct Triple { hipEvent_t a, b, c, d; int64_t sites; };   // hist = a..b, EM = c..d
@@ -88,6 +94,22 @@ hipEvent_t take_event(bvc_ctx *ctx)
     return e;
 }
 
+void give_back(bvc_ctx *ctx, hipEvent_t e) { if (e) ctx->ev_pool.push_back(e); }
+
+// Four timing events for one call, or none at all (never a partial set).
+bool take_timing_events(bvc_ctx *ctx, bvc_ctx::Triple &t)
+{
+    t.a = take_event(ctx); t.b = take_event(ctx); t.c = take_event(ctx); t.d = take_event(ctx);
+    if (t.a && t.b && t.c && t.d) return true;
+    give_back(ctx, t.a); give_back(ctx, t.b); give_back(ctx, t.c); give_back(ctx, t.d);
+    t.a = t.b = t.c = t.d = nullptr;
+    return false;
+}
+
+// Drains finished timing records into the running totals so that ev_pending stays bounded when the caller never
+// asks for the profile.
+void reap_timing(bvc_ctx *ctx, bool all);
+
 // Make the context's stream wait for every stage-2 launch still running on the side stream.
 int join_side(bvc_ctx *ctx)
 {
@@ -99,10 +121,13 @@ int join_side(bvc_ctx *ctx)
     return BVC_OK;
 }
 
-// The two stages on device pointers.
-int run_dense_device(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
-                     const int8_t *bases, const int8_t *quals, const int8_t *ref_base, double min_af,
-                     bvc_site_result *results)
+// The two stages on device pointers.  `stage1(counts)` launches the histogram pass of the call (dense, ragged, ...)
+// on the context's stream into a [n_sites][512] buffer of the ring; stage 2 (EM/LRT) follows on the same stream, or
+// on the side stream behind an event in overlap mode.
+template <class Stage1>
+int run_two_stages(bvc_ctx *ctx, int64_t n_sites, bool zero_counts, bool long_rows, Stage1 stage1,
+                   const int8_t *ref_base, double min_af, const int8_t *comb, const uint8_t *n_comb,
+                   bvc_site_result *results)
 {
     const size_t cbytes = (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t);
     const int buf = ctx->overlap ? ctx->flip : 0;
@@ -116,36 +141,120 @@ int run_dense_device(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t r
     int rc = ensure(ctx, reinterpret_cast<void **>(counts_p), cap_p, cbytes);
     if (rc != BVC_OK) return rc;
     uint32_t *counts = *counts_p;
-    const int split = choose_hist_split(n_sites, n_samples, ctx->n_cu);
     bvc_ctx::Triple t{nullptr, nullptr, nullptr, nullptr, n_sites};
-    if (ctx->profiling) { t.a = take_event(ctx); t.b = take_event(ctx); t.c = take_event(ctx); t.d = take_event(ctx); }
+    const bool timed = ctx->profiling && take_timing_events(ctx, t);
+    auto bail = [&](int code) {                 // an early exit returns the timing events to the pool
+        give_back(ctx, t.a); give_back(ctx, t.b); give_back(ctx, t.c); give_back(ctx, t.d);
+        return code;
+    };
+#define BVC_HIP_T(call)                                                                     \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess) return bail(fail(ctx, BVC_ERR_DEVICE, #call, e__));          \
+    } while (0)
 
     // stage 1 on the context's stream; the histogram buffer is free once the EM that read it has finished
     if (ctx->overlap && ctx->em_pending[buf]) {
-        BVC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_em_done[buf], 0));
+        BVC_HIP_T(hipStreamWaitEvent(ctx->stream, ctx->ev_em_done[buf], 0));
         ctx->em_pending[buf] = false;
     }
-    if (split > 1) BVC_HIP(ctx, hipMemsetAsync(counts, 0, cbytes, ctx->stream));
-    if (t.a) BVC_HIP(ctx, hipEventRecord(t.a, ctx->stream));
-    BVC_HIP(ctx, launch_hist_dense(ctx->stream, n_sites, n_samples, row_stride, bases, quals, nullptr, 0, counts, split));
-    if (t.b) BVC_HIP(ctx, hipEventRecord(t.b, ctx->stream));
+    if (zero_counts) BVC_HIP_T(hipMemsetAsync(counts, 0, cbytes, ctx->stream));
+    if (timed) BVC_HIP_T(hipEventRecord(t.a, ctx->stream));
+    BVC_HIP_T(stage1(counts));
+    if (timed) BVC_HIP_T(hipEventRecord(t.b, ctx->stream));
 
     // stage 2: same stream, or the side stream behind an event
     hipStream_t s2 = ctx->stream;
     if (ctx->overlap) {
         s2 = ctx->side;
-        BVC_HIP(ctx, hipEventRecord(ctx->ev_hist_done[buf], ctx->stream));
-        BVC_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_hist_done[buf], 0));
+        BVC_HIP_T(hipEventRecord(ctx->ev_hist_done[buf], ctx->stream));
+        BVC_HIP_T(hipStreamWaitEvent(s2, ctx->ev_hist_done[buf], 0));
     }
-    if (t.c) BVC_HIP(ctx, hipEventRecord(t.c, s2));
+    if (timed) BVC_HIP_T(hipEventRecord(t.c, s2));
     // underneath a long streaming pass the EM kernel keeps to a few wave slots; with short rows it is the longer
     // kernel and takes the chip
-    const bool shared = ctx->overlap && n_samples >= 200000;
-    BVC_HIP(ctx, launch_lrt(s2, n_sites, counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut, nullptr, nullptr, results, shared, n_samples));
-    if (t.d) { BVC_HIP(ctx, hipEventRecord(t.d, s2)); ctx->ev_pending.push_back(t); }
+    const bool shared = ctx->overlap && long_rows;
+    BVC_HIP_T(launch_lrt(ctx->ls, s2, n_sites, counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut, comb, n_comb, results, shared));
+    if (timed) {
+        BVC_HIP_T(hipEventRecord(t.d, s2));
+        ctx->ev_pending.push_back(t);
+        t = bvc_ctx::Triple{nullptr, nullptr, nullptr, nullptr, 0};
+        if (ctx->ev_pending.size() > 256) reap_timing(ctx, false);
+    }
     if (ctx->overlap) {
-        BVC_HIP(ctx, hipEventRecord(ctx->ev_em_done[buf], s2));
+        BVC_HIP_T(hipEventRecord(ctx->ev_em_done[buf], s2));
         ctx->em_pending[buf] = true;
+    }
+#undef BVC_HIP_T
+    return BVC_OK;
+}
+
+int run_dense_device(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                     const int8_t *bases, const int8_t *quals, const int8_t *ref_base, double min_af,
+                     bvc_site_result *results)
+{
+    const int split = choose_hist_split(ctx->ls, n_sites, n_samples);
+    return run_two_stages(ctx, n_sites, split > 1, n_samples >= 200000,
+                          [&](uint32_t *counts) {
+                              return launch_hist_dense(ctx->ls, ctx->stream, n_sites, n_samples, row_stride, bases, quals,
+                                                       nullptr, 0, counts, split);
+                          },
+                          ref_base, min_af, nullptr, nullptr, results);
+}
+
+int run_csr_device(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets, const int8_t *bases, const int8_t *quals,
+                   const int8_t *ref_base, double min_af, const int8_t *comb, const uint8_t *n_comb,
+                   bvc_site_result *results)
+{
+    return run_two_stages(ctx, n_sites, false, false,
+                          [&](uint32_t *counts) { return launch_hist_csr(ctx->ls, ctx->stream, n_sites, offsets, bases, quals, counts); },
+                          ref_base, min_af, comb, n_comb, results);
+}
+
+void reap_timing(bvc_ctx *ctx, bool all)
+{
+    size_t kept = 0;
+    for (size_t i = 0; i < ctx->ev_pending.size(); ++i) {
+        bvc_ctx::Triple &t = ctx->ev_pending[i];
+        if (!all && hipEventQuery(t.d) != hipSuccess) { (void)hipGetLastError(); ctx->ev_pending[kept++] = t; continue; }
+        float ms1 = 0.f, ms2 = 0.f;
+        if (hipEventElapsedTime(&ms1, t.a, t.b) == hipSuccess && hipEventElapsedTime(&ms2, t.c, t.d) == hipSuccess) {
+            ctx->prof.hist_ms += ms1; ctx->prof.em_ms += ms2;
+            ctx->prof.hist_launches += 1; ctx->prof.em_launches += 1; ctx->prof.sites += t.sites;
+        } else {
+            (void)hipGetLastError();
+        }
+        give_back(ctx, t.a); give_back(ctx, t.b); give_back(ctx, t.c); give_back(ctx, t.d);
+    }
+    ctx->ev_pending.resize(kept);
+}
+
+// Host-pointer calls go through device staging in chunks of sites; `upload(set, s0, ns)` enqueues the H2D copies of
+// a chunk on the copy stream into staging set `set`, `compute(set, s0, ns)` enqueues its kernels and the D2H copies
+// of its records on the context's stream.  The upload of chunk i+1 is issued before the (blocking) download of chunk
+// i, so it runs under chunk i's kernels.
+template <class Upload, class Compute>
+int run_chunks(bvc_ctx *ctx, int64_t n_sites, int64_t chunk, Upload upload, Compute compute)
+{
+    int set = 0;
+    int rc = upload(set, (int64_t)0, n_sites < chunk ? n_sites : chunk);
+    if (rc != BVC_OK) return rc;
+    BVC_HIP(ctx, hipEventRecord(ctx->ev_upload[set], ctx->copy));
+    for (int64_t s0 = 0; s0 < n_sites; s0 += chunk, set ^= 1) {
+        const int64_t ns = n_sites - s0 < chunk ? n_sites - s0 : chunk;
+        BVC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upload[set], 0));
+        rc = compute(set, s0, ns, /*download=*/false);
+        if (rc != BVC_OK) return rc;
+        const int64_t s1 = s0 + chunk;
+        if (s1 < n_sites) {
+            // the other set's previous chunk (i-1) has been downloaded synchronously below: it is free
+            rc = upload(set ^ 1, s1, n_sites - s1 < chunk ? n_sites - s1 : chunk);
+            if (rc != BVC_OK) return rc;
+            BVC_HIP(ctx, hipEventRecord(ctx->ev_upload[set ^ 1], ctx->copy));
+        }
+        rc = compute(set, s0, ns, /*download=*/true);
+        if (rc != BVC_OK) return rc;
+        BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return BVC_OK;
 }
@@ -164,7 +273,7 @@ int check_common(bvc_ctx *ctx, int64_t n_sites, const void *a, const void *b, co
 
 extern "C" {
 
-const char *bvc_version(void) { return "libbvc 0.1.0 (gfx950)"; }
+const char *bvc_version(void) { return "libbvc 0.2.0 (gfx950)"; }
 
 int bvc_device_count(void)
 {
@@ -176,6 +285,14 @@ int bvc_device_count(void)
         if (hipGetDeviceProperties(&p, d) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
     }
     return ok;
+}
+
+static int env_int(const char *name, int lo, int hi, int dflt)
+{
+    const char *e = getenv(name);
+    if (!e) return dflt;
+    const int v = atoi(e);
+    return (v >= lo && v <= hi) ? v : dflt;
 }
 
 int bvc_create(bvc_ctx **out, int device)
@@ -191,7 +308,12 @@ int bvc_create(bvc_ctx **out, int device)
     bvc_ctx *ctx = new (std::nothrow) bvc_ctx();
     if (!ctx) return BVC_ERR_ALLOC;
     ctx->device = device;
-    ctx->n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    ctx->ls.n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    // starting values of the tuning knobs (bvc_set_tuning changes them per context; results never depend on them)
+    ctx->ls.em_waves_per_cu = env_int("BVC_EM_WAVES_PER_CU", 1, 32, 0);
+    ctx->ls.em_wpb = env_int("BVC_EM_WPB", 1, 4, 4) == 1 ? 1 : 4;
+    ctx->ls.hist_split = env_int("BVC_HIST_SPLIT", 1, 64, 0);
+    ctx->ls.group_sites = env_int("BVC_GROUP_SITES", 1, 4, 0);
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return BVC_ERR_DEVICE; }
     // likelihood table from the host's exp(), as the CPU path computes it (src/BaseType.cpp:13,15)
     QualLut lut;
@@ -208,10 +330,13 @@ int bvc_create(bvc_ctx **out, int device)
         return BVC_ERR_ALLOC;
     }
     bool ok = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void **>(&ctx->d_grp_scratch), (BVC_MAX_GROUPS + 4) * sizeof(int64_t)) == hipSuccess;
+              hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&ctx->d_grp_scratch), (BVC_MAX_GROUPS + 4) * sizeof(int64_t)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&ctx->d_sink), 256) == hipSuccess;
     for (int b = 0; b < bvc_ctx::kRing && ok; ++b)
         ok = hipEventCreateWithFlags(&ctx->ev_hist_done[b], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&ctx->ev_em_done[b], hipEventDisableTiming) == hipSuccess;
+    for (int b = 0; b < 2 && ok; ++b) ok = hipEventCreateWithFlags(&ctx->ev_upload[b], hipEventDisableTiming) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); bvc_destroy(ctx); return BVC_ERR_DEVICE; }
     *out = ctx;
     return BVC_OK;
@@ -223,17 +348,22 @@ void bvc_destroy(bvc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    if (ctx->copy) { (void)hipStreamSynchronize(ctx->copy); (void)hipStreamDestroy(ctx->copy); }
     for (int b = 0; b < bvc_ctx::kRing; ++b) {
         if (ctx->ev_hist_done[b]) (void)hipEventDestroy(ctx->ev_hist_done[b]);
         if (ctx->ev_em_done[b]) (void)hipEventDestroy(ctx->ev_em_done[b]);
         if (ctx->d_cnt[b]) (void)hipFree(ctx->d_cnt[b]);
         if (ctx->d_grp[b]) (void)hipFree(ctx->d_grp[b]);
     }
+    for (int b = 0; b < 2; ++b) {
+        if (ctx->ev_upload[b]) (void)hipEventDestroy(ctx->ev_upload[b]);
+        if (ctx->d_stage[b]) (void)hipFree(ctx->d_stage[b]);
+    }
     for (auto &t : ctx->ev_pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.c); (void)hipEventDestroy(t.d); }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     if (ctx->d_grp_scratch) (void)hipFree(ctx->d_grp_scratch);
-    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->d_sink) (void)hipFree(ctx->d_sink);
     delete ctx;
 }
 
@@ -290,15 +420,7 @@ int bvc_get_profile(bvc_ctx *ctx, bvc_profile *out, int reset)
     BVC_HIP(ctx, hipSetDevice(ctx->device));
     BVC_HIP(ctx, hipStreamSynchronize(ctx->side));
     BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (auto &t : ctx->ev_pending) {
-        float ms1 = 0.f, ms2 = 0.f;
-        BVC_HIP(ctx, hipEventElapsedTime(&ms1, t.a, t.b));
-        BVC_HIP(ctx, hipEventElapsedTime(&ms2, t.c, t.d));
-        ctx->prof.hist_ms += ms1; ctx->prof.em_ms += ms2;
-        ctx->prof.hist_launches += 1; ctx->prof.em_launches += 1; ctx->prof.sites += t.sites;
-        ctx->ev_pool.push_back(t.a); ctx->ev_pool.push_back(t.b); ctx->ev_pool.push_back(t.c); ctx->ev_pool.push_back(t.d);
-    }
-    ctx->ev_pending.clear();
+    reap_timing(ctx, true);
     *out = ctx->prof;
     if (reset) ctx->prof = bvc_profile{};
     return BVC_OK;
@@ -316,36 +438,41 @@ int bvc_lrt_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_
     if (flags & BVC_PTR_DEVICE)
         return run_dense_device(ctx, n_sites, n_samples, row_stride, bases, quals, ref_base, min_af, results);
 
-    // host pointers: stage site chunks of at most ~1 GiB per array through device memory
+    // host pointers: site chunks of at most ~512 MiB per array through two staging sets
     const int64_t row_bytes = row_stride > 0 ? row_stride : 1;
-    int64_t chunk = ((int64_t)1 << 30) / row_bytes;
+    int64_t chunk = ((int64_t)1 << 29) / row_bytes;
     if (chunk < 1) chunk = 1;
     if (chunk > n_sites) chunk = n_sites;
-    const size_t arr = (size_t)chunk * (size_t)row_stride;
-    const size_t arr_al = (arr + 255) & ~(size_t)255;
+    const size_t arr_al = ((size_t)chunk * (size_t)row_stride + 255) & ~(size_t)255;
     const size_t ref_al = ((size_t)chunk + 255) & ~(size_t)255;
     const size_t need = 2 * arr_al + ref_al + (size_t)chunk * sizeof(bvc_site_result) + 256;
-    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage), &ctx->stage_cap, need);
-    if (rc != BVC_OK) return rc;
-    int8_t *d_b = reinterpret_cast<int8_t *>(ctx->d_stage);
-    int8_t *d_q = d_b + arr_al;
-    int8_t *d_r = d_q + arr_al;
-    bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(d_r + ref_al);
-    for (int64_t s0 = 0; s0 < n_sites; s0 += chunk) {
-        const int64_t ns = (n_sites - s0 < chunk) ? n_sites - s0 : chunk;
-        // the last row may be shorter than row_stride in the caller's allocation: copy exactly what is addressed
-        const size_t bytes = n_samples ? (size_t)(ns - 1) * (size_t)row_stride + (size_t)n_samples : 0;
-        if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_b, bases + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
-        if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_q, quals + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
-        BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base + s0, (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
-        rc = run_dense_device(ctx, ns, n_samples, row_stride, d_b, d_q, d_r, min_af, d_res);
-        if (rc == BVC_OK) rc = join_side(ctx);
+    const int n_sets = n_sites > chunk ? 2 : 1;
+    for (int k = 0; k < n_sets; ++k) {
+        rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage[k]), &ctx->stage_cap[k], need);
         if (rc != BVC_OK) return rc;
-        BVC_HIP(ctx, hipMemcpyAsync(results + s0, d_res, (size_t)ns * sizeof(bvc_site_result),
-                                    hipMemcpyDeviceToHost, ctx->stream));
-        BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    return BVC_OK;
+    auto d_b = [&](int set) { return reinterpret_cast<int8_t *>(ctx->d_stage[set]); };
+    auto d_q = [&](int set) { return d_b(set) + arr_al; };
+    auto d_r = [&](int set) { return d_q(set) + arr_al; };
+    auto d_res = [&](int set) { return reinterpret_cast<bvc_site_result *>(d_r(set) + ref_al); };
+    return run_chunks(ctx, n_sites, chunk,
+        [&](int set, int64_t s0, int64_t ns) -> int {
+            // the last row may be shorter than row_stride in the caller's allocation: copy exactly what is addressed
+            const size_t bytes = n_samples ? (size_t)(ns - 1) * (size_t)row_stride + (size_t)n_samples : 0;
+            if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_b(set), bases + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->copy));
+            if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_q(set), quals + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->copy));
+            BVC_HIP(ctx, hipMemcpyAsync(d_r(set), ref_base + s0, (size_t)ns, hipMemcpyHostToDevice, ctx->copy));
+            return BVC_OK;
+        },
+        [&](int set, int64_t s0, int64_t ns, bool download) -> int {
+            if (!download) {
+                int rc2 = run_dense_device(ctx, ns, n_samples, row_stride, d_b(set), d_q(set), d_r(set), min_af, d_res(set));
+                return rc2 == BVC_OK ? join_side(ctx) : rc2;
+            }
+            BVC_HIP(ctx, hipMemcpyAsync(results + s0, d_res(set), (size_t)ns * sizeof(bvc_site_result),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+            return BVC_OK;
+        });
 }
 
 int bvc_hist_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
@@ -356,26 +483,36 @@ int bvc_hist_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row
     if (rc != BVC_OK) return rc;
     if (n_samples < 0 || row_stride < n_samples) return fail(ctx, BVC_ERR_ARG, "need 0 <= n_samples <= row_stride");
     if (n_sites == 0) return BVC_OK;
-    const int split = choose_hist_split(n_sites, n_samples, ctx->n_cu);
+    const int split = choose_hist_split(ctx->ls, n_sites, n_samples);
     const size_t cbytes = (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t);
     if (flags & BVC_PTR_DEVICE) {
         if (split > 1) BVC_HIP(ctx, hipMemsetAsync(counts, 0, cbytes, ctx->stream));
-        BVC_HIP(ctx, launch_hist_dense(ctx->stream, n_sites, n_samples, row_stride, bases, quals, nullptr, 0, counts, split));
+        BVC_HIP(ctx, launch_hist_dense(ctx->ls, ctx->stream, n_sites, n_samples, row_stride, bases, quals, nullptr, 0, counts, split));
         return BVC_OK;
     }
     const size_t bytes = n_samples ? (size_t)(n_sites - 1) * (size_t)row_stride + (size_t)n_samples : 0;
     const size_t arr_al = (bytes + 255) & ~(size_t)255;
-    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage), &ctx->stage_cap, 2 * arr_al + cbytes + 256);
+    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage[0]), &ctx->stage_cap[0], 2 * arr_al + cbytes + 256);
     if (rc != BVC_OK) return rc;
-    int8_t *d_b = reinterpret_cast<int8_t *>(ctx->d_stage);
+    int8_t *d_b = reinterpret_cast<int8_t *>(ctx->d_stage[0]);
     int8_t *d_q = d_b + arr_al;
     uint32_t *d_c = reinterpret_cast<uint32_t *>(d_q + arr_al);
     if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_b, bases, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_q, quals, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (split > 1) BVC_HIP(ctx, hipMemsetAsync(d_c, 0, cbytes, ctx->stream));
-    BVC_HIP(ctx, launch_hist_dense(ctx->stream, n_sites, n_samples, row_stride, d_b, d_q, nullptr, 0, d_c, split));
+    BVC_HIP(ctx, launch_hist_dense(ctx->ls, ctx->stream, n_sites, n_samples, row_stride, d_b, d_q, nullptr, 0, d_c, split));
     BVC_HIP(ctx, hipMemcpyAsync(counts, d_c, cbytes, hipMemcpyDeviceToHost, ctx->stream));
     BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BVC_OK;
+}
+
+static int check_comb_host(bvc_ctx *ctx, int64_t n_sites, const int8_t *base_comb, const uint8_t *n_comb)
+{
+    for (int64_t s = 0; s < n_sites; ++s) {
+        if (n_comb[s] > 4) return fail(ctx, BVC_ERR_ARG, "n_comb > 4");
+        for (int c = 0; c < n_comb[s]; ++c)
+            if (base_comb[s * 4 + c] < 0 || base_comb[s * 4 + c] > 3) return fail(ctx, BVC_ERR_ARG, "base_comb entry outside 0..3");
+    }
     return BVC_OK;
 }
 
@@ -388,24 +525,19 @@ int bvc_lrt_hist(bvc_ctx *ctx, int64_t n_sites, const uint32_t *counts, const in
     if ((base_comb == nullptr) != (n_comb == nullptr)) return fail(ctx, BVC_ERR_ARG, "base_comb and n_comb go together");
     if (n_sites == 0) return BVC_OK;
     if (flags & BVC_PTR_DEVICE) {
-        BVC_HIP(ctx, launch_lrt(ctx->stream, n_sites, counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut, base_comb,
+        BVC_HIP(ctx, launch_lrt(ctx->ls, ctx->stream, n_sites, counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut, base_comb,
                                 n_comb, results));
         return BVC_OK;
     }
-    if (base_comb)
-        for (int64_t s = 0; s < n_sites; ++s) {
-            if (n_comb[s] > 4) return fail(ctx, BVC_ERR_ARG, "n_comb > 4");
-            for (int c = 0; c < n_comb[s]; ++c)
-                if (base_comb[s * 4 + c] < 0 || base_comb[s * 4 + c] > 3) return fail(ctx, BVC_ERR_ARG, "base_comb entry outside 0..3");
-        }
+    if (base_comb && (rc = check_comb_host(ctx, n_sites, base_comb, n_comb)) != BVC_OK) return rc;
     const size_t cbytes = (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t);
     const size_t sa = ((size_t)n_sites + 255) & ~(size_t)255;
     const size_t ca = ((size_t)n_sites * 4 + 255) & ~(size_t)255;
-    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage), &ctx->stage_cap,
+    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage[0]), &ctx->stage_cap[0],
                 cbytes + 2 * sa + ca + (size_t)n_sites * sizeof(bvc_site_result) + 256);
     if (rc != BVC_OK) return rc;
-    uint32_t *d_c = reinterpret_cast<uint32_t *>(ctx->d_stage);
-    int8_t *d_r = reinterpret_cast<int8_t *>(ctx->d_stage + cbytes);
+    uint32_t *d_c = reinterpret_cast<uint32_t *>(ctx->d_stage[0]);
+    int8_t *d_r = reinterpret_cast<int8_t *>(ctx->d_stage[0] + cbytes);
     uint8_t *d_nc = reinterpret_cast<uint8_t *>(d_r + sa);
     int8_t *d_cb = reinterpret_cast<int8_t *>(d_nc + sa);
     bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(d_cb + ca);
@@ -415,8 +547,60 @@ int bvc_lrt_hist(bvc_ctx *ctx, int64_t n_sites, const uint32_t *counts, const in
         BVC_HIP(ctx, hipMemcpyAsync(d_nc, n_comb, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
         BVC_HIP(ctx, hipMemcpyAsync(d_cb, base_comb, (size_t)n_sites * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    BVC_HIP(ctx, launch_lrt(ctx->stream, n_sites, d_c, BVC_NCLASS, d_r, min_af, ctx->d_lut,
+    BVC_HIP(ctx, launch_lrt(ctx->ls, ctx->stream, n_sites, d_c, BVC_NCLASS, d_r, min_af, ctx->d_lut,
                             base_comb ? d_cb : nullptr, base_comb ? d_nc : nullptr, d_res));
+    BVC_HIP(ctx, hipMemcpyAsync(results, d_res, (size_t)n_sites * sizeof(bvc_site_result), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BVC_OK;
+}
+
+int bvc_lrt_csr_comb(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
+                     const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
+                     double min_af, const int8_t *base_comb, const uint8_t *n_comb,
+                     bvc_site_result *results, uint32_t flags)
+{
+    int rc = check_common(ctx, n_sites, offsets, ref_base, results, results);
+    if (rc != BVC_OK) return rc;
+    if ((base_comb == nullptr) != (n_comb == nullptr)) return fail(ctx, BVC_ERR_ARG, "base_comb and n_comb go together");
+    if (n_sites == 0) return BVC_OK;
+    if (flags & BVC_PTR_DEVICE) {
+        if (!bases || !quals) return fail(ctx, BVC_ERR_ARG, "null data pointer");
+        return run_csr_device(ctx, n_sites, offsets, bases, quals, ref_base, min_af, base_comb, n_comb, results);
+    }
+    const int64_t total = offsets[n_sites];
+    if (offsets[0] != 0 || total < 0) return fail(ctx, BVC_ERR_ARG, "offsets must start at 0 and be non-decreasing");
+    for (int64_t s = 0; s < n_sites; ++s)
+        if (offsets[s + 1] < offsets[s]) return fail(ctx, BVC_ERR_ARG, "offsets must start at 0 and be non-decreasing");
+    if (total > 0 && (!bases || !quals)) return fail(ctx, BVC_ERR_ARG, "null data pointer");
+    if (base_comb && (rc = check_comb_host(ctx, n_sites, base_comb, n_comb)) != BVC_OK) return rc;
+    const size_t ta = ((size_t)total + 255) & ~(size_t)255;
+    const size_t oa = ((size_t)(n_sites + 1) * 8 + 255) & ~(size_t)255;
+    const size_t sa = ((size_t)n_sites + 255) & ~(size_t)255;
+    const size_t ca = ((size_t)n_sites * 4 + 255) & ~(size_t)255;
+    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage[0]), &ctx->stage_cap[0],
+                oa + 2 * ta + 2 * sa + ca + (size_t)n_sites * sizeof(bvc_site_result) + 256);
+    if (rc != BVC_OK) return rc;
+    int64_t *d_o = reinterpret_cast<int64_t *>(ctx->d_stage[0]);
+    int8_t *d_b = reinterpret_cast<int8_t *>(ctx->d_stage[0] + oa);
+    int8_t *d_q = d_b + ta;
+    int8_t *d_r = d_q + ta;
+    uint8_t *d_nc = reinterpret_cast<uint8_t *>(d_r + sa);
+    int8_t *d_cb = reinterpret_cast<int8_t *>(d_nc + sa);
+    bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(d_cb + ca);
+    BVC_HIP(ctx, hipMemcpyAsync(d_o, offsets, (size_t)(n_sites + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (total > 0) {
+        BVC_HIP(ctx, hipMemcpyAsync(d_b, bases, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP(ctx, hipMemcpyAsync(d_q, quals, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+    }
+    BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
+    if (base_comb) {
+        BVC_HIP(ctx, hipMemcpyAsync(d_nc, n_comb, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP(ctx, hipMemcpyAsync(d_cb, base_comb, (size_t)n_sites * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = run_csr_device(ctx, n_sites, d_o, d_b, d_q, d_r, min_af, base_comb ? d_cb : nullptr, base_comb ? d_nc : nullptr, d_res);
+    if (rc == BVC_OK) rc = join_side(ctx);
+    if (rc != BVC_OK) return rc;
     BVC_HIP(ctx, hipMemcpyAsync(results, d_res, (size_t)n_sites * sizeof(bvc_site_result), hipMemcpyDeviceToHost,
                                 ctx->stream));
     BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -427,50 +611,7 @@ int bvc_lrt_csr(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
                 const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
                 double min_af, bvc_site_result *results, uint32_t flags)
 {
-    int rc = check_common(ctx, n_sites, offsets, ref_base, results, results);
-    if (rc != BVC_OK) return rc;
-    if (n_sites == 0) return BVC_OK;
-    rc = join_side(ctx);                        // this path shares d_cnt[0] with overlapped dense calls
-    if (rc != BVC_OK) return rc;
-    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_cnt[0]), &ctx->cnt_cap[0],
-                (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t));
-    if (rc != BVC_OK) return rc;
-    if (flags & BVC_PTR_DEVICE) {
-        if (!bases || !quals) return fail(ctx, BVC_ERR_ARG, "null data pointer");
-        BVC_HIP(ctx, launch_hist_csr(ctx->stream, n_sites, offsets, bases, quals, ctx->d_cnt[0]));
-        BVC_HIP(ctx, launch_lrt(ctx->stream, n_sites, ctx->d_cnt[0], BVC_NCLASS, ref_base, min_af, ctx->d_lut,
-                                nullptr, nullptr, results));
-        return BVC_OK;
-    }
-    const int64_t total = offsets[n_sites];
-    if (offsets[0] != 0 || total < 0) return fail(ctx, BVC_ERR_ARG, "offsets must start at 0 and be non-decreasing");
-    for (int64_t s = 0; s < n_sites; ++s)
-        if (offsets[s + 1] < offsets[s]) return fail(ctx, BVC_ERR_ARG, "offsets must start at 0 and be non-decreasing");
-    if (total > 0 && (!bases || !quals)) return fail(ctx, BVC_ERR_ARG, "null data pointer");
-    const size_t ta = ((size_t)total + 255) & ~(size_t)255;
-    const size_t oa = ((size_t)(n_sites + 1) * 8 + 255) & ~(size_t)255;
-    const size_t sa = ((size_t)n_sites + 255) & ~(size_t)255;
-    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage), &ctx->stage_cap,
-                oa + 2 * ta + sa + (size_t)n_sites * sizeof(bvc_site_result) + 256);
-    if (rc != BVC_OK) return rc;
-    int64_t *d_o = reinterpret_cast<int64_t *>(ctx->d_stage);
-    int8_t *d_b = reinterpret_cast<int8_t *>(ctx->d_stage + oa);
-    int8_t *d_q = d_b + ta;
-    int8_t *d_r = d_q + ta;
-    bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(d_r + sa);
-    BVC_HIP(ctx, hipMemcpyAsync(d_o, offsets, (size_t)(n_sites + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (total > 0) {
-        BVC_HIP(ctx, hipMemcpyAsync(d_b, bases, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
-        BVC_HIP(ctx, hipMemcpyAsync(d_q, quals, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
-    }
-    BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
-    BVC_HIP(ctx, launch_hist_csr(ctx->stream, n_sites, d_o, d_b, d_q, ctx->d_cnt[0]));
-    BVC_HIP(ctx, launch_lrt(ctx->stream, n_sites, ctx->d_cnt[0], BVC_NCLASS, d_r, min_af, ctx->d_lut, nullptr,
-                            nullptr, d_res));
-    BVC_HIP(ctx, hipMemcpyAsync(results, d_res, (size_t)n_sites * sizeof(bvc_site_result), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return BVC_OK;
+    return bvc_lrt_csr_comb(ctx, n_sites, offsets, bases, quals, ref_base, min_af, nullptr, nullptr, results, flags);
 }
 
 int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
@@ -508,26 +649,38 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
             ctx->em_pending[buf] = false;
         }
         bvc_ctx::Triple t{nullptr, nullptr, nullptr, nullptr, ns};
-        if (ctx->profiling) { t.a = take_event(ctx); t.b = take_event(ctx); t.c = take_event(ctx); t.d = take_event(ctx); }
-        if (t.a) BVC_HIP(ctx, hipEventRecord(t.a, ctx->stream));
-        BVC_HIP(ctx, launch_hist_dense(ctx->stream, ns, n_samples, row_stride, b, q, g, n_groups, *gp, 1, ctx->d_grp_scratch));
-        if (t.b) BVC_HIP(ctx, hipEventRecord(t.b, ctx->stream));
+        const bool timed = ctx->profiling && take_timing_events(ctx, t);
+        auto bail = [&](int code) { give_back(ctx, t.a); give_back(ctx, t.b); give_back(ctx, t.c); give_back(ctx, t.d); return code; };
+#define BVC_HIP_T(call)                                                                     \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess) return bail(fail(ctx, BVC_ERR_DEVICE, #call, e__));          \
+    } while (0)
+        if (timed) BVC_HIP_T(hipEventRecord(t.a, ctx->stream));
+        BVC_HIP_T(launch_hist_dense(ctx->ls, ctx->stream, ns, n_samples, row_stride, b, q, g, n_groups, *gp, 1, ctx->d_grp_scratch));
+        if (timed) BVC_HIP_T(hipEventRecord(t.b, ctx->stream));
         hipStream_t s2 = ctx->stream;
         if (ctx->overlap) {
             s2 = ctx->side;
-            BVC_HIP(ctx, hipEventRecord(ctx->ev_hist_done[buf], ctx->stream));
-            BVC_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_hist_done[buf], 0));
+            BVC_HIP_T(hipEventRecord(ctx->ev_hist_done[buf], ctx->stream));
+            BVC_HIP_T(hipStreamWaitEvent(s2, ctx->ev_hist_done[buf], 0));
         }
-        if (t.c) BVC_HIP(ctx, hipEventRecord(t.c, s2));
-        BVC_HIP(ctx, launch_sum_groups(s2, ns, n_hist, *gp, *cp));
+        if (timed) BVC_HIP_T(hipEventRecord(t.c, s2));
+        BVC_HIP_T(launch_sum_groups(s2, ns, n_hist, *gp, *cp));
         const bool shared = ctx->overlap && n_samples >= 200000;
-        BVC_HIP(ctx, launch_lrt(s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared, n_samples, 12 /* = kGroupSharedWavesPerCu, em_kernel.hip */));
-        BVC_HIP(ctx, launch_lrt_groups(s2, ns, n_groups, *gp, r, min_af, ctx->d_lut, res, gres, shared));
-        if (t.d) { BVC_HIP(ctx, hipEventRecord(t.d, s2)); ctx->ev_pending.push_back(t); }
+        BVC_HIP_T(launch_lrt(ctx->ls, s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared, 12 /* = kGroupSharedWavesPerCu, em_kernel.hip */));
+        BVC_HIP_T(launch_lrt_groups(ctx->ls, s2, ns, n_groups, *gp, r, min_af, ctx->d_lut, res, gres, shared));
+        if (timed) {
+            BVC_HIP_T(hipEventRecord(t.d, s2));
+            ctx->ev_pending.push_back(t);
+            t = bvc_ctx::Triple{nullptr, nullptr, nullptr, nullptr, 0};
+            if (ctx->ev_pending.size() > 256) reap_timing(ctx, false);
+        }
         if (ctx->overlap) {
-            BVC_HIP(ctx, hipEventRecord(ctx->ev_em_done[buf], s2));
+            BVC_HIP_T(hipEventRecord(ctx->ev_em_done[buf], s2));
             ctx->em_pending[buf] = true;
         }
+#undef BVC_HIP_T
         return BVC_OK;
     };
 
@@ -535,64 +688,76 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
         return run_device(n_sites, bases, quals, ref_base, group_of_sample, results, grp_results);
 
     const int64_t row_bytes = row_stride > 0 ? row_stride : 1;
-    int64_t chunk = ((int64_t)1 << 30) / row_bytes;
+    int64_t chunk = ((int64_t)1 << 29) / row_bytes;
     if (chunk < 1) chunk = 1;
     if (chunk > n_sites) chunk = n_sites;
     const size_t arr_al = ((size_t)chunk * (size_t)row_stride + 255) & ~(size_t)255;
     const size_t ref_al = ((size_t)chunk + 255) & ~(size_t)255;
     const size_t g_al = ((size_t)n_samples + 255) & ~(size_t)255;
     const size_t res_al = ((size_t)chunk * sizeof(bvc_site_result) + 255) & ~(size_t)255;
-    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage), &ctx->stage_cap,
-                2 * arr_al + ref_al + g_al + res_al + (size_t)chunk * n_groups * sizeof(bvc_group_result) + 256);
-    if (rc != BVC_OK) return rc;
-    int8_t *d_b = reinterpret_cast<int8_t *>(ctx->d_stage);
-    int8_t *d_q = d_b + arr_al;
-    int8_t *d_r = d_q + arr_al;
-    uint8_t *d_g = reinterpret_cast<uint8_t *>(d_r + ref_al);
-    bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(d_g + g_al);
-    bvc_group_result *d_gres = reinterpret_cast<bvc_group_result *>(reinterpret_cast<char *>(d_res) + res_al);
-    BVC_HIP(ctx, hipMemcpyAsync(d_g, group_of_sample, (size_t)n_samples, hipMemcpyHostToDevice, ctx->stream));
-    for (int64_t s0 = 0; s0 < n_sites; s0 += chunk) {
-        const int64_t ns = (n_sites - s0 < chunk) ? n_sites - s0 : chunk;
-        const size_t bytes = n_samples ? (size_t)(ns - 1) * (size_t)row_stride + (size_t)n_samples : 0;
-        if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_b, bases + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
-        if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_q, quals + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->stream));
-        BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base + s0, (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
-        rc = run_device(ns, d_b, d_q, d_r, d_g, d_res, d_gres);
-        if (rc == BVC_OK) rc = join_side(ctx);
+    const size_t need = 2 * arr_al + ref_al + g_al + res_al + (size_t)chunk * n_groups * sizeof(bvc_group_result) + 256;
+    const int n_sets = n_sites > chunk ? 2 : 1;
+    for (int k = 0; k < n_sets; ++k) {
+        rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage[k]), &ctx->stage_cap[k], need);
         if (rc != BVC_OK) return rc;
-        BVC_HIP(ctx, hipMemcpyAsync(results + s0, d_res, (size_t)ns * sizeof(bvc_site_result), hipMemcpyDeviceToHost,
-                                    ctx->stream));
-        BVC_HIP(ctx, hipMemcpyAsync(grp_results + s0 * n_groups, d_gres, (size_t)ns * n_groups * sizeof(bvc_group_result),
-                                    hipMemcpyDeviceToHost, ctx->stream));
-        BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    return BVC_OK;
+    auto d_b = [&](int set) { return reinterpret_cast<int8_t *>(ctx->d_stage[set]); };
+    auto d_q = [&](int set) { return d_b(set) + arr_al; };
+    auto d_r = [&](int set) { return d_q(set) + arr_al; };
+    auto d_g = [&](int set) { return reinterpret_cast<uint8_t *>(d_r(set) + ref_al); };
+    auto d_res = [&](int set) { return reinterpret_cast<bvc_site_result *>(d_g(set) + g_al); };
+    auto d_gres = [&](int set) { return reinterpret_cast<bvc_group_result *>(reinterpret_cast<char *>(d_res(set)) + res_al); };
+    return run_chunks(ctx, n_sites, chunk,
+        [&](int set, int64_t s0, int64_t ns) -> int {
+            const size_t bytes = n_samples ? (size_t)(ns - 1) * (size_t)row_stride + (size_t)n_samples : 0;
+            // the group vector travels with the first chunk of each staging set
+            if (s0 < 2 * chunk && n_samples)
+                BVC_HIP(ctx, hipMemcpyAsync(d_g(set), group_of_sample, (size_t)n_samples, hipMemcpyHostToDevice, ctx->copy));
+            if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_b(set), bases + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->copy));
+            if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_q(set), quals + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->copy));
+            BVC_HIP(ctx, hipMemcpyAsync(d_r(set), ref_base + s0, (size_t)ns, hipMemcpyHostToDevice, ctx->copy));
+            return BVC_OK;
+        },
+        [&](int set, int64_t s0, int64_t ns, bool download) -> int {
+            if (!download) {
+                int rc2 = run_device(ns, d_b(set), d_q(set), d_r(set), d_g(set), d_res(set), d_gres(set));
+                return rc2 == BVC_OK ? join_side(ctx) : rc2;
+            }
+            BVC_HIP(ctx, hipMemcpyAsync(results + s0, d_res(set), (size_t)ns * sizeof(bvc_site_result), hipMemcpyDeviceToHost,
+                                        ctx->stream));
+            BVC_HIP(ctx, hipMemcpyAsync(grp_results + s0 * n_groups, d_gres(set), (size_t)ns * n_groups * sizeof(bvc_group_result),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+            return BVC_OK;
+        });
 }
 
-int bvc_set_tuning(const char *key, int value)
+int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value)
 {
-    if (!key) return BVC_ERR_ARG;
-    if (std::strcmp(key, "em_rows") == 0 && value >= -1 && value <= 1) { set_em_tuning(value, -1); return BVC_OK; }
-    if (std::strcmp(key, "em_waves_per_cu") == 0 && value >= 0 && value <= 32) { set_em_tuning(-2, value); return BVC_OK; }
-    return BVC_ERR_ARG;
+    if (!ctx) return BVC_ERR_ARG;
+    if (!key) return fail(ctx, BVC_ERR_ARG, "null tuning key");
+    if (std::strcmp(key, "em_waves_per_cu") == 0 && value >= 0 && value <= 32) { ctx->ls.em_waves_per_cu = value; return BVC_OK; }
+    if (std::strcmp(key, "em_wpb") == 0 && (value == 1 || value == 4)) { ctx->ls.em_wpb = value; return BVC_OK; }
+    if (std::strcmp(key, "hist_split") == 0 && value >= 0 && value <= 64) { ctx->ls.hist_split = value; return BVC_OK; }
+    if (std::strcmp(key, "group_sites") == 0 && (value == 0 || value == 1 || value == 2 || value == 4)) { ctx->ls.group_sites = value; return BVC_OK; }
+    return fail(ctx, BVC_ERR_ARG, "unknown tuning key or value out of range");
 }
 
 int bvc_stream_read_ms(bvc_ctx *ctx, const void *device_ptr, int64_t bytes, int repeats, double *ms_per_pass)
 {
     if (!ctx || !device_ptr || !ms_per_pass || bytes < 16 || repeats < 1) return ctx ? fail(ctx, BVC_ERR_ARG, "bad argument") : BVC_ERR_ARG;
     BVC_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_cnt[0]), &ctx->cnt_cap[0], 256);
-    if (rc != BVC_OK) return rc;
     hipEvent_t a = take_event(ctx), b = take_event(ctx);
-    BVC_HIP(ctx, launch_stream_read(ctx->stream, device_ptr, bytes, ctx->d_cnt[0]));        // warm-up
-    BVC_HIP(ctx, hipEventRecord(a, ctx->stream));
-    for (int i = 0; i < repeats; ++i) BVC_HIP(ctx, launch_stream_read(ctx->stream, device_ptr, bytes, ctx->d_cnt[0]));
-    BVC_HIP(ctx, hipEventRecord(b, ctx->stream));
-    BVC_HIP(ctx, hipEventSynchronize(b));
+    if (!a || !b) { give_back(ctx, a); give_back(ctx, b); return fail(ctx, BVC_ERR_DEVICE, "hipEventCreate failed"); }
+    auto bail = [&](int code) { give_back(ctx, a); give_back(ctx, b); return code; };
+    hipError_t e = launch_stream_read(ctx->stream, device_ptr, bytes, ctx->d_sink);        // warm-up
+    if (e == hipSuccess) e = hipEventRecord(a, ctx->stream);
+    for (int i = 0; i < repeats && e == hipSuccess; ++i) e = launch_stream_read(ctx->stream, device_ptr, bytes, ctx->d_sink);
+    if (e == hipSuccess) e = hipEventRecord(b, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(b);
     float ms = 0.f;
-    BVC_HIP(ctx, hipEventElapsedTime(&ms, a, b));
-    ctx->ev_pool.push_back(a); ctx->ev_pool.push_back(b);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    if (e != hipSuccess) return bail(fail(ctx, BVC_ERR_DEVICE, "stream read measurement", e));
+    give_back(ctx, a); give_back(ctx, b);
     *ms_per_pass = (double)ms / repeats;
     return BVC_OK;
 }

@@ -17,9 +17,6 @@
 //                                                             E   = sum_c       n_c e_c / m_c
 //   stop rule     delta = sum_c n_c |log m_c' - log m_c| < 1e-3
 // FP64 throughout; no MFMA (nothing here is a dense contraction).
-#include <atomic>
-#include <cstdlib>
-
 #include "bvc_device.h"
 #include "bvc_internal.h"
 
@@ -459,319 +456,19 @@ __global__ __launch_bounds__(64 * WPB) void lrt_kernel(int64_t n_sites, const ui
         uint32_t list = 0x3210u;                                 // default base_comb, src/BaseType.h:79
         int nc = 4;
         if (comb) {
-            nc = min((int)n_comb[site], 4);
-            list = 0;
-            for (int c = 0; c < nc; ++c) list |= (uint32_t)(comb[site * 4 + c] & 3) << (4 * c);
+            // entries outside 0..3 are dropped: in the reference depth[b] of such a key is 0, so the min_af
+            // filter (src/BaseType.cpp:79) removes it for every min_af > 0
+            const int want = min((int)n_comb[site], 4);
+            list = 0; nc = 0;
+            for (int c = 0; c < want; ++c) {
+                const int b = comb[site * 4 + c];
+                if ((unsigned)b < 4u) { list |= (uint32_t)b << (4 * nc); ++nc; }
+            }
         }
         SiteOut o;
         const bool mine = lrt_site<NS, WPB>(counts + site * hist_stride, ref_base[site], min_af, list, nc, lut, s_n, s_q, o);
         if (mine && (threadIdx.x & 63) == 0) store_result(results + site, o);
         wave_lds_sync<WPB>();                                    // s_n / s_q are reused by the next site
-    }
-}
-
-// =====================================================================================================
-// Rows layout: FOUR sites per wavefront.  Each DPP row of 16 lanes runs its own site through its own
-// fit / iteration state; the four rows share the instruction stream of the E+M pass, whose cross-lane
-// reductions then cost a quarter per site (quad sums for D, one packed row sum for E and delta, no
-// cross-row step at all).  Within a row, quad b (4 lanes) owns base b and each lane up to 8 classes, so a row
-// holds sites with at most 32 quality values per base -- the sites lrt_kernel<2> would take; sites with more
-// are left to lrt_kernel<4>/<8>.  Rows are not in lockstep: a row that finishes a fit moves on at once; only
-// the short transition code (log-likelihood, subset bookkeeping, result) runs with the other rows masked.
-// =====================================================================================================
-constexpr int kRowSlots = 8;
-constexpr double kFarU = 0.001953125;      // 2^-9: a row with a class at or above it cannot have converged
-constexpr double kNotConverged = 1.0;      // any value >= kEmEpsilon
-
-template <int NSL>
-__device__ __forceinline__ void rows_pass(const double (&sn)[kRowSlots], const double (&sd)[kRowSlots],
-                                          const double (&se)[kRowSlots], double (&syp)[kRowSlots], double fb,
-                                          double inv_n, int lane, double &ex_own, double &delta)
-{
-    const int row = lane >> 4;
-    double m[NSL], u[NSL], y[NSL];
-    double umax = 0.0;
-#pragma unroll
-    for (int k = 0; k < NSL; ++k) {
-        m[k] = fma(fb, sd[k], se[k]);
-        u[k] = fma(m[k], syp[k], -1.0);
-        umax = fmax(umax, fabs(u[k]));
-    }
-    const uint64_t far_m = __ballot(umax >= kFarU), jump_m = __ballot(umax > kLog1pMaxU);
-    const bool far_row = ((far_m >> (16 * row)) & 0xFFFFull) != 0;
-    const bool jump_row = ((jump_m >> (16 * row)) & 0xFFFFull) != 0;
-    double acc_d = 0.0, acc_e = 0.0, acc_delta = 0.0;
-#pragma unroll
-    for (int k = 0; k < NSL; ++k) {
-        double p = fma(-0.25, u[k], 1.0 / 3.0);
-        p = fma(p, u[k], -0.5);
-        p = fma(p, u[k], 1.0);
-        acc_delta = fma(sn[k], fabs(u[k] * p), acc_delta);
-        double t = fma(-syp[k], u[k], syp[k]);
-        t = fma(t, fma(-m[k], t, 1.0), t);
-        y[k] = fma(t, fma(-m[k], t, 1.0), t);
-    }
-    if (jump_m != 0) {                                          // some row is in the first passes of a fit
-#pragma unroll
-        for (int k = 0; k < NSL; ++k) {
-            const double yj = fast_rcp(m[k]);
-            y[k] = jump_row ? yj : y[k];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NSL; ++k) {
-        syp[k] = y[k];
-        const double r = sn[k] * y[k];
-        acc_d = fma(r, sd[k], acc_d);
-        acc_e = fma(r, se[k], acc_e);
-    }
-    // D: sum over the quad (the lane's base).  E and delta: lanes 0-7 of the row end with E, lanes 8-15 with delta.
-    const bool hi = (lane & 8) != 0;
-    const double send = hi ? acc_e : acc_delta, keep = hi ? acc_delta : acc_e;
-    double z = keep + dpp_f64<kDppRor8>(send);
-    double dq = acc_d;
-    double tz = dpp_f64<kDppXor1>(z), td = dpp_f64<kDppXor1>(dq);
-    z += tz; dq += td;
-    tz = dpp_f64<kDppXor2>(z); td = dpp_f64<kDppXor2>(dq);
-    z += tz; dq += td;
-    z += dpp_f64<kDppHalfMirror>(z);
-    // lanes 0-7 hold sum(keep of lanes 0-7) + sum(send of lanes 8-15) = E of the row; lanes 8-15 hold delta
-    const double e_row = dpp_f64<dpp_newbcast<0>()>(z);
-    const double d_row = dpp_f64<dpp_newbcast<8>()>(z);
-    ex_own = fb * inv_n * (dq + e_row);
-    delta = far_row ? kNotConverged : d_row;
-}
-
-__global__ __launch_bounds__(64) void lrt_rows_kernel(int64_t n_sites, const uint32_t *__restrict__ counts,
-                                                      int64_t hist_stride, const int8_t *__restrict__ ref_base,
-                                                      double min_af, const QualLut *__restrict__ lut,
-                                                      const int8_t *__restrict__ comb,
-                                                      const uint8_t *__restrict__ n_comb,
-                                                      bvc_site_result *__restrict__ results)
-{
-    __shared__ uint32_t s_n[4][4][32];           // [row][base][rank] non-empty classes in ascending quality
-    __shared__ uint8_t s_q[4][4][32];
-    enum { P_FETCH = 0, P_LEVEL = 1, P_EM = 2, P_DONE = 3 };
-    const int lane = threadIdx.x & 63;
-    const int row = lane >> 4, base = (lane >> 2) & 3, sub = lane & 3;
-    const bool writer = (lane & 15) == 0;
-    const int64_t n_rows = (int64_t)gridDim.x * 4;
-    int64_t site = (int64_t)blockIdx.x * 4 + row - n_rows;       // advanced before use
-
-    double sn[kRowSlots], sd[kRowSlots], se[kRowSlots], syp[kRowSlots];
-    int phase = P_FETCH, rslots = 0;
-    int dep0 = 0, dep1 = 0, dep2 = 0, dep3 = 0, ref = 0;
-    double inv_n = 0.0, depth_total = 0.0;
-    int n = 0, k = 0, c = 0, ncomb = 0, n_fit = 0, i_min = 0, status = 0, passes = 0, fits = 0, it = 0;
-    bool full_level = true;
-    uint32_t blist = 0, masks = 0;
-    double best_chi = 0.0, best_lr = 0.0, bb0 = 0, bb1 = 0, bb2 = 0, bb3 = 0;
-    double lr_alt = 0.0, chi = 0.0, bf0 = 0, bf1 = 0, bf2 = 0, bf3 = 0;
-    double fb = 0.0, ex_own = 0.0;
-#pragma unroll
-    for (int j = 0; j < kRowSlots; ++j) { sn[j] = 0.0; sd[j] = 0.0; se[j] = 1.0; syp[j] = 1.0; }
-
-    auto depth_of = [&](int b) { return b == 0 ? dep0 : (b == 1 ? dep1 : (b == 2 ? dep2 : dep3)); };
-
-    for (;;) {
-        // ---------------------------------------------------------------- transitions (rows diverge here)
-        while (phase == P_FETCH || phase == P_LEVEL) {
-            if (phase == P_FETCH) {
-                site += n_rows;
-                if (site >= n_sites) { phase = P_DONE; break; }
-                // this lane's 32 counts: qualities [32 sub, 32 sub + 32) of its base
-                const uint32_t *h = counts + site * hist_stride + base * 128 + sub * 32;
-                uint32_t cv[32];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(h + 4 * j);
-                    cv[4 * j] = v.x; cv[4 * j + 1] = v.y; cv[4 * j + 2] = v.z; cv[4 * j + 3] = v.w;
-                }
-                int cnt_l = 0, dep_l = 0;
-#pragma unroll
-                for (int j = 0; j < 32; ++j) { cnt_l += cv[j] != 0; dep_l += (int)cv[j]; }
-                // counts of the quad's four lanes, by quad broadcasts
-                const int c0 = dpp_i32<0x00>(cnt_l), c1 = dpp_i32<0x55>(cnt_l), c2 = dpp_i32<0xAA>(cnt_l), c3 = dpp_i32<0xFF>(cnt_l);
-                const int cnt_b = c0 + c1 + c2 + c3;
-                const int prefix = (sub > 0 ? c0 : 0) + (sub > 1 ? c1 : 0) + (sub > 2 ? c2 : 0);
-                int dep_b = dep_l + dpp_i32<kDppXor1>(dep_l);
-                dep_b += dpp_i32<kDppXor2>(dep_b);
-                dep0 = dpp_i32<dpp_newbcast<0>()>(dep_b); dep1 = dpp_i32<dpp_newbcast<4>()>(dep_b);
-                dep2 = dpp_i32<dpp_newbcast<8>()>(dep_b); dep3 = dpp_i32<dpp_newbcast<12>()>(dep_b);
-                const int m01 = max(dpp_i32<dpp_newbcast<0>()>(cnt_b), dpp_i32<dpp_newbcast<4>()>(cnt_b));
-                const int m23 = max(dpp_i32<dpp_newbcast<8>()>(cnt_b), dpp_i32<dpp_newbcast<12>()>(cnt_b));
-                const int maxcnt = max(m01, m23);
-                if (maxcnt > 32) continue;                           // lrt_kernel<4>/<8> take this site
-                int pos = prefix;
-#pragma unroll
-                for (int j = 0; j < 32; ++j)
-                    if (cv[j] != 0) {
-                        if (pos < 32) { s_n[row][base][pos] = cv[j]; s_q[row][base][pos] = (uint8_t)(sub * 32 + j); }
-                        ++pos;
-                    }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                rslots = (maxcnt + 3) >> 2;
-#pragma unroll
-                for (int j = 0; j < kRowSlots; ++j) {
-                    const int idx = sub + 4 * j;
-                    sn[j] = 0.0; sd[j] = 0.0; se[j] = 1.0; syp[j] = 1.0;
-                    if (idx < cnt_b) {
-                        const int q = s_q[row][base][idx];
-                        sn[j] = (double)s_n[row][base][idx];
-                        se[j] = lut->e[q];
-                        sd[j] = lut->a[q] - se[j];
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                ref = ref_base[site];
-                const int total_i = dep0 + dep1 + dep2 + dep3;
-                depth_total = (double)total_i;
-                passes = 0; fits = 0; status = 0; lr_alt = 0.0; chi = 0.0;
-                bf0 = bf1 = bf2 = bf3 = 0.0;
-                blist = 0; n = 0;
-                if (total_i > 0) {
-                    inv_n = 1.0 / depth_total;
-                    uint32_t list = 0x3210u;                         // default base_comb, src/BaseType.h:79
-                    int nc = 4;
-                    if (comb) {
-                        nc = min((int)n_comb[site], 4);
-                        list = 0;
-                        for (int t = 0; t < nc; ++t) list |= (uint32_t)(comb[site * 4 + t] & 3) << (4 * t);
-                    }
-                    for (int t = 0; t < nc; ++t) {                   // candidates with count frequency >= min_af
-                        const int b = (list >> (4 * t)) & 3;
-                        if ((double)depth_of(b) / depth_total >= min_af) { blist |= (uint32_t)b << (4 * n); ++n; }
-                    }
-                }
-                if (n == 0) {                                        // depth_total == 0 or no candidate: no call
-                    if (writer) {
-                        SiteOut o = SiteOut{};
-                        o.depth[0] = dep0; o.depth[1] = dep1; o.depth[2] = dep2; o.depth[3] = dep3;
-                        o.depth_total = depth_total;
-                        store_result(results + site, o);
-                    }
-                    continue;                                        // next site
-                }
-                k = n; full_level = true; c = 0; n_fit = 0; i_min = 0;
-                masks = subset_masks(n, k, ncomb);
-                phase = P_LEVEL;
-            } else {
-                if (c < ncomb) {                                     // next subset of this level
-                    const uint32_t pm = (masks >> (4 * c)) & 0xFu;
-                    ++c;
-                    uint32_t setmask = 0;
-                    for (int p = 0; p < 4; ++p)
-                        if ((pm >> p) & 1u) setmask |= 1u << ((blist >> (4 * p)) & 3u);
-                    int depth_sum = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) depth_sum += ((setmask >> j) & 1u) ? depth_of(j) : 0;
-                    if (depth_sum <= 0) continue;                    // freq_sum == 0: UpdateF skips it (:54)
-                    fb = ((setmask >> base) & 1u) ? (double)depth_of(base) / (double)depth_sum : 0.0;
-#pragma unroll
-                    for (int j = 0; j < kRowSlots; ++j) syp[j] = 1.0;
-                    it = 0;
-                    phase = P_EM;
-                } else {                                             // level finished (:96-109)
-                    bool finish = false;
-                    if (n_fit == 0) { status = 1; finish = true; }
-                    else {
-                        lr_alt = best_lr;
-                        if (full_level) { full_level = false; bf0 = bb0; bf1 = bb1; bf2 = bb2; bf3 = bb3; }
-                        else {
-                            chi = best_chi;
-                            if (chi < kLrtThreshold) {
-                                const uint32_t pm = (masks >> (4 * i_min)) & 0xFu;
-                                uint32_t nl = 0;
-                                int nn = 0;
-                                for (int p = 0; p < 4; ++p)
-                                    if ((pm >> p) & 1u) { nl |= ((blist >> (4 * p)) & 3u) << (4 * nn); ++nn; }
-                                blist = nl; n = k;
-                                bf0 = bb0; bf1 = bb1; bf2 = bb2; bf3 = bb3;
-                            } else {
-                                finish = true;
-                            }
-                        }
-                        if (!finish) {
-                            --k;
-                            if (k == 0) finish = true;
-                            else { masks = subset_masks(n, k, ncomb); c = 0; n_fit = 0; i_min = 0; }
-                        }
-                    }
-                    if (finish) {
-                        if (writer) {
-                            SiteOut o = SiteOut{};
-                            o.depth[0] = dep0; o.depth[1] = dep1; o.depth[2] = dep2; o.depth[3] = dep3;
-                            o.depth_total = depth_total;
-                            o.status = status; o.n_passes = passes; o.n_fits = fits;
-                            const bool no_model = status == 1 && full_level;     // bp[0] on an empty vector
-                            if (!no_model) {
-                                o.lr_alt = lr_alt; o.chi = chi; o.n_kept = n;
-                                o.base_frq[0] = bf0; o.base_frq[1] = bf1; o.base_frq[2] = bf2; o.base_frq[3] = bf3;
-                                int n_alt = 0, a0 = 0, a1 = 0, a2 = 0;
-                                double g0 = 0.0, g1 = 0.0, g2 = 0.0;
-#pragma unroll
-                                for (int p = 0; p < 4; ++p) {
-                                    const int b = (blist >> (4 * p)) & 3;
-                                    o.kept[p] = (p < n) ? b : 0;
-                                    if (p < n && b != ref && n_alt < 3) {
-                                        const double fr = b == 0 ? bf0 : (b == 1 ? bf1 : (b == 2 ? bf2 : bf3));
-                                        if (n_alt == 0) { a0 = b; g0 = fr; } else if (n_alt == 1) { a1 = b; g1 = fr; } else { a2 = b; g2 = fr; }
-                                        ++n_alt;
-                                    }
-                                }
-                                o.alt_base[0] = a0; o.alt_base[1] = a1; o.alt_base[2] = a2;
-                                o.af[0] = g0; o.af[1] = g1; o.af[2] = g2;
-                                o.n_alt = n_alt;
-                                if (n_alt > 0) {
-                                    const double r = (double)depth_of((int)(blist & 3u)) / depth_total;
-                                    double vq;
-                                    if (n == 1 && depth_total > 10 && r > 0.5) vq = 5000.0;
-                                    else if (chi <= 0) vq = 0.0;
-                                    else vq = kVarQualPending;
-                                    o.var_qual = vq;
-                                    o.called = 1;
-                                }
-                            }
-                            store_result(results + site, o);
-                        }
-                        phase = P_FETCH;
-                    }
-                }
-            }
-        }
-        if (__ballot(phase == P_EM) == 0) break;                     // every row has run out of sites
-
-        // ---------------------------------------------------------------- one E+M pass for the rows inside a fit
-        // slots evaluated: the largest count among the rows currently fitting (wave-uniform)
-        const int act = (phase == P_EM) ? rslots : 0;
-        const int wslots = max(max(__builtin_amdgcn_readlane(act, 0), __builtin_amdgcn_readlane(act, 16)),
-                               max(__builtin_amdgcn_readlane(act, 32), __builtin_amdgcn_readlane(act, 48)));
-        if (phase == P_EM) {
-            double delta;
-            if (wslots <= 2) rows_pass<2>(sn, sd, se, syp, fb, inv_n, lane, ex_own, delta);
-            else if (wslots <= 4) rows_pass<4>(sn, sd, se, syp, fb, inv_n, lane, ex_own, delta);
-            else rows_pass<kRowSlots>(sn, sd, se, syp, fb, inv_n, lane, ex_own, delta);
-            passes += 1;
-            const bool done = (it > 0 && delta < kEmEpsilon) || it == kEmIters;   // NaN never converges
-            if (!done) { fb = ex_own; ++it; }
-            else {
-                // fit finished (UpdateF, src/BaseType.cpp:58-68): log-likelihood and the four expected frequencies
-                double ll = 0.0;
-#pragma unroll
-                for (int j = 0; j < kRowSlots; ++j) ll = fma(-sn[j], log_pos(syp[j]), ll);   // empty slots: n = 0, yp = 1
-                ll = row_sum(ll);
-                const double e0 = dpp_f64<dpp_newbcast<0>()>(ex_own), e1 = dpp_f64<dpp_newbcast<4>()>(ex_own);
-                const double e2 = dpp_f64<dpp_newbcast<8>()>(ex_own), e3 = dpp_f64<dpp_newbcast<12>()>(ex_own);
-                const double chi_c = 2.0 * (lr_alt - ll);
-                if (n_fit == 0 || chi_c < best_chi) {                // std::min_element: first minimum, '<'
-                    best_chi = chi_c; best_lr = ll; i_min = n_fit;
-                    bb0 = e0; bb1 = e1; bb2 = e2; bb3 = e3;
-                }
-                ++n_fit; ++fits;
-                phase = P_LEVEL;
-            }
-        }
     }
 }
 
@@ -797,8 +494,10 @@ __global__ __launch_bounds__(64 * WPB) void lrt_groups_kernel(int64_t n_sites, i
         const uint32_t *hist = grp_counts + (site * (n_groups + 1) + g) * BVC_NCLASS;
         const bvc_site_result ov = overall[site];
         const int ref = ref_base[site];
-        uint32_t list = (uint32_t)(ref & 3);                     // base_comb = {ref} + alt_bases (:614-615)
-        int nc = 1;
+        // base_comb = {ref} + alt_bases (:614-615); a ref outside 0..3 has depth 0 in the reference and falls to
+        // the min_af filter, so it is left out here
+        uint32_t list = (unsigned)ref < 4u ? (uint32_t)ref : 0u;
+        int nc = (unsigned)ref < 4u ? 1 : 0;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             if (i < ov.n_alt) { list |= (uint32_t)(ov.alt_base[i] & 3) << (4 * nc); ++nc; }
@@ -854,90 +553,48 @@ __global__ void sum_groups_kernel(int64_t total, int n_hist, const uint32_t *__r
 
 }  // namespace
 
-// -1 (default) and 0: one site per wave; 1: four sites per wave for the <= 32-class sites (BVC_EM_ROWS or bvc_set_tuning)
-static std::atomic<int> g_em_rows_mode{[] { const char *e = getenv("BVC_EM_ROWS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }()};
-static std::atomic<int> g_em_waves_per_cu{[] { const char *e = getenv("BVC_EM_WAVES_PER_CU"); const int v = e ? atoi(e) : 0; return (v > 0 && v <= 32) ? v : 0; }()};
-
-// waves per EM workgroup: 0 = default (4), 1 or 4 forced (BVC_EM_WPB; experiments only)
-static std::atomic<int> g_em_wpb{[] { const char *e = getenv("BVC_EM_WPB"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 4) ? v : 0; }()};
-
-void set_em_tuning(int rows_mode, int waves_per_cu)
-{
-    if (rows_mode >= -1 && rows_mode <= 1) g_em_rows_mode.store(rows_mode);
-    if (waves_per_cu >= 0 && waves_per_cu <= 32) g_em_waves_per_cu.store(waves_per_cu);
-}
-
 // Waves the EM kernels keep on the chip.  `shared` = the launch runs underneath a streaming histogram kernel
-// (overlap mode with long rows): 8 per CU = two 4-wave workgroups (swept 4..24 on MI355X at N = 1e6) leaves that kernel its wave slots and registers.
-// Otherwise the kernel has the chip to itself for most of its life and takes 24 per CU.
-// BVC_EM_WAVES_PER_CU / bvc_set_tuning override both.
-
+// (overlap mode with long rows): 8 per CU = two 4-wave workgroups (swept 4..24 on MI355X at N = 1e6) leaves that
+// kernel its wave slots and registers.  Otherwise the kernel has the chip to itself for most of its life and
+// takes 24 per CU.  The context's em_waves_per_cu (bvc_set_tuning / BVC_EM_WAVES_PER_CU) overrides both.
+//
 // Group mode's stage 2 (sum, overall LRT, per-group LRT) is a third longer and its histogram pass slower than the
 // plain call's: 12 waves per CU balance the two streams there (swept 4..32 on MI355X, k = 5, N = 1e6).
 constexpr int kGroupSharedWavesPerCu = 12;
 
-static int64_t em_grid_cap(bool shared, int shared_waves_per_cu = 0)
+static int64_t em_grid_cap(const LaunchState &st, bool shared, int shared_waves_per_cu = 0)
 {
-    static std::atomic<int> n_cu_dev[kMaxDevices];
-    std::atomic<int> &n_cu_a = n_cu_dev[current_device_slot()];
-    int n_cu = n_cu_a.load();
-    if (n_cu == 0) {
-        n_cu = 256;
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            hipDeviceProp_t p;
-            if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) n_cu = p.multiProcessorCount;
-        }
-        n_cu_a.store(n_cu);
-    }
     int per_cu = shared ? (shared_waves_per_cu > 0 ? shared_waves_per_cu : 8) : 24;
-    if (g_em_waves_per_cu.load() > 0) per_cu = g_em_waves_per_cu.load();
-    return (int64_t)per_cu * n_cu;
+    if (st.em_waves_per_cu > 0) per_cu = st.em_waves_per_cu;
+    return (int64_t)per_cu * st.n_cu;
 }
 
 template <int WPB>
-static void launch_lrt_variants(hipStream_t stream, int64_t want_waves, bool skip2, int64_t n_sites,
+static void launch_lrt_variants(hipStream_t stream, int64_t want_waves, int64_t n_sites,
                                 const uint32_t *counts, int64_t hist_stride, const int8_t *ref_base, double min_af,
                                 const QualLut *lut, const int8_t *comb, const uint8_t *n_comb,
                                 bvc_site_result *results)
 {
     // Every variant visits every site; a wave skips a site at once when it belongs to another variant.
     const dim3 grid((unsigned)((want_waves + WPB - 1) / WPB)), block(64 * WPB);
-    if (!skip2)
-        hipLaunchKernelGGL((lrt_kernel<2, WPB>), grid, block, 0, stream, n_sites, counts, hist_stride, ref_base,
-                           min_af, lut, comb, n_comb, results);
+    hipLaunchKernelGGL((lrt_kernel<2, WPB>), grid, block, 0, stream, n_sites, counts, hist_stride, ref_base,
+                       min_af, lut, comb, n_comb, results);
     hipLaunchKernelGGL((lrt_kernel<4, WPB>), grid, block, 0, stream, n_sites, counts, hist_stride, ref_base, min_af,
                        lut, comb, n_comb, results);
     hipLaunchKernelGGL((lrt_kernel<8, WPB>), grid, block, 0, stream, n_sites, counts, hist_stride, ref_base, min_af,
                        lut, comb, n_comb, results);
 }
 
-hipError_t launch_lrt(hipStream_t stream, int64_t n_sites, const uint32_t *counts, int64_t hist_stride,
-                      const int8_t *ref_base, double min_af, const QualLut *lut,
+hipError_t launch_lrt(const LaunchState &st, hipStream_t stream, int64_t n_sites, const uint32_t *counts,
+                      int64_t hist_stride, const int8_t *ref_base, double min_af, const QualLut *lut,
                       const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results, bool shared,
-                      int64_t depth_hint, int shared_waves_per_cu)
+                      int shared_waves_per_cu)
 {
     if (n_sites <= 0) return hipSuccess;
-    const int64_t cap = em_grid_cap(shared, shared_waves_per_cu);
+    const int64_t cap = em_grid_cap(st, shared, shared_waves_per_cu);
     const int64_t want_waves = n_sites < cap ? n_sites : cap;
-    // Layout of the common (<= 32 classes per base) sites: one site per wave, or four (rows).  Four per wave quarter
-    // the reduction work per site but need four times the sites to fill the chip and 248 registers per lane.  The
-    // rows layout was the faster one for deep tiles of >= 12,288 sites until the site-per-wave kernel got its even
-    // SIMD load and its shorter pass; measured since (MI355X, serial mode, N = 1e6): 16,000 sites 1.66 vs 1.69 ms,
-    // 32,000 sites 3.33 vs 3.31 ms, and N = 1e4, 40,000 sites 2.58 vs 2.87 ms -- so it is used only on request
-    // (bvc_set_tuning("em_rows", 1) / BVC_EM_ROWS=1) and stays as the A/B alternative.
-    (void)depth_hint;
-    const bool rows = g_em_rows_mode.load() > 0;
-    if (rows) {
-        // four sites per wave: a quarter of the waves hold the same number of sites in flight
-        const int64_t want = (n_sites + 3) / 4;
-        const dim3 rgrid((unsigned)(want < cap ? want : cap));
-        hipLaunchKernelGGL(lrt_rows_kernel, rgrid, dim3(64), 0, stream, n_sites, counts, hist_stride,
-                           ref_base, min_af, lut, comb, n_comb, results);
-    }
-    const int wpb = g_em_wpb.load() ? g_em_wpb.load() : 4;
-    if (wpb == 1) launch_lrt_variants<1>(stream, want_waves, rows, n_sites, counts, hist_stride, ref_base, min_af, lut, comb, n_comb, results);
-    else launch_lrt_variants<4>(stream, want_waves, rows, n_sites, counts, hist_stride, ref_base, min_af, lut, comb, n_comb, results);
+    if (st.em_wpb == 1) launch_lrt_variants<1>(stream, want_waves, n_sites, counts, hist_stride, ref_base, min_af, lut, comb, n_comb, results);
+    else launch_lrt_variants<4>(stream, want_waves, n_sites, counts, hist_stride, ref_base, min_af, lut, comb, n_comb, results);
     hipLaunchKernelGGL(var_qual_kernel, dim3((unsigned)((n_sites + 255) / 256)), dim3(256), 0, stream, n_sites, results);
     return hipGetLastError();
 }
@@ -956,16 +613,15 @@ static void launch_group_variants(hipStream_t stream, int64_t want_waves, int64_
                        min_af, lut, overall, grp_results);
 }
 
-hipError_t launch_lrt_groups(hipStream_t stream, int64_t n_sites, int n_groups, const uint32_t *grp_counts,
-                             const int8_t *ref_base, double min_af, const QualLut *lut,
+hipError_t launch_lrt_groups(const LaunchState &st, hipStream_t stream, int64_t n_sites, int n_groups,
+                             const uint32_t *grp_counts, const int8_t *ref_base, double min_af, const QualLut *lut,
                              const bvc_site_result *overall, bvc_group_result *grp_results, bool shared)
 {
     if (n_sites <= 0 || n_groups <= 0) return hipSuccess;
-    const int64_t cap = em_grid_cap(shared, kGroupSharedWavesPerCu);
+    const int64_t cap = em_grid_cap(st, shared, kGroupSharedWavesPerCu);
     const int64_t n_work = n_sites * n_groups;
     const int64_t want_waves = n_work < cap ? n_work : cap;
-    const int wpb = g_em_wpb.load() ? g_em_wpb.load() : 4;
-    if (wpb == 1) launch_group_variants<1>(stream, want_waves, n_sites, n_groups, grp_counts, ref_base, min_af, lut, overall, grp_results);
+    if (st.em_wpb == 1) launch_group_variants<1>(stream, want_waves, n_sites, n_groups, grp_counts, ref_base, min_af, lut, overall, grp_results);
     else launch_group_variants<4>(stream, want_waves, n_sites, n_groups, grp_counts, ref_base, min_af, lut, overall, grp_results);
     return hipGetLastError();
 }

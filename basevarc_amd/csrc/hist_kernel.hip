@@ -10,8 +10,6 @@
 // The LDS histogram is replicated kCopies times with copy = lane % kCopies, laid out [class][copy], so the
 // bank of an update is lane % 32 whatever the data are: the heavily skewed keys of real pileups (>90 %
 // reference base, a handful of quality values) cannot cause bank or same-address conflicts.
-#include <atomic>
-
 #include "bvc_device.h"
 #include "bvc_internal.h"
 
@@ -249,6 +247,102 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
     }
 }
 
+// Group mode, any sample order, NSITE sites per workgroup pass.  What the one-site kernel above pays over the dense
+// kernel is its third load stream: one group byte per two data bytes, re-read (from L2 / Infinity Cache) for every
+// site.  Here a pass takes NSITE consecutive sites through the same sample chunks, so each 16-byte chunk of
+// group_of_sample is loaded once per NSITE sites and stays in registers.  LDS: [site in pass][hist][class][copy],
+// copies = 1 << LOG2C chosen by the launcher to fit 64 KiB (k = 5: two sites x six histograms x two copies).
+// Needs 16-byte aligned rows and group vector; the one-site kernel takes every other call.
+template <int NSITE, int LOG2C>
+__global__ __launch_bounds__(kHistThreads) void hist_dense_groups_multi_kernel(
+    int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *__restrict__ bases,
+    const int8_t *__restrict__ quals, const uint8_t *__restrict__ group_of_sample, int n_groups,
+    uint32_t *__restrict__ grp_counts, const int64_t *__restrict__ bounds)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    if (bounds && bounds[0] == 0) return;        // samples are ordered by group: hist_dense_ranges_kernel has the call
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    const int n_hist = n_groups + 1;
+    const int site_words = (n_hist * BVC_NCLASS) << LOG2C;
+    const uint32_t lane_off = (uint32_t)tid & ((1u << LOG2C) - 1u);
+    for (int i = tid * 4; i < NSITE * site_words; i += kHistThreads * 4)
+        *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    const int64_t n_pass = (n_sites + NSITE - 1) / NSITE;
+    const int64_t n16 = n_samples >> 4;
+    const u32x4 *gv = reinterpret_cast<const u32x4 *>(group_of_sample);
+    for (int64_t pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+        const int64_t site0 = pass * NSITE;
+        const int nv = (int)(n_sites - site0 < NSITE ? n_sites - site0 : NSITE);   // sites of this pass (last one may be short)
+        const u32x4 *bv[NSITE], *qv[NSITE];
+#pragma unroll
+        for (int s = 0; s < NSITE; ++s) {
+            const int64_t site = site0 + (s < nv ? s : 0);                        // absent sites re-read site0 and count nothing
+            bv[s] = reinterpret_cast<const u32x4 *>(bases + site * row_stride);
+            qv[s] = reinterpret_cast<const u32x4 *>(quals + site * row_stride);
+        }
+        // offsets of the six (n_hist) histograms a sample can fall into, per byte of the group word
+        auto hoff = [&](uint32_t g) { return (g < (uint32_t)n_groups ? g : (uint32_t)n_groups) << (9 + LOG2C); };
+        for (int64_t c = tid; c < n16; c += kHistThreads) {
+            const u32x4 g = gv[c];
+            u32x4 b[NSITE], q[NSITE];
+#pragma unroll
+            for (int s = 0; s < NSITE; ++s) {
+                b[s] = __builtin_nontemporal_load(&bv[s][c]);
+                q[s] = __builtin_nontemporal_load(&qv[s][c]);
+            }
+            const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
+            uint32_t bad = 0;
+#pragma unroll
+            for (int s = 0; s < NSITE; ++s)
+                bad |= ((b[s].x | b[s].y | b[s].z | b[s].w) & 0xFCFCFCFCu) | ((q[s].x | q[s].y | q[s].z | q[s].w) & 0x80808080u);
+            const bool all_valid = __ballot(bad != 0) == 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t ho = hoff((gw[w] >> (8 * k)) & 0xFFu) + lane_off;
+#pragma unroll
+                    for (int s = 0; s < NSITE; ++s) {
+                        const uint32_t bw = w == 0 ? b[s].x : (w == 1 ? b[s].y : (w == 2 ? b[s].z : b[s].w));
+                        const uint32_t qw = w == 0 ? q[s].x : (w == 1 ? q[s].y : (w == 2 ? q[s].z : q[s].w));
+                        const uint32_t bb = (bw >> (8 * k)) & 0xFFu, qq = (qw >> (8 * k)) & 0xFFu;
+                        if (s < nv && (all_valid || (bb < 4u && qq < 128u)))
+                            __hip_atomic_fetch_add(&hist[s * site_words + ho + ((bb << (7 + LOG2C)) | (qq << LOG2C))], 1u,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+        }
+        for (int64_t i = (n16 << 4) + tid; i < n_samples; i += kHistThreads) {
+            const uint32_t ho = hoff(group_of_sample[i]) + lane_off;
+#pragma unroll
+            for (int s = 0; s < NSITE; ++s) {
+                if (s >= nv) continue;
+                const uint32_t bb = (uint8_t)reinterpret_cast<const int8_t *>(bv[s])[i];
+                const uint32_t qq = (uint8_t)reinterpret_cast<const int8_t *>(qv[s])[i];
+                if (bb < 4u && qq < 128u)
+                    __hip_atomic_fetch_add(&hist[s * site_words + ho + ((bb << (7 + LOG2C)) | (qq << LOG2C))], 1u,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        const int keys = n_hist * BVC_NCLASS;
+        for (int key = tid; key < NSITE * keys; key += kHistThreads) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int v = 0; v < (1 << LOG2C); ++v) {
+                sum += hist[(key << LOG2C) + v];
+                hist[(key << LOG2C) + v] = 0;
+            }
+            const int s = key / keys;
+            if (s < nv) grp_counts[(site0 + s) * keys + (key - s * keys)] = sum;
+        }
+        __syncthreads();
+    }
+}
+
 // Group mode, samples ordered by group (every group a contiguous run of columns, ungrouped samples last): the
 // histogram of (site, group) is then the plain histogram of a column range, so the pass keeps the dense kernel's
 // 32 conflict-free LDS copies and its wave-wide fast path, and needs no per-sample group byte.
@@ -347,34 +441,112 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_ranges_kernel(
     }
 }
 
-// Ragged pileup: site s owns elements offsets[s] .. offsets[s+1]).  Byte loads (rows start anywhere).
+// Ragged (CSR) pileup: site s owns elements offsets[s] .. offsets[s+1]) of the concatenated arrays -- the vectors
+// bt_f builds per position (/root/reference/src/BaseVarC.cpp:550-559).  Real pileups are ragged: at the depths of the
+// reference's test data a site has 1-28 observations, at CMDB scale (1e6 samples, low coverage) 1e4-1e5.  Two kernels
+// split the sites by length (each walks all sites and takes its own):
+//   hist_csr_wave_kernel   len <  kCsrLong: one WAVEFRONT per site, a private one-copy histogram per wave (2 KiB);
+//                          short sites would otherwise pay a 64 KiB fold each
+//   hist_csr_block_kernel  len >= kCsrLong: one workgroup per site with the dense kernel's 32 conflict-free copies,
+//                          16-byte loads over the aligned middle of the range, head and tail sample by sample
+constexpr int64_t kCsrLong = 4096;
+constexpr int kCsrWaves = kHistThreads / 64;
 
-__global__ __launch_bounds__(kHistThreads) void hist_csr_kernel(
+__global__ __launch_bounds__(kHistThreads) void hist_csr_wave_kernel(
     int64_t n_sites, const int64_t *__restrict__ offsets, const int8_t *__restrict__ bases,
     const int8_t *__restrict__ quals, uint32_t *__restrict__ counts)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    __shared__ uint32_t hist_all[kCsrWaves][BVC_NCLASS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *hist = hist_all[wave];
+    for (int k = lane; k < BVC_NCLASS; k += 64) hist[k] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int64_t site = (int64_t)blockIdx.x * kCsrWaves + wave; site < n_sites; site += (int64_t)gridDim.x * kCsrWaves) {
+        const int64_t o0 = offsets[site], o1 = offsets[site + 1];
+        if (o1 - o0 >= kCsrLong) continue;                       // hist_csr_block_kernel's
+        for (int64_t i = o0 + lane; i < o1; i += 64) {
+            const uint32_t b = (uint8_t)bases[i], q = (uint8_t)quals[i];
+            if (b < 4u && q < 128u)
+                __hip_atomic_fetch_add(&hist[(b << 7) | q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t *dst = counts + site * BVC_NCLASS;
+#pragma unroll
+        for (int k = 0; k < BVC_NCLASS / 64; ++k) {
+            dst[k * 64 + lane] = hist[k * 64 + lane];
+            hist[k * 64 + lane] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(kHistThreads) void hist_csr_block_kernel(
+    int64_t n_sites, const int64_t *__restrict__ offsets, const int8_t *__restrict__ bases,
+    const int8_t *__restrict__ quals, uint32_t *__restrict__ counts)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [class][copy]
     const int tid = threadIdx.x;
     const uint32_t lane_off = (uint32_t)(tid & (kCopies - 1));
+    __builtin_amdgcn_s_setprio(3);
     for (int i = tid * 4; i < kLdsWords; i += kHistThreads * 4)
         *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
-    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
-        const int64_t o0 = offsets[site], o1 = offsets[site + 1];
-        for (int64_t i = o0 + tid; i < o1; i += kHistThreads) {
+    auto scalar = [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0 + tid; i < i1; i += kHistThreads) {
             const uint32_t b = (uint8_t)bases[i], q = (uint8_t)quals[i];
             if (b < 4u && q < 128u)
                 __hip_atomic_fetch_add(&hist[((b << 7) | q) * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+    };
+    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
+        const int64_t s0 = offsets[site], s1 = offsets[site + 1];
+        if (s1 - s0 < kCsrLong) continue;                        // hist_csr_wave_kernel's (workgroup-uniform)
+        // [s0, s1) = unaligned head, whole 16-sample chunks [c0, c1) of the concatenated arrays, unaligned tail
+        const int64_t c0 = (s0 + 15) >> 4, c1 = s1 >> 4;
+        if (ALIGNED && c0 < c1) {
+            scalar(s0, c0 << 4);
+            const u32x4 *bv = reinterpret_cast<const u32x4 *>(bases);
+            const u32x4 *qv = reinterpret_cast<const u32x4 *>(quals);
+            constexpr int64_t kBlockChunks = (int64_t)kUnroll * kHistThreads;
+            int64_t cb = c0;
+            for (; cb + kBlockChunks <= c1; cb += kBlockChunks) {
+                u32x4 b[kUnroll], q[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    b[u] = __builtin_nontemporal_load(&bv[cb + tid + (int64_t)u * kHistThreads]);
+                    q[u] = __builtin_nontemporal_load(&qv[cb + tid + (int64_t)u * kHistThreads]);
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) count_chunk(hist, b[u], q[u], lane_off);
+            }
+            for (int64_t ct = cb + tid; ct < c1; ct += kHistThreads) {
+                const u32x4 b = __builtin_nontemporal_load(&bv[ct]);
+                const u32x4 q = __builtin_nontemporal_load(&qv[ct]);
+                count_word_checked(hist, b.x, q.x, lane_off); count_word_checked(hist, b.y, q.y, lane_off);
+                count_word_checked(hist, b.z, q.z, lane_off); count_word_checked(hist, b.w, q.w, lane_off);
+            }
+            scalar(c1 << 4, s1);
+        } else {
+            scalar(s0, s1);
+        }
         __syncthreads();
         for (int key = tid; key < BVC_NCLASS; key += kHistThreads) {
-            uint32_t s = 0;
-            for (int v = 0; v < kCopies; ++v) {
-                s += hist[key * kCopies + v];
-                hist[key * kCopies + v] = 0;
+            uint32_t sum = 0;
+#pragma unroll
+            for (int v = 0; v < kCopies; v += 4) {
+                const int cc = (v + 4 * (key & 7)) & (kCopies - 1);      // rotated: the lanes of a ds_read_b128 group spread over banks
+                u32x4 *p = reinterpret_cast<u32x4 *>(&hist[key * kCopies + cc]);
+                const u32x4 x = *p;
+                sum += x.x + x.y + x.z + x.w;
+                *p = u32x4{0u, 0u, 0u, 0u};
             }
-            counts[site * BVC_NCLASS + key] = s;
+            counts[site * BVC_NCLASS + key] = sum;
         }
         __syncthreads();
     }
@@ -405,13 +577,12 @@ hipError_t launch_stream_read(hipStream_t stream, const void *src, int64_t bytes
     return hipGetLastError();
 }
 
-int choose_hist_split(int64_t n_sites, int64_t n_samples, int n_cu)
+int choose_hist_split(const LaunchState &st, int64_t n_sites, int64_t n_samples)
 {
-    static const int forced = [] { const char *e = getenv("BVC_HIST_SPLIT"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : 0; }();
-    if (forced) return forced;
+    if (st.hist_split > 0) return st.hist_split;
     // Two 512-thread workgroups fit a CU (2 x 64 KiB LDS).  With fewer sites than that, cut each site's
     // sample range so the whole chip streams; parts are merged with global atomics on 512 words.
-    const int64_t want = (int64_t)n_cu * 4;
+    const int64_t want = (int64_t)st.n_cu * 4;
     if (n_sites >= want || n_samples < (1 << 16)) return 1;
     int64_t split = (want + n_sites - 1) / n_sites;
     const int64_t max_split = n_samples / (1 << 15);             // keep >= 32k samples per part
@@ -421,51 +592,43 @@ int choose_hist_split(int64_t n_sites, int64_t n_samples, int n_cu)
     return (int)split;
 }
 
-hipError_t launch_hist_dense(hipStream_t stream, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+// Kernels with more than 48 KiB of dynamic LDS need the attribute raised once per device; the context remembers
+// which of its kernels have been done (no process-wide state).
+enum KernelSlot : uint32_t {
+    kSlotDense0 = 0, kSlotDense1, kSlotRanges0, kSlotRanges1, kSlotCsr0, kSlotCsr1, kSlotGroupByte,
+    kSlotGroup = 8,            // + log2c (0..5)
+    kSlotGroupMulti2 = 16,     // + log2c (0..3)
+    kSlotGroupMulti4 = 20,     // + log2c (0..2)
+};
+
+static hipError_t raise_lds(LaunchState &st, uint32_t slot, const void *kernel, size_t bytes)
+{
+    if (st.attr_done & (1u << slot)) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) st.attr_done |= 1u << slot;
+    return e;
+}
+
+hipError_t launch_hist_dense(LaunchState &st, hipStream_t stream, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                              const int8_t *bases, const int8_t *quals, const uint8_t *group_of_sample,
                              int n_groups, uint32_t *counts, int split, int64_t *group_scratch)
 {
     if (n_sites <= 0) return hipSuccess;
-    static std::atomic<bool> attr_done_dev[kMaxDevices][2], gattr_done_dev[kMaxDevices][7], rattr_done_dev[kMaxDevices][2];
-    std::atomic<bool> *attr_done = attr_done_dev[current_device_slot()];
-    std::atomic<bool> *gattr_done = gattr_done_dev[current_device_slot()];
-    std::atomic<bool> *rattr_done = rattr_done_dev[current_device_slot()];
     const bool aligned = ((reinterpret_cast<uintptr_t>(bases) | reinterpret_cast<uintptr_t>(quals)) & 15u) == 0 &&
                          (row_stride & 15) == 0;
     const size_t lds = (size_t)kLdsWords * sizeof(uint32_t);
     if (group_of_sample) {                       // counts = [site][n_groups + 1][512]
         const bool galigned = aligned && (reinterpret_cast<uintptr_t>(group_of_sample) & 15u) == 0;
-        int log2c = 0;
-        while (log2c < 5 && (size_t)(n_groups + 1) * BVC_NCLASS * (2u << log2c) <= (size_t)kLdsWords) ++log2c;
-        using GroupKernel = void (*)(int64_t, int64_t, int64_t, const int8_t *, const int8_t *, const uint8_t *, int, int,
-                                     uint32_t *, const int64_t *);
-        static const GroupKernel aligned_kernels[6] = {
-            hist_dense_groups_kernel<true, 0>, hist_dense_groups_kernel<true, 1>, hist_dense_groups_kernel<true, 2>,
-            hist_dense_groups_kernel<true, 3>, hist_dense_groups_kernel<true, 4>, hist_dense_groups_kernel<true, 5>};
-        GroupKernel gk = galigned ? aligned_kernels[log2c] : hist_dense_groups_kernel<false, -1>;
-        const int gslot = galigned ? 1 + log2c : 0;
-        if (!gattr_done[gslot]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gk),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)lds);
-            if (e != hipSuccess) return e;
-            gattr_done[gslot] = true;
-        }
-        const size_t glds = ((size_t)(n_groups + 1) * BVC_NCLASS << log2c) * sizeof(uint32_t);
-        const int64_t ggrid = n_sites < 4096 ? n_sites : 4096;
+        const int n_hist = n_groups + 1;
         const bool try_ranges = group_scratch != nullptr && n_samples > 0;
         if (try_ranges) {
             // Decided on the device, without a host round trip: the bounds kernel marks whether the samples are
             // ordered by group; the range kernel and the general kernel are both launched and the one whose turn
             // it is not returns at once.
-            const int n_hist = n_groups + 1;
             auto rk = aligned ? hist_dense_ranges_kernel<true> : hist_dense_ranges_kernel<false>;
-            if (!rattr_done[aligned]) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rk),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
-                rattr_done[aligned] = true;
-            }
-            hipError_t e = hipMemsetAsync(group_scratch, 0, (size_t)(BVC_MAX_GROUPS + 4) * sizeof(int64_t), stream);
+            hipError_t e = raise_lds(st, aligned ? kSlotRanges1 : kSlotRanges0, reinterpret_cast<const void *>(rk), lds);
+            if (e != hipSuccess) return e;
+            e = hipMemsetAsync(group_scratch, 0, (size_t)(BVC_MAX_GROUPS + 4) * sizeof(int64_t), stream);
             if (e != hipSuccess) return e;
             const int64_t bgrid = (n_samples + 255) / 256;
             hipLaunchKernelGGL(group_bounds_kernel, dim3((unsigned)(bgrid < 1024 ? bgrid : 1024)), dim3(256), 0, stream,
@@ -474,18 +637,51 @@ hipError_t launch_hist_dense(hipStream_t stream, int64_t n_sites, int64_t n_samp
             hipLaunchKernelGGL(rk, dim3((unsigned)(n_work < 4096 ? n_work : 4096)), dim3(kHistThreads), lds, stream,
                                n_sites, n_samples, row_stride, bases, quals, n_hist, group_scratch, counts);
         }
+        const int64_t *bounds = try_ranges ? group_scratch : nullptr;
+        // general order.  Aligned calls with at least two sites: NSITE sites per workgroup pass share each chunk of
+        // group bytes (NSITE = st.group_sites: 2 by default, 4 when the histograms fit with one copy)
+        using MultiKernel = void (*)(int64_t, int64_t, int64_t, const int8_t *, const int8_t *, const uint8_t *, int,
+                                     uint32_t *, const int64_t *);
+        static const MultiKernel multi2[4] = {hist_dense_groups_multi_kernel<2, 0>, hist_dense_groups_multi_kernel<2, 1>,
+                                              hist_dense_groups_multi_kernel<2, 2>, hist_dense_groups_multi_kernel<2, 3>};
+        static const MultiKernel multi4[3] = {hist_dense_groups_multi_kernel<4, 0>, hist_dense_groups_multi_kernel<4, 1>,
+                                              hist_dense_groups_multi_kernel<4, 2>};
+        int nsite = st.group_sites > 0 ? st.group_sites : 2;
+        if (!galigned || n_sites < 2) nsite = 1;
+        while (nsite > 1 && (size_t)nsite * n_hist * BVC_NCLASS > (size_t)kLdsWords) nsite >>= 1;   // one copy must fit
+        if (nsite > 1) {
+            int log2c = 0;
+            const int max_log2c = nsite == 2 ? 3 : 2;
+            while (log2c < max_log2c && (size_t)nsite * n_hist * BVC_NCLASS * (2u << log2c) <= (size_t)kLdsWords) ++log2c;
+            const MultiKernel mk = nsite == 2 ? multi2[log2c] : multi4[log2c];
+            const size_t mlds = ((size_t)nsite * n_hist * BVC_NCLASS << log2c) * sizeof(uint32_t);
+            hipError_t e = raise_lds(st, (nsite == 2 ? kSlotGroupMulti2 : kSlotGroupMulti4) + log2c,
+                                     reinterpret_cast<const void *>(mk), lds);
+            if (e != hipSuccess) return e;
+            const int64_t n_pass = (n_sites + nsite - 1) / nsite;
+            hipLaunchKernelGGL(mk, dim3((unsigned)(n_pass < 4096 ? n_pass : 4096)), dim3(kHistThreads), mlds, stream,
+                               n_sites, n_samples, row_stride, bases, quals, group_of_sample, n_groups, counts, bounds);
+            return hipGetLastError();
+        }
+        int log2c = 0;
+        while (log2c < 5 && (size_t)n_hist * BVC_NCLASS * (2u << log2c) <= (size_t)kLdsWords) ++log2c;
+        using GroupKernel = void (*)(int64_t, int64_t, int64_t, const int8_t *, const int8_t *, const uint8_t *, int, int,
+                                     uint32_t *, const int64_t *);
+        static const GroupKernel aligned_kernels[6] = {
+            hist_dense_groups_kernel<true, 0>, hist_dense_groups_kernel<true, 1>, hist_dense_groups_kernel<true, 2>,
+            hist_dense_groups_kernel<true, 3>, hist_dense_groups_kernel<true, 4>, hist_dense_groups_kernel<true, 5>};
+        GroupKernel gk = galigned ? aligned_kernels[log2c] : hist_dense_groups_kernel<false, -1>;
+        hipError_t e = raise_lds(st, galigned ? kSlotGroup + log2c : kSlotGroupByte, reinterpret_cast<const void *>(gk), 2 * lds);
+        if (e != hipSuccess) return e;
+        const size_t glds = ((size_t)n_hist * BVC_NCLASS << log2c) * sizeof(uint32_t);
+        const int64_t ggrid = n_sites < 4096 ? n_sites : 4096;
         hipLaunchKernelGGL(gk, dim3((unsigned)ggrid), dim3(kHistThreads), glds, stream, n_sites, n_samples,
-                           row_stride, bases, quals, group_of_sample, n_groups, log2c, counts,
-                           try_ranges ? group_scratch : nullptr);
+                           row_stride, bases, quals, group_of_sample, n_groups, log2c, counts, bounds);
         return hipGetLastError();
     }
     auto kern = aligned ? hist_dense_kernel<true> : hist_dense_kernel<false>;
-    if (!attr_done[aligned]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done[aligned] = true;
-    }
+    hipError_t e = raise_lds(st, aligned ? kSlotDense1 : kSlotDense0, reinterpret_cast<const void *>(kern), lds);
+    if (e != hipSuccess) return e;
     const int64_t n_work = n_sites * split;
     const int64_t grid = n_work < 4096 ? n_work : 4096;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kHistThreads), lds, stream, n_sites, n_samples,
@@ -493,22 +689,21 @@ hipError_t launch_hist_dense(hipStream_t stream, int64_t n_sites, int64_t n_samp
     return hipGetLastError();
 }
 
-hipError_t launch_hist_csr(hipStream_t stream, int64_t n_sites, const int64_t *offsets,
+hipError_t launch_hist_csr(LaunchState &st, hipStream_t stream, int64_t n_sites, const int64_t *offsets,
                            const int8_t *bases, const int8_t *quals, uint32_t *counts)
 {
     if (n_sites <= 0) return hipSuccess;
-    static std::atomic<bool> attr_done_dev[kMaxDevices];
-    std::atomic<bool> &attr_done = attr_done_dev[current_device_slot()];
+    // both arrays are indexed by the same element offsets, so one alignment test covers every site
+    const bool aligned = ((reinterpret_cast<uintptr_t>(bases) | reinterpret_cast<uintptr_t>(quals)) & 15u) == 0;
     const size_t lds = (size_t)kLdsWords * sizeof(uint32_t);
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(hist_csr_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    const int64_t grid = n_sites < 4096 ? n_sites : 4096;
-    hipLaunchKernelGGL(hist_csr_kernel, dim3((unsigned)grid), dim3(kHistThreads), lds, stream, n_sites, offsets,
-                       bases, quals, counts);
+    auto bk = aligned ? hist_csr_block_kernel<true> : hist_csr_block_kernel<false>;
+    hipError_t e = raise_lds(st, aligned ? kSlotCsr1 : kSlotCsr0, reinterpret_cast<const void *>(bk), lds);
+    if (e != hipSuccess) return e;
+    const int64_t wgrid = (n_sites + kCsrWaves - 1) / kCsrWaves;
+    hipLaunchKernelGGL(hist_csr_wave_kernel, dim3((unsigned)(wgrid < 8192 ? wgrid : 8192)), dim3(kHistThreads), 0, stream,
+                       n_sites, offsets, bases, quals, counts);
+    hipLaunchKernelGGL(bk, dim3((unsigned)(n_sites < 4096 ? n_sites : 4096)), dim3(kHistThreads), lds, stream, n_sites,
+                       offsets, bases, quals, counts);
     return hipGetLastError();
 }
 

@@ -2,16 +2,15 @@
 // Integer arithmetic only, so any site can be regenerated bit for bit on the CPU by the test oracle
 // without ever storing or moving the tile.  Not part of the reference: it exists because the
 // benchmark configs (1e5 sites x 1e6 samples = 200 GB) can only be produced where they are consumed.
-#include <atomic>
-
 #include "bvc_internal.h"
-#include "synth_tables.inc"
 
 namespace bvc {
 namespace {
 
-__device__ __constant__ uint32_t c_af_thr[64];
-__device__ __constant__ uint32_t c_err_thr[64];
+// The threshold tables are compiled into the code object as constant-address-space data (no runtime upload, so no
+// per-device "done once" state): the include below defines SYNTH_AF_THR / SYNTH_ERR_THR in device constant memory.
+#define SYNTH_TABLE __device__ __constant__ const
+#include "synth_tables.inc"
 
 __device__ __host__ __forceinline__ uint64_t mix64(uint64_t z)
 {
@@ -35,7 +34,7 @@ __device__ __forceinline__ SiteParams site_params(uint64_t seed, int64_t site)
     p.alt2 = (p.alt == ((p.ref + 1) & 3)) ? ((p.ref + 2) & 3) : ((p.ref + 1) & 3);
     const bool poly = ((hs >> 20) & 0xFFFF) % 100 < 20;
     const bool second = ((hs >> 36) & 0xFFFF) % 100 < 2;
-    p.thr1 = poly ? c_af_thr[(hs >> 52) & 63] : 0u;
+    p.thr1 = poly ? SYNTH_AF_THR[(hs >> 52) & 63] : 0u;
     p.thr2 = (poly && second) ? p.thr1 / 4 : 0u;
     p.hs2 = mix64(hs ^ 0xD1B54A32D192ED03ULL);
     return p;
@@ -54,7 +53,7 @@ __device__ __forceinline__ uint32_t draw(const SiteParams &p, int64_t i, uint32_
     uint32_t b = p.ref;
     if (r_allele < p.thr1) b = p.alt;
     else if (r_allele - p.thr1 < p.thr2) b = p.alt2;
-    if (r_err < c_err_thr[q]) b = (b + 1 + r_sub) & 3;
+    if (r_err < SYNTH_ERR_THR[q]) b = (b + 1 + r_sub) & 3;
     return (r_cov < cov_thr16) ? (b | (q << 8)) : 0xFFu;
 }
 
@@ -102,14 +101,6 @@ hipError_t launch_synth_dense(hipStream_t stream, uint64_t seed, int64_t site0, 
                               int8_t *bases, int8_t *quals, int8_t *ref_base)
 {
     if (n_sites <= 0 || n_samples < 0) return hipSuccess;
-    static std::atomic<bool> tables_done_dev[kMaxDevices];       // __constant__ symbols are per device
-    std::atomic<bool> &tables_done = tables_done_dev[current_device_slot()];
-    if (!tables_done) {
-        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_af_thr), SYNTH_AF_THR, sizeof(SYNTH_AF_THR));
-        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_err_thr), SYNTH_ERR_THR, sizeof(SYNTH_ERR_THR));
-        if (e != hipSuccess) return e;
-        tables_done = true;
-    }
     const int aligned = ((reinterpret_cast<uintptr_t>(bases) | reinterpret_cast<uintptr_t>(quals)) & 15u) == 0 &&
                         (row_stride & 15) == 0;
     int64_t gx = ((n_samples >> 4) + 255) / 256;

@@ -49,7 +49,7 @@ assert GROUP_DTYPE.itemsize == C.sizeof(GroupResult) == 48
 EXPORTS = [
     "bvc_version", "bvc_device_count", "bvc_create", "bvc_destroy", "bvc_last_error", "bvc_set_stream",
     "bvc_synchronize", "bvc_set_overlap", "bvc_join", "bvc_set_profiling", "bvc_get_profile", "bvc_lrt_dense", "bvc_lrt_dense_groups",
-    "bvc_lrt_csr", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense", "bvc_stream_read_ms", "bvc_set_tuning",
+    "bvc_lrt_csr", "bvc_lrt_csr_comb", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense", "bvc_stream_read_ms", "bvc_set_tuning",
 ]
 
 _lib = None
@@ -96,7 +96,9 @@ def load_library():
     L.bvc_lrt_hist.argtypes = [vp, i64, vp, vp, dbl, vp, vp, vp, u32]
     L.bvc_synth_dense.restype = C.c_int
     L.bvc_synth_dense.argtypes = [vp, C.c_uint64, i64, i64, i64, i64, u32, vp, vp, vp]
-    L.bvc_set_tuning.restype = C.c_int; L.bvc_set_tuning.argtypes = [C.c_char_p, C.c_int]
+    L.bvc_lrt_csr_comb.restype = C.c_int
+    L.bvc_lrt_csr_comb.argtypes = [vp, i64, vp, vp, vp, vp, dbl, vp, vp, vp, u32]
+    L.bvc_set_tuning.restype = C.c_int; L.bvc_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
     L.bvc_stream_read_ms.restype = C.c_int
     L.bvc_stream_read_ms.argtypes = [vp, vp, i64, C.c_int, C.POINTER(C.c_double)]
     _lib = L
@@ -198,16 +200,36 @@ class Context:
                                                  _np_ptr(out), _np_ptr(gout), BVC_PTR_HOST))
         return out, gout
 
-    def lrt_csr(self, offsets, bases, quals, ref_base, min_af):
+    def lrt_csr(self, offsets, bases, quals, ref_base, min_af, base_comb=None, n_comb=None):
+        """Ragged sites (the vectors bt_f builds); base_comb/n_comb: optional per-site SetBase lists."""
         o = np.ascontiguousarray(offsets, dtype=np.int64)
         b = np.ascontiguousarray(bases, dtype=np.int8)
         q = np.ascontiguousarray(quals, dtype=np.int8)
         r = np.ascontiguousarray(ref_base, dtype=np.int8)
         n = len(o) - 1
         out = np.zeros(n, dtype=SITE_DTYPE)
-        self._check(self._L.bvc_lrt_csr(self._h, n, _np_ptr(o), _np_ptr(b), _np_ptr(q), _np_ptr(r), float(min_af),
-                                        _np_ptr(out), BVC_PTR_HOST))
+        cb = nc = None
+        if base_comb is not None:
+            cb = np.ascontiguousarray(base_comb, dtype=np.int8).reshape(-1, 4)
+            nc = np.ascontiguousarray(n_comb, dtype=np.uint8)
+        self._check(self._L.bvc_lrt_csr_comb(self._h, n, _np_ptr(o), _np_ptr(b), _np_ptr(q), _np_ptr(r), float(min_af),
+                                             _np_ptr(cb) if cb is not None else None,
+                                             _np_ptr(nc) if nc is not None else None, _np_ptr(out), BVC_PTR_HOST))
         return out
+
+    def lrt_csr_device(self, offsets_t, bases_t, quals_t, ref_t, min_af, results_t=None):
+        """offsets_t: int64 [n_sites + 1]; bases_t/quals_t: int8 [total] CUDA tensors (asynchronous on the stream)."""
+        import torch
+        ns = offsets_t.numel() - 1
+        if results_t is None:
+            results_t = torch.empty(ns * SITE_DTYPE.itemsize, dtype=torch.uint8, device=bases_t.device)
+        self._check(self._L.bvc_lrt_csr(self._h, ns, _dev_ptr(offsets_t), _dev_ptr(bases_t), _dev_ptr(quals_t),
+                                        _dev_ptr(ref_t), float(min_af), _dev_ptr(results_t), BVC_PTR_DEVICE))
+        return results_t
+
+    def set_tuning(self, key, value):
+        """Launch policy of this context (include/bvc.h); results never depend on it."""
+        self._check(self._L.bvc_set_tuning(self._h, key.encode(), int(value)))
 
     def hist_dense(self, bases, quals):
         b = np.ascontiguousarray(bases, dtype=np.int8)
@@ -283,12 +305,6 @@ def _stream_read_gbs(self, tensor, repeats=5):
 
 
 Context.stream_read_gbs = _stream_read_gbs
-
-
-def set_tuning(key, value):
-    """Process-wide kernel tuning knob (include/bvc.h: "em_rows", "em_waves_per_cu"); results do not depend on it."""
-    if load_library().bvc_set_tuning(key.encode(), int(value)) != 0:
-        raise BvcError(f"bvc_set_tuning({key!r}, {value}) rejected")
 
 
 def results_from_tensor(results_t):

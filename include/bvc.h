@@ -21,7 +21,8 @@
  *     and bvc_last_error(ctx) gives the text.  "No call" (LRT() == false) is called = 0, not an error.
  *   - the caller owns all input/output buffers; the library owns only device scratch inside the context.
  *   - one context = one device + one HIP stream; contexts are independent (one per host thread, as
- *     bt_f runs on T std::threads in the reference, src/BaseVarC.cpp:263-266).
+ *     bt_f runs on T std::threads in the reference, src/BaseVarC.cpp:263-266); the library keeps no
+ *     process-wide mutable state.
  *   - there is NO CPU fallback: without a usable gfx950 device bvc_create fails.
  */
 #ifndef BVC_H
@@ -117,6 +118,11 @@ int  bvc_get_profile(bvc_ctx *ctx, bvc_profile *out, int reset);
  * (the caller's "no read / N / indel" cases, src/BaseVarC.cpp:427, 551-559) is skipped.
  * Equivalent per site to:  BaseType bt(bases, quals, ref_base[s], min_af); bt.LRT();
  * (src/BaseVarC.cpp:612-613).  min_af is the caller's value (src/BaseVarC.cpp:541-543).
+ * ref_base[s] is 0..3 (A,C,G,T).  Any other value (the caller's -1 for a non-ACGT reference letter) means "no
+ * base equals the reference": every kept base is then an ALT, as `b != ref_base` decides in src/BaseType.cpp:112,
+ * and in group mode it contributes no candidate to {ref} + alt_bases (its depth is 0 in the reference, so the
+ * min_af filter of src/BaseType.cpp:79 drops it).  The reference's caller never produces such a site
+ * (src/BaseVarC.cpp:199-203).
  */
 int bvc_lrt_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                   const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
@@ -143,6 +149,15 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
 int bvc_lrt_csr(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
                 const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
                 double min_af, bvc_site_result *results, uint32_t flags);
+/*
+ * The same with BaseType::SetBase (src/BaseType.h:67): base_comb[s * 4 + c], c < n_comb[s] <= 4, are the candidate
+ * bases of site s in SetBase order; both NULL means the default {A,C,G,T} (src/BaseType.h:79).  This is the whole
+ * of  BaseType bt(bases, quals, ref, min_af); bt.SetBase(v); bt.LRT();  in one call (src/BaseVarC.cpp:642-644).
+ */
+int bvc_lrt_csr_comb(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
+                     const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
+                     double min_af, const int8_t *base_comb, const uint8_t *n_comb,
+                     bvc_site_result *results, uint32_t flags);
 
 /* ---- the two stages on their own (used by the parity tests; also valid entry points) -------------- */
 /* Stage 1: counts[s * 512 + base * 128 + qual] = number of covered samples of that class (exact). */
@@ -161,10 +176,15 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
                     int64_t row_stride, uint32_t cov_thr16, int8_t *bases, int8_t *quals,
                     int8_t *ref_base);
 
-/* ---- tuning (process-wide; additive, no counterpart in the reference) ------------------------------- */
-/* key "em_rows": -1 default (= 0), 0 one site per wavefront, 1 four sites per wavefront (A/B alternative);
- * key "em_waves_per_cu": 0 default policy, 1..32 resident EM wavefronts per CU.  Results do not depend on them. */
-int bvc_set_tuning(const char *key, int value);
+/* ---- tuning (per context; additive, no counterpart in the reference) -------------------------------- */
+/* Launch policy of THIS context; results never depend on it.  Keys:
+ *   "em_waves_per_cu"  0 = default policy, 1..32 resident EM wavefronts per CU
+ *   "em_wpb"           waves per EM workgroup: 4 (default) or 1
+ *   "hist_split"       0 = by tile shape, 1..64 workgroups sharing a site in the dense histogram pass
+ *   "group_sites"      0 = default (2); 1, 2 or 4 sites per workgroup pass of the any-order group histogram
+ * A new context starts from the environment variables BVC_EM_WAVES_PER_CU, BVC_EM_WPB, BVC_HIST_SPLIT,
+ * BVC_GROUP_SITES when they are set. */
+int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value);
 
 /* ---- measurement aid ------------------------------------------------------------------------------- */
 /* Streams `bytes` of device memory once with 16-byte loads per lane and nothing else; HIP-event time in ms.

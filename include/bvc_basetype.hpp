@@ -3,7 +3,7 @@
 // Mirrors /root/reference/src/BaseType.h:59-74 (constructor, SetBase, LRT, the public fields var_qual,
 // depth_total, alt_bases, depth, af_lrt) so that per-site callers written against the reference class --
 // bt_f at src/BaseVarC.cpp:612-615 and :642-652, WriteVcf at src/BaseType.cpp:141-234 -- compile against it
-// unchanged.  One object = one site = one device round trip; that is the compatibility path.  The
+// unchanged.  One object = one site = ONE device round trip (bvc_lrt_csr_comb); that is the compatibility path.  The
 // throughput path is bvc::BaseTypeBatch below: gather a tile of sites, one call, one record per site.
 //
 // Header-only; link with -lbvc.  Errors surface as std::runtime_error (the reference's own failure mode is
@@ -72,16 +72,15 @@ class BaseType {
     {
         if (done_) throw std::logic_error("BaseType::LRT is single-shot (the reference consumes its vectors, src/BaseType.cpp:76)");
         done_ = true;
-        const int64_t n = static_cast<int64_t>(bases.size());
-        static const int8_t none_b = -1, none_q = 0;
-        uint32_t counts[BVC_NCLASS];
-        ctx_->check(bvc_hist_dense(ctx_->get(), 1, n ? n : 1, n ? n : 1, n ? bases.data() : &none_b,
-                                   n ? quals.data() : &none_q, counts, BVC_PTR_HOST));
+        // one device round trip: the site as a one-row ragged batch with its SetBase list (bvc_lrt_csr_comb)
+        const int64_t offsets[2] = {0, static_cast<int64_t>(bases.size())};
+        static const int8_t none = 0;
         int8_t comb[4] = {0, 0, 0, 0};
         for (size_t i = 0; i < base_comb.size(); ++i) comb[i] = base_comb[i];
         const uint8_t nc = static_cast<uint8_t>(base_comb.size());
         bvc_site_result r;
-        ctx_->check(bvc_lrt_hist(ctx_->get(), 1, counts, &ref_base, min_af, comb, &nc, &r, BVC_PTR_HOST));
+        ctx_->check(bvc_lrt_csr_comb(ctx_->get(), 1, offsets, bases.empty() ? &none : bases.data(),
+                                     quals.empty() ? &none : quals.data(), &ref_base, min_af, comb, &nc, &r, BVC_PTR_HOST));
         record = r;
         var_qual = r.var_qual;
         depth_total = r.depth_total;

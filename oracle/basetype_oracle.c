@@ -241,6 +241,7 @@ static int lrt_on_model(site_model *sm, int8_t ref_base, double min_af,
     fit_set fs;
 
     memset(out, 0, sizeof(*out));
+    out->tie_gap = HUGE_VAL;
     for (j = 0; j < 4; ++j) out->depth[j] = sm->depth[j];
     out->depth_total = sm->depth_total;
     if (sm->depth_total == 0) return 0;                    /* :75 */
@@ -271,6 +272,8 @@ static int lrt_on_model(site_model *sm, int8_t ref_base, double min_af,
         best = chi_c[0];
         for (c = 1; c < fs.n_fit; ++c)                     /* std::min_element: first minimum, '<' */
             if (chi_c[c] < best) { best = chi_c[c]; i_min = c; }
+        for (c = 0; c < fs.n_fit; ++c)                     /* diagnostic: how close the runner-up was */
+            if (c != i_min && chi_c[c] - best < out->tie_gap) out->tie_gap = chi_c[c] - best;
         lr_alt = fs.lr[i_min];
         chi = chi_c[i_min];
         if (chi < ORC_LRT_THRESHOLD) {

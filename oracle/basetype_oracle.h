@@ -50,6 +50,9 @@ typedef struct orc_result {
     int32_t n_fits;        /* EM() calls */
     int32_t n_passes;      /* singleEM() calls */
     int32_t status;        /* 0 ok; 1 = reference behaviour undefined (bp[0] on empty vector) */
+    double  tie_gap;       /* diagnostic: smallest (runner-up chi - best chi) over the nested levels that had >= 2
+                              fitted subsets (+inf when none had): which subset std::min_element picks is decided by
+                              the last bits of the sums when this is at rounding level */
 } orc_result;
 
 /* htslib kfunc.c restatement (third-party, absent from /root/reference). */

@@ -24,9 +24,18 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
-    assert d["value"] == pytest.approx(2000 / (d["ms_per_step"] / 1e3), rel=1e-3)
+    # a step is one pass over the whole resident workload (8000 sites here, in calls of 2000)
+    assert d["config"]["sites_per_step"] == 8000 and d["config"]["sites_per_call"] == 2000
+    assert d["value"] == pytest.approx(8000 / (d["ms_per_step"] / 1e3), rel=1e-3)
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s"
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3) and 0 < rf["frac"] < 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["cpu_model"] and cb["single_thread"]["cores"] == 1 and cb["single_thread"]["value"] > 0
+    assert cb["gpu_check_same_sites"]["mismatches"] == 0 and cb["gpu_check_hist_form"]["mismatches"] == 0
+    # the other single-GPU configurations ride along as sub-records with their own roofline
+    legs = d["legs"]
+    for name in ("config1_1e4x1e4", "config4_groups5_interleaved", "config4_groups5_ordered", "csr_coverage10pct"):
+        assert legs[name]["value"] > 0 and 0 < legs[name]["roofline"]["frac"] < 1, name
+    assert legs["config1_1e4x1e4"]["roofline"]["bound"] == "fp64_valu_issue"

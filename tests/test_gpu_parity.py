@@ -27,14 +27,22 @@ def ctx():
     c.close()
 
 
-def assert_site_matches(rec, exp, where="", path_strict=True):
+def assert_site_matches(rec, exp, where="", path_strict=True, faithful_drift=False):
     """rec: numpy record of bvc_site_result; exp: oracle dict.
 
     path_strict also compares the diagnostics n_fits / n_passes.  They are bit-exact except when two
     subsets of a level tie in chi to rounding (two pure-error alleles whose fitted frequencies both reach
     ~1e-17: which one the nested test drops first is decided by the last bits of a sum over samples).
     Either order ends in the same model, calls and AF; only the diagnostics differ.  The tile-sized tests
-    therefore pass path_strict=False and bound the fraction of such sites instead."""
+    pass path_strict=False and hand every such site to assert_path_difference_is_a_tie.
+
+    faithful_drift: only for comparisons with the FAITHFUL per-sample oracle at N >= 1e5.  chi is a difference
+    of two log-likelihoods; the reference adds N per-sample logs one by one in a double, which drifts by up to
+    N*u*|loglik| (measured 2.4e-6 on chi at N = 1e6), while a sum of <= 512 class terms does not.  That the drift
+    is the reference's accumulator and nothing else is shown by test_chi_at_1e6_matches_the_compensated_oracle
+    (GPU == per-sample oracle with long-double sums to 1e-9) and tests/test_oracle.py (CPU, N = 2e5).  With the
+    flag the absolute floor grows by 2e-10*|loglik| (about 1.6e-5 at N = 1e6); without it the floor is the
+    north_star's 1e-6."""
     assert int(rec["status"]) == exp["status"], where
     assert [int(x) for x in rec["depth"]] == exp["depth"], where
     assert float(rec["depth_total"]) == exp["depth_total"], where
@@ -48,17 +56,31 @@ def assert_site_matches(rec, exp, where="", path_strict=True):
     for i in range(exp["n_alt"]):
         a, b = float(rec["af"][i]), exp["af"][i]
         assert (math.isnan(a) and math.isnan(b)) or abs(a - b) <= AF_ATOL, (where, a, b)
-    # chi is a difference of two log-likelihoods, each a sum over all samples.  The per-sample CPU path
-    # adds them one by one, which drifts by up to N*u*|loglik| (N = 1e6: ~1e-5); the histogram sum does
-    # not.  The absolute floor below is 2e-10*|loglik|: invisible at the depths of the reference's test
-    # data (|loglik| ~ 1e1..1e3), ~1.5e-5 at N = 1e6.
-    floor = 1e-6 + 2e-10 * abs(exp["lr_alt"])
+    floor = 1e-6 + (2e-10 * abs(exp["lr_alt"]) if faithful_drift else 0.0)
     for name in ("chi", "var_qual"):
         a, b = float(rec[name]), exp[name]
         if math.isnan(b):
             assert math.isnan(a), (where, name, a, b)
         else:
             assert a == pytest.approx(b, rel=QUAL_RTOL, abs=floor), (where, name)
+
+
+# A tie: the runner-up subset of some nested level is within this many ulps of the log-likelihood of the best one
+# (chi = 2 * (lr_alt - lr): a difference of sums of up to 512 rounded terms; the GPU and the CPU evaluate log() with
+# different last-bit errors and add in different orders).
+TIE_ULPS = 4096
+
+
+def assert_path_difference_is_a_tie(rec, exp, where=""):
+    """n_passes / n_fits may differ from the oracle's only where std::min_element's choice among
+    the subsets of a level (src/BaseType.cpp:99) hangs on rounding.  For a site whose diagnostics differ, the oracle's
+    own record must show such a tie; the results proper were already compared by assert_site_matches."""
+    if int(rec["n_passes"]) == exp["n_passes"] and int(rec["n_fits"]) == exp["n_fits"]:
+        return 0
+    tol = TIE_ULPS * 2.0 ** -52 * max(1.0, abs(exp["lr_alt"]))
+    assert exp["tie_gap"] <= tol, (where, "pass count differs without a tie", int(rec["n_passes"]), exp["n_passes"],
+                                   exp["tie_gap"], tol)
+    return 1
 
 
 def pad_rows(sites, width=None, fill=-1):
@@ -469,47 +491,48 @@ def test_config2_1e4_sites_by_1e4_samples(ctx):
     hb, hq, hr = b.cpu().numpy(), q.cpu().numpy(), r.cpu().numpy()
     # every site against the histogram form of the oracle (fast) ...
     exp_h, _ = orc.dense_batch(hb, hq, hr, m, use_hist=True)
+    ties = 0
     for s in range(ns):
         assert_site_matches(res[s], exp_h[s], where=f"config2 hist-oracle site {s}", path_strict=False)
-    same_path = np.mean([int(res[s]["n_passes"]) == exp_h[s]["n_passes"] for s in range(ns)])
-    assert same_path > 0.99, same_path
+        ties += assert_path_difference_is_a_tie(res[s], exp_h[s], where=f"config2 site {s}")
+    assert ties < 0.01 * ns, ties
     # ... and a 400-site sample against the faithful per-sample oracle (77 ms/site/core)
     pick = np.random.default_rng(0).choice(ns, 400, replace=False)
     exp_f, _ = orc.dense_batch(hb[pick], hq[pick], hr[pick], m, use_hist=False)
     for j, s in enumerate(pick):
         assert_site_matches(res[s], exp_f[j], where=f"config2 faithful site {s}", path_strict=False)
+        assert_path_difference_is_a_tie(res[s], exp_f[j], where=f"config2 faithful site {s}")
     called = int(res["called"].sum())
     assert 0.05 * ns < called < 0.5 * ns          # ~20 % polymorphic sites in the mixture
 
 
-@pytest.mark.parametrize("rows", [0, 1])
-def test_both_em_layouts_match_the_oracle(ctx, rows):
-    """One site per wavefront and four sites per wavefront (rows) are two layouts of the same arithmetic."""
+@pytest.mark.parametrize("knob,value", [("em_wpb", 1), ("em_waves_per_cu", 3), ("hist_split", 5), ("em_waves_per_cu", 32)])
+def test_tuning_knobs_are_per_context_and_never_change_a_record(ctx, knob, value):
+    """bvc_set_tuning acts on ONE context (no process-wide state) and only moves work around: the records of a tuned
+    context equal, byte for byte, those of an untouched one, and both match the oracle."""
     import torch
-    from basevarc_amd.lib import results_from_tensor, set_tuning
-    try:
-        set_tuning("em_rows", rows)
-        for n, ns in ((3000, 401), (40000, 97)):
+    from basevarc_amd import Context
+    from basevarc_amd.lib import results_from_tensor
+    with Context(0) as tuned:
+        tuned.set_tuning(knob, value)
+        with pytest.raises(Exception):
+            tuned.set_tuning("em_rows", 1)                      # removed knob: rejected, not ignored
+        for n, ns in ((3000, 401), (70000, 97)):
             m = caller_min_af(n)
             b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
             q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
             r = torch.empty(ns, dtype=torch.int8, device="cuda")
             ctx.synth_dense_device(9, 777, b, q, r)
-            res = results_from_tensor(ctx.lrt_dense_device(b, q, r, m))
+            ctx.synchronize()
+            plain = ctx.lrt_dense_device(b, q, r, m)
+            ctx.synchronize()
+            other = tuned.lrt_dense_device(b, q, r, m)
+            tuned.synchronize()
+            assert np.array_equal(plain.cpu().numpy(), other.cpu().numpy()), (knob, value, n)
+            res = results_from_tensor(other)
             exp, _ = orc.dense_batch(b.cpu().numpy(), q.cpu().numpy(), r.cpu().numpy(), m, use_hist=True)
             for s in range(ns):
-                assert_site_matches(res[s], exp[s], where=f"rows={rows} n={n} site={s}", path_strict=False)
-        rng = np.random.default_rng(rows)
-        sites = [random_site(rng, nind, af=af, second_af=af2, qlo=qlo, qhi=qhi)
-                 for nind in (1, 7, 60, 900) for af, af2 in ((0.0, 0.0), (0.05, 0.0), (0.3, 0.1))
-                 for qlo, qhi in ((2, 41), (0, 127), (30, 33))]
-        B, Q, R = pad_rows(sites)
-        got = ctx.lrt_dense(B, Q, R, 0.001)
-        for s, (bb, qq, rr) in enumerate(sites):
-            assert_site_matches(got[s], orc.basetype_lrt(bb, qq, rr, 0.001), where=f"rows={rows} mixed site {s}",
-                                path_strict=False)
-    finally:
-        set_tuning("em_rows", -1)
+                assert_site_matches(res[s], exp[s], where=f"{knob}={value} n={n} site={s}", path_strict=False)
 
 
 def test_overlap_mode_gives_identical_records(ctx):
@@ -592,16 +615,116 @@ def test_full_size_sites_1e6_samples(ctx):
     res = results_from_tensor(ctx.lrt_dense_device(b, q, r, m))
     hb, hq, hr = b.cpu().numpy(), q.cpu().numpy(), r.cpu().numpy()
     assert (counts.sum(axis=1) == n).all()             # checksum of every histogram = sample count
+    ties = 0
     for s in range(ns):
         if s < 32:                                     # independent recount with numpy on a subset (slow in Python)
             key = hb[s].astype(np.int64) * 128 + hq[s]
             assert np.array_equal(counts[s], np.bincount(key, minlength=512).astype(np.uint32)), s
         assert np.array_equal(counts[s], orc.dense_hist(hb[s], hq[s])), s
-        assert_site_matches(res[s], orc.hist_lrt(counts[s], hr[s], m), where=f"1e6 hist-oracle site {s}",
-                            path_strict=False)
-    same_path = np.mean([int(res[s]["n_passes"]) == orc.hist_lrt(counts[s], hr[s], m)["n_passes"] for s in range(ns)])
-    assert same_path > 0.97, same_path
+        e = orc.hist_lrt(counts[s], hr[s], m)
+        assert_site_matches(res[s], e, where=f"1e6 hist-oracle site {s}", path_strict=False)
+        ties += assert_path_difference_is_a_tie(res[s], e, where=f"1e6 site {s}")
+    assert ties <= 0.03 * ns, ties
     # faithful per-sample oracle on 4 sites (about 20 s each, run in parallel on the host cores)
     exp_f, _ = orc.dense_batch(hb[:4], hq[:4], hr[:4], m, use_hist=False)
     for s in range(4):
-        assert_site_matches(res[s], exp_f[s], where=f"1e6 faithful site {s}", path_strict=False)
+        assert_site_matches(res[s], exp_f[s], where=f"1e6 faithful site {s}", path_strict=False, faithful_drift=True)
+        assert_path_difference_is_a_tie(res[s], exp_f[s], where=f"1e6 faithful site {s}")
+
+
+def test_chi_at_1e6_matches_the_compensated_oracle(ctx):
+    """The north_star's "AF/LRT within 1e-6" at N = 1e6, and why the comparison with the FAITHFUL oracle needs a wider
+    floor there.  Four synthetic sites (one polymorphic by construction of the seed) through three CPU forms:
+      faithful      per-sample loops, double accumulators            (the reference's arithmetic)
+      compensated   the same loops, sums over samples in long double (ORC_MODE_COMPENSATED)
+      histogram     EM on the (base, qual) counts                    (what the GPU computes, on the CPU)
+    GPU chi / var_qual must equal the compensated per-sample oracle to 1e-9 (relative, plus a few ulps of the
+    log-likelihood chi is a difference of); the faithful oracle's distance from the compensated one must cover
+    what the widened floor of assert_site_matches(faithful_drift=True) allows, and stay inside N*u*|loglik|."""
+    import torch
+    from basevarc_amd.lib import results_from_tensor
+    ns, n = 4, 1_000_000
+    m = caller_min_af(n)
+    b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    r = torch.empty(ns, dtype=torch.int8, device="cuda")
+    ctx.synth_dense_device(2, 5000, b, q, r)
+    res = results_from_tensor(ctx.lrt_dense_device(b, q, r, m))
+    hb, hq, hr = b.cpu().numpy(), q.cpu().numpy(), r.cpu().numpy()
+    exp_f, _ = orc.dense_batch(hb, hq, hr, m, use_hist=False)
+    exp_c, _ = orc.dense_batch(hb, hq, hr, m, use_hist=False, compensated=True)
+    worst_gpu = worst_faithful = 0.0
+    for s in range(ns):
+        f, c, g = exp_f[s], exp_c[s], res[s]
+        assert_site_matches(g, c, where=f"1e6 compensated site {s}", path_strict=False)       # 1e-6 floor, no drift term
+        assert_path_difference_is_a_tie(g, c, where=f"1e6 compensated site {s}")
+        ulp_ll = abs(c["lr_alt"]) * 2.0 ** -52
+        for name in ("chi", "lr_alt"):
+            tol = 1e-9 * max(1.0, abs(c[name])) + 256 * ulp_ll
+            assert abs(float(g[name]) - c[name]) <= tol, (s, name, float(g[name]), c[name], tol)
+        if c["called"] and c["var_qual"] not in (5000.0, 10000.0):
+            assert float(g["var_qual"]) == pytest.approx(c["var_qual"], rel=1e-9, abs=1e-8), s
+        worst_gpu = max(worst_gpu, abs(float(g["chi"]) - c["chi"]))
+        drift = abs(f["chi"] - c["chi"])
+        worst_faithful = max(worst_faithful, drift)
+        assert drift <= 2 * n * 2.0 ** -53 * abs(f["lr_alt"]), (s, drift)            # inside the N*u*|loglik| bound
+        assert drift <= 2e-10 * abs(f["lr_alt"]), (s, drift)                          # ... and inside the test floor
+        np.testing.assert_allclose([float(x) for x in g["af"][:c["n_alt"]]], c["af"], rtol=0, atol=1e-10)
+    # the faithful sum is orders of magnitude farther from the compensated one than the GPU is
+    assert worst_faithful > 100 * worst_gpu, (worst_faithful, worst_gpu)
+    print(f"max |chi_gpu - chi_compensated| = {worst_gpu:.3e}; max |chi_faithful - chi_compensated| = {worst_faithful:.3e}")
+
+
+def _group_labels(n, k, layout):
+    if layout == "ordered":
+        return (np.arange(n) * k // n).astype(np.uint8)          # k equal groups as contiguous runs of columns
+    return (np.arange(n) % k).astype(np.uint8)                   # SURVEY 8d: group = sample % k
+
+
+@pytest.mark.parametrize("layout", ["interleaved", "ordered"])
+def test_config5_groups_at_1e6_samples(ctx, layout):
+    """BASELINE.json configs[4]: --group with k = 5 populations on N = 1e6 samples (src/BaseVarC.cpp:617-661), both
+    sample orders (i % 5: the any-order histogram kernel; contiguous runs: the column-range kernel).  65 sites (an odd
+    count: the two-sites-per-pass kernel's short last pass) against the oracle's histogram form of the caller's group
+    loop, 2 of them also against the faithful per-sample group loop."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from basevarc_amd.lib import GROUP_DTYPE, results_from_tensor
+    ns, n, k = 65, 1_000_000, 5
+    m = caller_min_af(n)
+    stride = (n + 127) // 128 * 128
+    b = torch.empty((ns, stride), dtype=torch.int8, device="cuda")[:, :n]
+    q = torch.empty((ns, stride), dtype=torch.int8, device="cuda")[:, :n]
+    r = torch.empty(ns, dtype=torch.int8, device="cuda")
+    ctx.synth_dense_device(3, 12345, b, q, r)
+    g = _group_labels(n, k, layout)
+    g[::97] = 255                                                  # some samples in no group (interleaved case only)
+    if layout == "ordered":
+        g = np.sort(np.minimum(g, k)).astype(np.uint8)
+        g[g == k] = 255
+    gt = torch.from_numpy(g).cuda()
+    res_t, gres_t = ctx.lrt_dense_groups_device(b, q, r, m, gt, k)
+    ctx.synchronize()
+    res = results_from_tensor(res_t)
+    gres = gres_t.cpu().numpy().view(GROUP_DTYPE).reshape(ns, k)
+    hb, hq, hr = b.cpu().numpy(), q.cpu().numpy(), r.cpu().numpy()
+
+    def check(s, use_hist):
+        o, gd, ga, ran, pres = orc.dense_site_groups(hb[s], hq[s], int(hr[s]), m, g, k, use_hist=use_hist)
+        assert_site_matches(res[s], o, where=f"groups 1e6 {layout} site {s} hist={use_hist}", path_strict=False,
+                            faithful_drift=not use_hist)
+        assert np.array_equal(gres[s]["depth"], gd), (layout, s)
+        assert np.array_equal(gres[s]["ran"], ran) and np.array_equal(gres[s]["present"], pres), (layout, s)
+        np.testing.assert_allclose(gres[s]["af"], ga, rtol=0, atol=AF_ATOL, err_msg=f"{layout} site {s}")
+        return int(o["called"]), int(np.sum(ran))
+
+    with ThreadPoolExecutor(8) as pool:                            # the C calls release the GIL
+        out = list(pool.map(lambda s: check(s, True), range(ns)))
+        called = sum(c for c, _ in out)
+        assert called >= 3 and sum(rn for _, rn in out) >= 3 * k, out    # the sample holds called sites with group runs
+        # faithful per-sample group loop on two called sites (about a minute each, side by side)
+        pick = [s for s, (c, _) in enumerate(out) if c][:2]
+        list(pool.map(lambda s: check(s, False), pick))
+    # the depth columns of the groups and of "no group" add up to the overall depth
+    assert np.array_equal(gres["depth"].sum(axis=1) + np.array([np.bincount(hb[s][g == 255], minlength=4)[:4] for s in range(ns)]),
+                          res["depth"])

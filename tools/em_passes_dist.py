@@ -4,7 +4,7 @@ import sys, time
 import numpy as np
 import torch
 from basevarc_amd import Context, caller_min_af
-from basevarc_amd.lib import SITE_DTYPE, set_tuning
+from basevarc_amd.lib import SITE_DTYPE
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
@@ -36,7 +36,7 @@ for G in (2048, 2560, 6144):
 # EM-only timing via lrt_hist-like path: time lrt_dense minus hist? use profiling
 ctx.set_profiling(True)
 for cap in (0, 4, 6, 8, 12, 16, 24, 32):
-    set_tuning("em_waves_per_cu", cap)
+    ctx.set_tuning("em_waves_per_cu", cap)
     for _ in range(3):
         ctx.lrt_dense_device(b, q, r, caller_min_af(N), res)
     ctx.synchronize(); ctx.profile(reset=True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 CSV output (kernel trace, --stats, --pmc passes) into profiles/.
 
-usage: tools/pmc_summary.py <round tag> <dir with rocprofv3 output dirs> [n_samples sites_per_launch]
+usage: tools/pmc_summary.py <round tag> <dir with rocprofv3 output dirs> [n_samples sites_per_launch row_align]
 
 HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 reports exactly half the bytes of a wide (16 B/lane) coalesced streaming read, so the read side is doubled
@@ -22,7 +22,8 @@ def short(name):
     m = re.search(r"(lrt_groups_kernel|lrt_kernel)<(\d+)", name)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
-    for k in ("hist_dense_groups_kernel", "hist_dense_kernel", "hist_csr_kernel", "lrt_rows_kernel", "var_qual_kernel",
+    for k in ("hist_dense_groups_multi_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel", "hist_dense_wave_kernel",
+              "hist_dense_kernel", "hist_csr_block_kernel", "hist_csr_wave_kernel", "group_bounds_kernel", "var_qual_kernel",
               "synth_dense_kernel", "sum_groups_kernel", "stream_read_kernel"):
         if k in name:
             return k
@@ -47,6 +48,7 @@ def main():
     tag, base = sys.argv[1], sys.argv[2]
     n_samples = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
     sites = int(sys.argv[4]) if len(sys.argv) > 4 else 4000
+    row_align = int(sys.argv[5]) if len(sys.argv) > 5 else 128
     lines = [f"# rocprofv3 PMC summary ({tag})", "",
              "Per-dispatch averages; each counter group from its own `rocprofv3 --pmc ... --kernel-trace` pass.", ""]
     summary = {}
@@ -65,24 +67,44 @@ def main():
                 summary.setdefault(k, {})[name] = sum(v) / len(v)
                 summary[k]["ms_under_pmc_" + name] = sum(dd) / len(dd) / 1e6
         lines.append("")
-    h = summary.get("hist_dense_kernel", {})
-    if "FETCH_SIZE" in h:
+    # HBM traffic per launch of every histogram kernel that has a FETCH_SIZE pass -> profiles/pmc_traffic.json, keyed by
+    # kernel and stamped with the sha256 of hist_kernel.hip (bench.py drops the figure when the source has changed)
+    import hashlib
+    import subprocess
+    sha = hashlib.sha256(open(os.path.join(ROOT, "basevarc_amd", "csrc", "hist_kernel.hip"), "rb").read()).hexdigest()[:16]
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        commit = None
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        doc = json.load(open(path))
+        if doc.get("hist_kernel_sha16") != sha or "kernels" not in doc:
+            doc = {}
+    except Exception:
+        doc = {}
+    doc.update({"hist_kernel_sha16": sha, "commit": commit, "summary": f"profiles/{tag}_pmc_summary.md",
+                "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of 16 B/lane streams), WRITE_SIZE KiB x 1024"})
+    doc.setdefault("kernels", {})
+    alg = 2.0 * n_samples * sites
+    for kname in ("hist_dense_kernel", "hist_dense_groups_multi_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel"):
+        h = summary.get(kname, {})
+        if "FETCH_SIZE" not in h or h["FETCH_SIZE"] < 1000:        # the kernel that returned at once has no traffic
+            continue
         fetch = h["FETCH_SIZE"] * 1024 * 2          # gfx950: FETCH_SIZE counts 64 B per 128-B request
         write = h.get("WRITE_SIZE", 0.0) * 1024
-        alg = 2.0 * n_samples * sites
-        t = {"kernel": "hist_dense_kernel", "n_samples": n_samples, "sites_per_launch": sites,
-             "fetch_size_kib_raw": h["FETCH_SIZE"], "write_size_kib_raw": h.get("WRITE_SIZE"),
-             "hbm_read_bytes_per_launch": fetch, "hbm_write_bytes_per_launch": write,
-             "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": alg,
-             "traffic_over_algorithmic": (fetch + write) / alg,
-             "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of 16 B/lane streams), WRITE_SIZE KiB x 1024",
-             "source": f"profiles/{tag}_pmc_summary.md"}
-        json.dump(t, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
-        lines += ["## HBM traffic of hist_dense_kernel per launch", "",
+        doc["kernels"][kname] = {
+            "n_samples": n_samples, "sites_per_launch": sites, "row_align": row_align,
+            "fetch_size_kib_raw": h["FETCH_SIZE"], "write_size_kib_raw": h.get("WRITE_SIZE"),
+            "hbm_read_bytes_per_launch": fetch, "hbm_write_bytes_per_launch": write,
+            "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": alg,
+            "traffic_over_algorithmic": (fetch + write) / alg}
+        lines += [f"## HBM traffic of {kname} per launch", "",
                   f"- FETCH_SIZE raw {h['FETCH_SIZE']:.1f} KiB -> read bytes (x1024 x2) = {fetch:.4g}",
                   f"- WRITE_SIZE raw {h.get('WRITE_SIZE', 0):.1f} KiB -> write bytes = {write:.4g}",
                   f"- algorithmic bytes (2 B x {sites} sites x {n_samples} samples) = {alg:.4g}",
                   f"- traffic / algorithmic = {(fetch + write) / alg:.4f}", ""]
+    json.dump(doc, open(path, "w"), indent=1)
     open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.md"), "w").write("\n".join(lines))
     print("\n".join(lines))
 
