@@ -35,6 +35,8 @@ struct bvc_ctx {
     uint32_t *d_grp[kRing] = {nullptr, nullptr, nullptr};   // [sites][groups + 1][512] in group mode
     size_t grp_cap[kRing] = {0, 0, 0};
     uint32_t *d_sink = nullptr;        // 256-byte sink of the streaming-read measurement kernel (private to it)
+    uint8_t *d_grp_labels = nullptr;   // group mode: the call's group vector clamped to 0..n_groups (hist_kernel.hip)
+    size_t grp_labels_cap = 0;
     int64_t *d_grp_scratch = nullptr;  // group mode: "samples ordered by group" flag + column bounds (hist_kernel.hip)
     // staging for BVC_PTR_HOST calls: two sets, so that the upload of chunk i+1 (copy stream) runs under the kernels
     // of chunk i
@@ -313,7 +315,7 @@ int bvc_create(bvc_ctx **out, int device)
     ctx->ls.em_waves_per_cu = env_int("BVC_EM_WAVES_PER_CU", 1, 32, 0);
     ctx->ls.em_wpb = env_int("BVC_EM_WPB", 1, 4, 4) == 1 ? 1 : 4;
     ctx->ls.hist_split = env_int("BVC_HIST_SPLIT", 1, 64, 0);
-    ctx->ls.group_sites = env_int("BVC_GROUP_SITES", 1, 4, 0);
+    ctx->ls.group_pipe = env_int("BVC_GROUP_PIPE", 0, 1, 1);
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return BVC_ERR_DEVICE; }
     // likelihood table from the host's exp(), as the CPU path computes it (src/BaseType.cpp:13,15)
     QualLut lut;
@@ -363,6 +365,7 @@ void bvc_destroy(bvc_ctx *ctx)
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     if (ctx->d_grp_scratch) (void)hipFree(ctx->d_grp_scratch);
+    if (ctx->d_grp_labels) (void)hipFree(ctx->d_grp_labels);
     if (ctx->d_sink) (void)hipFree(ctx->d_sink);
     delete ctx;
 }
@@ -644,6 +647,9 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
         if (rc2 != BVC_OK) return rc2;
         rc2 = ensure(ctx, reinterpret_cast<void **>(gp), gcap, gbytes);
         if (rc2 != BVC_OK) return rc2;
+        if ((size_t)n_samples + 16 > ctx->grp_labels_cap) { int rj = join_side(ctx); if (rj != BVC_OK) return rj; }
+        rc2 = ensure(ctx, reinterpret_cast<void **>(&ctx->d_grp_labels), &ctx->grp_labels_cap, (size_t)n_samples + 16);
+        if (rc2 != BVC_OK) return rc2;
         if (ctx->overlap && ctx->em_pending[buf]) {
             BVC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_em_done[buf], 0));
             ctx->em_pending[buf] = false;
@@ -657,7 +663,7 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
         if (e__ != hipSuccess) return bail(fail(ctx, BVC_ERR_DEVICE, #call, e__));          \
     } while (0)
         if (timed) BVC_HIP_T(hipEventRecord(t.a, ctx->stream));
-        BVC_HIP_T(launch_hist_dense(ctx->ls, ctx->stream, ns, n_samples, row_stride, b, q, g, n_groups, *gp, 1, ctx->d_grp_scratch));
+        BVC_HIP_T(launch_hist_dense(ctx->ls, ctx->stream, ns, n_samples, row_stride, b, q, g, n_groups, *gp, 1, ctx->d_grp_scratch, ctx->d_grp_labels));
         if (timed) BVC_HIP_T(hipEventRecord(t.b, ctx->stream));
         hipStream_t s2 = ctx->stream;
         if (ctx->overlap) {
@@ -738,7 +744,7 @@ int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value)
     if (std::strcmp(key, "em_waves_per_cu") == 0 && value >= 0 && value <= 32) { ctx->ls.em_waves_per_cu = value; return BVC_OK; }
     if (std::strcmp(key, "em_wpb") == 0 && (value == 1 || value == 4)) { ctx->ls.em_wpb = value; return BVC_OK; }
     if (std::strcmp(key, "hist_split") == 0 && value >= 0 && value <= 64) { ctx->ls.hist_split = value; return BVC_OK; }
-    if (std::strcmp(key, "group_sites") == 0 && (value == 0 || value == 1 || value == 2 || value == 4)) { ctx->ls.group_sites = value; return BVC_OK; }
+    if (std::strcmp(key, "group_pipe") == 0 && (value == 0 || value == 1)) { ctx->ls.group_pipe = value; return BVC_OK; }
     return fail(ctx, BVC_ERR_ARG, "unknown tuning key or value out of range");
 }
 

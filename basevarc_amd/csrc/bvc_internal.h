@@ -14,7 +14,7 @@ struct LaunchState {
     int em_waves_per_cu = 0;   // 0 = default policy (em_kernel.hip); 1..32 resident EM wavefronts per CU
     int em_wpb = 4;            // waves per EM workgroup: 4, or 1 (A/B runs)
     int hist_split = 0;        // 0 = by tile shape; 1..64 workgroups sharing a site in the dense histogram pass
-    int group_sites = 0;       // 0 = default (2); 1, 2, 4 sites per workgroup pass of the any-order group histogram
+    int group_pipe = 1;        // any-order group histogram: issue the next chunk's loads before counting the current one
     uint32_t attr_done = 0;    // kernels whose dynamic-LDS attribute has been raised on this context's device
 };
 
@@ -30,9 +30,11 @@ struct QualLut {
 // Stage 1: dense pileup rows -> per-site class counts.  counts must be zeroed by the caller when split > 1.
 hipError_t launch_hist_dense(LaunchState &st, hipStream_t stream, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                              const int8_t *bases, const int8_t *quals, const uint8_t *group_of_sample,
-                             int n_groups, uint32_t *counts, int split, int64_t *group_scratch = nullptr);
-// group_scratch: BVC_MAX_GROUPS + 4 int64 of device memory; when given, calls whose samples are ordered by group
-// take the column-range kernel (decided on the device).
+                             int n_groups, uint32_t *counts, int split, int64_t *group_scratch = nullptr,
+                             uint8_t *hist_of_sample = nullptr);
+// Group mode needs group_scratch (BVC_MAX_GROUPS + 4 int64 of device memory) and hist_of_sample (n_samples bytes,
+// 16-byte aligned): calls whose samples are ordered by group take the column-range kernel (decided on the device),
+// the others index their histograms with the clamped labels written to hist_of_sample.
 // Number of sample-range splits per site launch_hist_dense should use for this shape (1 = none).
 int choose_hist_split(const LaunchState &st, int64_t n_sites, int64_t n_samples);
 

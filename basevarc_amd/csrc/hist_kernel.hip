@@ -26,19 +26,47 @@ constexpr int kHistThreads = BVC_HIST_THREADS;
 constexpr int kCopies = 32;                         // one copy per LDS bank
 constexpr int kLdsWords = BVC_NCLASS * kCopies;     // 16384 words = 64 KiB
 constexpr int kUnroll = BVC_HIST_UNROLL;            // 16-byte loads in flight per lane and array
+constexpr int64_t kWaveRowMax = 16384;              // dense rows up to this length go one wavefront per site
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void count_word(uint32_t *__restrict__ hist, uint32_t bw, uint32_t qw, uint32_t lane_off)
+// (byte BYTE of `word`) << shift in ONE VALU instruction (SDWA source-byte select); the compiler's own selection for
+// the same expression is a shift plus a mask-and-or.  The histogram kernels are HBM-bound on their own but share
+// the chip with the FP64-VALU-bound EM kernel in overlap mode, so every VALU instruction they do not issue is the
+// EM kernel's.
+template <int BYTE>
+__device__ __forceinline__ uint32_t shl_byte(uint32_t word, uint32_t shift)
 {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t b = (bw >> (8 * i)) & 0xFFu;
-        const uint32_t q = (qw >> (8 * i)) & 0xFFu;
-        const uint32_t key = (b << 7) | q;                       // class = base * 128 + qual
-        __hip_atomic_fetch_add(&hist[key * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    uint32_t r;
+    static_assert(BYTE >= 0 && BYTE < 4, "byte index");
+    if (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(shift), "v"(word));
+    if (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(shift), "v"(word));
+    if (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(shift), "v"(word));
+    if (BYTE == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(shift), "v"(word));
+    return r;
+}
+
+// LDS addresses as plain 32-bit integers: the fast paths below assemble the byte address of a counter with bit
+// operations and add one to it; going through a generic pointer would cost an extra VALU add of the array's base per
+// sample.  lds_address(hist) + offsets are formed once per lane.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+__device__ __forceinline__ uint32_t lds_address(uint32_t *p) { return (uint32_t)(uintptr_t)(lds_u32 *)p; }
+
+__device__ __forceinline__ void lds_add_one(uint32_t lds_byte_address)
+{
+    __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)lds_byte_address, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Four covered samples (every base byte 0..3, every qual byte 0..127): byte address of the counter =
+// base << 14 | qual << 7 | copy << 2 (class = base * 128 + qual, 32 copies of 4 bytes), three VALU instructions each.
+// lane_base = LDS address of the lane's copy of class 0 (the array is 64 KiB aligned in its address bits below 16).
+__device__ __forceinline__ void count_word(uint32_t lane_base, uint32_t bw, uint32_t qw)
+{
+    lds_add_one(shl_byte<0>(bw, 14u) + shl_byte<0>(qw, 7u) + lane_base);   // disjoint bits: + is |, and one v_add3_u32
+    lds_add_one(shl_byte<1>(bw, 14u) + shl_byte<1>(qw, 7u) + lane_base);   // disjoint bits: + is |, and one v_add3_u32
+    lds_add_one(shl_byte<2>(bw, 14u) + shl_byte<2>(qw, 7u) + lane_base);   // disjoint bits: + is |, and one v_add3_u32
+    lds_add_one(shl_byte<3>(bw, 14u) + shl_byte<3>(qw, 7u) + lane_base);   // disjoint bits: + is |, and one v_add3_u32
 }
 
 __device__ __forceinline__ void count_word_checked(uint32_t *__restrict__ hist, uint32_t bw, uint32_t qw,
@@ -60,8 +88,9 @@ __device__ __forceinline__ void count_chunk(uint32_t *__restrict__ hist, const u
 {
     const uint32_t bad = ((b.x | b.y | b.z | b.w) & 0xFCFCFCFCu) | ((q.x | q.y | q.z | q.w) & 0x80808080u);
     if (__ballot(bad != 0) == 0) {
-        count_word(hist, b.x, q.x, lane_off); count_word(hist, b.y, q.y, lane_off);
-        count_word(hist, b.z, q.z, lane_off); count_word(hist, b.w, q.w, lane_off);
+        const uint32_t lane_base = lds_address(hist) + (lane_off << 2);
+        count_word(lane_base, b.x, q.x); count_word(lane_base, b.y, q.y);
+        count_word(lane_base, b.z, q.z); count_word(lane_base, b.w, q.w);
     } else {
         count_word_checked(hist, b.x, q.x, lane_off); count_word_checked(hist, b.y, q.y, lane_off);
         count_word_checked(hist, b.z, q.z, lane_off); count_word_checked(hist, b.w, q.w, lane_off);
@@ -165,75 +194,39 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_kernel(
 
 // Group mode (--group, /root/reference/src/BaseVarC.cpp:617-661): one pass builds n_groups + 1 histograms per
 // site (the last one collects samples that belong to no group, :352-356).  LDS holds [hist][class][copy]
-// with as many copies as fit 64 KiB (copies = 1 << log2c); fewer copies than banks means some conflicts,
-// which the spread of keys over groups softens.
-// LOG2C >= 0: the number of copies is a compile-time constant (the address is then five VALU instructions per
-// sample); LOG2C < 0: taken from the argument.
-template <bool ALIGNED, int LOG2C>
-__global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
+// with as many copies as fit 64 KiB (copies = 1 << log2c); fewer copies than banks means bank conflicts
+// (PMC: 69 % of this kernel's LDS cycles), which the spread of keys over groups softens.
+//
+// What bounds it (rocprofv3 counters, profiles/r02_pmc_groups.md): NOT a third load stream -- the group bytes are
+// served by L2 and HBM traffic is 1.007 x the algorithmic bytes -- but issue: per sample one LDS atomic with ~3-way
+// bank conflicts plus the VALU instructions that build its address, and under the EM kernels of the previous call
+// the VALU is the shared resource.  Hence the fast kernel below spends five VALU instructions per sample (the
+// compiler's selection for the same expression needs more than eight).
+
+// Generic form: any alignment, group vector as the caller gave it (labels >= n_groups mean "no group").
+__global__ __launch_bounds__(kHistThreads) void hist_dense_groups_bytes_kernel(
     int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *__restrict__ bases,
-    const int8_t *__restrict__ quals, const uint8_t *__restrict__ group_of_sample, int n_groups, int log2c_arg,
+    const int8_t *__restrict__ quals, const uint8_t *__restrict__ group_of_sample, int n_groups, int log2c,
     uint32_t *__restrict__ grp_counts, const int64_t *__restrict__ bounds)
 {
-    const int log2c = LOG2C >= 0 ? LOG2C : log2c_arg;
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     if (bounds && bounds[0] == 0) return;        // samples are ordered by group: hist_dense_ranges_kernel has the call
-    __builtin_amdgcn_s_setprio(3);               // as in hist_dense_kernel: ahead of the EM kernels it shares the chip with
     const int tid = threadIdx.x;
     const int n_hist = n_groups + 1;
     const int words = (n_hist * BVC_NCLASS) << log2c;
     const uint32_t lane_off = (uint32_t)tid & ((1u << log2c) - 1u);
     for (int i = tid; i < words; i += kHistThreads) hist[i] = 0;
     __syncthreads();
-
-    auto add_valid = [&](uint32_t b, uint32_t q, uint32_t g) {
-        const uint32_t h = g < (uint32_t)n_groups ? g : (uint32_t)n_groups;
-        __hip_atomic_fetch_add(&hist[((h << (9 + log2c)) | (b << (7 + log2c)) | (q << log2c)) + lane_off], 1u,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto add = [&](uint32_t b, uint32_t q, uint32_t g) {
-        if (b < 4u && q < 128u) add_valid(b, q, g);
-    };
-
     for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
         const int8_t *brow = bases + site * row_stride;
         const int8_t *qrow = quals + site * row_stride;
-        const int64_t n16 = ALIGNED ? (n_samples >> 4) : 0;
-        if (ALIGNED) {
-            const u32x4 *bv = reinterpret_cast<const u32x4 *>(brow);
-            const u32x4 *qv = reinterpret_cast<const u32x4 *>(qrow);
-            const u32x4 *gv = reinterpret_cast<const u32x4 *>(group_of_sample);
-            // the common case (every sample of the wave covered) skips the per-sample test, as in count_chunk
-            auto count16 = [&](const u32x4 b, const u32x4 q, const u32x4 g) {
-                const uint32_t bw[4] = {b.x, b.y, b.z, b.w}, qw[4] = {q.x, q.y, q.z, q.w}, gw[4] = {g.x, g.y, g.z, g.w};
-                const uint32_t bad = ((b.x | b.y | b.z | b.w) & 0xFCFCFCFCu) | ((q.x | q.y | q.z | q.w) & 0x80808080u);
-                if (__ballot(bad != 0) == 0) {
-#pragma unroll
-                    for (int w = 0; w < 4; ++w)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            add_valid((bw[w] >> (8 * k)) & 0xFFu, (qw[w] >> (8 * k)) & 0xFFu, (gw[w] >> (8 * k)) & 0xFFu);
-                } else {
-#pragma unroll
-                    for (int w = 0; w < 4; ++w)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            add((bw[w] >> (8 * k)) & 0xFFu, (qw[w] >> (8 * k)) & 0xFFu, (gw[w] >> (8 * k)) & 0xFFu);
-                }
-            };
-            int64_t c = tid;
-            for (; c + kHistThreads < n16; c += 2 * kHistThreads) {        // two 16-byte loads per array in flight
-                const u32x4 b0 = __builtin_nontemporal_load(&bv[c]), b1 = __builtin_nontemporal_load(&bv[c + kHistThreads]);
-                const u32x4 q0 = __builtin_nontemporal_load(&qv[c]), q1 = __builtin_nontemporal_load(&qv[c + kHistThreads]);
-                const u32x4 g0 = gv[c], g1 = gv[c + kHistThreads];
-                count16(b0, q0, g0);
-                count16(b1, q1, g1);
-            }
-            for (; c < n16; c += kHistThreads)
-                count16(__builtin_nontemporal_load(&bv[c]), __builtin_nontemporal_load(&qv[c]), gv[c]);
+        for (int64_t i = tid; i < n_samples; i += kHistThreads) {
+            const uint32_t b = (uint8_t)brow[i], q = (uint8_t)qrow[i], g = group_of_sample[i];
+            const uint32_t h = g < (uint32_t)n_groups ? g : (uint32_t)n_groups;
+            if (b < 4u && q < 128u)
+                __hip_atomic_fetch_add(&hist[((h << (9 + log2c)) | (b << (7 + log2c)) | (q << log2c)) + lane_off], 1u,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        for (int64_t i = (n16 << 4) + tid; i < n_samples; i += kHistThreads)
-            add((uint8_t)brow[i], (uint8_t)qrow[i], group_of_sample[i]);
         __syncthreads();
         for (int key = tid; key < n_hist * BVC_NCLASS; key += kHistThreads) {
             uint32_t s = 0;
@@ -247,97 +240,106 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
     }
 }
 
-// Group mode, any sample order, NSITE sites per workgroup pass.  What the one-site kernel above pays over the dense
-// kernel is its third load stream: one group byte per two data bytes, re-read (from L2 / Infinity Cache) for every
-// site.  Here a pass takes NSITE consecutive sites through the same sample chunks, so each 16-byte chunk of
-// group_of_sample is loaded once per NSITE sites and stays in registers.  LDS: [site in pass][hist][class][copy],
-// copies = 1 << LOG2C chosen by the launcher to fit 64 KiB (k = 5: two sites x six histograms x two copies).
-// Needs 16-byte aligned rows and group vector; the one-site kernel takes every other call.
-template <int NSITE, int LOG2C>
-__global__ __launch_bounds__(kHistThreads) void hist_dense_groups_multi_kernel(
+// Four covered samples of one lane in group mode: counter byte address =
+//   hist << (11 + L) | base << (9 + L) | qual << (2 + L) | copy << 2      (L = log2 of the copies)
+// glane = (group byte << (11 + L)) + lane_base is shared by ... one sample only, but costs two instructions; the
+// base and qual terms one SDWA shift each, and one three-operand add joins them: five VALU instructions per sample.
+template <int LOG2C>
+__device__ __forceinline__ void count_group_word(uint32_t lane_base, uint32_t bw, uint32_t qw, uint32_t gw)
+{
+    constexpr uint32_t SG = 11 + LOG2C, SB = 9 + LOG2C, SQ = 2 + LOG2C;
+    lds_add_one(shl_byte<0>(bw, SB) + shl_byte<0>(qw, SQ) + (shl_byte<0>(gw, SG) + lane_base));
+    lds_add_one(shl_byte<1>(bw, SB) + shl_byte<1>(qw, SQ) + (shl_byte<1>(gw, SG) + lane_base));
+    lds_add_one(shl_byte<2>(bw, SB) + shl_byte<2>(qw, SQ) + (shl_byte<2>(gw, SG) + lane_base));
+    lds_add_one(shl_byte<3>(bw, SB) + shl_byte<3>(qw, SQ) + (shl_byte<3>(gw, SG) + lane_base));
+}
+
+// Fast form: 16-byte aligned rows; `hist_of_sample` is the group vector already clamped to 0..n_groups by
+// group_bounds_kernel (one pass over 1 byte per sample per CALL, shared by all the sites of the tile).
+// PIPE: the loads of the next 16-sample chunk are issued before the current one is counted, so a wave keeps bytes
+// in flight while it works (its counting takes about as long as the loads' latency).
+template <int LOG2C, bool PIPE>
+__global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
     int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *__restrict__ bases,
-    const int8_t *__restrict__ quals, const uint8_t *__restrict__ group_of_sample, int n_groups,
+    const int8_t *__restrict__ quals, const uint8_t *__restrict__ hist_of_sample, int n_groups,
     uint32_t *__restrict__ grp_counts, const int64_t *__restrict__ bounds)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     if (bounds && bounds[0] == 0) return;        // samples are ordered by group: hist_dense_ranges_kernel has the call
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);               // as in hist_dense_kernel: ahead of the EM kernels it shares the chip with
     const int tid = threadIdx.x;
     const int n_hist = n_groups + 1;
-    const int site_words = (n_hist * BVC_NCLASS) << LOG2C;
+    const int words = (n_hist * BVC_NCLASS) << LOG2C;
     const uint32_t lane_off = (uint32_t)tid & ((1u << LOG2C) - 1u);
-    for (int i = tid * 4; i < NSITE * site_words; i += kHistThreads * 4)
+    const uint32_t lane_base = lds_address(hist) + (lane_off << 2);
+    for (int i = tid * 4; i < words; i += kHistThreads * 4)
         *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
 
-    const int64_t n_pass = (n_sites + NSITE - 1) / NSITE;
-    const int64_t n16 = n_samples >> 4;
-    const u32x4 *gv = reinterpret_cast<const u32x4 *>(group_of_sample);
-    for (int64_t pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
-        const int64_t site0 = pass * NSITE;
-        const int nv = (int)(n_sites - site0 < NSITE ? n_sites - site0 : NSITE);   // sites of this pass (last one may be short)
-        const u32x4 *bv[NSITE], *qv[NSITE];
-#pragma unroll
-        for (int s = 0; s < NSITE; ++s) {
-            const int64_t site = site0 + (s < nv ? s : 0);                        // absent sites re-read site0 and count nothing
-            bv[s] = reinterpret_cast<const u32x4 *>(bases + site * row_stride);
-            qv[s] = reinterpret_cast<const u32x4 *>(quals + site * row_stride);
-        }
-        // offsets of the six (n_hist) histograms a sample can fall into, per byte of the group word
-        auto hoff = [&](uint32_t g) { return (g < (uint32_t)n_groups ? g : (uint32_t)n_groups) << (9 + LOG2C); };
-        for (int64_t c = tid; c < n16; c += kHistThreads) {
-            const u32x4 g = gv[c];
-            u32x4 b[NSITE], q[NSITE];
-#pragma unroll
-            for (int s = 0; s < NSITE; ++s) {
-                b[s] = __builtin_nontemporal_load(&bv[s][c]);
-                q[s] = __builtin_nontemporal_load(&qv[s][c]);
-            }
-            const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
-            uint32_t bad = 0;
-#pragma unroll
-            for (int s = 0; s < NSITE; ++s)
-                bad |= ((b[s].x | b[s].y | b[s].z | b[s].w) & 0xFCFCFCFCu) | ((q[s].x | q[s].y | q[s].z | q[s].w) & 0x80808080u);
-            const bool all_valid = __ballot(bad != 0) == 0;
+    auto add_checked = [&](uint32_t b, uint32_t q, uint32_t h) {
+        if (b < 4u && q < 128u)
+            __hip_atomic_fetch_add(&hist[((h << (9 + LOG2C)) | (b << (7 + LOG2C)) | (q << LOG2C)) + lane_off], 1u,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // the common case (every sample of the wave covered) skips the per-sample test, as in count_chunk
+    auto count16 = [&](const u32x4 b, const u32x4 q, const u32x4 g) {
+        const uint32_t bad = ((b.x | b.y | b.z | b.w) & 0xFCFCFCFCu) | ((q.x | q.y | q.z | q.w) & 0x80808080u);
+        if (__ballot(bad != 0) == 0) {
+            count_group_word<LOG2C>(lane_base, b.x, q.x, g.x); count_group_word<LOG2C>(lane_base, b.y, q.y, g.y);
+            count_group_word<LOG2C>(lane_base, b.z, q.z, g.z); count_group_word<LOG2C>(lane_base, b.w, q.w, g.w);
+        } else {
+            const uint32_t bw[4] = {b.x, b.y, b.z, b.w}, qw[4] = {q.x, q.y, q.z, q.w}, gw[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
             for (int w = 0; w < 4; ++w)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t ho = hoff((gw[w] >> (8 * k)) & 0xFFu) + lane_off;
-#pragma unroll
-                    for (int s = 0; s < NSITE; ++s) {
-                        const uint32_t bw = w == 0 ? b[s].x : (w == 1 ? b[s].y : (w == 2 ? b[s].z : b[s].w));
-                        const uint32_t qw = w == 0 ? q[s].x : (w == 1 ? q[s].y : (w == 2 ? q[s].z : q[s].w));
-                        const uint32_t bb = (bw >> (8 * k)) & 0xFFu, qq = (qw >> (8 * k)) & 0xFFu;
-                        if (s < nv && (all_valid || (bb < 4u && qq < 128u)))
-                            __hip_atomic_fetch_add(&hist[s * site_words + ho + ((bb << (7 + LOG2C)) | (qq << LOG2C))], 1u,
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
+                for (int k = 0; k < 4; ++k)
+                    add_checked((bw[w] >> (8 * k)) & 0xFFu, (qw[w] >> (8 * k)) & 0xFFu, (gw[w] >> (8 * k)) & 0xFFu);
         }
-        for (int64_t i = (n16 << 4) + tid; i < n_samples; i += kHistThreads) {
-            const uint32_t ho = hoff(group_of_sample[i]) + lane_off;
-#pragma unroll
-            for (int s = 0; s < NSITE; ++s) {
-                if (s >= nv) continue;
-                const uint32_t bb = (uint8_t)reinterpret_cast<const int8_t *>(bv[s])[i];
-                const uint32_t qq = (uint8_t)reinterpret_cast<const int8_t *>(qv[s])[i];
-                if (bb < 4u && qq < 128u)
-                    __hip_atomic_fetch_add(&hist[s * site_words + ho + ((bb << (7 + LOG2C)) | (qq << LOG2C))], 1u,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    const int64_t n16 = n_samples >> 4;
+    const u32x4 *gv = reinterpret_cast<const u32x4 *>(hist_of_sample);
+    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
+        const int8_t *brow = bases + site * row_stride;
+        const int8_t *qrow = quals + site * row_stride;
+        const u32x4 *bv = reinterpret_cast<const u32x4 *>(brow);
+        const u32x4 *qv = reinterpret_cast<const u32x4 *>(qrow);
+        if (PIPE) {
+            int64_t c = tid;
+            u32x4 b0 = u32x4{0u, 0u, 0u, 0u}, q0 = b0, g0 = b0;
+            if (c < n16) { b0 = __builtin_nontemporal_load(&bv[c]); q0 = __builtin_nontemporal_load(&qv[c]); g0 = gv[c]; }
+            while (c < n16) {
+                const int64_t cn = c + kHistThreads;
+                u32x4 b1 = b0, q1 = q0, g1 = g0;
+                if (cn < n16) { b1 = __builtin_nontemporal_load(&bv[cn]); q1 = __builtin_nontemporal_load(&qv[cn]); g1 = gv[cn]; }
+                count16(b0, q0, g0);
+                b0 = b1; q0 = q1; g0 = g1;
+                c = cn;
             }
+        } else {
+            int64_t c = tid;
+            for (; c + kHistThreads < n16; c += 2 * kHistThreads) {        // two 16-byte loads per array in flight
+                const u32x4 b0 = __builtin_nontemporal_load(&bv[c]), q0 = __builtin_nontemporal_load(&qv[c]);
+                const u32x4 g0 = gv[c];
+                const u32x4 b1 = __builtin_nontemporal_load(&bv[c + kHistThreads]), q1 = __builtin_nontemporal_load(&qv[c + kHistThreads]);
+                const u32x4 g1 = gv[c + kHistThreads];
+                count16(b0, q0, g0);
+                count16(b1, q1, g1);
+            }
+            for (; c < n16; c += kHistThreads)
+                count16(__builtin_nontemporal_load(&bv[c]), __builtin_nontemporal_load(&qv[c]), gv[c]);
         }
+        for (int64_t i = (n16 << 4) + tid; i < n_samples; i += kHistThreads)
+            add_checked((uint8_t)brow[i], (uint8_t)qrow[i], hist_of_sample[i]);
         __syncthreads();
-        const int keys = n_hist * BVC_NCLASS;
-        for (int key = tid; key < NSITE * keys; key += kHistThreads) {
-            uint32_t sum = 0;
+        for (int key = tid; key < n_hist * BVC_NCLASS; key += kHistThreads) {
+            uint32_t s = 0;
 #pragma unroll
             for (int v = 0; v < (1 << LOG2C); ++v) {
-                sum += hist[(key << LOG2C) + v];
+                s += hist[(key << LOG2C) + v];
                 hist[(key << LOG2C) + v] = 0;
             }
-            const int s = key / keys;
-            if (s < nv) grp_counts[(site0 + s) * keys + (key - s * keys)] = sum;
+            grp_counts[site * n_hist * BVC_NCLASS + key] = s;
         }
         __syncthreads();
     }
@@ -347,13 +349,15 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_multi_kernel(
 // histogram of (site, group) is then the plain histogram of a column range, so the pass keeps the dense kernel's
 // 32 conflict-free LDS copies and its wave-wide fast path, and needs no per-sample group byte.
 // scratch[0] = 0 when group_of_sample is non-decreasing after clamping to n_groups, scratch[1 + h] = first sample of
-// histogram h, scratch[1 + n_hist] = n_samples (scratch is zeroed before the launch).
+// histogram h, scratch[1 + n_hist] = n_samples (scratch is zeroed before the launch).  The same pass writes the
+// clamped labels (hist_of_sample) the any-order kernel indexes its histograms with.
 __global__ void group_bounds_kernel(const uint8_t *__restrict__ group_of_sample, int64_t n_samples, int n_groups,
-                                    int64_t *__restrict__ scratch)
+                                    int64_t *__restrict__ scratch, uint8_t *__restrict__ hist_of_sample)
 {
     const int n_hist = n_groups + 1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += (int64_t)gridDim.x * blockDim.x) {
         const int h = min((int)group_of_sample[i], n_groups);
+        hist_of_sample[i] = (uint8_t)h;                          // label clamped to "no group" = n_groups
         if (i == 0)
             for (int t = 0; t <= h; ++t) scratch[1 + t] = 0;
         if (i == n_samples - 1) {
@@ -445,39 +449,78 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_ranges_kernel(
 // bt_f builds per position (/root/reference/src/BaseVarC.cpp:550-559).  Real pileups are ragged: at the depths of the
 // reference's test data a site has 1-28 observations, at CMDB scale (1e6 samples, low coverage) 1e4-1e5.  Two kernels
 // split the sites by length (each walks all sites and takes its own):
-//   hist_csr_wave_kernel   len <  kCsrLong: one WAVEFRONT per site, a private one-copy histogram per wave (2 KiB);
-//                          short sites would otherwise pay a 64 KiB fold each
+//   hist_wave_kernel       len <  kCsrLong: one WAVEFRONT per site, a private two-copy histogram per wave (4 KiB);
+//                          short sites would otherwise pay a 64 KiB fold each.  The same kernel takes dense tiles
+//                          with short rows (BASELINE configs[1]: 1e4 samples per site)
 //   hist_csr_block_kernel  len >= kCsrLong: one workgroup per site with the dense kernel's 32 conflict-free copies,
 //                          16-byte loads over the aligned middle of the range, head and tail sample by sample
 constexpr int64_t kCsrLong = 4096;
 constexpr int kCsrWaves = kHistThreads / 64;
+constexpr int kWaveCopies = 2;                     // copies of a wave's private histogram (copy = lane & 1)
 
-__global__ __launch_bounds__(kHistThreads) void hist_csr_wave_kernel(
-    int64_t n_sites, const int64_t *__restrict__ offsets, const int8_t *__restrict__ bases,
-    const int8_t *__restrict__ quals, uint32_t *__restrict__ counts)
+// One wavefront counts elements [s0, s1) of the arrays into its private LDS histogram [class][kWaveCopies].
+// ALIGNED: both arrays start on a 16-byte boundary, so whole 16-element chunks of the range load as one dwordx4 per
+// lane; head and tail element by element.
+template <bool ALIGNED>
+__device__ __forceinline__ void wave_count_range(uint32_t *__restrict__ hist, const int8_t *__restrict__ bases,
+                                                 const int8_t *__restrict__ quals, int64_t s0, int64_t s1, int lane)
 {
-    __shared__ uint32_t hist_all[kCsrWaves][BVC_NCLASS];
+    const uint32_t copy = (uint32_t)lane & (kWaveCopies - 1);
+    auto one = [&](uint32_t b, uint32_t q) {
+        if (b < 4u && q < 128u)
+            __hip_atomic_fetch_add(&hist[((b << 7) | q) * kWaveCopies + copy], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto scalar = [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0 + lane; i < i1; i += 64) one((uint8_t)bases[i], (uint8_t)quals[i]);
+    };
+    const int64_t c0 = (s0 + 15) >> 4, c1 = s1 >> 4;
+    if (ALIGNED && c0 < c1) {
+        scalar(s0, c0 << 4);
+        const u32x4 *bv = reinterpret_cast<const u32x4 *>(bases);
+        const u32x4 *qv = reinterpret_cast<const u32x4 *>(quals);
+        for (int64_t c = c0 + lane; c < c1; c += 64) {
+            const u32x4 b = bv[c], q = qv[c];
+            const uint32_t bw[4] = {b.x, b.y, b.z, b.w}, qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) one((bw[w] >> (8 * k)) & 0xFFu, (qw[w] >> (8 * k)) & 0xFFu);
+        }
+        scalar(c1 << 4, s1);
+    } else {
+        scalar(s0, s1);
+    }
+}
+
+// One wavefront per site: short ragged sites (DENSE = false: [offsets[s], offsets[s+1]), the long ones are left to
+// hist_csr_block_kernel) or short dense rows (DENSE = true: [s * row_stride, s * row_stride + n_samples)).
+template <bool ALIGNED, bool DENSE>
+__global__ __launch_bounds__(kHistThreads) void hist_wave_kernel(
+    int64_t n_sites, const int64_t *__restrict__ offsets, int64_t n_samples, int64_t row_stride,
+    const int8_t *__restrict__ bases, const int8_t *__restrict__ quals, uint32_t *__restrict__ counts)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t hist_all[kCsrWaves][BVC_NCLASS * kWaveCopies];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *hist = hist_all[wave];
-    for (int k = lane; k < BVC_NCLASS; k += 64) hist[k] = 0;
+    for (int k = lane; k < BVC_NCLASS * kWaveCopies; k += 64) hist[k] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     for (int64_t site = (int64_t)blockIdx.x * kCsrWaves + wave; site < n_sites; site += (int64_t)gridDim.x * kCsrWaves) {
-        const int64_t o0 = offsets[site], o1 = offsets[site + 1];
-        if (o1 - o0 >= kCsrLong) continue;                       // hist_csr_block_kernel's
-        for (int64_t i = o0 + lane; i < o1; i += 64) {
-            const uint32_t b = (uint8_t)bases[i], q = (uint8_t)quals[i];
-            if (b < 4u && q < 128u)
-                __hip_atomic_fetch_add(&hist[(b << 7) | q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        const int64_t o0 = DENSE ? site * row_stride : offsets[site];
+        const int64_t o1 = DENSE ? o0 + n_samples : offsets[site + 1];
+        if (!DENSE && o1 - o0 >= kCsrLong) continue;             // hist_csr_block_kernel's
+        wave_count_range<ALIGNED>(hist, bases, quals, o0, o1, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         uint32_t *dst = counts + site * BVC_NCLASS;
 #pragma unroll
         for (int k = 0; k < BVC_NCLASS / 64; ++k) {
-            dst[k * 64 + lane] = hist[k * 64 + lane];
-            hist[k * 64 + lane] = 0;
+            const int key = k * 64 + lane;
+            uint32_t sum = 0;
+#pragma unroll
+            for (int v = 0; v < kWaveCopies; ++v) { sum += hist[key * kWaveCopies + v]; hist[key * kWaveCopies + v] = 0; }
+            dst[key] = sum;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -506,7 +549,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_csr_block_kernel(
     };
     for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
         const int64_t s0 = offsets[site], s1 = offsets[site + 1];
-        if (s1 - s0 < kCsrLong) continue;                        // hist_csr_wave_kernel's (workgroup-uniform)
+        if (s1 - s0 < kCsrLong) continue;                        // hist_wave_kernel's (workgroup-uniform)
         // [s0, s1) = unaligned head, whole 16-sample chunks [c0, c1) of the concatenated arrays, unaligned tail
         const int64_t c0 = (s0 + 15) >> 4, c1 = s1 >> 4;
         if (ALIGNED && c0 < c1) {
@@ -597,8 +640,7 @@ int choose_hist_split(const LaunchState &st, int64_t n_sites, int64_t n_samples)
 enum KernelSlot : uint32_t {
     kSlotDense0 = 0, kSlotDense1, kSlotRanges0, kSlotRanges1, kSlotCsr0, kSlotCsr1, kSlotGroupByte,
     kSlotGroup = 8,            // + log2c (0..5)
-    kSlotGroupMulti2 = 16,     // + log2c (0..3)
-    kSlotGroupMulti4 = 20,     // + log2c (0..2)
+    kSlotGroupPipe = 16,       // + log2c (0..5)
 };
 
 static hipError_t raise_lds(LaunchState &st, uint32_t slot, const void *kernel, size_t bytes)
@@ -611,72 +653,64 @@ static hipError_t raise_lds(LaunchState &st, uint32_t slot, const void *kernel, 
 
 hipError_t launch_hist_dense(LaunchState &st, hipStream_t stream, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                              const int8_t *bases, const int8_t *quals, const uint8_t *group_of_sample,
-                             int n_groups, uint32_t *counts, int split, int64_t *group_scratch)
+                             int n_groups, uint32_t *counts, int split, int64_t *group_scratch, uint8_t *hist_of_sample)
 {
     if (n_sites <= 0) return hipSuccess;
     const bool aligned = ((reinterpret_cast<uintptr_t>(bases) | reinterpret_cast<uintptr_t>(quals)) & 15u) == 0 &&
                          (row_stride & 15) == 0;
     const size_t lds = (size_t)kLdsWords * sizeof(uint32_t);
     if (group_of_sample) {                       // counts = [site][n_groups + 1][512]
-        const bool galigned = aligned && (reinterpret_cast<uintptr_t>(group_of_sample) & 15u) == 0;
         const int n_hist = n_groups + 1;
-        const bool try_ranges = group_scratch != nullptr && n_samples > 0;
-        if (try_ranges) {
-            // Decided on the device, without a host round trip: the bounds kernel marks whether the samples are
-            // ordered by group; the range kernel and the general kernel are both launched and the one whose turn
-            // it is not returns at once.
-            auto rk = aligned ? hist_dense_ranges_kernel<true> : hist_dense_ranges_kernel<false>;
-            hipError_t e = raise_lds(st, aligned ? kSlotRanges1 : kSlotRanges0, reinterpret_cast<const void *>(rk), lds);
-            if (e != hipSuccess) return e;
-            e = hipMemsetAsync(group_scratch, 0, (size_t)(BVC_MAX_GROUPS + 4) * sizeof(int64_t), stream);
-            if (e != hipSuccess) return e;
-            const int64_t bgrid = (n_samples + 255) / 256;
-            hipLaunchKernelGGL(group_bounds_kernel, dim3((unsigned)(bgrid < 1024 ? bgrid : 1024)), dim3(256), 0, stream,
-                               group_of_sample, n_samples, n_groups, group_scratch);
-            const int64_t n_work = n_sites * n_hist;
-            hipLaunchKernelGGL(rk, dim3((unsigned)(n_work < 4096 ? n_work : 4096)), dim3(kHistThreads), lds, stream,
-                               n_sites, n_samples, row_stride, bases, quals, n_hist, group_scratch, counts);
-        }
-        const int64_t *bounds = try_ranges ? group_scratch : nullptr;
-        // general order.  Aligned calls with at least two sites: NSITE sites per workgroup pass share each chunk of
-        // group bytes (NSITE = st.group_sites: 2 by default, 4 when the histograms fit with one copy)
-        using MultiKernel = void (*)(int64_t, int64_t, int64_t, const int8_t *, const int8_t *, const uint8_t *, int,
-                                     uint32_t *, const int64_t *);
-        static const MultiKernel multi2[4] = {hist_dense_groups_multi_kernel<2, 0>, hist_dense_groups_multi_kernel<2, 1>,
-                                              hist_dense_groups_multi_kernel<2, 2>, hist_dense_groups_multi_kernel<2, 3>};
-        static const MultiKernel multi4[3] = {hist_dense_groups_multi_kernel<4, 0>, hist_dense_groups_multi_kernel<4, 1>,
-                                              hist_dense_groups_multi_kernel<4, 2>};
-        int nsite = st.group_sites > 0 ? st.group_sites : 2;
-        if (!galigned || n_sites < 2) nsite = 1;
-        while (nsite > 1 && (size_t)nsite * n_hist * BVC_NCLASS > (size_t)kLdsWords) nsite >>= 1;   // one copy must fit
-        if (nsite > 1) {
-            int log2c = 0;
-            const int max_log2c = nsite == 2 ? 3 : 2;
-            while (log2c < max_log2c && (size_t)nsite * n_hist * BVC_NCLASS * (2u << log2c) <= (size_t)kLdsWords) ++log2c;
-            const MultiKernel mk = nsite == 2 ? multi2[log2c] : multi4[log2c];
-            const size_t mlds = ((size_t)nsite * n_hist * BVC_NCLASS << log2c) * sizeof(uint32_t);
-            hipError_t e = raise_lds(st, (nsite == 2 ? kSlotGroupMulti2 : kSlotGroupMulti4) + log2c,
-                                     reinterpret_cast<const void *>(mk), lds);
-            if (e != hipSuccess) return e;
-            const int64_t n_pass = (n_sites + nsite - 1) / nsite;
-            hipLaunchKernelGGL(mk, dim3((unsigned)(n_pass < 4096 ? n_pass : 4096)), dim3(kHistThreads), mlds, stream,
-                               n_sites, n_samples, row_stride, bases, quals, group_of_sample, n_groups, counts, bounds);
-            return hipGetLastError();
-        }
+        if (n_samples <= 0)                      // no columns at all: every histogram is empty
+            return hipMemsetAsync(counts, 0, (size_t)n_sites * n_hist * BVC_NCLASS * sizeof(uint32_t), stream);
+        if (!group_scratch || !hist_of_sample) return hipErrorInvalidValue;
+        // Decided on the device, without a host round trip: the bounds kernel marks whether the samples are ordered by
+        // group (and writes the clamped labels); the range kernel and the any-order kernel are both launched and the
+        // one whose turn it is not returns at once.
+        auto rk = aligned ? hist_dense_ranges_kernel<true> : hist_dense_ranges_kernel<false>;
+        hipError_t e = raise_lds(st, aligned ? kSlotRanges1 : kSlotRanges0, reinterpret_cast<const void *>(rk), lds);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(group_scratch, 0, (size_t)(BVC_MAX_GROUPS + 4) * sizeof(int64_t), stream);
+        if (e != hipSuccess) return e;
+        const int64_t bgrid = (n_samples + 255) / 256;
+        hipLaunchKernelGGL(group_bounds_kernel, dim3((unsigned)(bgrid < 1024 ? bgrid : 1024)), dim3(256), 0, stream,
+                           group_of_sample, n_samples, n_groups, group_scratch, hist_of_sample);
+        const int64_t n_work = n_sites * n_hist;
+        hipLaunchKernelGGL(rk, dim3((unsigned)(n_work < 4096 ? n_work : 4096)), dim3(kHistThreads), lds, stream,
+                           n_sites, n_samples, row_stride, bases, quals, n_hist, group_scratch, counts);
         int log2c = 0;
         while (log2c < 5 && (size_t)n_hist * BVC_NCLASS * (2u << log2c) <= (size_t)kLdsWords) ++log2c;
-        using GroupKernel = void (*)(int64_t, int64_t, int64_t, const int8_t *, const int8_t *, const uint8_t *, int, int,
-                                     uint32_t *, const int64_t *);
-        static const GroupKernel aligned_kernels[6] = {
-            hist_dense_groups_kernel<true, 0>, hist_dense_groups_kernel<true, 1>, hist_dense_groups_kernel<true, 2>,
-            hist_dense_groups_kernel<true, 3>, hist_dense_groups_kernel<true, 4>, hist_dense_groups_kernel<true, 5>};
-        GroupKernel gk = galigned ? aligned_kernels[log2c] : hist_dense_groups_kernel<false, -1>;
-        hipError_t e = raise_lds(st, galigned ? kSlotGroup + log2c : kSlotGroupByte, reinterpret_cast<const void *>(gk), 2 * lds);
-        if (e != hipSuccess) return e;
         const size_t glds = ((size_t)n_hist * BVC_NCLASS << log2c) * sizeof(uint32_t);
         const int64_t ggrid = n_sites < 4096 ? n_sites : 4096;
-        hipLaunchKernelGGL(gk, dim3((unsigned)ggrid), dim3(kHistThreads), glds, stream, n_sites, n_samples,
-                           row_stride, bases, quals, group_of_sample, n_groups, log2c, counts, bounds);
+        if (aligned) {                           // hist_of_sample is the context's own 256-byte aligned buffer
+            using FastKernel = void (*)(int64_t, int64_t, int64_t, const int8_t *, const int8_t *, const uint8_t *, int,
+                                        uint32_t *, const int64_t *);
+            static const FastKernel fast[2][6] = {
+                {hist_dense_groups_kernel<0, false>, hist_dense_groups_kernel<1, false>, hist_dense_groups_kernel<2, false>,
+                 hist_dense_groups_kernel<3, false>, hist_dense_groups_kernel<4, false>, hist_dense_groups_kernel<5, false>},
+                {hist_dense_groups_kernel<0, true>, hist_dense_groups_kernel<1, true>, hist_dense_groups_kernel<2, true>,
+                 hist_dense_groups_kernel<3, true>, hist_dense_groups_kernel<4, true>, hist_dense_groups_kernel<5, true>}};
+            const int pipe = st.group_pipe ? 1 : 0;
+            const FastKernel fk = fast[pipe][log2c];
+            e = raise_lds(st, (pipe ? kSlotGroupPipe : kSlotGroup) + log2c, reinterpret_cast<const void *>(fk), lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(fk, dim3((unsigned)ggrid), dim3(kHistThreads), glds, stream, n_sites, n_samples, row_stride,
+                               bases, quals, hist_of_sample, n_groups, counts, group_scratch);
+        } else {
+            e = raise_lds(st, kSlotGroupByte, reinterpret_cast<const void *>(hist_dense_groups_bytes_kernel), lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(hist_dense_groups_bytes_kernel, dim3((unsigned)ggrid), dim3(kHistThreads), glds, stream,
+                               n_sites, n_samples, row_stride, bases, quals, group_of_sample, n_groups, log2c, counts,
+                               group_scratch);
+        }
+        return hipGetLastError();
+    }
+    if (split == 1 && n_samples <= kWaveRowMax && n_sites >= (int64_t)st.n_cu * 2 * kCsrWaves) {
+        // short rows, many sites: one wavefront per site (a 64 KiB fold per 10 KB row is what the block kernel would pay)
+        auto wk = aligned ? hist_wave_kernel<true, true> : hist_wave_kernel<false, true>;
+        const int64_t wgrid = (n_sites + kCsrWaves - 1) / kCsrWaves;
+        hipLaunchKernelGGL(wk, dim3((unsigned)(wgrid < 8192 ? wgrid : 8192)), dim3(kHistThreads), 0, stream, n_sites,
+                           (const int64_t *)nullptr, n_samples, row_stride, bases, quals, counts);
         return hipGetLastError();
     }
     auto kern = aligned ? hist_dense_kernel<true> : hist_dense_kernel<false>;
@@ -700,8 +734,9 @@ hipError_t launch_hist_csr(LaunchState &st, hipStream_t stream, int64_t n_sites,
     hipError_t e = raise_lds(st, aligned ? kSlotCsr1 : kSlotCsr0, reinterpret_cast<const void *>(bk), lds);
     if (e != hipSuccess) return e;
     const int64_t wgrid = (n_sites + kCsrWaves - 1) / kCsrWaves;
-    hipLaunchKernelGGL(hist_csr_wave_kernel, dim3((unsigned)(wgrid < 8192 ? wgrid : 8192)), dim3(kHistThreads), 0, stream,
-                       n_sites, offsets, bases, quals, counts);
+    auto wk = aligned ? hist_wave_kernel<true, false> : hist_wave_kernel<false, false>;
+    hipLaunchKernelGGL(wk, dim3((unsigned)(wgrid < 8192 ? wgrid : 8192)), dim3(kHistThreads), 0, stream,
+                       n_sites, offsets, (int64_t)0, (int64_t)0, bases, quals, counts);
     hipLaunchKernelGGL(bk, dim3((unsigned)(n_sites < 4096 ? n_sites : 4096)), dim3(kHistThreads), lds, stream, n_sites,
                        offsets, bases, quals, counts);
     return hipGetLastError();

@@ -25,6 +25,10 @@ static bool read_exact(BgzfReader &r, void *dst, size_t n) { return r.read(dst, 
 
 static int32_t le32(const unsigned char *p) { return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
 
+// Every length field of the file is checked against what was actually read before it is used (the reference gets
+// this from htslib): a truncated or corrupt file ends the parse with `false`, never with a read past a buffer.
+static const int32_t kMaxHeaderText = 1 << 28, kMaxRefs = 1 << 24, kMaxRefName = 1 << 16, kMaxRecord = 1 << 28;
+
 bool BamFile::open(const std::string &path)
 {
     path_ = path;
@@ -33,14 +37,17 @@ bool BamFile::open(const std::string &path)
     unsigned char b[8];
     if (!read_exact(r, b, 8) || std::memcmp(b, "BAM\1", 4) != 0) return false;
     const int32_t l_text = le32(b + 4);
+    if (l_text < 0 || l_text > kMaxHeaderText) return false;
     header_.resize((size_t)l_text);
     if (l_text && !read_exact(r, &header_[0], (size_t)l_text)) return false;
     if (!read_exact(r, b, 4)) return false;
     const int32_t n_ref = le32(b);
+    if (n_ref < 0 || n_ref > kMaxRefs) return false;
     ref_names_.clear();
     for (int32_t i = 0; i < n_ref; ++i) {
         if (!read_exact(r, b, 4)) return false;
         const int32_t l = le32(b);
+        if (l < 1 || l > kMaxRefName) return false;
         std::string name((size_t)l, '\0');
         if (!read_exact(r, &name[0], (size_t)l) || !read_exact(r, b, 4)) return false;
         name.resize(std::strlen(name.c_str()));
@@ -66,32 +73,41 @@ int BamFile::ref_index(const std::string &name) const
     return -1;
 }
 
-static bool read_record(BgzfReader &r, BamRecord &rec, std::vector<unsigned char> &buf)
+// One alignment record (SAM specification 4.2).  Returns false at end of file AND on a malformed record; `bad` tells
+// the two apart.
+static bool read_record(BgzfReader &r, BamRecord &rec, std::vector<unsigned char> &buf, bool &bad)
 {
     unsigned char b4[4];
-    if (!read_exact(r, b4, 4)) return false;
+    bad = false;
+    const size_t got = r.read(b4, 4);
+    if (got == 0) return false;                                   // clean end of file
+    bad = true;
+    if (got != 4) return false;
     const int32_t bs = le32(b4);
-    if (bs < 32) return false;
+    if (bs < 32 || bs > kMaxRecord) return false;
     buf.resize((size_t)bs);
     if (!read_exact(r, buf.data(), buf.size())) return false;
     const unsigned char *p = buf.data();
     rec.ref_id = le32(p);
     rec.pos = le32(p + 4);
-    const int l_rn = p[8];
+    const int64_t l_rn = p[8];
     rec.mapq = p[9];
-    const int n_cig = p[12] | (p[13] << 8);
+    const int64_t n_cig = p[12] | (p[13] << 8);
     rec.flag = (uint16_t)(p[14] | (p[15] << 8));
-    const int32_t l_seq = le32(p + 16);
+    const int64_t l_seq = le32(p + 16);
+    // fixed part + read name + cigar + packed bases + qualities must lie inside the block
+    if (l_seq < 0 || 32 + l_rn + 4 * n_cig + (l_seq + 1) / 2 + l_seq > (int64_t)bs) return false;
     const unsigned char *q = p + 32 + l_rn;
     rec.cigar.clear();
-    for (int i = 0; i < n_cig; ++i, q += 4) {
+    for (int64_t i = 0; i < n_cig; ++i, q += 4) {
         const uint32_t c = (uint32_t)le32(q);
         rec.cigar.emplace_back(kCigarOps[(c & 15) < 9 ? (c & 15) : 0], (int32_t)(c >> 4));
     }
     rec.seq.resize((size_t)l_seq);
-    for (int32_t i = 0; i < l_seq; ++i) rec.seq[i] = kSeqNt16[(q[i >> 1] >> ((i & 1) ? 0 : 4)) & 15];
+    for (int64_t i = 0; i < l_seq; ++i) rec.seq[(size_t)i] = kSeqNt16[(q[i >> 1] >> ((i & 1) ? 0 : 4)) & 15];
     q += (l_seq + 1) / 2;
     rec.qual.assign(reinterpret_cast<const char *>(q), (size_t)l_seq);
+    bad = false;
     return true;
 }
 
@@ -148,7 +164,8 @@ bool BamFile::fetch(int rid, int32_t beg, int32_t end, int min_mapq, std::vector
     if (!(bai_linear_offset(path_, rid, beg, voff) && r.seek(voff))) r.seek(first_record_);
     BamRecord rec;
     std::vector<unsigned char> buf;
-    while (read_record(r, rec, buf)) {
+    bool bad = false;
+    while (read_record(r, rec, buf, bad)) {
         if (rec.ref_id < 0 || rec.ref_id < rid) continue;
         if (rec.ref_id > rid || rec.pos >= end) break;                  // coordinate-sorted
         if ((rec.flag & 0x4) || rec.cigar.empty()) continue;
@@ -157,118 +174,129 @@ bool BamFile::fetch(int rid, int32_t beg, int32_t end, int min_mapq, std::vector
         if (rec.mapq < min_mapq) continue;                              // :298
         out.push_back(rec);
     }
+    // not "this sample has no reads here": the file is damaged, and a pileup made from the readable part would be
+    // silently incomplete
+    if (bad) throw std::runtime_error("ERROR: truncated or corrupt BAM record in " + path_);
     return true;
 }
 
 // ---- pileup rule ---------------------------------------------------------------------------------------
-static int get_offset(const BamRecord &r, int32_t pos)                   // src/BamProcess.cpp:232-261
-{
-    uint32_t offset = (uint32_t)(pos - (r.pos + 1));
-    uint32_t track = (uint32_t)r.pos;
-    for (auto const &cf : r.cigar) {
-        const char t = cf.first;
-        if (t != 'I' && t != 'S' && t != 'H') track += (uint32_t)cf.second;
-        if (track < (uint32_t)pos) {
-            switch (t) {
-            case 'I': case 'S': offset += (uint32_t)cf.second; break;
-            case 'D': case 'P': case 'N': offset -= (uint32_t)cf.second; break;
-            default: break;
-            }
-        } else {
-            break;
-        }
-    }
-    if (r.seq.empty() || offset > r.seq.length() - 1) throw std::out_of_range("index offset is out of range of the sequence");
-    return (int)offset;
-}
+// What has to come out is fixed by the reference (BamProcess::FindSnpAtPos / GetAllele / GetOffset,
+// src/BamProcess.cpp:4-94, 214-261): per position, the entry of the FIRST read that covers it; an indel token when
+// the position is the last reference base in front of an insertion or deletion; the next read instead when the first
+// one has a deletion or reference skip there.  How it is computed here is different: the reference re-scans a read's
+// CIGAR from its first operation for every position (twice: once to find the operation, once for the query offset).
+// Here each read's CIGAR is walked ONCE into prefix tables in the coordinates the rule uses, and because positions
+// only ascend, a cursor per table only ever moves forward: the work is O(operations + positions), not their product.
+//
+// The rule's coordinates, kept exactly (they are what the outputs depend on):
+//   ref_after[k]   "sx": read start + lengths of every operation except H and I.  Soft clips and pads advance it too.
+//   qry_after[k]   "sy": lengths of M, I, S and X ('=' does not count): where an insertion's bases are cut from.
+//   aln_after[k]   GetOffset's "track": read start + lengths of every operation except I, S and H.
+//   shift_after[k] GetOffset's running correction of the query offset: + I, + S, - D, - P, - N.
+namespace {
 
-static void get_allele(const BamRecord &r, int32_t pos, AlleleInfo &ale)  // src/BamProcess.cpp:214-230
-{
-    const int offset = get_offset(r, pos);
-    switch (r.seq[offset]) {
-    case 'A': ale.base = 0; break;
-    case 'C': ale.base = 1; break;
-    case 'G': ale.base = 2; break;
-    case 'T': ale.base = 3; break;
-    default: ale.base = 4;
+struct ReadWalk {
+    std::vector<int32_t> ref_after, qry_after, aln_after, shift_after;
+    size_t k_ref = 0, k_aln = 0;               // cursors (positions are queried in ascending order)
+    bool built = false;
+
+    void build(const BamRecord &r)
+    {
+        const size_t nc = r.cigar.size();
+        ref_after.resize(nc); qry_after.resize(nc); aln_after.resize(nc); shift_after.resize(nc);
+        int32_t sx = r.pos, sy = 0, track = r.pos, shift = 0;
+        for (size_t k = 0; k < nc; ++k) {
+            const char op = r.cigar[k].first;
+            const int32_t l = r.cigar[k].second;
+            if (op == 'M' || op == 'I' || op == 'S' || op == 'X') sy += l;
+            if (op != 'H' && op != 'I') sx += l;
+            if (op != 'I' && op != 'S' && op != 'H') track += l;
+            if (op == 'I' || op == 'S') shift += l;
+            else if (op == 'D' || op == 'P' || op == 'N') shift -= l;
+            ref_after[k] = sx; qry_after[k] = sy; aln_after[k] = track; shift_after[k] = shift;
+        }
+        built = true;
     }
-    ale.qual = (uint8_t)r.qual[offset];          // qualities[offset] - 33 on the ASCII form
-    ale.mapq = r.mapq;
-    ale.rpr = (uint8_t)(offset + 1);
-    ale.is_indel = 0;
-    ale.strand = (r.reverse() || r.mate_reverse()) ? 0 : 1;
-}
+
+    // Operation that holds `pos`: the first one whose ref_after reaches it (never an H or I: those leave ref_after
+    // where the operation before them put it, which did not reach pos).  nc when the CIGAR ends short of pos.
+    size_t op_at(int32_t pos)
+    {
+        while (k_ref < ref_after.size() && ref_after[k_ref] < pos) ++k_ref;
+        return k_ref;
+    }
+
+    // Query offset of `pos` as GetOffset computes it: the corrections of all operations in front of the first one
+    // whose aln_after reaches pos.
+    int64_t query_offset(const BamRecord &r, int32_t pos)
+    {
+        while (k_aln < aln_after.size() && aln_after[k_aln] < pos) ++k_aln;
+        const int32_t shift = k_aln == 0 ? 0 : shift_after[k_aln - 1];
+        return (int64_t)(uint32_t)((uint32_t)(pos - (r.pos + 1)) + (uint32_t)shift);   // unsigned 32-bit, as in the reference
+    }
+};
+
+inline uint8_t strand_of(const BamRecord &r) { return (r.reverse() || r.mate_reverse()) ? 0 : 1; }
+
+}  // namespace
 
 void find_snp_at_pos(const std::vector<BamRecord> &rv, int32_t rg_s, const std::string &refseq,
                      const std::vector<int32_t> &pv, PosAlleleMap &allele_m)
 {
     if (rv.empty()) return;
-    size_t i = 0, j = 0;
-    const size_t last = rv.size() - 1;
-    const BamRecord *r = &rv[0];
-    AlleleInfo ale;
+    std::vector<ReadWalk> walks(rv.size());
+    auto walk_of = [&](size_t j) -> ReadWalk & {
+        if (!walks[j].built) walks[j].build(rv[j]);
+        return walks[j];
+    };
+    auto covers = [&](size_t j, int32_t pos) { return pos >= rv[j].pos + 1 && pos <= rv[j].end_pos(); };
+
+    size_t first = 0;                          // first read that has not ended in front of the current position
+    AlleleInfo ale;                            // one object for the whole call, as in the reference: an indel entry
+                                               // keeps the mapq of the base entry made before it
     for (int32_t pos : pv) {
-        if (pos < r->pos + 1) continue;
-        bool eof = false, next = false;
-        while (pos > r->end_pos()) {
-            if (i == last) { eof = true; break; }
-            r = &rv[++i]; j = i;
-            if (pos < r->pos + 1) { next = true; break; }
-        }
-        if (next || eof) continue;
-        for (;;) {
-            const auto &c = r->cigar;
-            const size_t nc = c.size();
-            size_t k;
-            int sx = r->pos, sy = 0;
-            for (k = 0; k < nc; ++k) {
-                const char op = c[k].first;
-                const int l = c[k].second;
-                if (op == 'M' || op == 'I' || op == 'S' || op == 'X') sy += l;
-                if (op == 'H' || op == 'I') continue;
-                sx += l;                             // note: soft clips and pads advance sx too, as in the reference
-                if (pos <= sx) break;
-            }
-            if (k >= nc) break;                      // the reference asserts here
-            const size_t sk = k;
-            const char op = c[sk].first;
-            int indel = 0;
-            std::string indel_str;
-            if (sx == pos && sk + 1 < nc) {
-                const char op2 = c[sk + 1].first;
-                const int l2 = c[sk + 1].second;
-                if (op2 == 'D') { indel = -l2; indel_str = "-" + refseq.substr((size_t)(pos - rg_s + 1), (size_t)l2); }
-                else if (op2 == 'I') { indel = l2; indel_str = "+" + r->seq.substr((size_t)sy, (size_t)l2); }
-                else if (op2 == 'P' && sk + 2 < nc) {
-                    indel_str = "N";
-                    int l3 = 0;                      // the reference's loop re-reads c[sk] (src/BamProcess.cpp:60-62)
-                    for (size_t kk = sk + 2; kk < nc; ++kk) {
-                        const char o = c[sk].first;
-                        if (o == 'I') l3 += c[sk].second;
-                        else if (o == 'D' || o == 'M' || o == 'N' || o == 'X') break;
-                    }
-                    if (l3 > 0) indel = l3;
+        while (first + 1 < rv.size() && rv[first].end_pos() < pos) ++first;
+        if (!covers(first, pos)) continue;     // nobody covers it (later reads start even further right)
+        for (size_t j = first;; ++j) {
+            const BamRecord &r = rv[j];
+            ReadWalk &w = walk_of(j);
+            const size_t k = w.op_at(pos);
+            if (k >= r.cigar.size()) break;    // CIGAR shorter than the read's span claims (the reference asserts)
+            const char op = r.cigar[k].first;
+            // last reference base of its operation, with an insertion or a deletion next: the indel token
+            if (w.ref_after[k] == pos && k + 1 < r.cigar.size()) {
+                const char next_op = r.cigar[k + 1].first;
+                const int32_t next_len = r.cigar[k + 1].second;
+                // (a pad next never yields a token: the reference's scan for the insertion behind it re-reads the
+                // current operation, which is never an insertion, src/BamProcess.cpp:60-66)
+                if ((next_op == 'D' || next_op == 'I') && next_len != 0) {
+                    ale.strand = strand_of(r);
+                    ale.base = 5; ale.qual = r.mapq; ale.rpr = 0; ale.is_indel = 1;
+                    ale.indel = next_op == 'D' ? "-" + refseq.substr((size_t)(pos - rg_s + 1), (size_t)next_len)
+                                               : "+" + r.seq.substr((size_t)w.qry_after[k], (size_t)next_len);
+                    allele_m.insert({pos, ale});
+                    break;
                 }
             }
-            if (indel != 0) {
-                ale.strand = (r->reverse() || r->mate_reverse()) ? 0 : 1;
-                ale.base = 5; ale.qual = r->mapq; ale.rpr = 0; ale.is_indel = 1; ale.indel = indel_str;
-                allele_m.insert({pos, ale});
-                break;
-            }
-            if (op != 'D' && op != 'N') {
-                get_allele(*r, pos, ale);
+            if (op != 'D' && op != 'N') {      // a base of this read
+                const int64_t off = w.query_offset(r, pos);
+                if (r.seq.empty() || off > (int64_t)r.seq.length() - 1)
+                    throw std::out_of_range("index offset is out of range of the sequence");
+                const char c = r.seq[(size_t)off];
+                ale.base = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
+                ale.qual = (uint8_t)r.qual[(size_t)off];
+                ale.mapq = r.mapq;
+                ale.rpr = (uint8_t)(off + 1);
+                ale.is_indel = 0;
+                ale.strand = strand_of(r);
                 ale.indel.clear();
                 allele_m.insert({pos, ale});
                 break;
-            } else if (j < last) {
-                r = &rv[++j];
-                if (pos < r->pos + 1 || pos > r->end_pos()) break;
-            } else {
-                break;
             }
+            // deleted or skipped in this read: the NEXT read gets the position, if it covers it
+            if (j + 1 >= rv.size() || !covers(j + 1, pos)) break;
         }
-        r = &rv[i]; j = i;
     }
 }
 

@@ -3,6 +3,9 @@
 #include <string>
 #include <vector>
 
+#include <sstream>
+
+#include "bam.h"
 #include "pileup.h"
 #include "stats.h"
 
@@ -52,6 +55,23 @@ bvchost_site *bvchost_site_parse(const char *lines, int32_t pos)
     }
     return s;
 }
+// The same from binary batch records: `blob` = per batch  u32 samples-in-batch | u32 payload bytes | payload.
+bvchost_site *bvchost_site_parse_bin(const char *blob, size_t len, int32_t n_batches, int32_t pos)
+{
+    bvchost_site *s = new bvchost_site();
+    s->col.pos = pos;
+    int32_t j = 0;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(blob), *end = p + len;
+    auto u32 = [](const unsigned char *q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); };
+    for (int32_t b = 0; b < n_batches && end - p >= 8; ++b) {
+        const uint32_t n_in = u32(p), n = u32(p + 4);
+        p += 8;
+        if ((size_t)(end - p) < n || !parse_pileup_bin(p, n, j, s->col)) { delete s; return nullptr; }
+        p += n;
+        j += (int32_t)n_in;
+    }
+    return s;
+}
 void bvchost_site_free(bvchost_site *s) { delete s; }
 int32_t bvchost_site_size(const bvchost_site *s) { return (int32_t)s->col.aiv.size(); }
 // fields: 0 base, 1 mapq, 2 qual, 3 rpr, 4 strand, 5 is_indel, 6 sample index
@@ -92,6 +112,48 @@ size_t bvchost_format_token(int base, int mapq, int qual, int rpr, int strand, c
     std::string s;
     format_pileup_token(base < 0 ? nullptr : &a, s);
     return copy_out(s, out, cap);
+}
+
+// The per-sample pileup rule on caller-made reads (tests).  `reads`: one read per line,
+// "pos0 flag mapq cigar seq q,q,q,..." (pos0 = 0-based leftmost, qualities raw phred); `positions`: ascending, 1-based.
+// Output: the temp-batch tokens of those positions for this one sample, in order (". " where the sample has no entry).
+size_t bvchost_pileup_tokens(const char *reads, const int32_t *positions, int32_t n_pos, int32_t rg_s, const char *refseq,
+                             char *out, size_t cap)
+{
+    std::vector<BamRecord> rv;
+    std::istringstream in(reads);
+    std::string line;
+    while (std::getline(in, line)) {
+        if (line.empty()) continue;
+        std::istringstream ls(line);
+        BamRecord r;
+        int flag = 0, mapq = 0;
+        std::string cigar, quals;
+        ls >> r.pos >> flag >> mapq >> cigar >> r.seq >> quals;
+        r.flag = (uint16_t)flag; r.mapq = (uint8_t)mapq; r.ref_id = 0;
+        for (size_t i = 0; i < cigar.size();) {
+            int32_t l = 0;
+            while (i < cigar.size() && cigar[i] >= '0' && cigar[i] <= '9') l = l * 10 + (cigar[i++] - '0');
+            r.cigar.emplace_back(cigar[i++], l);
+        }
+        std::istringstream qs(quals);
+        std::string tok;
+        while (std::getline(qs, tok, ',')) r.qual.push_back((char)std::atoi(tok.c_str()));
+        rv.push_back(r);
+    }
+    std::vector<int32_t> pv(positions, positions + n_pos);
+    PosAlleleMap m;
+    std::string res;
+    try {
+        find_snp_at_pos(rv, rg_s, refseq, pv, m);
+    } catch (const std::exception &e) {
+        return copy_out(std::string("!") + e.what(), out, cap);
+    }
+    for (int32_t p : pv) {
+        auto it = m.find(p);
+        format_pileup_token(it == m.end() ? nullptr : &it->second, res);
+    }
+    return copy_out(res, out, cap);
 }
 
 }  // extern "C"

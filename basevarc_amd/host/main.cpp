@@ -13,6 +13,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <ctime>
 #include <fstream>
 #include <iostream>
@@ -57,13 +58,14 @@ static const char *BASETYPE_MESSAGE =
     "  --keep_tmp,              Don't remove tmp files when basetype finished\n"
     "  --verbose,    -v         Set verbose output\n"
     "  --gpus           <INT>   MI355X devices to use [all]\n"
-    "  --tile           <INT>   Positions per device call [4096]\n";
+    "  --tile           <INT>   Positions per device call [4096]\n"
+    "  --tmp-format     <STR>   Temp-batch files written by the load phase: text (as BaseVarC) or bin [text]\n";
 
 namespace opt {
 static bool verbose = false, rerun = false, load = false, keep_tmp = false;
 static int mapq = 10, thread = 1, batch = 10, gpus = 0, tile = 4096;
 static double maf = 0.001;
-static std::string input, reference, posfile, group, region, output;
+static std::string input, reference, posfile, group, region, output, tmp_format = "text";
 }  // namespace opt
 
 static const char *shortopts = "hva:i:r:p:s:o:q:t:b:g:";
@@ -76,7 +78,8 @@ static const struct option longopts[] = {
     {"region", required_argument, NULL, 's'}, {"output", required_argument, NULL, 'o'},
     {"batch", required_argument, NULL, 'b'}, {"thread", required_argument, NULL, 't'},
     {"mapq", required_argument, NULL, 'q'},  {"gpus", required_argument, NULL, 9},
-    {"tile", required_argument, NULL, 10},   {NULL, 0, NULL, 0}};
+    {"tile", required_argument, NULL, 10},   {"tmp-format", required_argument, NULL, 11},
+    {NULL, 0, NULL, 0}};
 
 static void parse_options(int argc, char **argv, const char *msg)          // src/BaseVarC.cpp:797-827
 {
@@ -99,10 +102,12 @@ static void parse_options(int argc, char **argv, const char *msg)          // sr
         case 6: opt::keep_tmp = true; break;
         case 9: arg >> opt::gpus; break;
         case 10: arg >> opt::tile; break;
+        case 11: arg >> opt::tmp_format; break;
         case 'v': opt::verbose = true; break;
         default: die = true;
         }
     }
+    if (opt::tmp_format != "text" && opt::tmp_format != "bin") die = true;
     if (die || opt::input.empty() || opt::output.empty()) {
         std::cerr << msg;
         std::exit(die ? EXIT_FAILURE : EXIT_SUCCESS);
@@ -164,24 +169,37 @@ static void bt_r(const std::vector<std::string> &bams, const std::vector<int32_t
         names += sm + '\t';
     }
     names += "\n";
+    const bool bin = opt::tmp_format == "bin";
     std::vector<BgzfWriter *> fpv;
     for (int i = 0; i < thread; ++i) {
         BgzfWriter *fp = new BgzfWriter(tmp_name(i, ib));
         if (!fp->ok()) throw std::runtime_error("ERROR: fail to write " + tmp_name(i, ib));
-        fp->write(names);
+        if (bin) { std::string h; bin_batch_header((uint32_t)(b1 - b0), names, h); fp->write(h); }
+        else fp->write(names);
         fpv.push_back(fp);
     }
     const size_t psize = pv.size();
     const size_t window = psize % thread + psize / thread;
-    std::string out;
+    std::string out, payload;
     for (size_t i = 0, j = 0; i < psize; ++i) {
         const int32_t p = pv[i];
         out.clear();
-        for (auto const &m : allele_mv) {
-            auto it = m.find(p);
-            format_pileup_token(it == m.end() ? nullptr : &it->second, out);
+        if (bin) {                              // one record per position: u32 payload bytes + the entries present
+            payload.clear();
+            for (size_t k = 0; k < allele_mv.size(); ++k) {
+                auto it = allele_mv[k].find(p);
+                if (it != allele_mv[k].end()) bin_batch_entry(it->second, (uint32_t)k, payload);
+            }
+            const uint32_t n = (uint32_t)payload.size();
+            for (int t = 0; t < 4; ++t) out.push_back((char)((n >> (8 * t)) & 0xff));
+            out += payload;
+        } else {
+            for (auto const &m : allele_mv) {
+                auto it = m.find(p);
+                format_pileup_token(it == m.end() ? nullptr : &it->second, out);
+            }
+            out += "\n";
         }
-        out += "\n";
         if (i == (j + 1) * window && j + 1 < (size_t)thread) ++j;
         fpv[j]->write(out);
     }
@@ -209,19 +227,24 @@ struct TileRunner {
     std::vector<SiteColumn> sites;
     std::vector<int8_t> refs;
 
+    // tile buffers live as long as the runner: a flush refills them, it does not reallocate them
+    std::vector<bvc_site_result> res;
+    std::vector<bvc_group_result> gres;
+    std::vector<int64_t> offsets;
+    std::vector<int8_t> bases, quals;
+
     void flush()
     {
         const int64_t ns = (int64_t)sites.size();
         if (ns == 0) return;
-        std::vector<bvc_site_result> res((size_t)ns);
-        std::vector<bvc_group_result> gres;
+        res.resize((size_t)ns);
         const int ng = groups ? (int)groups->names.size() : 0;
         int rc;
         double t0 = StageClock::now(), t1;
         if (ng == 0) {
             // ragged form: exactly the vectors bt_f builds (src/BaseVarC.cpp:550-559)
-            std::vector<int64_t> offsets(1, 0);
-            std::vector<int8_t> bases, quals;
+            offsets.assign(1, 0);
+            bases.clear(); quals.clear();
             for (auto const &s : sites) {
                 for (auto const &a : s.aiv)
                     if (a.is_indel == 0) { bases.push_back((int8_t)a.base); quals.push_back((int8_t)a.qual); }
@@ -234,8 +257,9 @@ struct TileRunner {
         } else {
             // dense [site][column] tile with -1 for "no observation"; columns are the samples ordered by group
             // (Groups::order_columns), the group of each column is shared by all sites
-            const int64_t stride = ((int64_t)n_samples + 15) / 16 * 16;
-            std::vector<int8_t> bases((size_t)(ns * stride), (int8_t)-1), quals((size_t)(ns * stride), (int8_t)0);
+            const int64_t stride = ((int64_t)n_samples + 127) / 128 * 128;
+            bases.assign((size_t)(ns * stride), (int8_t)-1);
+            quals.assign((size_t)(ns * stride), (int8_t)0);
             for (int64_t s = 0; s < ns; ++s)
                 for (size_t k = 0; k < sites[s].aiv.size(); ++k) {
                     const AlleleInfo &a = sites[s].aiv[k];
@@ -272,16 +296,66 @@ struct TileRunner {
     }
 };
 
+// One temp-batch file of a thread, in either form (detected from its first bytes).
+struct BatchInput {
+    BgzfReader rd;
+    bool bin = false;
+    uint32_t n_in_batch = 0;                   // binary form: samples of this batch (the text form counts tokens)
+    std::string names;                         // first line without its newline: tab-terminated sample names
+    std::vector<unsigned char> rec;
+
+    explicit BatchInput(const std::string &path) : rd(path)
+    {
+        unsigned char head[16];
+        const size_t got = rd.read(head, 8);
+        if (got == 8 && std::memcmp(head, kBinBatchMagic, 8) == 0) {
+            bin = true;
+            if (rd.read(head, 8) != 8) throw std::runtime_error("ERROR: truncated temp batch " + path);
+            n_in_batch = (uint32_t)head[0] | ((uint32_t)head[1] << 8) | ((uint32_t)head[2] << 16) | ((uint32_t)head[3] << 24);
+            const uint32_t l = (uint32_t)head[4] | ((uint32_t)head[5] << 8) | ((uint32_t)head[6] << 16) | ((uint32_t)head[7] << 24);
+            names.resize(l);
+            if (l && rd.read(&names[0], l) != l) throw std::runtime_error("ERROR: truncated temp batch " + path);
+            if (!names.empty() && names.back() == '\n') names.pop_back();
+        } else {                                // text form: start over and take the names line
+            rd.seek(0);
+            rd.getline(names);
+        }
+    }
+
+    // The next position's entries of this batch; returns the number of samples the batch spans (the `j` advance).
+    int32_t next(int32_t j0, SiteColumn &site, std::string &line, StageClock &clk)
+    {
+        double t0 = StageClock::now();
+        if (bin) {
+            unsigned char b4[4];
+            if (rd.read(b4, 4) != 4) { clk.read += StageClock::now() - t0; return (int32_t)n_in_batch; }
+            const uint32_t n = (uint32_t)b4[0] | ((uint32_t)b4[1] << 8) | ((uint32_t)b4[2] << 16) | ((uint32_t)b4[3] << 24);
+            rec.resize(n);
+            if (n && rd.read(rec.data(), n) != n) throw std::runtime_error("ERROR: truncated temp batch record");
+            double t1 = StageClock::now();
+            clk.read += t1 - t0;
+            if (!parse_pileup_bin(rec.data(), n, j0, site)) throw std::runtime_error("ERROR: malformed temp batch record");
+            clk.parse += StageClock::now() - t1;
+            return (int32_t)n_in_batch;
+        }
+        const bool got = rd.getline(line);
+        double t1 = StageClock::now();
+        clk.read += t1 - t0;
+        const int32_t adv = got ? parse_pileup_line(line.data(), line.size(), j0, site) : 0;
+        clk.parse += StageClock::now() - t1;
+        return adv;
+    }
+};
+
 static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32_t> &pv, const std::string &refseq,
                  const std::string &chr, int32_t rg_s, int32_t N, int thread, int ithread, int device)
 {
     BgzfWriter fpv(opt::output + "." + std::to_string(ithread) + ".vcf.gz");
     BgzfWriter fpc(opt::output + "." + std::to_string(ithread) + ".cvg.gz");
-    std::vector<BgzfReader *> fpiv;
-    for (auto const &f : ftmp_v) fpiv.push_back(new BgzfReader(f));
+    std::vector<BatchInput *> fpiv;
+    for (auto const &f : ftmp_v) fpiv.push_back(new BatchInput(f));
     std::string sams, line;
-    for (auto fp : fpiv)
-        if (fp->getline(line)) sams += line;
+    for (auto fp : fpiv) sams += fp->names;
     if (!sams.empty()) sams.pop_back();                                 // names are tab-terminated
     std::vector<std::string> names;
     { std::istringstream iss(sams); std::string id; while (std::getline(iss, id, '\t')) names.push_back(id); }
@@ -333,14 +407,7 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
         site.clear();
         site.pos = p;
         int32_t j = 0;
-        for (auto fp : fpiv) {
-            double t0 = StageClock::now();
-            const bool got = fp->getline(line);
-            double t1 = StageClock::now();
-            tr.clk.read += t1 - t0;
-            if (got) j += parse_pileup_line(line.data(), line.size(), j, site);
-            tr.clk.parse += StageClock::now() - t1;
-        }
+        for (auto fp : fpiv) j += fp->next(j, site, line, tr.clk);
         if (!site.aiv.empty()) {
             const char rc = refseq[(size_t)(p - rg_s)];
             const int8_t ref_base = rc == 'A' ? 0 : rc == 'C' ? 1 : rc == 'G' ? 2 : rc == 'T' ? 3 : -1;
@@ -447,11 +514,22 @@ static void run_basetype(int argc, char **argv)                          // src/
                 try { bt_s(ftmp_vv[(size_t)i], pv, refseq, chr, rg_s, N, thread, i, i % gpus); }
                 catch (const std::exception &e) { std::lock_guard<std::mutex> g(mu); if (werr.empty()) werr = e.what(); }
             });
+        // Every worker is joined BEFORE anything can throw: unwinding past a joinable std::thread is std::terminate,
+        // which would lose the error text and leave the other threads in the middle of their device calls.
+        for (auto &w : workers) w.join();
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (!werr.empty()) {
+                for (int i = 0; i < thread; ++i) {                       // partial sub-files are of no use; the temp
+                    std::remove((opt::output + "." + std::to_string(i) + ".vcf.gz").c_str());   // batches stay for --rerun
+                    std::remove((opt::output + "." + std::to_string(i) + ".cvg.gz").c_str());
+                }
+                throw std::runtime_error(werr);
+            }
+        }
         // merge the per-thread sub-files in thread (= position) order (src/BaseVarC.cpp:268-296)
         BgzfWriter fov(opt::output + ".vcf.gz"), foc(opt::output + ".cvg.gz");
         for (int i = 0; i < thread; ++i) {
-            workers[(size_t)i].join();
-            if (!werr.empty()) throw std::runtime_error(werr);
             const std::string subvcf = opt::output + "." + std::to_string(i) + ".vcf.gz";
             const std::string subcvg = opt::output + "." + std::to_string(i) + ".cvg.gz";
             // the reference re-reads and re-compresses the sub-files line by line (src/BaseVarC.cpp:279-290); BGZF

@@ -94,6 +94,66 @@ int parse_pileup_line(const char *line, size_t len, int32_t j0, SiteColumn &site
     return j - j0;
 }
 
+// ---- temp-batch binary form ---------------------------------------------------------------------------
+const char kBinBatchMagic[8] = {'B', 'V', 'C', 'B', 'A', 'T', '1', '\n'};
+
+static inline void put_u32(std::string &o, uint32_t v) { for (int i = 0; i < 4; ++i) o.push_back((char)((v >> (8 * i)) & 0xff)); }
+static inline uint32_t get_u32(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+void bin_batch_header(uint32_t n_samples_in_batch, const std::string &names_line, std::string &out)
+{
+    out.append(kBinBatchMagic, 8);
+    put_u32(out, n_samples_in_batch);
+    put_u32(out, (uint32_t)names_line.size());
+    out += names_line;
+}
+
+void bin_batch_entry(const AlleleInfo &a, uint32_t j, std::string &payload)
+{
+    put_u32(payload, j);
+    payload.push_back((char)a.base); payload.push_back((char)a.mapq); payload.push_back((char)a.qual);
+    payload.push_back((char)a.rpr);
+    payload.push_back((char)((a.strand & 1) | (a.is_indel ? 2 : 0)));
+    if (a.is_indel) {
+        const size_t n = a.indel.size() < 0xffff ? a.indel.size() : 0xffff;
+        payload.push_back((char)(n & 0xff)); payload.push_back((char)(n >> 8));
+        payload.append(a.indel.data(), n);
+    }
+}
+
+bool parse_pileup_bin(const unsigned char *p, size_t len, int32_t j0, SiteColumn &site)
+{
+    const unsigned char *end = p + len;
+    AlleleInfo &ai = g_carry;
+    while (p < end) {
+        if (end - p < 9) return false;
+        const int32_t j = j0 + (int32_t)get_u32(p);
+        const unsigned flags = p[8];
+        if (flags & 2) {                                         // indel token: only is_indel / indel change (:431-436)
+            if (end - p < 11) return false;
+            const size_t n = (size_t)p[9] | ((size_t)p[10] << 8);
+            if ((size_t)(end - p) < 11 + n) return false;
+            ai.is_indel = 1;
+            ai.indel.assign(reinterpret_cast<const char *>(p + 11), n);
+            site.aiv.push_back(ai);
+            site.sample.push_back(j);
+            p += 11 + n;
+        } else {                                                 // base token, through the same bit-field widths
+            ai.is_indel = 0;
+            ai.base = (uint8_t)(p[4] & 7);
+            ai.mapq = p[5]; ai.qual = p[6]; ai.rpr = p[7];
+            ai.strand = (uint8_t)(flags & 1);
+            if (ai.base != 4) {                                  // skip N base, :427
+                site.aiv.push_back(ai);
+                site.aiv.back().indel.clear();
+                site.sample.push_back(j);
+            }
+            p += 9;
+        }
+    }
+    return true;
+}
+
 // ---- headers ---------------------------------------------------------------------------------------
 const char *const kCvgHeader =
     "##fileformat=CVGv1.0\n"

@@ -69,6 +69,22 @@ int parse_pileup_line(const char *line, size_t len, int32_t j0, SiteColumn &site
 // The parser carries one AlleleInfo across calls within a thread, as bt_s does; call this at thread start.
 void reset_parser_carry();
 
+// ---- temp-batch binary form (additive: `--tmp-format bin`; the text form above stays the default) ----------------
+// Same content as the text form, without the tokenising: a BGZF stream of
+//   magic "BVCBAT1\n" | u32 samples in this batch | u32 length + the text form's first line (tab-terminated names)
+// and then, per position of the thread's window, one record
+//   u32 payload bytes | entries...      entry = u32 sample-in-batch | u8 base mapq qual rpr flags | [u16 n + indel text]
+// (flags: bit 0 strand, bit 1 indel).  Only samples WITH data take space: at low coverage the text form spends two
+// bytes (". ") on every absent sample and the parser a branch, this form nothing.  Little-endian.
+extern const char kBinBatchMagic[8];
+void bin_batch_header(uint32_t n_samples_in_batch, const std::string &names_line, std::string &out);
+// Appends sample `j`'s entry to a position record under construction (payload only).
+void bin_batch_entry(const AlleleInfo &a, uint32_t j, std::string &payload);
+// Decodes one position record's payload; sample indices are offset by j0.  Reproduces the text parser's observable
+// quirks: N bases dropped, and the one long-lived AlleleInfo whose fields an indel entry inherits
+// (src/BaseVarC.cpp:392, 407-440) -- so both forms give identical SiteColumns.  Returns false on a malformed record.
+bool parse_pileup_bin(const unsigned char *payload, size_t len, int32_t j0, SiteColumn &site);
+
 // ---- emission (f2) -------------------------------------------------------------------------------------
 extern const char *const kCvgHeader;
 extern const char *const kVcfHeader;

@@ -118,32 +118,26 @@ double bt_fisher_exact(int n11, int n12, int n21, int n22)
     return p;
 }
 
-// Sum of the ranks (average rank for ties) of the first n1 elements of x: src/Algorithm.cpp:27-53.
-// sortidx sorts DESCENDING (src/BaseVarUtils.h:31-36), so rank 1 is the largest value.  The reference reads
-// idx[i+1] one past the end on the last iteration before testing i + 1 < s; the value is unused, so the
-// read is simply not made here.
+// Rank sum of the first sample in the pooled data (what rankR1 returns, src/Algorithm.cpp:27-53): values ranked in
+// DESCENDING order (the reference sorts with '>', src/BaseVarUtils.h:31-36, so rank 1 is the largest), every run of
+// equal values sharing the mean of the ranks it spans.  Computed run by run: a run occupying ranks lo..hi gives each
+// of its members (lo + hi) / 2, and only the members that came from the first sample (pooled index < n1) are summed.
 static double rank_r1(const std::vector<double> &x, size_t n1)
 {
-    std::vector<size_t> idx(x.size());
-    std::iota(idx.begin(), idx.end(), 0);
-    std::sort(idx.begin(), idx.end(), [&x](size_t a, size_t b) { return x[a] > x[b]; });
-    const int s = (int)idx.size();
-    int k = 0, n = 0;
+    const size_t n = x.size();
+    std::vector<size_t> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&x](size_t a, size_t b) { return x[a] > x[b]; });
     double r1 = 0.0;
-    for (int i = 0; i < s; ++i) {
-        const size_t id1 = idx[i];
-        if (i + 1 < s && x[id1] == x[idx[i + 1]]) {
-            k += i + 1;
-            n++;
-        } else if (k > 0) {
-            k += i + 1;
-            const double avg = (double)k / (n + 1);
-            for (int j = i; i - n - j <= 0; j--)
-                if (idx[j] < n1) r1 += avg;
-            k = 0; n = 0;
-        } else if (id1 < n1) {
-            r1 += i + 1;
-        }
+    for (size_t lo = 0; lo < n;) {
+        size_t hi = lo;                                         // [lo, hi] = one run of equal values (0-based places)
+        size_t from_first = order[lo] < n1 ? 1 : 0;
+        while (hi + 1 < n && x[order[hi + 1]] == x[order[lo]]) { ++hi; from_first += order[hi] < n1 ? 1 : 0; }
+        // ranks lo+1 .. hi+1: their sum is an integer, divided once by the run length as the reference does
+        const size_t len = hi - lo + 1;
+        const double shared = len == 1 ? (double)(lo + 1) : (double)((lo + 1 + hi + 1) * len / 2) / (double)len;
+        for (size_t t = 0; t < from_first; ++t) r1 += shared;   // added one member at a time, like the reference's loop
+        lo = hi + 1;
     }
     return r1;
 }

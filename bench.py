@@ -79,7 +79,7 @@ def group_labels(np, n, k, layout):
 def hist_kernel_name(groups, layout):
     if groups <= 0:
         return "hist_dense_kernel"
-    return "hist_dense_ranges_kernel" if layout == "ordered" else "hist_dense_groups_multi_kernel"
+    return "hist_dense_ranges_kernel" if layout == "ordered" else "hist_dense_groups_kernel"
 
 
 def main():

@@ -181,9 +181,10 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
  *   "em_waves_per_cu"  0 = default policy, 1..32 resident EM wavefronts per CU
  *   "em_wpb"           waves per EM workgroup: 4 (default) or 1
  *   "hist_split"       0 = by tile shape, 1..64 workgroups sharing a site in the dense histogram pass
- *   "group_sites"      0 = default (2); 1, 2 or 4 sites per workgroup pass of the any-order group histogram
+ *   "group_pipe"       any-order group histogram: 1 (default) issues the next chunk's loads before counting the
+ *                      current one, 0 loads two chunks then counts both
  * A new context starts from the environment variables BVC_EM_WAVES_PER_CU, BVC_EM_WPB, BVC_HIST_SPLIT,
- * BVC_GROUP_SITES when they are set. */
+ * BVC_GROUP_PIPE when they are set. */
 int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value);
 
 /* ---- measurement aid ------------------------------------------------------------------------------- */

@@ -9,8 +9,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("thread,grouped", [(1, False), (4, False), (2, True)])
-def test_basetype_command_on_reference_test_data(tmp_path, thread, grouped):
+@pytest.mark.parametrize("thread,grouped,tmp_format", [(1, False, "text"), (4, False, "text"), (2, True, "text"),
+                                                       (3, False, "bin"), (2, True, "bin")])
+def test_basetype_command_on_reference_test_data(tmp_path, thread, grouped, tmp_format):
     from basevarc_amd import build as b
     from tests import hostref
     exe, _ = b.build_host()
@@ -20,6 +21,8 @@ def test_basetype_command_on_reference_test_data(tmp_path, thread, grouped):
     pipe = hostref.Pipeline(mapq=20, batch=10, thread=thread)
     cmd = [exe, "basetype", "--rerun", "-q", "20", "-t", str(thread), "-b", "10", "-i", lst, "-s", hostref.REGION,
            "-r", fa, "-o", out]
+    if tmp_format != "text":                                      # additive: binary temp batches, same outputs
+        cmd += ["--tmp-format", tmp_format]
     group_of = None
     if grouped:                                                   # --group <SampleID Group>; 7 samples left ungrouped
         group_of = {n: ["EAS", "AFR", "EUR"][i % 3] for i, n in enumerate(pipe.names) if i % 14 != 5}
@@ -54,3 +57,47 @@ def test_basetype_command_on_reference_test_data(tmp_path, thread, grouped):
     # temp files and directories are gone (no --keep_tmp), sub-files merged
     import os
     assert not os.path.exists(out + ".tmp.thread.0") and not os.path.exists(out + ".0.vcf.gz")
+
+
+def test_keep_tmp_leaves_the_batches_and_rerun_reuses_them(tmp_path):
+    """--keep_tmp (src/BaseVarC.cpp:458-462): the temp directories and batch files survive the run; a second run with
+    --rerun finds them complete, extracts nothing and writes the same outputs."""
+    import os
+    from basevarc_amd import build as b
+    from tests import hostref
+    exe, _ = b.build_host()
+    fa = hostref.write_fasta(str(tmp_path / "chr17.fa"))
+    lst = hostref.write_bam_list(str(tmp_path / "bam.list"))
+    out = str(tmp_path / "test.out")
+    cmd = [exe, "basetype", "-q", "20", "-t", "2", "-b", "25", "-i", lst, "-s", hostref.REGION, "-r", fa, "-o", out, "--keep_tmp"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    files = [f"{out}.tmp.thread.{t}/batch.{ib}" for t in range(2) for ib in range(4)]
+    assert all(os.path.exists(f) for f in files)
+    first = {k: open(out + k, "rb").read() for k in (".vcf.gz", ".cvg.gz")}
+    r = subprocess.run(cmd + ["--rerun"], capture_output=True, text=True)
+    assert r.returncode == 0 and "begin to extract reads from bam" not in r.stderr
+    assert all(gzip.decompress(open(out + k, "rb").read()) == gzip.decompress(v) for k, v in first.items())
+    r = subprocess.run(cmd[:-1] + ["--rerun"], capture_output=True, text=True)     # without --keep_tmp: cleaned up
+    assert r.returncode == 0 and not any(os.path.exists(f) for f in files) and not os.path.exists(out + ".tmp.thread.0")
+
+
+def test_a_failing_worker_thread_ends_the_program_with_its_message(tmp_path):
+    """ADVICE (main.cpp): an error inside the phase-2 worker threads (here: more than 32 population groups, thrown by
+    every bt_s thread) must come out as exit code 1 with the message on stderr -- not as std::terminate from unwinding
+    past joinable threads -- and must leave the temp batches in place for --rerun."""
+    import os
+    from basevarc_amd import build as b
+    from tests import hostref
+    exe, _ = b.build_host()
+    fa = hostref.write_fasta(str(tmp_path / "chr17.fa"))
+    lst = hostref.write_bam_list(str(tmp_path / "bam.list"))
+    out = str(tmp_path / "test.out")
+    names = hostref.Pipeline(mapq=20, batch=25, thread=1).names
+    gf = tmp_path / "groups.txt"
+    gf.write_text("".join(f"{n} G{i % 40:02d}\n" for i, n in enumerate(names)))          # 40 groups > BVC_MAX_GROUPS
+    r = subprocess.run([exe, "basetype", "-q", "20", "-t", "4", "-b", "25", "-i", lst, "-s", hostref.REGION, "-r", fa,
+                        "-o", out, "-g", str(gf)], capture_output=True, text=True)
+    assert r.returncode == 1, (r.returncode, r.stderr[-500:])
+    assert "more than 32 population groups" in r.stderr
+    assert os.path.exists(f"{out}.tmp.thread.0/batch.0") and not os.path.exists(out + ".0.vcf.gz")

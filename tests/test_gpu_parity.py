@@ -535,6 +535,38 @@ def test_tuning_knobs_are_per_context_and_never_change_a_record(ctx, knob, value
                 assert_site_matches(res[s], exp[s], where=f"{knob}={value} n={n} site={s}", path_strict=False)
 
 
+def test_group_kernel_variants_give_identical_records(ctx):
+    """Any-order group histogram: pipelined and two-chunk load schedules ("group_pipe"), and rows off the 16-byte grid
+    (generic byte kernel), against each other byte for byte."""
+    import torch
+    from basevarc_amd import Context
+    ns, n, k = 37, 50_000, 5
+    m = caller_min_af(n)
+    rng = np.random.default_rng(8)
+    b = torch.empty((ns, n + 16), dtype=torch.int8, device="cuda")
+    q = torch.empty((ns, n + 16), dtype=torch.int8, device="cuda")
+    r = torch.empty(ns, dtype=torch.int8, device="cuda")
+    ctx.synth_dense_device(11, 4242, b[:, :n], q[:, :n], r, cov_thr16=60000)
+    g = torch.from_numpy(rng.integers(0, 7, n).astype(np.uint8)).cuda()      # labels 5, 6 = no group
+    ctx.synchronize()
+    base = ctx.lrt_dense_groups_device(b[:, :n], q[:, :n], r, m, g, k)
+    ctx.synchronize()
+    ref = [t.cpu().numpy().copy() for t in base]
+    with Context(0) as other:
+        other.set_tuning("group_pipe", 0)
+        out = other.lrt_dense_groups_device(b[:, :n], q[:, :n], r, m, g, k)
+        other.synchronize()
+        assert all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(out, ref))
+    # the same rows shifted by one byte: unaligned -> generic kernel
+    fb = torch.zeros(ns * (n + 16) + 1, dtype=torch.int8, device="cuda")
+    fq = torch.zeros_like(fb)
+    fb[1:] = b.reshape(-1); fq[1:] = q.reshape(-1)
+    ub = fb[1:].view(ns, n + 16)[:, :n]; uq = fq[1:].view(ns, n + 16)[:, :n]
+    out = ctx.lrt_dense_groups_device(ub, uq, r, m, g, k)
+    ctx.synchronize()
+    assert all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(out, ref))
+
+
 def test_overlap_mode_gives_identical_records(ctx):
     """Stage 2 on the side stream under the next call's stage 1 (bvc_set_overlap): same bytes out."""
     import torch

@@ -184,3 +184,304 @@ def test_load_phase_writes_the_temp_batch_files_of_the_test_data(tmp_path, threa
         raw = open(f, "rb").read()
         assert raw[:4] == b"\x1f\x8b\x08\x04" and raw[12:14] == b"BC" and raw[-28:-12] == raw[-28:][:16]   # BGZF + EOF block
         assert gzip.decompress(raw).decode() == text, (t, ib)
+
+
+# ----------------------------------------------------------------------------- the per-sample pileup rule (f4)
+def _token(e):
+    if e is None:
+        return ". "
+    if e["is_indel"]:
+        return e["indel"] + " "
+    return f"{e['base']},{e['mapq']},{e['qual']},{e['rpr']},{e['strand']} "
+
+
+def _random_read(rng, pos, rich):
+    """A read at 0-based `pos` with a CIGAR over M I D N S H P = X (rich) or M I D S (plain)."""
+    ops = []
+    if rich and rng.random() < 0.2:
+        ops.append(("H", int(rng.integers(1, 6))))
+    if rng.random() < 0.4:
+        ops.append(("S", int(rng.integers(1, 9))))
+    ops.append((str(rng.choice(list("M=X") if rich else ["M"])), int(rng.integers(1, 30))))
+    for _ in range(int(rng.integers(0, 6))):
+        op = str(rng.choice(list("MIDNP=X") if rich else list("MID")))
+        if op == ops[-1][0]:
+            continue
+        ops.append((op, int(rng.integers(1, 12 if op in "MX=" else 5))))
+    if ops[-1][0] not in "M=X":
+        ops.append(("M", int(rng.integers(1, 20))))
+    if rng.random() < 0.3:
+        ops.append(("S", int(rng.integers(1, 9))))
+    if rich and rng.random() < 0.15:
+        ops.append(("H", int(rng.integers(1, 6))))
+    qlen = sum(l for o, l in ops if o in "MIS=X")
+    seq = "".join(rng.choice(list("ACGTN"), qlen, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+    qual = [int(x) for x in rng.integers(2, 42, qlen)]
+    flag = int(rng.choice([0, 16, 32, 99, 147, 163]))
+    return dict(pos=pos, flag=flag, mapq=int(rng.integers(20, 61)), cigar=ops, seq=seq, qual=qual)
+
+
+@pytest.mark.parametrize("rich", [False, True])
+def test_pileup_rule_matches_the_statement_by_statement_restatement(H, rich):
+    """The host's single-pass pileup walk (prefix tables + forward cursors, basevarc_amd/host/bam.cpp) against the
+    restatement of BamProcess::FindSnpAtPos / GetAllele / GetOffset that rescans every CIGAR per position
+    (tests/golden/make_testdata_pileup.py, src/BamProcess.cpp:4-94, 214-261): first covering read, deletion
+    fall-through to the next read, indel tokens, soft clips / pads / '=' counted the way the reference counts them."""
+    from tests.golden import make_testdata_pileup as ref
+    H.bvchost_pileup_tokens.restype = C.c_size_t
+    H.bvchost_pileup_tokens.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_size_t]
+    rng = np.random.default_rng(77 + rich)
+    checked = indels = fall = 0
+    for case in range(60):
+        rg_s = int(rng.integers(100, 200))
+        span = int(rng.integers(50, 400))
+        refseq = "".join(rng.choice(list("ACGT"), span + 1200))
+        n_reads = int(rng.integers(1, 25))
+        starts = np.sort(rng.integers(rg_s - 30, rg_s + span, n_reads))
+        rv = [_random_read(rng, int(p), rich) for p in starts]
+        pv = [p for p in range(rg_s, rg_s + span) if rng.random() < 0.9]
+        try:
+            want = ref.find_snp_at_pos(rv, pv, refseq=refseq, rg_s=rg_s)
+        except (IndexError, AssertionError):
+            continue                                  # the restatement hit the reference's out-of-range / assert case
+        text = "".join(f"{r['pos']} {r['flag']} {r['mapq']} " + "".join(f"{l}{o}" for o, l in r["cigar"]) +
+                       f" {r['seq']} " + ",".join(map(str, r["qual"])) + "\n" for r in rv)
+        buf = C.create_string_buffer(1 << 20)
+        arr = (C.c_int32 * len(pv))(*pv)
+        H.bvchost_pileup_tokens(text.encode(), arr, len(pv), rg_s, refseq.encode(), buf, len(buf))
+        got = buf.value.decode()
+        exp = "".join(_token(want.get(p)) for p in pv)
+        assert got == exp, (case, got[:300], exp[:300])
+        checked += len(pv)
+        indels += sum(1 for e in want.values() if e["is_indel"])
+        # a position whose first covering read has a deletion there and whose entry comes from a later read
+        fall += sum(1 for p, e in want.items() if not e["is_indel"] and any(
+            r["pos"] + 1 <= p <= ref.end_pos(r) for r in rv) and e["mapq"] != next(
+            r for r in rv if ref.end_pos(r) >= p)["mapq"])
+    assert checked > 3000 and indels > 20 and fall > 0, (checked, indels, fall)
+
+
+def test_truncated_and_corrupt_bam_files_are_rejected_not_read_past(tmp_path):
+    """ADVICE (bam.cpp): every length field is checked against the block it sits in.  A BAM cut in the middle of a
+    record, and one whose l_seq / n_cigar fields are garbage, must end `--load` with an error message and exit
+    code 1 -- not a crash, not a silent short read.  (tools/sanitize_cpu.sh runs this under ASan + UBSan.)"""
+    import gzip
+    import shutil
+    import struct
+    import subprocess
+    from basevarc_amd import build as b
+    from tests import hostref
+    exe, _ = b.build_host()
+    fa = hostref.write_fasta(str(tmp_path / "chr17.fa"))
+    src = open(hostref.write_bam_list(str(tmp_path / "bam.list"))).read().split()[0]
+    raw = gzip.decompress(open(src, "rb").read())        # BGZF is a series of gzip members
+
+    def bgzf(data, path):
+        from tools.host_bench import _bgzf_write
+        tmp = str(path) + ".raw"
+        open(tmp, "wb").write(data)
+        _bgzf_write(tmp, str(path))
+        os.remove(tmp)
+
+    # locate the first record
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    off = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, off)[0]
+    off += 4
+    for _ in range(n_ref):
+        l = struct.unpack_from("<i", raw, off)[0]
+        off += 4 + l + 4
+    bs = struct.unpack_from("<i", raw, off)[0]
+    cases = {
+        "cut_mid_record": raw[:off + 4 + bs // 2],
+        "huge_l_seq": raw[:off + 4 + 16] + struct.pack("<i", 1 << 30) + raw[off + 4 + 20:],
+        "negative_l_seq": raw[:off + 4 + 16] + struct.pack("<i", -5) + raw[off + 4 + 20:],
+        "huge_n_cigar": raw[:off + 4 + 12] + struct.pack("<H", 65535) + raw[off + 4 + 14:],
+        "negative_l_text": raw[:4] + struct.pack("<i", -1) + raw[8:],
+    }
+    for name, data in cases.items():
+        d = tmp_path / name
+        d.mkdir()
+        bad = d / "bad.bam"
+        bgzf(data, bad)
+        if os.path.exists(src + ".bai"):
+            shutil.copy(src + ".bai", str(bad) + ".bai")
+        lst = d / "bam.list"
+        lst.write_text(str(bad) + "\n")
+        r = subprocess.run([exe, "basetype", "--load", "-q", "20", "-t", "1", "-b", "10", "-i", str(lst), "-s",
+                            hostref.REGION, "-r", fa, "-o", str(d / "out")], capture_output=True, text=True)
+        assert r.returncode == 1, (name, r.returncode, r.stderr[-500:])
+        assert "ERROR" in r.stderr or "can not open" in r.stderr, (name, r.stderr[-500:])
+
+
+# ----------------------------------------------------------------------------- binary temp-batch form (additive)
+def _decode_bin_batch(raw):
+    """Python reader of the `--tmp-format bin` stream (basevarc_amd/host/pileup.h): -> (names line, n_in_batch,
+    per position: list of (sample, base, mapq, qual, rpr, strand, indel or None))."""
+    import struct
+    assert raw[:8] == b"BVCBAT1\n"
+    n_in, l = struct.unpack_from("<II", raw, 8)
+    names = raw[16:16 + l].decode()
+    off = 16 + l
+    positions = []
+    while off < len(raw):
+        (n,) = struct.unpack_from("<I", raw, off)
+        off += 4
+        end, ents = off + n, []
+        while off < end:
+            j, base, mapq, qual, rpr, flags = struct.unpack_from("<IBBBBB", raw, off)
+            off += 9
+            indel = None
+            if flags & 2:
+                (k,) = struct.unpack_from("<H", raw, off)
+                indel = raw[off + 2:off + 2 + k].decode()
+                off += 2 + k
+            ents.append((j, base, mapq, qual, rpr, flags & 1, indel))
+        assert off == end
+        positions.append(ents)
+    return names, n_in, positions
+
+
+def test_binary_temp_batches_hold_what_the_text_batches_hold(tmp_path):
+    """`--load --tmp-format bin`: same file names, BGZF framing and EOF block as the text form (so --rerun's
+    completeness check works on them), and position by position the entries of the text tokens."""
+    import gzip
+    import subprocess
+    from basevarc_amd import build as b
+    from tests import hostref
+    exe, _ = b.build_host()
+    fa = hostref.write_fasta(str(tmp_path / "chr17.fa"))
+    lst = hostref.write_bam_list(str(tmp_path / "bam.list"))
+    thread, batch = 3, 37
+    outs = {}
+    for fmt in ("text", "bin"):
+        outs[fmt] = str(tmp_path / f"{fmt}.out")
+        subprocess.run([exe, "basetype", "--load", "-q", "20", "-t", str(thread), "-b", str(batch), "-i", lst, "-s",
+                        hostref.REGION, "-r", fa, "-o", outs[fmt], "--tmp-format", fmt], check=True, capture_output=True)
+    n_indel = n_base = 0
+    for t in range(thread):
+        for ib in range(3):
+            raw_t = open(f"{outs['text']}.tmp.thread.{t}/batch.{ib}", "rb").read()
+            raw_b = open(f"{outs['bin']}.tmp.thread.{t}/batch.{ib}", "rb").read()
+            assert raw_b[:4] == b"\x1f\x8b\x08\x04" and raw_b[12:14] == b"BC" and raw_b[-28:] == raw_t[-28:]
+            lines = gzip.decompress(raw_t).decode().split("\n")
+            names, n_in, positions = _decode_bin_batch(gzip.decompress(raw_b))
+            assert names == lines[0] + "\n" and n_in == lines[0].count("\t")
+            body = lines[1:-1]
+            assert len(positions) == len(body)
+            for ents, line in zip(positions, body):
+                toks = line.split(" ")[:-1]
+                assert len(toks) == n_in
+                want = []
+                for j, tok in enumerate(toks):
+                    if tok == ".":
+                        continue
+                    if tok[0] in "+-N":
+                        want.append((j, tok))
+                        n_indel += 1
+                    else:
+                        want.append((j,) + tuple(int(x) for x in tok.split(",")))
+                        n_base += 1
+                got = [(e[0], e[6]) if e[6] is not None else (e[0], e[1], e[2], e[3], e[4], e[5]) for e in ents]
+                assert got == want
+    assert n_base > 100000 and n_indel > 10
+    assert os.path.getsize(f"{outs['bin']}.tmp.thread.0/batch.0") < os.path.getsize(f"{outs['text']}.tmp.thread.0/batch.0")
+
+
+def test_binary_and_text_parsers_build_the_same_site_columns(H):
+    """parse_pileup_bin reproduces the text parser, including the one long-lived AlleleInfo whose fields an indel
+    entry inherits across samples, batches and positions (src/BaseVarC.cpp:392, 407-440) and the dropped N bases."""
+    import struct
+    H.bvchost_site_parse_bin.restype = C.c_void_p
+    H.bvchost_site_parse_bin.argtypes = [C.c_char_p, C.c_size_t, C.c_int32, C.c_int32]
+    rng = np.random.default_rng(3)
+    for trial in range(30):
+        H.bvchost_reset_parser()
+        text_sites, bin_sites = [], []
+        script = []                                               # the same entries for both parsers, position by position
+        for p in range(12):
+            n_batches = int(rng.integers(1, 4))
+            batches = []
+            for _ in range(n_batches):
+                n_in = int(rng.integers(1, 9))
+                ents = []
+                for j in range(n_in):
+                    u = rng.random()
+                    if u < 0.35:
+                        continue
+                    if u < 0.5:
+                        ents.append((j, None, str(rng.choice(["+AC", "-T", "+GGGT", "-"]))))
+                    else:
+                        ents.append((j, (int(rng.integers(0, 5)), int(rng.integers(0, 61)), int(rng.integers(0, 42)),
+                                         int(rng.integers(1, 151)), int(rng.integers(0, 2))), None))
+                batches.append((n_in, ents))
+            script.append(batches)
+        for fmt in ("text", "bin"):
+            H.bvchost_reset_parser()
+            for p, batches in enumerate(script):
+                if fmt == "text":
+                    lines = []
+                    for n_in, ents in batches:
+                        d = {j: (b, i) for j, b, i in ents}
+                        lines.append("".join((". " if j not in d else (d[j][1] + " " if d[j][0] is None else
+                                              ",".join(map(str, d[j][0])) + " ")) for j in range(n_in)))
+                    h = H.bvchost_site_parse("\n".join(lines).encode(), p)
+                else:
+                    blob, sizes = b"", []
+                    for n_in, ents in batches:
+                        pay = b""
+                        for j, bq, indel in ents:
+                            if indel is None:
+                                pay += struct.pack("<IBBBBB", j, bq[0], bq[1], bq[2], bq[3], bq[4])
+                            else:
+                                pay += struct.pack("<IBBBBBH", j, 5, 0, 0, 0, 2, len(indel)) + indel.encode()
+                        blob += struct.pack("<II", n_in, len(pay)) + pay
+                    h = H.bvchost_site_parse_bin(blob, len(blob), len(batches), p)
+                n = H.bvchost_site_size(h)
+                rec = [tuple(H.bvchost_site_field(h, k, f) for f in range(7)) for k in range(n)]
+                (text_sites if fmt == "text" else bin_sites).append(rec)
+                H.bvchost_site_free(h)
+        assert text_sites == bin_sites, trial
+
+
+# ----------------------------------------------------------------------------- --rerun (src/BaseVarC.cpp:218-246)
+def test_rerun_resumes_extraction_at_the_first_incomplete_batch(tmp_path):
+    """--rerun looks at every <out>.tmp.thread.<t>/batch.<b>: a batch counts as done only when all its per-thread
+    files are BGZF with the EOF block.  Extraction restarts at the FIRST incomplete batch and redoes everything from
+    there (src/BaseVarC.cpp:218-246); with every file complete nothing is extracted."""
+    import gzip
+    import subprocess
+    import time
+    from basevarc_amd import build as b
+    from tests import hostref
+    exe, _ = b.build_host()
+    fa = hostref.write_fasta(str(tmp_path / "chr17.fa"))
+    lst = hostref.write_bam_list(str(tmp_path / "bam.list"))
+    out = str(tmp_path / "test.out")
+    thread, batch = 2, 10
+    base = [exe, "basetype", "-q", "20", "-t", str(thread), "-b", str(batch), "-i", lst, "-s", hostref.REGION, "-r", fa,
+            "-o", out, "--load"]
+    subprocess.run(base, check=True, capture_output=True)
+    files = {(t, ib): f"{out}.tmp.thread.{t}/batch.{ib}" for t in range(thread) for ib in range(10)}
+    good = {k: open(f, "rb").read() for k, f in files.items()}
+    # every file complete: --rerun extracts nothing
+    r = subprocess.run(base + ["--rerun"], check=True, capture_output=True, text=True)
+    assert "begin to extract reads from bam" not in r.stderr
+    # damage: batch 3 of thread 0 loses its EOF block (a writer that was killed), batch 7 of thread 1 is gone
+    open(files[(0, 3)], "wb").write(good[(0, 3)][:-28])
+    os.remove(files[(1, 7)])
+    old = time.time() - 3600
+    for f in files.values():
+        if os.path.exists(f):
+            os.utime(f, (old, old))
+    r = subprocess.run(base + ["--rerun"], check=True, capture_output=True, text=True)
+    assert "begin to extract reads from bam" in r.stderr
+    for (t, ib), f in files.items():
+        assert open(f, "rb").read() == good[(t, ib)], (t, ib)              # everything is whole again
+        rewritten = os.path.getmtime(f) > old + 1800
+        assert rewritten == (ib >= 3), (t, ib, rewritten)                  # batches 0-2 untouched, 3-9 redone
+    # without --rerun everything is extracted again, whatever is there
+    for f in files.values():
+        os.utime(f, (old, old))
+    subprocess.run(base, check=True, capture_output=True)
+    assert all(os.path.getmtime(f) > old + 1800 for f in files.values())

@@ -22,8 +22,8 @@ def short(name):
     m = re.search(r"(lrt_groups_kernel|lrt_kernel)<(\d+)", name)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
-    for k in ("hist_dense_groups_multi_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel", "hist_dense_wave_kernel",
-              "hist_dense_kernel", "hist_csr_block_kernel", "hist_csr_wave_kernel", "group_bounds_kernel", "var_qual_kernel",
+    for k in ("hist_dense_groups_bytes_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel", "hist_wave_kernel",
+              "hist_dense_kernel", "hist_csr_block_kernel", "group_bounds_kernel", "var_qual_kernel",
               "synth_dense_kernel", "sum_groups_kernel", "stream_read_kernel"):
         if k in name:
             return k
@@ -87,7 +87,7 @@ def main():
                 "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of 16 B/lane streams), WRITE_SIZE KiB x 1024"})
     doc.setdefault("kernels", {})
     alg = 2.0 * n_samples * sites
-    for kname in ("hist_dense_kernel", "hist_dense_groups_multi_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel"):
+    for kname in ("hist_dense_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel"):
         h = summary.get(kname, {})
         if "FETCH_SIZE" not in h or h["FETCH_SIZE"] < 1000:        # the kernel that returned at once has no traffic
             continue

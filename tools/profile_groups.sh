@@ -1,11 +1,10 @@
 #!/bin/bash
-# Group mode (k = 5, N = 1e6) on the GPU box: timing of the any-order histogram kernel with 1 / 2 / 4 sites per workgroup
-# pass (alone and under the EM kernels), then PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_*) for each, serial mode.
-# usage: bash tools/profile_groups.sh <tag> "<group_sites values>" [extra bench flags]
+# Group mode (k = 5, N = 1e6) on the GPU box: timing of the any-order histogram kernel without / with load pipelining (alone and under the EM kernels), then PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_*) for each, serial mode.
+# usage: bash tools/profile_groups.sh <tag> "<group_pipe values>" [extra bench flags]
 # Output under gpurun_out/<tag>/; tools/pmc_summary.py <tag> gpurun_out/<tag>/gs<N> summarises a pass set.
 set -e
 TAG=${1:-rXX_groups}
-GS=${2:-"1 2 4"}
+GS=${2:-"0 1"}
 EXTRA=$3
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
@@ -14,14 +13,14 @@ cd $R
 B="--groups 5 --cpu-sites 0 --no-verify --no-legs --total-sites 24000 $EXTRA"
 for gs in $GS; do
   for mode in "" "--no-overlap"; do
-    BVC_GROUP_SITES=$gs python bench.py $B $mode --steps 8 --warmup 1 2>/dev/null | python -c "
+    BVC_GROUP_PIPE=$gs python bench.py $B $mode --steps 8 --warmup 1 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print('group_sites',$gs,'$mode','sites/s',round(d['value']),'ms/call',round(d['ms_per_step']/d['config']['calls_per_step_per_gpu'],4),d['kernels_ms_per_call'])" | tee -a $O/timing.txt
+d=json.loads(sys.stdin.readline()); print('group_pipe',$gs,'$mode','sites/s',round(d['value']),'ms/call',round(d['ms_per_step']/d['config']['calls_per_step_per_gpu'],4),d['kernels_ms_per_call'])" | tee -a $O/timing.txt
   done
 done
 cd /tmp && export TMPDIR=/tmp
 for gs in $GS; do
-  export BVC_GROUP_SITES=$gs
+  export BVC_GROUP_PIPE=$gs
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/gs$gs/pmc_$c -- python3 $R/bench.py $B --no-overlap --steps 2 --warmup 1 > $O/gs${gs}_pmc_$c.log 2>&1
   done
