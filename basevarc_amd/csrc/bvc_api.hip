@@ -674,7 +674,7 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
         if (timed) BVC_HIP_T(hipEventRecord(t.c, s2));
         BVC_HIP_T(launch_sum_groups(s2, ns, n_hist, *gp, *cp));
         const bool shared = ctx->overlap && n_samples >= 200000;
-        BVC_HIP_T(launch_lrt(ctx->ls, s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared, 12 /* = kGroupSharedWavesPerCu, em_kernel.hip */));
+        BVC_HIP_T(launch_lrt(ctx->ls, s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared, 8 /* = kGroupSharedWavesPerCu, em_kernel.hip */));
         BVC_HIP_T(launch_lrt_groups(ctx->ls, s2, ns, n_groups, *gp, r, min_af, ctx->d_lut, res, gres, shared));
         if (timed) {
             BVC_HIP_T(hipEventRecord(t.d, s2));

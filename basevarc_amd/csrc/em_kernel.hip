@@ -559,8 +559,8 @@ __global__ void sum_groups_kernel(int64_t total, int n_hist, const uint32_t *__r
 // takes 24 per CU.  The context's em_waves_per_cu (bvc_set_tuning / BVC_EM_WAVES_PER_CU) overrides both.
 //
 // Group mode's stage 2 (sum, overall LRT, per-group LRT) is a third longer and its histogram pass slower than the
-// plain call's: 12 waves per CU balance the two streams there (swept 4..32 on MI355X, k = 5, N = 1e6).
-constexpr int kGroupSharedWavesPerCu = 12;
+// plain call's; swept 8..24 on MI355X (k = 5, N = 1e6, round 2 kernels): 8 waves per CU is as good as any (2.68e6 sites/s at 8, 2.58-2.65e6 at 12-24).
+constexpr int kGroupSharedWavesPerCu = 8;
 
 static int64_t em_grid_cap(const LaunchState &st, bool shared, int shared_waves_per_cu = 0)
 {

@@ -101,3 +101,21 @@ def test_a_failing_worker_thread_ends_the_program_with_its_message(tmp_path):
     assert r.returncode == 1, (r.returncode, r.stderr[-500:])
     assert "more than 32 population groups" in r.stderr
     assert os.path.exists(f"{out}.tmp.thread.0/batch.0") and not os.path.exists(out + ".0.vcf.gz")
+
+
+def test_more_gpus_requested_than_present_degrades_to_the_devices_there(tmp_path):
+    """`--gpus 2 -t 4` on a box with one MI355X: threads map to device i mod min(--gpus, devices present) =
+    device 0 (host/main.cpp), the run succeeds and writes what a plain run writes."""
+    from basevarc_amd import build as b
+    from tests import hostref
+    exe, _ = b.build_host()
+    fa = hostref.write_fasta(str(tmp_path / "chr17.fa"))
+    lst = hostref.write_bam_list(str(tmp_path / "bam.list"))
+    outs = []
+    for extra, name in ((["--gpus", "2"], "g2"), ([], "plain")):
+        out = str(tmp_path / name)
+        r = subprocess.run([exe, "basetype", "-q", "20", "-t", "4", "-b", "25", "-i", lst, "-s", hostref.REGION, "-r", fa,
+                            "-o", out] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([gzip.decompress(open(out + k, "rb").read()) for k in (".vcf.gz", ".cvg.gz")])
+    assert outs[0] == outs[1]

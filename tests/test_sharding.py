@@ -67,3 +67,16 @@ def test_two_ranks_over_gloo(tmp_path):
     exp, _ = orc.dense_batch(b, q, r, 0.001, use_hist=True, threads=1)
     assert got["called"].tolist() == [e["called"] for e in exp]
     assert [list(x) for x in got["depth"]] == [e["depth"] for e in exp]
+
+
+def test_bench_shards_one_workload_when_strong_and_disjoint_ranges_when_weak():
+    """bench.py, N > 1 (BASELINE configs[3]): the SAME total_sites are split by site -- rank r owns
+    shard_range(total, r, W), the union is the workload, nothing overlaps -- and tiles never straddle a rank."""
+    total, tile = 100_000, 4000
+    for world in (2, 4, 8):
+        owned = [shard_range(total, r, world) for r in range(world)]
+        assert owned[0][0] == 0 and owned[-1][1] == total
+        assert sum(hi - lo for lo, hi in owned) == total
+        for lo, hi in owned:
+            sizes = [min(tile, hi - lo - s) for s in range(0, hi - lo, tile)]
+            assert sum(sizes) == hi - lo and all(0 < s <= tile for s in sizes)

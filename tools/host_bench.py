@@ -1,8 +1,15 @@
 #!/usr/bin/env python3
-"""Throughput of the host side of `BaseVarC basetype` (phase 2: temp-batch text -> tiles -> libbvc -> CVG/VCF)
-on synthetic temp-batch files.  Needs a GPU.  usage: tools/host_bench.py [n_samples] [n_positions] [threads]"""
+"""End-to-end throughput of the host side of `BaseVarC basetype`, phase 2 (temp batches -> tiles -> libbvc -> CVG/VCF),
+on synthetic temp-batch files in both forms (the reference's text and the additive binary one).  Needs a GPU.
+
+usage: tools/host_bench.py [n_samples] [n_positions] [threads] [coverage] [batch]
+The files are written by the host library's own generator (bvchost_write_synth_batches) under a temp directory.
+"""
+import ctypes as C
 import gzip
+import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -10,66 +17,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np  # noqa: E402
-
-from oracle import orc  # noqa: E402
-
-
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-    npos = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
-    thread = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    batch = 500
-    from basevarc_amd import build as b
-    exe, _ = b.build_host()
-    d = tempfile.mkdtemp(prefix="bvc_host_bench_")
-    out = os.path.join(d, "bench.out")
-    start = 1000
-    # reference: all 'A' region; contig "chrS"
-    fa = os.path.join(d, "s.fa")
-    length = start + npos + 2000
-    with open(fa, "w") as f:
-        f.write(">chrS\n" + "A" * length + "\n")
-    open(fa + ".fai", "w").write(f"chrS\t{length}\t6\t{length}\t{length + 1}\n")
-    open(os.path.join(d, "bam.list"), "w").write("".join(f"s{i}.bam\n" for i in range(n)))
-    bq = orc.synth_tile(11, 0, npos, n, cov_thr16=45875)            # 70 % coverage
-    B, Q = bq[0], bq[1]
-    rng = np.random.default_rng(0)
-    mapq = rng.integers(20, 61, (npos, n))
-    rpr = rng.integers(1, 151, (npos, n))
-    strand = rng.integers(0, 2, (npos, n))
-    nb = 1 + (n - 1) // batch
-    window = npos % thread + npos // thread
-    total = 0
-    for t in range(thread):
-        os.makedirs(f"{out}.tmp.thread.{t}", exist_ok=True)
-        lo, hi = min(npos, t * window), (npos if t == thread - 1 else min(npos, (t + 1) * window))
-        for ib in range(nb):
-            cols = range(ib * batch, min(n, (ib + 1) * batch))
-            lines = ["".join(f"S{j}\t" for j in cols) + "\n"]
-            for p in range(lo, hi):
-                lines.append("".join(f"{B[p, j]},{mapq[p, j]},{Q[p, j]},{rpr[p, j]},{strand[p, j]} " if B[p, j] >= 0 else ". "
-                                     for j in cols) + "\n")
-            text = "".join(lines).encode()
-            total += len(text)
-            # BGZF-compatible: plain gzip members are not BGZF; write through the host library's own writer instead
-            raw = os.path.join(d, f"raw.{t}.{ib}")
-            open(raw, "wb").write(text)
-            _bgzf_write(raw, f"{out}.tmp.thread.{t}/batch.{ib}")
-            os.remove(raw)
-    t0 = time.perf_counter()
-    r = subprocess.run([exe, "basetype", "--rerun", "-t", str(thread), "-b", str(batch), "-i", os.path.join(d, "bam.list"),
-                        "-s", f"chrS:{start}-{start + npos}", "-r", fa, "-o", out], capture_output=True, text=True,
-                       env=dict(os.environ, BVC_HOST_PROFILE="1"))
-    dt = time.perf_counter() - t0
-    assert r.returncode == 0, r.stderr[-2000:]
-    for l in r.stderr.splitlines():
-        if l.startswith("[profile]"):
-            print(l)
-    n_cvg = gzip.decompress(open(out + ".cvg.gz", "rb").read()).count(b"\n") - 3
-    n_vcf = sum(1 for l in gzip.decompress(open(out + ".vcf.gz", "rb").read()).split(b"\n") if l and not l.startswith(b"#"))
-    print({"n_samples": n, "positions": npos, "threads": thread, "text_MB": total / 1e6, "seconds": dt,
-           "positions_per_s": npos / dt, "text_MB_per_s": total / 1e6 / dt, "cvg_lines": n_cvg, "vcf_lines": n_vcf})
 
 
 def _bgzf_write(src, dst):
@@ -86,6 +33,58 @@ def _bgzf_write(src, dst):
             f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize) + comp +
                     struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
         f.write(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    npos = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+    thread = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    cov = float(sys.argv[4]) if len(sys.argv) > 4 else 0.7
+    batch = int(sys.argv[5]) if len(sys.argv) > 5 else 500
+    from basevarc_amd import build as b
+    exe, hostlib = b.build_host()
+    H = C.CDLL(hostlib)
+    H.bvchost_write_synth_batches.restype = C.c_int64
+    H.bvchost_write_synth_batches.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32]
+    d = tempfile.mkdtemp(prefix="bvc_host_bench_", dir=os.environ.get("BVC_BENCH_TMP", None))
+    try:
+        start = 1000
+        fa = os.path.join(d, "s.fa")
+        length = start + npos + 2000
+        with open(fa, "w") as f:
+            f.write(">chrS\n" + "A" * length + "\n")
+        open(fa + ".fai", "w").write(f"chrS\t{length}\t6\t{length}\t{length + 1}\n")
+        open(os.path.join(d, "bam.list"), "w").write("".join(f"s{i}.bam\n" for i in range(n)))
+        for fmt in ("text", "bin"):
+            out = os.path.join(d, f"bench_{fmt}.out")
+            for t in range(thread):
+                os.makedirs(f"{out}.tmp.thread.{t}", exist_ok=True)
+            t0 = time.perf_counter()
+            entries = H.bvchost_write_synth_batches(out.encode(), n, npos, thread, batch, int(round(cov * 1000)), 11, fmt == "bin")
+            gen_s = time.perf_counter() - t0
+            assert entries >= 0
+            size = sum(os.path.getsize(os.path.join(dp, f)) for t in range(thread)
+                       for dp, _, fs in os.walk(f"{out}.tmp.thread.{t}") for f in fs)
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "basetype", "--rerun", "-t", str(thread), "-b", str(batch), "-i", os.path.join(d, "bam.list"),
+                                "-s", f"chrS:{start}-{start + npos}", "-r", fa, "-o", out], capture_output=True, text=True,
+                               env=dict(os.environ, BVC_HOST_PROFILE="1"))
+            dt = time.perf_counter() - t0
+            assert r.returncode == 0, r.stderr[-2000:]
+            prof = [l for l in r.stderr.splitlines() if l.startswith("[profile]")]
+            n_cvg = gzip.decompress(open(out + ".cvg.gz", "rb").read()).count(b"\n") - 3
+            n_vcf = sum(1 for l in gzip.decompress(open(out + ".vcf.gz", "rb").read()).split(b"\n") if l and not l.startswith(b"#"))
+            print(json.dumps({"tmp_format": fmt, "n_samples": n, "positions": npos, "threads": thread, "coverage": cov,
+                              "entries": entries, "batch_files_MB": round(size / 1e6, 1), "generate_s": round(gen_s, 2),
+                              "seconds": round(dt, 3), "positions_per_s": round(npos / dt, 1),
+                              "entries_per_s": round(entries / dt), "cvg_lines": n_cvg, "vcf_lines": n_vcf, "profile": prof}))
+            for k in (".cvg.gz", ".vcf.gz"):
+                os.replace(out + k, os.path.join(d, f"{fmt}{k}"))
+        same = all(gzip.decompress(open(os.path.join(d, "text" + k), "rb").read()) ==
+                   gzip.decompress(open(os.path.join(d, "bin" + k), "rb").read()) for k in (".cvg.gz", ".vcf.gz"))
+        print(json.dumps({"text_and_bin_outputs_identical": same}))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":

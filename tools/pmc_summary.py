@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 CSV output (kernel trace, --stats, --pmc passes) into profiles/.
 
-usage: tools/pmc_summary.py <round tag> <dir with rocprofv3 output dirs> [n_samples sites_per_launch row_align]
+usage: tools/pmc_summary.py <round tag> <dir>[,<dir>...] [n_samples sites_per_launch row_align]
+each <dir> holds the pmc_* output directories of one bench configuration (tools/profile_round.sh)
 
 HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 reports exactly half the bytes of a wide (16 B/lane) coalesced streaming read, so the read side is doubled
@@ -45,28 +46,33 @@ def counters(d):
 
 
 def main():
-    tag, base = sys.argv[1], sys.argv[2]
+    tag, bases = sys.argv[1], sys.argv[2].split(",")
     n_samples = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
     sites = int(sys.argv[4]) if len(sys.argv) > 4 else 4000
     row_align = int(sys.argv[5]) if len(sys.argv) > 5 else 128
     lines = [f"# rocprofv3 PMC summary ({tag})", "",
-             "Per-dispatch averages; each counter group from its own `rocprofv3 --pmc ... --kernel-trace` pass.", ""]
+             "Per-dispatch averages; each counter group from its own `rocprofv3 --pmc ... --kernel-trace` pass "
+             "(serial mode: one kernel on the chip at a time).", ""]
     summary = {}
-    for sub in sorted(glob.glob(os.path.join(base, "pmc_*"))):
-        if not os.path.isdir(sub):
-            continue
-        c = counters(sub)
-        lines += [f"## pass {os.path.basename(sub)}", "", "| kernel | dispatches | avg ms | counter | avg value |", "|---|---|---|---|---|"]
-        for k in sorted(c):
-            dur = c[k].pop("_dur_ns")
-            # skip warm-up dispatch of each kernel
-            for name, vals in sorted(c[k].items()):
-                v = vals[1:] if len(vals) > 2 else vals
-                dd = dur[1:] if len(dur) > 2 else dur
-                lines.append(f"| {k} | {len(vals)} | {sum(dd) / len(dd) / 1e6:.4f} | {name} | {sum(v) / len(v):.6g} |")
-                summary.setdefault(k, {})[name] = sum(v) / len(v)
-                summary[k]["ms_under_pmc_" + name] = sum(dd) / len(dd) / 1e6
-        lines.append("")
+    for base in bases:
+        for sub in sorted(glob.glob(os.path.join(base, "pmc_*"))):
+            if not os.path.isdir(sub):
+                continue
+            c = counters(sub)
+            lines += [f"## {os.path.basename(base.rstrip('/'))}: pass {os.path.basename(sub)}", "",
+                      "| kernel | dispatches | avg ms | counter | avg value |", "|---|---|---|---|---|"]
+            for k in sorted(c):
+                if k.startswith("__amd") or k in ("synth_dense_kernel", "stream_read_kernel"):
+                    continue
+                dur = c[k].pop("_dur_ns")
+                # skip warm-up dispatch of each kernel
+                for name, vals in sorted(c[k].items()):
+                    v = vals[1:] if len(vals) > 2 else vals
+                    dd = dur[1:] if len(dur) > 2 else dur
+                    lines.append(f"| {k} | {len(vals)} | {sum(dd) / len(dd) / 1e6:.4f} | {name} | {sum(v) / len(v):.6g} |")
+                    summary.setdefault(k, {})[name] = sum(v) / len(v)
+                    summary[k]["ms_under_pmc_" + name] = sum(dd) / len(dd) / 1e6
+            lines.append("")
     # HBM traffic per launch of every histogram kernel that has a FETCH_SIZE pass -> profiles/pmc_traffic.json, keyed by
     # kernel and stamped with the sha256 of hist_kernel.hip (bench.py drops the figure when the source has changed)
     import hashlib

@@ -1,22 +1,35 @@
 #!/bin/bash
-# Standard per-round capture on the GPU box: bench lines (overlap, serial), rocprofv3 kernel stats of both,
-# PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_*) in serial mode.  usage: bash tools/profile_round.sh r01
-# Output under gpurun_out/<tag>_*; tools/pmc_summary.py turns it into profiles/.
+# Standard per-round capture on the GPU box: the default bench line (overlap) and a serial one, rocprofv3 kernel
+# stats of both, and PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_*) in serial mode for the three histogram kernels of the
+# dense entry points: plain, any-order groups, groups ordered by column.  usage: bash tools/profile_round.sh r02
+# Output under gpurun_out/<tag>/; `python tools/pmc_summary.py <tag> gpurun_out/<tag>/dense,gpurun_out/<tag>/groups_interleaved,gpurun_out/<tag>/groups_ordered`
+# turns the passes into profiles/<tag>_pmc_summary.md and profiles/pmc_traffic.json.
 set -e
 TAG=${1:-rXX}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-python bench.py > $O/${TAG}_bench_overlap.log 2> $O/${TAG}_bench_overlap.err
-python bench.py --no-overlap --cpu-sites 0 > $O/${TAG}_bench_serial.log 2> $O/${TAG}_bench_serial.err
+python bench.py > $O/bench_overlap.json 2> $O/bench_overlap.err
+python bench.py --no-overlap --cpu-sites 0 --no-legs > $O/bench_serial.json 2> $O/bench_serial.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace_overlap -- python3 $R/bench.py --steps 50 --warmup 2 --cpu-sites 0 --no-verify > $O/${TAG}_trace_overlap.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace_serial -- python3 $R/bench.py --steps 50 --warmup 2 --cpu-sites 0 --no-verify --no-overlap > $O/${TAG}_trace_serial.log 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 6 --warmup 1 --total-sites 16000 --cpu-sites 0 --no-overlap --no-verify > $O/pmc_$c.log 2>&1
+Q="--cpu-sites 0 --no-verify --no-legs"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_overlap -- python3 $R/bench.py --steps 4 --warmup 1 $Q > $O/trace_overlap.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_serial -- python3 $R/bench.py --steps 4 --warmup 1 $Q --no-overlap > $O/trace_serial.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_legs -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-sites 0 --no-verify > $O/trace_legs.log 2>&1
+P="--steps 2 --warmup 1 --total-sites 16000 $Q --no-overlap"
+for cfg in "dense:" "groups_interleaved:--groups 5" "groups_ordered:--groups 5 --group-layout ordered"; do
+  name=${cfg%%:*}; flags=${cfg#*:}
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$name/pmc_$c -- python3 $R/bench.py $P $flags > $O/${name}_pmc_$c.log 2>&1
+  done
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/$name/pmc_SQ -- python3 $R/bench.py $P $flags > $O/${name}_pmc_SQ.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/$name/pmc_SQ2 -- python3 $R/bench.py $P $flags > $O/${name}_pmc_SQ2.log 2>&1
 done
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_SQ -- python3 $R/bench.py --steps 6 --warmup 1 --total-sites 16000 --cpu-sites 0 --no-overlap --no-verify > $O/pmc_SQ.log 2>&1
 cd $R
-grep '^{' $O/${TAG}_bench_overlap.log | cut -c1-300
-grep '^{' $O/${TAG}_bench_serial.log | cut -c1-300
+for a in 16 128 256 1024 4096; do
+  python bench.py --row-align $a --steps 5 --warmup 1 $Q 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('row_align',$a,'stride',d['config']['row_stride'],'sites/s',round(d['value']),'hist ms',round(d['roofline']['avg_launch_ms'],4),'frac',round(d['roofline']['frac'],4))" | tee -a $O/row_align.txt
+done
+cut -c1-400 $O/bench_overlap.json

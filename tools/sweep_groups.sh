@@ -2,7 +2,7 @@
 # Group mode (k = 5), overlap: EM grid cap sweep.  usage: bash tools/sweep_groups.sh "4 6 8 12"
 cd $GRAFT_REPO_ROOT
 for w in ${1:-4 6 8 12}; do
-  BVC_EM_WAVES_PER_CU=$w python bench.py --groups 5 $2 --steps 60 --warmup 3 --cpu-sites 0 --no-verify 2>/dev/null | python -c "
+  BVC_EM_WAVES_PER_CU=$w python bench.py --groups 5 $2 --steps 6 --warmup 1 --cpu-sites 0 --no-verify --no-legs --total-sites 40000 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print('cap',$w,'sites/s',round(d['value']),'step',round(d['ms_per_step'],4),'k',list(d['kernels_ms_per_step'].values()))"
+d=json.loads(sys.stdin.readline()); print('cap',$w,'sites/s',round(d['value']),'step',round(d['ms_per_step'],4),'k',list(d['kernels_ms_per_call'].values()))"
 done
