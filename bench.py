@@ -270,16 +270,18 @@ def main():
 
 
 # ------------------------------------------------------------------------------------------------ legs
-def timed_calls(ctx, fn, n_calls, warm=2):
-    """Runs fn(i) n_calls times with every launch timed by HIP events; returns (wall seconds, profile dict)."""
+def timed_calls(ctx, fn, n_calls, warm=2, profile_every=4):
+    """Runs fn(i) n_calls times, every profile_every-th launch timed by HIP events (timing events on every call would
+    cost the two-stream overlap 10-20 us per call); returns (wall seconds, profile dict)."""
     import torch
     for i in range(warm):
         fn(i)
     ctx.join(); torch.cuda.synchronize()
-    ctx.set_profiling(True)
+    ctx.set_profiling(False)
     ctx.profile(reset=True)
     t0 = time.perf_counter()
     for i in range(n_calls):
+        ctx.set_profiling(i % profile_every == 0)
         fn(i)
     ctx.join(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -306,7 +308,7 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
             i = j % len(use)
             b, q, r = tiles[use[i]]
             ctx.lrt_dense_groups_device(b, q, r, min_af, g, k, res[i], gres[i])
-        n_calls = 4 * len(use)
+        n_calls = 8 * len(use)
         dt, prof = timed_calls(ctx, fn, n_calls)
         hist_ms = prof["hist_ms"] / max(1, prof["hist_launches"])
         alg = 2.0 * a.tile_sites * n
@@ -357,7 +359,7 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
     def fn_csr(j):
         o, b, q, r = csr[j % len(csr)]
         ctx.lrt_csr_device(o, b, q, r, min_af, res[j % len(csr)])
-    n_calls = 20
+    n_calls = 40
     dt, prof = timed_calls(ctx, fn_csr, n_calls)
     hist_ms = prof["hist_ms"] / max(1, prof["hist_launches"])
     em_ms = prof["em_ms"] / max(1, prof["em_launches"])
@@ -404,8 +406,7 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
         "value": n_calls * ns1 / dt, "unit": "sites/s", "ms_per_call": dt / n_calls * 1e3,
         "bound_by": "lrt_kernel (FP64 VALU)",
         "roofline": em_roofline(rec, em_ms),
-        "hist_dense_kernel_ms_per_call": hist_ms,
-        "hist_dense_kernel_GBs": 2.0 * ns1 * n1 / (hist_ms * 1e-3) / 1e9 if hist_ms > 0 else None,
+        "hist_wave_kernel_ms_per_call_under_the_em": hist_ms,     # 0.05 ms alone (profiles/r02_kernel_stats_legs.csv)
     }
     return legs
 
