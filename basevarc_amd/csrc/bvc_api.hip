@@ -443,7 +443,7 @@ int bvc_lrt_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_
 
     // host pointers: site chunks of at most ~512 MiB per array through two staging sets
     const int64_t row_bytes = row_stride > 0 ? row_stride : 1;
-    int64_t chunk = ((int64_t)1 << 29) / row_bytes;
+    int64_t chunk = ctx->ls.host_chunk_bytes / row_bytes;
     if (chunk < 1) chunk = 1;
     if (chunk > n_sites) chunk = n_sites;
     const size_t arr_al = ((size_t)chunk * (size_t)row_stride + 255) & ~(size_t)255;
@@ -694,7 +694,7 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
         return run_device(n_sites, bases, quals, ref_base, group_of_sample, results, grp_results);
 
     const int64_t row_bytes = row_stride > 0 ? row_stride : 1;
-    int64_t chunk = ((int64_t)1 << 29) / row_bytes;
+    int64_t chunk = ctx->ls.host_chunk_bytes / row_bytes;
     if (chunk < 1) chunk = 1;
     if (chunk > n_sites) chunk = n_sites;
     const size_t arr_al = ((size_t)chunk * (size_t)row_stride + 255) & ~(size_t)255;
@@ -745,6 +745,7 @@ int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value)
     if (std::strcmp(key, "em_wpb") == 0 && (value == 1 || value == 4)) { ctx->ls.em_wpb = value; return BVC_OK; }
     if (std::strcmp(key, "hist_split") == 0 && value >= 0 && value <= 64) { ctx->ls.hist_split = value; return BVC_OK; }
     if (std::strcmp(key, "group_pipe") == 0 && (value == 0 || value == 1)) { ctx->ls.group_pipe = value; return BVC_OK; }
+    if (std::strcmp(key, "host_chunk_kib") == 0 && value >= 1 && value <= (1 << 21)) { ctx->ls.host_chunk_bytes = (int64_t)value << 10; return BVC_OK; }
     return fail(ctx, BVC_ERR_ARG, "unknown tuning key or value out of range");
 }
 

@@ -14,6 +14,7 @@ struct LaunchState {
     int em_waves_per_cu = 0;   // 0 = default policy (em_kernel.hip); 1..32 resident EM wavefronts per CU
     int em_wpb = 4;            // waves per EM workgroup: 4, or 1 (A/B runs)
     int hist_split = 0;        // 0 = by tile shape; 1..64 workgroups sharing a site in the dense histogram pass
+    int64_t host_chunk_bytes = (int64_t)1 << 29;   // BVC_PTR_HOST calls: bytes per array and staging chunk
     int group_pipe = 1;        // any-order group histogram: issue the next chunk's loads before counting the current one
     uint32_t attr_done = 0;    // kernels whose dynamic-LDS attribute has been raised on this context's device
 };

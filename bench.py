@@ -365,7 +365,19 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
     em_ms = prof["em_ms"] / max(1, prof["em_launches"])
     alg = 2.0 * covered                                          # 2 B per COVERED sample
     rec = results_from_tensor(res[0])
+    csr_check = None
+    if a.cpu_sites != 0 and not a.no_verify:                     # 16 sites of CSR tile 0 against the oracle's histogram form
+        from oracle import orc
+        o, b, q, r = csr[0]
+        oh = o.cpu().numpy()
+        bad = 0
+        pick = np.linspace(0, csr_sites - 1, 16).astype(int)
+        for s_ in pick:
+            bs, qs = b[oh[s_]:oh[s_ + 1]].cpu().numpy(), q[oh[s_]:oh[s_ + 1]].cpu().numpy()
+            bad += not record_ok(rec[s_], orc.hist_lrt(orc.dense_hist(bs, qs), int(r[s_].item()), min_af))
+        csr_check = {"sites_checked": int(len(pick)), "mismatches": int(bad)}
     legs["csr_coverage10pct"] = {
+        "gpu_check_hist_form": csr_check,
         "workload": f"ragged (CSR) sites, bvc_lrt_csr: N = {n} samples at {cov:.0%} coverage = {covered / csr_sites:.0f} "
                     f"observations per site on average, {n_calls} calls of {csr_sites} sites over {len(csr)} tiles",
         "value": n_calls * csr_sites / dt, "unit": "sites/s", "ms_per_call": dt / n_calls * 1e3,

@@ -183,6 +183,9 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
  *   "hist_split"       0 = by tile shape, 1..64 workgroups sharing a site in the dense histogram pass
  *   "group_pipe"       any-order group histogram: 1 (default) issues the next chunk's loads before counting the
  *                      current one, 0 loads two chunks then counts both
+ *   "host_chunk_kib"   BVC_PTR_HOST calls stage the tile through device memory in chunks of sites of at most this
+ *                      many KiB per array (default 524288 = 512 MiB); the upload of chunk i+1 runs under the kernels
+ *                      of chunk i
  * A new context starts from the environment variables BVC_EM_WAVES_PER_CU, BVC_EM_WPB, BVC_HIST_SPLIT,
  * BVC_GROUP_PIPE when they are set. */
 int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value);

@@ -306,6 +306,78 @@ def test_csr_matches_dense(ctx):
         assert_site_matches(got[s], orc.basetype_lrt(b, q, r, 0.001), where=f"csr {s}")
 
 
+def test_csr_mixed_lengths_alignments_and_device_pointers(ctx):
+    """bvc_lrt_csr takes its sites by length: shorter than 4096 observations one wavefront per site, longer ones one
+    workgroup per site with 16-byte loads over the aligned middle of the range.  Lengths either side of the switch
+    and of the 16-byte grid, in one call, through host pointers, device pointers (arrays starting off the 16-byte
+    grid: byte path) and overlap mode; records against the oracle's histogram form of each site."""
+    import torch
+    from basevarc_amd.lib import results_from_tensor
+    rng = np.random.default_rng(55)
+    lens = [0, 1, 15, 16, 17, 63, 64, 65, 1000, 4095, 4096, 4097, 4111, 8192, 10000, 70001, 3, 0, 5000, 131072 + 7]
+    rng.shuffle(lens)
+    sites = []
+    for n in lens:
+        b, q, r = random_site(rng, n, af=float(rng.choice([0.0, 0.02, 0.3])), qlo=2, qhi=60)
+        if n > 100:
+            b[rng.random(n) < 0.01] = 4                         # a few N bases inside (skipped)
+        sites.append((b, q, r))
+    offs = np.zeros(len(sites) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(b) for b, _, _ in sites])
+    B = np.concatenate([b for b, _, _ in sites]); Q = np.concatenate([q for _, q, _ in sites])
+    R = np.array([r for _, _, r in sites], dtype=np.int8)
+    m = 0.001
+    exp = []
+    for b, q, r in sites:
+        ok = (b >= 0) & (b < 4)
+        exp.append(orc.hist_lrt(np.bincount(b[ok].astype(np.int64) * 128 + q[ok], minlength=512).astype(np.uint32), r, m))
+    got = ctx.lrt_csr(offs, B, Q, R, m)
+    for s in range(len(sites)):
+        assert_site_matches(got[s], exp[s], where=f"csr host site {s} len {lens[s]}")
+    ot = torch.from_numpy(offs).cuda()
+    rt = torch.from_numpy(R).cuda()
+    for shift in (0, 5):                                         # 5: arrays start off the 16-byte grid
+        fb = torch.zeros(len(B) + 64, dtype=torch.int8, device="cuda")
+        fq = torch.zeros_like(fb)
+        fb[shift:shift + len(B)] = torch.from_numpy(B).cuda()
+        fq[shift:shift + len(B)] = torch.from_numpy(Q).cuda()
+        for overlap in (False, True):
+            ctx.set_overlap(overlap)
+            try:
+                outs = [ctx.lrt_csr_device(ot, fb[shift:], fq[shift:], rt, m) for _ in range(3)]
+                ctx.join()
+                ctx.synchronize()
+            finally:
+                ctx.set_overlap(False)
+            for o in outs:
+                res = results_from_tensor(o)
+                assert res.tobytes() == got.tobytes(), (shift, overlap)
+
+
+def test_short_dense_rows_take_the_wave_kernel(ctx):
+    """Dense tiles with rows of at most 16384 samples and thousands of sites go one wavefront per site
+    (hist_wave_kernel): counts against numpy for row lengths either side of the switch, aligned and not."""
+    import torch
+    rng = np.random.default_rng(66)
+    for n, stride, off in ((1, 16, 0), (17, 32, 0), (1000, 1000, 3), (16384, 16384, 0), (16385, 16400, 0), (4099, 4112, 16)):
+        ns = 4100
+        bh = rng.integers(-1, 5, (ns, stride)).astype(np.int8)
+        qh = rng.integers(-3, 64, (ns, stride)).astype(np.int8)
+        flat_b = torch.zeros(off + ns * stride + 64, dtype=torch.int8, device="cuda")
+        flat_q = torch.zeros_like(flat_b)
+        flat_b[off:off + ns * stride] = torch.from_numpy(bh.reshape(-1)).cuda()
+        flat_q[off:off + ns * stride] = torch.from_numpy(qh.reshape(-1)).cuda()
+        bt = flat_b[off:off + ns * stride].view(ns, stride)[:, :n]
+        qt = flat_q[off:off + ns * stride].view(ns, stride)[:, :n]
+        counts = ctx.hist_dense_device(bt, qt).cpu().numpy().view(np.uint32)
+        ctx.synchronize()
+        for s in rng.choice(ns, 200, replace=False):
+            b, q = bh[s, :n], qh[s, :n]
+            ok = (b >= 0) & (b < 4) & (q >= 0)
+            want = np.bincount(b[ok].astype(np.int64) * 128 + q[ok], minlength=512).astype(np.uint32)
+            assert np.array_equal(counts[s], want), (n, stride, off, s)
+
+
 def test_group_mode_matches_callers_group_loop(ctx):
     """bvc_lrt_dense_groups vs the caller's --group loop (src/BaseVarC.cpp:617-661) restated in the oracle."""
     rng = np.random.default_rng(33)
@@ -565,6 +637,32 @@ def test_group_kernel_variants_give_identical_records(ctx):
     out = ctx.lrt_dense_groups_device(ub, uq, r, m, g, k)
     ctx.synchronize()
     assert all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(out, ref))
+
+
+def test_host_pointer_calls_pipeline_their_chunks(ctx):
+    """BVC_PTR_HOST calls stage the tile through two device buffers, chunk by chunk, the upload of chunk i+1 under the
+    kernels of chunk i.  With the chunk size turned down ("host_chunk_kib") a 300-site tile goes through in dozens of
+    chunks, with and without groups and overlap: the records must be those of the one-chunk call, byte for byte."""
+    from basevarc_amd import Context
+    rng = np.random.default_rng(12)
+    ns, n, k = 301, 20000, 4
+    sites = [random_site(rng, n, af=[0.0, 0.05, 0.4][s % 3]) for s in range(ns)]
+    B, Q, R = pad_rows(sites, width=n + 48)
+    B[:, n:] = 7                                                 # junk in the row padding
+    m = caller_min_af(n)
+    g = rng.integers(0, k + 1, n + 48).astype(np.uint8)
+    one = ctx.lrt_dense(B, Q, R, m)
+    one_g = ctx.lrt_dense_groups(B, Q, R, m, g, k)
+    for overlap in (False, True):
+        for kib in (20, 137, 1000):                              # 1, 6 and 51 sites per chunk
+            with Context(0) as c:
+                c.set_tuning("host_chunk_kib", kib)
+                c.set_overlap(overlap)
+                assert c.lrt_dense(B, Q, R, m).tobytes() == one.tobytes(), (overlap, kib)
+                res, gres = c.lrt_dense_groups(B, Q, R, m, g, k)
+                assert res.tobytes() == one_g[0].tobytes() and gres.tobytes() == one_g[1].tobytes(), (overlap, kib)
+    exp = orc.basetype_lrt(sites[7][0], sites[7][1], sites[7][2], m)
+    assert_site_matches(one[7], exp, where="chunked host call, site 7")
 
 
 def test_overlap_mode_gives_identical_records(ctx):
