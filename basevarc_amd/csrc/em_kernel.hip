@@ -492,6 +492,29 @@ __global__ __launch_bounds__(64 * WPB) void lrt_groups_kernel(int64_t n_sites, i
         const int64_t site = w / n_groups;
         const int g = (int)(w % n_groups);
         const uint32_t *hist = grp_counts + (site * (n_groups + 1) + g) * BVC_NCLASS;
+        if (!overall[site].called) {
+            // Not called overall: no group run at all (:633-636), only the depth columns na:nc:ng:nt (:640).  One
+            // variant writes them from a plain sum of the histogram rows; the others have nothing to do here.  (Four
+            // sites in five are like this: no compaction, no ballots, and two of the three variants touch no memory.)
+            if (NS == 2) {
+                const int lane = threadIdx.x & 63, row = lane >> 4, t = lane & 15;
+                int d = 0;
+#pragma unroll
+                for (int lvl = 0; lvl < 8; ++lvl) d += (int)hist[row * 128 + t + 16 * lvl];
+                d = row_sum(d);
+                const int d0 = __builtin_amdgcn_readlane(d, 0), d1 = __builtin_amdgcn_readlane(d, 16);
+                const int d2 = __builtin_amdgcn_readlane(d, 32), d3 = __builtin_amdgcn_readlane(d, 48);
+                if (lane == 0) {
+                    bvc_group_result r;
+                    for (int j = 0; j < 3; ++j) r.af[j] = 0.0;
+                    r.depth[0] = d0; r.depth[1] = d1; r.depth[2] = d2; r.depth[3] = d3;
+                    r.ran = 0; r.present = 0;
+                    for (int j = 0; j < 6; ++j) r.pad[j] = 0;
+                    grp_results[site * n_groups + g] = r;
+                }
+            }
+            continue;
+        }
         const bvc_site_result ov = overall[site];
         const int ref = ref_base[site];
         // base_comb = {ref} + alt_bases (:614-615); a ref outside 0..3 has depth 0 in the reference and falls to
@@ -502,14 +525,13 @@ __global__ __launch_bounds__(64 * WPB) void lrt_groups_kernel(int64_t n_sites, i
         for (int i = 0; i < 3; ++i)
             if (i < ov.n_alt) { list |= (uint32_t)(ov.alt_base[i] & 3) << (4 * nc); ++nc; }
         SiteOut o;
-        // The histogram is always loaded (depths are reported for every group, :640); the LRT itself runs only
-        // when the overall call succeeded and the group has covered samples (:633-636, :641).
-        const bool mine = lrt_site<NS, WPB>(hist, ref, min_af, list, ov.called ? nc : 0, lut, s_n, s_q, o);
+        // called overall: the group's own LRT, when it has covered samples (:641; lrt_site returns at once otherwise)
+        const bool mine = lrt_site<NS, WPB>(hist, ref, min_af, list, nc, lut, s_n, s_q, o);
         if (mine && (threadIdx.x & 63) == 0) {
             bvc_group_result r;
             for (int j = 0; j < 4; ++j) r.depth[j] = o.depth[j];
             for (int j = 0; j < 6; ++j) r.pad[j] = 0;
-            r.ran = (ov.called && o.depth_total > 0) ? 1 : 0;
+            r.ran = o.depth_total > 0 ? 1 : 0;
             r.present = 0;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {

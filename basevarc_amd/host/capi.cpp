@@ -178,7 +178,8 @@ int64_t bvchost_write_synth_batches(const char *out_prefix, int32_t n_samples, i
         const size_t hi = t == thread - 1 ? (size_t)n_pos : std::min((size_t)n_pos, (size_t)(t + 1) * window);
         for (int32_t ib = 0; ib < nb; ++ib) {
             const int32_t j0 = ib * batch, j1 = std::min(n_samples, (ib + 1) * batch);
-            BgzfWriter fp(std::string(out_prefix) + ".tmp.thread." + std::to_string(t) + "/batch." + std::to_string(ib), 1);
+            // bin: 0 text, 1 binary deflated, 2 binary stored ("raw")
+            BgzfWriter fp(std::string(out_prefix) + ".tmp.thread." + std::to_string(t) + "/batch." + std::to_string(ib), bin == 2 ? 0 : 1);
             if (!fp.ok()) return -1;
             std::string names;
             for (int32_t j = j0; j < j1; ++j) names += "S" + std::to_string(j) + "\t";

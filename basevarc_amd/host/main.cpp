@@ -59,7 +59,8 @@ static const char *BASETYPE_MESSAGE =
     "  --verbose,    -v         Set verbose output\n"
     "  --gpus           <INT>   MI355X devices to use [all]\n"
     "  --tile           <INT>   Positions per device call [4096]\n"
-    "  --tmp-format     <STR>   Temp-batch files written by the load phase: text (as BaseVarC) or bin [text]\n";
+    "  --tmp-format     <STR>   Temp-batch files written by the load phase: text (as BaseVarC), bin (binary\n"
+    "                           records, deflated) or raw (binary records, stored: fastest to read back) [text]\n";
 
 namespace opt {
 static bool verbose = false, rerun = false, load = false, keep_tmp = false;
@@ -107,7 +108,7 @@ static void parse_options(int argc, char **argv, const char *msg)          // sr
         default: die = true;
         }
     }
-    if (opt::tmp_format != "text" && opt::tmp_format != "bin") die = true;
+    if (opt::tmp_format != "text" && opt::tmp_format != "bin" && opt::tmp_format != "raw") die = true;
     if (die || opt::input.empty() || opt::output.empty()) {
         std::cerr << msg;
         std::exit(die ? EXIT_FAILURE : EXIT_SUCCESS);
@@ -169,10 +170,14 @@ static void bt_r(const std::vector<std::string> &bams, const std::vector<int32_t
         names += sm + '\t';
     }
     names += "\n";
-    const bool bin = opt::tmp_format == "bin";
+    const bool bin = opt::tmp_format != "text";
+    // "raw": the same binary records in stored (deflate level 0) BGZF blocks -- still valid BGZF with the EOF block the
+    // --rerun check looks for, but reading them back is a copy instead of an inflate (half of the compute phase's
+    // host time once the tokenising is gone)
+    const int level = opt::tmp_format == "raw" ? 0 : 6;
     std::vector<BgzfWriter *> fpv;
     for (int i = 0; i < thread; ++i) {
-        BgzfWriter *fp = new BgzfWriter(tmp_name(i, ib));
+        BgzfWriter *fp = new BgzfWriter(tmp_name(i, ib), level);
         if (!fp->ok()) throw std::runtime_error("ERROR: fail to write " + tmp_name(i, ib));
         if (bin) { std::string h; bin_batch_header((uint32_t)(b1 - b0), names, h); fp->write(h); }
         else fp->write(names);

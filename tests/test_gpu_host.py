@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("thread,grouped,tmp_format", [(1, False, "text"), (4, False, "text"), (2, True, "text"),
-                                                       (3, False, "bin"), (2, True, "bin")])
+                                                       (3, False, "bin"), (2, True, "bin"), (2, False, "raw")])
 def test_basetype_command_on_reference_test_data(tmp_path, thread, grouped, tmp_format):
     from basevarc_amd import build as b
     from tests import hostref

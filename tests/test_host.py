@@ -354,7 +354,7 @@ def test_binary_temp_batches_hold_what_the_text_batches_hold(tmp_path):
     lst = hostref.write_bam_list(str(tmp_path / "bam.list"))
     thread, batch = 3, 37
     outs = {}
-    for fmt in ("text", "bin"):
+    for fmt in ("text", "bin", "raw"):
         outs[fmt] = str(tmp_path / f"{fmt}.out")
         subprocess.run([exe, "basetype", "--load", "-q", "20", "-t", str(thread), "-b", str(batch), "-i", lst, "-s",
                         hostref.REGION, "-r", fa, "-o", outs[fmt], "--tmp-format", fmt], check=True, capture_output=True)
@@ -384,6 +384,9 @@ def test_binary_temp_batches_hold_what_the_text_batches_hold(tmp_path):
                         n_base += 1
                 got = [(e[0], e[6]) if e[6] is not None else (e[0], e[1], e[2], e[3], e[4], e[5]) for e in ents]
                 assert got == want
+            # "raw": the same records in stored BGZF blocks
+            raw_r = open(f"{outs['raw']}.tmp.thread.{t}/batch.{ib}", "rb").read()
+            assert raw_r[-28:] == raw_t[-28:] and gzip.decompress(raw_r) == gzip.decompress(raw_b)
     assert n_base > 100000 and n_indel > 10
     assert os.path.getsize(f"{outs['bin']}.tmp.thread.0/batch.0") < os.path.getsize(f"{outs['text']}.tmp.thread.0/batch.0")
 

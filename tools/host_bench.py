@@ -55,12 +55,12 @@ def main():
             f.write(">chrS\n" + "A" * length + "\n")
         open(fa + ".fai", "w").write(f"chrS\t{length}\t6\t{length}\t{length + 1}\n")
         open(os.path.join(d, "bam.list"), "w").write("".join(f"s{i}.bam\n" for i in range(n)))
-        for fmt in ("text", "bin"):
+        for fmt in ("text", "bin", "raw"):
             out = os.path.join(d, f"bench_{fmt}.out")
             for t in range(thread):
                 os.makedirs(f"{out}.tmp.thread.{t}", exist_ok=True)
             t0 = time.perf_counter()
-            entries = H.bvchost_write_synth_batches(out.encode(), n, npos, thread, batch, int(round(cov * 1000)), 11, fmt == "bin")
+            entries = H.bvchost_write_synth_batches(out.encode(), n, npos, thread, batch, int(round(cov * 1000)), 11, {"text": 0, "bin": 1, "raw": 2}[fmt])
             gen_s = time.perf_counter() - t0
             assert entries >= 0
             size = sum(os.path.getsize(os.path.join(dp, f)) for t in range(thread)
@@ -81,8 +81,8 @@ def main():
             for k in (".cvg.gz", ".vcf.gz"):
                 os.replace(out + k, os.path.join(d, f"{fmt}{k}"))
         same = all(gzip.decompress(open(os.path.join(d, "text" + k), "rb").read()) ==
-                   gzip.decompress(open(os.path.join(d, "bin" + k), "rb").read()) for k in (".cvg.gz", ".vcf.gz"))
-        print(json.dumps({"text_and_bin_outputs_identical": same}))
+                   gzip.decompress(open(os.path.join(d, f + k), "rb").read()) for k in (".cvg.gz", ".vcf.gz") for f in ("bin", "raw"))
+        print(json.dumps({"text_bin_and_raw_outputs_identical": same}))
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
