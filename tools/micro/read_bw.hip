@@ -4,6 +4,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -w -o tools/micro/read_bw tools/micro/read_bw.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <vector>
 #include <algorithm>
@@ -158,9 +159,11 @@ static double best_ms(F launch, int reps = 21)       // median of `reps` timed l
     return t[t.size() / 2];
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const int64_t n_rows = 4000, row_bytes = 1000000;            // the bench tile: 4000 sites x 1e6 samples, 2 arrays
+    // the bench tile: 4000 sites x 1e6 samples, 2 arrays; argv[1] = row stride in bytes (round 1: 1000000, rows start
+    // mid-line on odd sites; round 2's tiles: 1000064, every row on a 128-byte line)
+    const int64_t n_rows = 4000, row_bytes = argc > 1 ? atoll(argv[1]) : 1000064;
     const int64_t bytes_each = n_rows * row_bytes, total = 2 * bytes_each;
     char *buf; uint32_t *sink;
     hipMalloc(&buf, total); hipMalloc(&sink, 64);
