@@ -333,7 +333,7 @@ int bvc_create(bvc_ctx **out, int device)
     }
     bool ok = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void **>(&ctx->d_grp_scratch), (BVC_MAX_GROUPS + 4) * sizeof(int64_t)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&ctx->d_grp_scratch), kGroupScratchWords * sizeof(int64_t)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&ctx->d_sink), 256) == hipSuccess;
     for (int b = 0; b < bvc_ctx::kRing && ok; ++b)
         ok = hipEventCreateWithFlags(&ctx->ev_hist_done[b], hipEventDisableTiming) == hipSuccess &&
@@ -647,8 +647,9 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
         if (rc2 != BVC_OK) return rc2;
         rc2 = ensure(ctx, reinterpret_cast<void **>(gp), gcap, gbytes);
         if (rc2 != BVC_OK) return rc2;
-        if ((size_t)n_samples + 16 > ctx->grp_labels_cap) { int rj = join_side(ctx); if (rj != BVC_OK) return rj; }
-        rc2 = ensure(ctx, reinterpret_cast<void **>(&ctx->d_grp_labels), &ctx->grp_labels_cap, (size_t)n_samples + 16);
+        const size_t lbytes = (size_t)n_samples + 256;                 // the call's labels clamped to 0..n_groups
+        if (lbytes > ctx->grp_labels_cap) { int rj = join_side(ctx); if (rj != BVC_OK) return rj; }
+        rc2 = ensure(ctx, reinterpret_cast<void **>(&ctx->d_grp_labels), &ctx->grp_labels_cap, lbytes);
         if (rc2 != BVC_OK) return rc2;
         if (ctx->overlap && ctx->em_pending[buf]) {
             BVC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_em_done[buf], 0));

@@ -33,7 +33,8 @@ hipError_t launch_hist_dense(LaunchState &st, hipStream_t stream, int64_t n_site
                              const int8_t *bases, const int8_t *quals, const uint8_t *group_of_sample,
                              int n_groups, uint32_t *counts, int split, int64_t *group_scratch = nullptr,
                              uint8_t *hist_of_sample = nullptr);
-// Group mode needs group_scratch (BVC_MAX_GROUPS + 4 int64 of device memory) and hist_of_sample (n_samples bytes,
+constexpr int kGroupScratchWords = BVC_MAX_GROUPS + 4;
+// Group mode needs group_scratch (kGroupScratchWords int64 of device memory) and hist_of_sample (n_samples bytes,
 // 16-byte aligned): calls whose samples are ordered by group take the column-range kernel (decided on the device),
 // the others index their histograms with the clamped labels written to hist_of_sample.
 // Number of sample-range splits per site launch_hist_dense should use for this shape (1 = none).

@@ -26,6 +26,7 @@ constexpr int kHistThreads = BVC_HIST_THREADS;
 constexpr int kCopies = 32;                         // one copy per LDS bank
 constexpr int kLdsWords = BVC_NCLASS * kCopies;     // 16384 words = 64 KiB
 constexpr int kUnroll = BVC_HIST_UNROLL;            // 16-byte loads in flight per lane and array
+constexpr int kGroupDepth = 2;                      // chunks prefetched per trip of the group kernel's sample loop (swept 1..4)
 constexpr int64_t kWaveRowMax = 16384;              // dense rows up to this length go one wavefront per site
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -56,6 +57,37 @@ __device__ __forceinline__ uint32_t lds_address(uint32_t *p) { return (uint32_t)
 __device__ __forceinline__ void lds_add_one(uint32_t lds_byte_address)
 {
     __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)lds_byte_address, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The any-order group kernel's sample loop: each trip issues the loads of the next D chunks (of three 16-byte
+// streams) before it counts the current D, so that a wave has bytes in flight while it works through its LDS atomics.
+// Chunk c belongs to thread c mod kHistThreads; an out-of-range chunk reads nothing and carries base bytes 0xFF, which
+// the counting skips.  (Depth 1 / 2 / 3 / 4 measure 1.34 / 1.29 / 1.31 / 1.47 ms alone:
+// profiles/r02_slot_kernel_experiment.txt.)
+template <int D, class Load, class Count>
+__device__ __forceinline__ void stream_chunks(int64_t n16, int tid, Load load, Count count)
+{
+    u32x4 b[D], q[D], g[D], nb[D], nq[D], ng[D];
+    auto fetch = [&](int64_t c0, u32x4 (&xb)[D], u32x4 (&xq)[D], u32x4 (&xg)[D]) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int64_t c = c0 + (int64_t)d * kHistThreads;
+            xb[d] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            xq[d] = u32x4{0u, 0u, 0u, 0u}; xg[d] = xq[d];
+            if (c < n16) load(c, xb[d], xq[d], xg[d]);
+        }
+    };
+    int64_t c = tid;
+    fetch(c, b, q, g);
+    while (c < n16) {
+        const int64_t cn = c + (int64_t)D * kHistThreads;
+        fetch(cn, nb, nq, ng);
+#pragma unroll
+        for (int d = 0; d < D; ++d) count(b[d], q[d], g[d]);
+#pragma unroll
+        for (int d = 0; d < D; ++d) { b[d] = nb[d]; q[d] = nq[d]; g[d] = ng[d]; }
+        c = cn;
+    }
 }
 
 // Four covered samples (every base byte 0..3, every qual byte 0..127): byte address of the counter =
@@ -256,8 +288,7 @@ __device__ __forceinline__ void count_group_word(uint32_t lane_base, uint32_t bw
 
 // Fast form: 16-byte aligned rows; `hist_of_sample` is the group vector already clamped to 0..n_groups by
 // group_bounds_kernel (one pass over 1 byte per sample per CALL, shared by all the sites of the tile).
-// PIPE: the loads of the next 16-sample chunk are issued before the current one is counted, so a wave keeps bytes
-// in flight while it works (its counting takes about as long as the loads' latency).
+// PIPE: the loads of the next two 16-sample chunks are issued before the current two are counted (stream_chunks).
 template <int LOG2C, bool PIPE>
 __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
     int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *__restrict__ bases,
@@ -304,30 +335,21 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
         const int8_t *qrow = quals + site * row_stride;
         const u32x4 *bv = reinterpret_cast<const u32x4 *>(brow);
         const u32x4 *qv = reinterpret_cast<const u32x4 *>(qrow);
+        auto load = [&](int64_t c, u32x4 &b, u32x4 &q, u32x4 &g) {
+            b = __builtin_nontemporal_load(&bv[c]); q = __builtin_nontemporal_load(&qv[c]); g = gv[c];
+        };
         if (PIPE) {
-            int64_t c = tid;
-            u32x4 b0 = u32x4{0u, 0u, 0u, 0u}, q0 = b0, g0 = b0;
-            if (c < n16) { b0 = __builtin_nontemporal_load(&bv[c]); q0 = __builtin_nontemporal_load(&qv[c]); g0 = gv[c]; }
-            while (c < n16) {
-                const int64_t cn = c + kHistThreads;
-                u32x4 b1 = b0, q1 = q0, g1 = g0;
-                if (cn < n16) { b1 = __builtin_nontemporal_load(&bv[cn]); q1 = __builtin_nontemporal_load(&qv[cn]); g1 = gv[cn]; }
-                count16(b0, q0, g0);
-                b0 = b1; q0 = q1; g0 = g1;
-                c = cn;
-            }
+            stream_chunks<kGroupDepth>(n16, tid, load, count16);
         } else {
             int64_t c = tid;
             for (; c + kHistThreads < n16; c += 2 * kHistThreads) {        // two 16-byte loads per array in flight
-                const u32x4 b0 = __builtin_nontemporal_load(&bv[c]), q0 = __builtin_nontemporal_load(&qv[c]);
-                const u32x4 g0 = gv[c];
-                const u32x4 b1 = __builtin_nontemporal_load(&bv[c + kHistThreads]), q1 = __builtin_nontemporal_load(&qv[c + kHistThreads]);
-                const u32x4 g1 = gv[c + kHistThreads];
+                u32x4 b0, q0, g0, b1, q1, g1;
+                load(c, b0, q0, g0);
+                load(c + kHistThreads, b1, q1, g1);
                 count16(b0, q0, g0);
                 count16(b1, q1, g1);
             }
-            for (; c < n16; c += kHistThreads)
-                count16(__builtin_nontemporal_load(&bv[c]), __builtin_nontemporal_load(&qv[c]), gv[c]);
+            for (; c < n16; c += kHistThreads) { u32x4 b0, q0, g0; load(c, b0, q0, g0); count16(b0, q0, g0); }
         }
         for (int64_t i = (n16 << 4) + tid; i < n_samples; i += kHistThreads)
             add_checked((uint8_t)brow[i], (uint8_t)qrow[i], hist_of_sample[i]);
@@ -670,7 +692,7 @@ hipError_t launch_hist_dense(LaunchState &st, hipStream_t stream, int64_t n_site
         auto rk = aligned ? hist_dense_ranges_kernel<true> : hist_dense_ranges_kernel<false>;
         hipError_t e = raise_lds(st, aligned ? kSlotRanges1 : kSlotRanges0, reinterpret_cast<const void *>(rk), lds);
         if (e != hipSuccess) return e;
-        e = hipMemsetAsync(group_scratch, 0, (size_t)(BVC_MAX_GROUPS + 4) * sizeof(int64_t), stream);
+        e = hipMemsetAsync(group_scratch, 0, (size_t)kGroupScratchWords * sizeof(int64_t), stream);
         if (e != hipSuccess) return e;
         const int64_t bgrid = (n_samples + 255) / 256;
         hipLaunchKernelGGL(group_bounds_kernel, dim3((unsigned)(bgrid < 1024 ? bgrid : 1024)), dim3(256), 0, stream,

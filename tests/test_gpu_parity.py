@@ -607,36 +607,54 @@ def test_tuning_knobs_are_per_context_and_never_change_a_record(ctx, knob, value
                 assert_site_matches(res[s], exp[s], where=f"{knob}={value} n={n} site={s}", path_strict=False)
 
 
-def test_group_kernel_variants_give_identical_records(ctx):
-    """Any-order group histogram: pipelined and two-chunk load schedules ("group_pipe"), and rows off the 16-byte grid
-    (generic byte kernel), against each other byte for byte."""
+@pytest.mark.parametrize("pattern", ["random", "mod5", "runs", "one_group", "sorted"])
+def test_group_kernel_variants_give_identical_records(ctx, pattern):
+    """Group mode picks its histogram kernel on the device: sorted labels -> column ranges; any other order -> the
+    class-bank kernel; rows off the 16-byte grid -> the byte kernel.  Whatever runs, the records are the same bytes:
+    each label pattern through the default path, with the unpipelined load schedule, and through the byte kernel
+    (rows shifted by one byte), plus the oracle on a few sites."""
     import torch
     from basevarc_amd import Context
-    ns, n, k = 37, 50_000, 5
+    from basevarc_amd.lib import GROUP_DTYPE, results_from_tensor
+    ns, n, k = 37, 50_000 + 9, 5
     m = caller_min_af(n)
     rng = np.random.default_rng(8)
-    b = torch.empty((ns, n + 16), dtype=torch.int8, device="cuda")
-    q = torch.empty((ns, n + 16), dtype=torch.int8, device="cuda")
+    b = torch.empty((ns, n + 23), dtype=torch.int8, device="cuda")
+    q = torch.empty((ns, n + 23), dtype=torch.int8, device="cuda")
     r = torch.empty(ns, dtype=torch.int8, device="cuda")
     ctx.synth_dense_device(11, 4242, b[:, :n], q[:, :n], r, cov_thr16=60000)
-    g = torch.from_numpy(rng.integers(0, 7, n).astype(np.uint8)).cuda()      # labels 5, 6 = no group
+    labels = {"random": rng.integers(0, 7, n),                       # labels 5, 6 = no group
+              "mod5": np.arange(n) % 5,
+              "runs": (np.arange(n) // 700) % 6,                     # long runs, not sorted: 32 equal labels per lane set
+              "one_group": np.full(n, 2),
+              "sorted": np.sort(rng.integers(0, 6, n))}[pattern].astype(np.uint8)
+    g = torch.from_numpy(labels).cuda()
     ctx.synchronize()
     base = ctx.lrt_dense_groups_device(b[:, :n], q[:, :n], r, m, g, k)
     ctx.synchronize()
     ref = [t.cpu().numpy().copy() for t in base]
-    with Context(0) as other:
-        other.set_tuning("group_pipe", 0)
-        out = other.lrt_dense_groups_device(b[:, :n], q[:, :n], r, m, g, k)
-        other.synchronize()
-        assert all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(out, ref))
-    # the same rows shifted by one byte: unaligned -> generic kernel
-    fb = torch.zeros(ns * (n + 16) + 1, dtype=torch.int8, device="cuda")
+    for knob in ("group_pipe",):
+        with Context(0) as other:
+            other.set_tuning(knob, 0)
+            out = other.lrt_dense_groups_device(b[:, :n], q[:, :n], r, m, g, k)
+            other.synchronize()
+            assert all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(out, ref)), (pattern, knob)
+    # the same rows shifted by one byte: unaligned -> generic byte kernel
+    fb = torch.zeros(ns * (n + 23) + 1, dtype=torch.int8, device="cuda")
     fq = torch.zeros_like(fb)
     fb[1:] = b.reshape(-1); fq[1:] = q.reshape(-1)
-    ub = fb[1:].view(ns, n + 16)[:, :n]; uq = fq[1:].view(ns, n + 16)[:, :n]
+    ub = fb[1:].view(ns, n + 23)[:, :n]; uq = fq[1:].view(ns, n + 23)[:, :n]
     out = ctx.lrt_dense_groups_device(ub, uq, r, m, g, k)
     ctx.synchronize()
-    assert all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(out, ref))
+    assert all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(out, ref)), pattern
+    res = results_from_tensor(base[0])
+    gres = ref[1].view(GROUP_DTYPE).reshape(ns, k)
+    hb, hq, hr = b[:, :n].cpu().numpy(), q[:, :n].cpu().numpy(), r.cpu().numpy()
+    for s in (0, 5, 17, 36):
+        o, gd, ga, ran, pres = orc.dense_site_groups(hb[s], hq[s], int(hr[s]), m, labels, k, use_hist=True)
+        assert_site_matches(res[s], o, where=f"{pattern} site {s}", path_strict=False)
+        assert np.array_equal(gres[s]["depth"], gd) and np.array_equal(gres[s]["ran"], ran), (pattern, s)
+        np.testing.assert_allclose(gres[s]["af"], ga, rtol=0, atol=AF_ATOL)
 
 
 def test_host_pointer_calls_pipeline_their_chunks(ctx):

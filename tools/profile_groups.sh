@@ -1,6 +1,7 @@
 #!/bin/bash
-# Group mode (k = 5, N = 1e6) on the GPU box: timing of the any-order histogram kernel without / with load pipelining (alone and under the EM kernels), then PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_*) for each, serial mode.
-# usage: bash tools/profile_groups.sh <tag> "<group_pipe values>" [extra bench flags]
+# Group mode (k = 5, N = 1e6, labels i % 5) on the GPU box: the any-order histogram kernels A/B -- slot kernel
+# (BVC_GROUP_PIPE=1) against the class-bank kernel (=0) -- timing alone and under the EM kernels, then PMC passes
+# (FETCH_SIZE, SQ_*) for each, serial mode.  usage: bash tools/profile_groups.sh <tag> "<BVC_GROUP_PIPE values>"
 # Output under gpurun_out/<tag>/; tools/pmc_summary.py <tag> gpurun_out/<tag>/gs<N> summarises a pass set.
 set -e
 TAG=${1:-rXX_groups}
@@ -21,10 +22,8 @@ done
 cd /tmp && export TMPDIR=/tmp
 for gs in $GS; do
   export BVC_GROUP_PIPE=$gs
-  for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/gs$gs/pmc_$c -- python3 $R/bench.py $B --no-overlap --steps 2 --warmup 1 > $O/gs${gs}_pmc_$c.log 2>&1
-  done
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/gs$gs/pmc_FETCH_SIZE -- python3 $R/bench.py $B --no-overlap --steps 2 --warmup 1 > $O/gs${gs}_pmc_FETCH_SIZE.log 2>&1
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/gs$gs/pmc_SQ -- python3 $R/bench.py $B --no-overlap --steps 2 --warmup 1 > $O/gs${gs}_pmc_SQ.log 2>&1
-  rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d $O/gs$gs/pmc_SQ2 -- python3 $R/bench.py $B --no-overlap --steps 2 --warmup 1 > $O/gs${gs}_pmc_SQ2.log 2>&1 || echo "SQ2 pass failed (counter names)"
+  rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/gs$gs/pmc_SQ2 -- python3 $R/bench.py $B --no-overlap --steps 2 --warmup 1 > $O/gs${gs}_pmc_SQ2.log 2>&1
 done
 cat $O/timing.txt
