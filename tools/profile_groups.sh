@@ -1,6 +1,6 @@
 #!/bin/bash
-# Group mode (k = 5, N = 1e6, labels i % 5) on the GPU box: the any-order histogram kernels A/B -- slot kernel
-# (BVC_GROUP_PIPE=1) against the class-bank kernel (=0) -- timing alone and under the EM kernels, then PMC passes
+# Group mode (k = 5, N = 1e6, labels i % 5) on the GPU box: the any-order histogram kernel A/B -- loads issued ahead
+# (BVC_GROUP_PIPE=1) or two chunks loaded then counted (=0) -- timing alone and under the EM kernels, then PMC passes
 # (FETCH_SIZE, SQ_*) for each, serial mode.  usage: bash tools/profile_groups.sh <tag> "<BVC_GROUP_PIPE values>"
 # Output under gpurun_out/<tag>/; tools/pmc_summary.py <tag> gpurun_out/<tag>/gs<N> summarises a pass set.
 set -e
