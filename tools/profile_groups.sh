@@ -14,9 +14,7 @@ cd $R
 B="--groups 5 --cpu-sites 0 --no-verify --no-legs --total-sites 24000 $EXTRA"
 for gs in $GS; do
   for mode in "" "--no-overlap"; do
-    BVC_GROUP_PIPE=$gs python bench.py $B $mode --steps 8 --warmup 1 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); print('group_pipe',$gs,'$mode','sites/s',round(d['value']),'ms/call',round(d['ms_per_step']/d['config']['calls_per_step_per_gpu'],4),d['kernels_ms_per_call'])" | tee -a $O/timing.txt
+    BVC_GROUP_PIPE=$gs python bench.py $B $mode --steps 8 --warmup 1 2>/dev/null | python tools/bench_line.py group_pipe $gs $mode | tee -a $O/timing.txt
   done
 done
 cd /tmp && export TMPDIR=/tmp

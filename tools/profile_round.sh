@@ -28,8 +28,6 @@ for cfg in "dense:" "groups_interleaved:--groups 5" "groups_ordered:--groups 5 -
 done
 cd $R
 for a in 16 128 256 1024 4096; do
-  python bench.py --row-align $a --steps 5 --warmup 1 $Q 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); print('row_align',$a,'stride',d['config']['row_stride'],'sites/s',round(d['value']),'hist ms',round(d['roofline']['avg_launch_ms'],4),'frac',round(d['roofline']['frac'],4))" | tee -a $O/row_align.txt
+  python bench.py --row-align $a --steps 5 --warmup 1 $Q 2>/dev/null | python tools/bench_line.py row_align $a | tee -a $O/row_align.txt
 done
 cut -c1-400 $O/bench_overlap.json

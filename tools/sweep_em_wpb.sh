@@ -3,8 +3,6 @@
 cd $GRAFT_REPO_ROOT
 for w in ${1:-8 10 12}; do
  for b in 1 4; do
-  BVC_EM_WPB=$b BVC_EM_WAVES_PER_CU=$w python bench.py --steps 100 --warmup 5 --cpu-sites 0 --no-verify $2 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); print('wpb',$b,'cap',$w,'sites/s',round(d['value']),'step',round(d['ms_per_step'],4),'k',d['kernels_ms_per_step'])"
+  BVC_EM_WPB=$b BVC_EM_WAVES_PER_CU=$w python bench.py --steps 4 --warmup 1 --cpu-sites 0 --no-verify --no-legs $2 2>/dev/null | python tools/bench_line.py wpb $b cap $w
  done
 done
