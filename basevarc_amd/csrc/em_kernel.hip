@@ -111,14 +111,19 @@ constexpr uint32_t hi_word(double x) { return (uint32_t)(__builtin_bit_cast(uint
 constexpr uint32_t kSureBelowHi = hi_word(kEmEpsilon / (1.0 + 0.00390625));        // hi(A) <  this: converged
 constexpr uint32_t kSureAboveHi = hi_word(kEmEpsilon / (1.0 - 0.00390625)) + 1u;   // hi(A) >= this: not converged
 
-template <int NS>
+// NA <= NS: slots that can hold a class at this site.  A site whose bases have at most 16 * NA quality values leaves
+// slots NA..NS-1 empty in every lane, and an empty slot adds exact zeros to every sum (n = 0) and 0 to max|u|
+// (m = y = 1), so leaving them out changes no bit of the result -- only the instruction count (NS = 4 with three
+// active slots: Illumina's ~40 quality values; NS = 8 with six: the whole BAM range 0..93).
+template <int NS, int NA = NS>
 __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double inv_n, int lane)
 {
+    static_assert(NA >= 1 && NA <= NS, "active slots");
     double acc_d = 0.0, acc_e = 0.0, acc_a;
     double m[NS], u[NS];
     double umax = 0.0;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
+    for (int k = 0; k < NA; ++k) {
         m[k] = fma(f.fb, S.d[k], S.e[k]);
         u[k] = fma(m[k], S.yp[k], -1.0);
         umax = fmax(umax, fabs(u[k]));
@@ -130,7 +135,7 @@ __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double in
     // long decided when its branch comes, instead of stalling the wave between u and the Newton steps.
     const bool jump = __ballot(umax > kLog1pMaxU) != 0;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
+    for (int k = 0; k < NA; ++k) {
         double y = fma(-S.yp[k], u[k], S.yp[k]);
         y = fma(y, fma(-m[k], y, 1.0), y);
         S.yp[k] = fma(y, fma(-m[k], y, 1.0), y);
@@ -138,10 +143,10 @@ __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double in
     }
     if (jump) {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) S.yp[k] = fast_rcp(m[k]);
+        for (int k = 0; k < NA; ++k) S.yp[k] = fast_rcp(m[k]);
     }
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
+    for (int k = 0; k < NA; ++k) {
         const double r = S.n[k] * S.yp[k];
         acc_d = fma(r, S.d[k], acc_d);
         acc_e = fma(r, S.e[k], acc_e);
@@ -166,7 +171,7 @@ __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double in
     if (a_hi >= kSureBelowHi && a_hi < kSureAboveHi) {           // rare: the bracket straddles eps
         double ex = 0.0;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
+        for (int k = 0; k < NA; ++k) {
             double p = fma(-0.25, u[k], 1.0 / 3.0);
             p = fma(p, u[k], -0.5);
             p = fma(p, u[k], 1.0);
@@ -181,7 +186,7 @@ __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double in
 // EM (src/Algorithm.cpp:115-130) followed by UpdateF's log-likelihood sum (src/BaseType.cpp:58-62).
 // f0 = the lane's initial frequency.  Returns the log-likelihood of the last pass; ex = expect_allele_prob
 // of that pass (one M step ahead of the frequencies the log-likelihood belongs to, as in the reference).
-template <int NS>
+template <int NS, int NA = NS>
 __device__ __forceinline__ double em_fit(Slots<NS> &S, int lane, double f0, double inv_n,
                                          double (&ex)[4], int &passes)
 {
@@ -190,16 +195,16 @@ __device__ __forceinline__ double em_fit(Slots<NS> &S, int lane, double f0, doub
     // every fit starts from yp = 1 (not from the previous fit's, which may hold NaNs): its first pass then
     // has |u| = |m - 1| and takes the big tier, whose reciprocal does not depend on yp
 #pragma unroll
-    for (int k = 0; k < NS; ++k) S.yp[k] = 1.0;
+    for (int k = 0; k < NA; ++k) S.yp[k] = 1.0;
     // pass 0 + at most kEmIters update passes; two passes per trip so that 1/m can alternate between two register
     // sets instead of being copied back every pass
     for (int it = 0;; it += 2) {
-        o = em_pass<NS>(S, f, inv_n, lane);
+        o = em_pass<NS, NA>(S, f, inv_n, lane);
         passes += 1;
         if (it > 0 && o.converged) break;
         if (it == kEmIters) break;
         f.fb = o.ex_own;
-        o = em_pass<NS>(S, f, inv_n, lane);
+        o = em_pass<NS, NA>(S, f, inv_n, lane);
         passes += 1;
         if (o.converged) break;
         if (it + 1 == kEmIters) break;
@@ -211,7 +216,7 @@ __device__ __forceinline__ double em_fit(Slots<NS> &S, int lane, double f0, doub
     ex[3] = lane_value<48>(o.ex_own);
     double ll = 0.0;                           // sum_c n_c log m_c = -sum_c n_c log(1/m_c)
 #pragma unroll
-    for (int k = 0; k < NS; ++k) ll = fma(-S.n[k], log_pos(S.yp[k]), ll);
+    for (int k = 0; k < NA; ++k) ll = fma(-S.n[k], log_pos(S.yp[k]), ll);
     return rows_total(row_sum(ll));
 }
 
@@ -326,7 +331,10 @@ __device__ bool lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
             f[j] = (depth_sum > 0 && ((setmask >> j) & 1u)) ? (double)depth[j] / (double)depth_sum : 0.0;
         const double freq_sum = ((f[0] + f[1]) + f[2]) + f[3];
         if (freq_sum == 0) return false;
-        loglik = em_fit<NS>(S, lane, pick4(f, row), inv_n, ex, passes);
+        // (wave-uniform) the variant's narrower form when the site leaves its last slots empty
+        constexpr int kNarrow = NS == 4 ? 3 : (NS == 8 ? 6 : NS);
+        if (kNarrow < NS && nslots <= kNarrow) loglik = em_fit<NS, kNarrow>(S, lane, pick4(f, row), inv_n, ex, passes);
+        else loglik = em_fit<NS>(S, lane, pick4(f, row), inv_n, ex, passes);
         fits += 1;
         return true;
     };
