@@ -113,8 +113,8 @@ constexpr uint32_t kSureAboveHi = hi_word(kEmEpsilon / (1.0 - 0.00390625)) + 1u;
 
 // NA <= NS: slots that can hold a class at this site.  A site whose bases have at most 16 * NA quality values leaves
 // slots NA..NS-1 empty in every lane, and an empty slot adds exact zeros to every sum (n = 0) and 0 to max|u|
-// (m = y = 1), so leaving them out changes no bit of the result -- only the instruction count (NS = 4 with three
-// active slots: Illumina's ~40 quality values; NS = 8 with six: the whole BAM range 0..93).
+// (m = y = 1), so leaving them out changes no bit of the result -- only the instruction count (NS = 2 with one active
+// slot: binned qualities, <= 16 values; NS = 4 with three: Illumina's ~40 values; NS = 8 with six: BAM's 0..93).
 template <int NS, int NA = NS>
 __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double inv_n, int lane)
 {
@@ -332,7 +332,7 @@ __device__ bool lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
         const double freq_sum = ((f[0] + f[1]) + f[2]) + f[3];
         if (freq_sum == 0) return false;
         // (wave-uniform) the variant's narrower form when the site leaves its last slots empty
-        constexpr int kNarrow = NS == 4 ? 3 : (NS == 8 ? 6 : NS);
+        constexpr int kNarrow = NS == 2 ? 1 : (NS == 4 ? 3 : 6);   // <= 16 values (binned qualities), <= 48, <= 96
         if (kNarrow < NS && nslots <= kNarrow) loglik = em_fit<NS, kNarrow>(S, lane, pick4(f, row), inv_n, ex, passes);
         else loglik = em_fit<NS>(S, lane, pick4(f, row), inv_n, ex, passes);
         fits += 1;

@@ -22,8 +22,11 @@ dev = torch.device("cuda:0")
 ctx = Context(0)
 g = torch.Generator(device=dev); g.manual_seed(7)
 m = caller_min_af(N)
-for name, qlo, qhi in (("Q10-40 (31 values, NS=2)", 10, 40), ("Q2-41 (40 values, NS=4)", 2, 41), ("Q1-93 (93 values, NS=8)", 1, 93)):
+BINNED = torch.tensor([2, 12, 23, 37], dtype=torch.int8, device=dev)          # NovaSeq-style binned qualities
+for name, qlo, qhi in (("binned Q2/12/23/37 (4 values, NS=2 one slot)", 0, 3), ("Q10-40 (31 values, NS=2)", 10, 40), ("Q2-41 (40 values, NS=4)", 2, 41), ("Q1-93 (93 values, NS=8)", 1, 93)):
     q = torch.randint(qlo, qhi + 1, (S, N), generator=g, device=dev, dtype=torch.int8)
+    if name.startswith("binned"):
+        q = BINNED[q.long()]
     ref = torch.randint(0, 4, (S, 1), generator=g, device=dev, dtype=torch.int8)
     af = torch.where(torch.rand((S, 1), generator=g, device=dev) < 0.2, torch.rand((S, 1), generator=g, device=dev) * 0.3, torch.zeros((S, 1), device=dev))
     u = torch.rand((S, N), generator=g, device=dev)
