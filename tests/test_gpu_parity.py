@@ -876,3 +876,50 @@ def test_config5_groups_at_1e6_samples(ctx, layout):
     # the depth columns of the groups and of "no group" add up to the overall depth
     assert np.array_equal(gres["depth"].sum(axis=1) + np.array([np.bincount(hb[s][g == 255], minlength=4)[:4] for s in range(ns)]),
                           res["depth"])
+
+
+def test_error_behaviour_of_the_c_abi(ctx):
+    """SURVEY 8b, "Errors": every entry point returns a status, nothing throws across the ABI, bvc_last_error carries
+    the text, "no call" is not an error, and a context stays usable after a rejected call."""
+    import ctypes as C
+    from basevarc_amd.lib import BvcError, SITE_DTYPE, load_library
+    L = load_library()
+    h = C.c_void_p()
+    assert L.bvc_create(C.byref(h), 99) == -3 and not h.value          # BVC_ERR_NO_DEVICE, no context
+    assert L.bvc_create(None, 0) == -1                                   # BVC_ERR_ARG
+    assert L.bvc_last_error(None) == b"null context"
+    B = np.zeros((2, 8), dtype=np.int8); R = np.zeros(2, dtype=np.int8)
+    out = np.zeros(2, dtype=SITE_DTYPE)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    hh = ctx._h
+    # n_samples > row_stride, negative sizes, null pointers
+    assert L.bvc_lrt_dense(hh, 2, 8, 4, vp(B), vp(B), vp(R), 0.001, vp(out), 0) == -1
+    assert b"row_stride" in L.bvc_last_error(hh)
+    assert L.bvc_lrt_dense(hh, -1, 8, 8, vp(B), vp(B), vp(R), 0.001, vp(out), 0) == -1
+    assert L.bvc_lrt_dense(hh, 2, 8, 8, None, vp(B), vp(R), 0.001, vp(out), 0) == -1
+    assert L.bvc_lrt_dense(hh, 2, 8, 8, vp(B), vp(B), vp(R), 0.001, None, 0) == -1
+    assert L.bvc_lrt_dense(hh, 0, 8, 8, None, None, None, 0.001, None, 0) == 0       # nothing to do is not an error
+    # groups: n_groups out of range, null group vector
+    g = np.zeros(8, dtype=np.uint8); gout = np.zeros((2, 40), dtype=np.uint8)
+    for k in (0, 33):
+        assert L.bvc_lrt_dense_groups(hh, 2, 8, 8, vp(B), vp(B), vp(R), 0.001, vp(g), k, vp(out), vp(gout), 0) == -1
+    assert L.bvc_lrt_dense_groups(hh, 2, 8, 8, vp(B), vp(B), vp(R), 0.001, None, 2, vp(out), vp(gout), 0) == -1
+    # ragged: offsets must start at 0 and not decrease
+    with pytest.raises(BvcError, match="offsets"):
+        ctx.lrt_csr([1, 4, 8], B.reshape(-1)[:8], B.reshape(-1)[:8], R, 0.001)
+    with pytest.raises(BvcError, match="offsets"):
+        ctx.lrt_csr([0, 6, 4], B.reshape(-1)[:8], B.reshape(-1)[:8], R, 0.001)
+    # SetBase lists: more than four entries, entries outside 0..3, one of the two arrays missing
+    cnt = np.zeros((1, 512), dtype=np.uint32)
+    with pytest.raises(BvcError, match="n_comb"):
+        ctx.lrt_hist(cnt, [0], 0.001, [[0, 1, 2, 3]], [5])
+    with pytest.raises(BvcError, match="base_comb"):
+        ctx.lrt_hist(cnt, [0], 0.001, [[0, 7, 0, 0]], [2])
+    assert L.bvc_lrt_hist(hh, 1, vp(cnt), vp(R), 0.001, vp(B), None, vp(out), 0) == -1
+    with pytest.raises(BvcError):
+        ctx.set_tuning("no_such_knob", 1)
+    with pytest.raises(BvcError):
+        ctx.set_tuning("em_waves_per_cu", 1000)
+    # the context is still good, and a site without a call is a record, not an error
+    rec = ctx.lrt_dense(np.full((1, 50), 2, dtype=np.int8), np.full((1, 50), 30, dtype=np.int8), [2], 0.001)
+    assert int(rec[0]["called"]) == 0 and int(rec[0]["status"]) == 0 and rec[0]["depth"].tolist() == [0, 0, 50, 0]
