@@ -96,14 +96,20 @@ def main():
         a.gpus = world
     # One rank per GPU.  (Rehearsal on a 1-GPU box: BVC_BENCH_BACKEND=gloo lets ranks share device 0.)
     backend = os.environ.get("BVC_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    shared_device = backend != "nccl"        # gloo rehearsal: the ranks share the devices present
+    dev_index = local_rank if not shared_device else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)      # RCCL; used for barrier + max only
+            try:
+                dist.init_process_group("nccl", device_id=dev)  # RCCL; used for barrier + max only
+            except Exception as e:                              # the data path needs no collective: time with gloo instead
+                print(f"[bench] rank {rank}: nccl rendezvous failed ({e}); using gloo for the barrier", file=sys.stderr, flush=True)
+                backend = "gloo-after-nccl-failure"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
 
@@ -124,7 +130,7 @@ def main():
         lo, hi = rank * a.total_sites, (rank + 1) * a.total_sites
     my_sites = hi - lo
     free_b, _ = torch.cuda.mem_get_info(dev)
-    budget = free_b // (world if backend != "nccl" else 1) - (16 << 30)     # room for the legs and scratch
+    budget = free_b // (world if shared_device else 1) - (16 << 30)         # room for the legs and scratch
     fit_sites = max(a.tile_sites, int(budget // (2 * stride)) // a.tile_sites * a.tile_sites)
     res_sites = min(my_sites, fit_sites)                         # sites actually resident (= my_sites on MI355X)
     tile_sizes = [min(a.tile_sites, res_sites - s) for s in range(0, res_sites, a.tile_sites)]
@@ -225,7 +231,7 @@ def main():
             "n_samples": n, "sites_per_step": sites_per_step_all, "sites_per_call": a.tile_sites,
             "calls_per_step_per_gpu": n_tiles, "resident_GB_per_gpu": round(2 * res_sites * stride / 1e9, 1),
             "row_stride": stride, "min_af": min_af,
-            "sharding": f"sites x{world} ({a.scaling}), no collective" if world > 1 else "1 GPU", "seed": a.seed,
+            "sharding": f"sites x{world} ({a.scaling}), no collective; barrier over {backend}" if world > 1 else "1 GPU", "seed": a.seed,
             "overlap": not a.no_overlap,
         },
         "roofline": {
