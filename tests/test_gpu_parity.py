@@ -71,13 +71,15 @@ def assert_site_matches(rec, exp, where="", path_strict=True, faithful_drift=Fal
 TIE_ULPS = 4096
 
 
-def assert_path_difference_is_a_tie(rec, exp, where=""):
+def assert_path_difference_is_a_tie(rec, exp, where="", faithful_n=0):
     """n_passes / n_fits may differ from the oracle's only where std::min_element's choice among
     the subsets of a level (src/BaseType.cpp:99) hangs on rounding.  For a site whose diagnostics differ, the oracle's
-    own record must show such a tie; the results proper were already compared by assert_site_matches."""
+    own record must show such a tie; the results proper were already compared by assert_site_matches.
+    faithful_n: the oracle record comes from the faithful per-sample form over that many samples, whose log-likelihoods
+    (and so its tie gap) carry the drift of a one-by-one double sum, up to N*u*|loglik| each."""
     if int(rec["n_passes"]) == exp["n_passes"] and int(rec["n_fits"]) == exp["n_fits"]:
         return 0
-    tol = TIE_ULPS * 2.0 ** -52 * max(1.0, abs(exp["lr_alt"]))
+    tol = (TIE_ULPS * 2.0 ** -52 + 2 * faithful_n * 2.0 ** -53) * max(1.0, abs(exp["lr_alt"]))
     assert exp["tie_gap"] <= tol, (where, "pass count differs without a tie", int(rec["n_passes"]), exp["n_passes"],
                                    exp["tie_gap"], tol)
     return 1
@@ -568,12 +570,11 @@ def test_config2_1e4_sites_by_1e4_samples(ctx):
         assert_site_matches(res[s], exp_h[s], where=f"config2 hist-oracle site {s}", path_strict=False)
         ties += assert_path_difference_is_a_tie(res[s], exp_h[s], where=f"config2 site {s}")
     assert ties < 0.01 * ns, ties
-    # ... and a 400-site sample against the faithful per-sample oracle (77 ms/site/core)
-    pick = np.random.default_rng(0).choice(ns, 400, replace=False)
-    exp_f, _ = orc.dense_batch(hb[pick], hq[pick], hr[pick], m, use_hist=False)
-    for j, s in enumerate(pick):
-        assert_site_matches(res[s], exp_f[j], where=f"config2 faithful site {s}", path_strict=False)
-        assert_path_difference_is_a_tie(res[s], exp_f[j], where=f"config2 faithful site {s}")
+    # ... and EVERY site against the faithful per-sample oracle (about 20 ms per site and core)
+    exp_f, _ = orc.dense_batch(hb, hq, hr, m, use_hist=False)
+    for s in range(ns):
+        assert_site_matches(res[s], exp_f[s], where=f"config2 faithful site {s}", path_strict=False)
+        assert_path_difference_is_a_tie(res[s], exp_f[s], where=f"config2 faithful site {s}", faithful_n=n)
     called = int(res["called"].sum())
     assert 0.05 * ns < called < 0.5 * ns          # ~20 % polymorphic sites in the mixture
 
@@ -777,7 +778,7 @@ def test_full_size_sites_1e6_samples(ctx):
     exp_f, _ = orc.dense_batch(hb[:4], hq[:4], hr[:4], m, use_hist=False)
     for s in range(4):
         assert_site_matches(res[s], exp_f[s], where=f"1e6 faithful site {s}", path_strict=False, faithful_drift=True)
-        assert_path_difference_is_a_tie(res[s], exp_f[s], where=f"1e6 faithful site {s}")
+        assert_path_difference_is_a_tie(res[s], exp_f[s], where=f"1e6 faithful site {s}", faithful_n=n)
 
 
 def test_chi_at_1e6_matches_the_compensated_oracle(ctx):
