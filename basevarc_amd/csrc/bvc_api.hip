@@ -27,7 +27,9 @@ struct bvc_ctx {
     size_t cnt_cap[kRing] = {0, 0, 0};
     // overlap mode: stage 2 of call i runs on `side` while stage 1 of call i+1 streams on `stream`
     bool overlap = false;
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr;        // stage 2 of even calls
+    hipStream_t side_b = nullptr, side_c = nullptr;   // further stage-2 streams (two_em_streams below)
+    int side_flip = 0;
     int flip = 0;
     hipEvent_t ev_hist_done[kRing] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_em_done[kRing] = {nullptr, nullptr, nullptr};
@@ -123,6 +125,18 @@ int join_side(bvc_ctx *ctx)
     return BVC_OK;
 }
 
+// Stage 2 of consecutive calls on alternating side streams?  An EM launch ends in a long tail of few busy waves (sites
+// differ 4x in EM work and a launch has 1.6-2 sites per wave); on two streams the next launch's workgroups move in as
+// the previous one's drain: +20-28 % where the EM is the bound (1e4 x 1e4: 1.46e7 -> 1.76e7 sites/s; ragged sites at
+// 10 % coverage: 7.9e6 -> 1.02e7).  Underneath a long histogram pass the EM is not the bound and a second launch only
+// adds to the crowd (-0.4 % on the headline), so long rows keep one stream.  (profiles/r02_sweep_em_streams.txt)
+hipStream_t em_stream(bvc_ctx *ctx, bool long_rows)
+{
+    const int n = ctx->ls.em_streams > 0 ? ctx->ls.em_streams : (long_rows ? 1 : 2);
+    const int k = ctx->side_flip++ % n;
+    return k == 0 ? ctx->side : (k == 1 ? ctx->side_b : ctx->side_c);
+}
+
 // The two stages on device pointers.  `stage1(counts)` launches the histogram pass of the call (dense, ragged, ...)
 // on the context's stream into a [n_sites][512] buffer of the ring; stage 2 (EM/LRT) follows on the same stream, or
 // on the side stream behind an event in overlap mode.
@@ -168,7 +182,7 @@ int run_two_stages(bvc_ctx *ctx, int64_t n_sites, bool zero_counts, bool long_ro
     // stage 2: same stream, or the side stream behind an event
     hipStream_t s2 = ctx->stream;
     if (ctx->overlap) {
-        s2 = ctx->side;
+        s2 = em_stream(ctx, long_rows);
         BVC_HIP_T(hipEventRecord(ctx->ev_hist_done[buf], ctx->stream));
         BVC_HIP_T(hipStreamWaitEvent(s2, ctx->ev_hist_done[buf], 0));
     }
@@ -316,6 +330,7 @@ int bvc_create(bvc_ctx **out, int device)
     ctx->ls.em_wpb = env_int("BVC_EM_WPB", 1, 4, 4) == 1 ? 1 : 4;
     ctx->ls.hist_split = env_int("BVC_HIST_SPLIT", 1, 64, 0);
     ctx->ls.group_pipe = env_int("BVC_GROUP_PIPE", 0, 1, 1);
+    ctx->ls.em_streams = env_int("BVC_EM_STREAMS", 0, 3, 0);
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return BVC_ERR_DEVICE; }
     // likelihood table from the host's exp(), as the CPU path computes it (src/BaseType.cpp:13,15)
     QualLut lut;
@@ -332,6 +347,8 @@ int bvc_create(bvc_ctx **out, int device)
         return BVC_ERR_ALLOC;
     }
     bool ok = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->side_b, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->side_c, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&ctx->d_grp_scratch), kGroupScratchWords * sizeof(int64_t)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&ctx->d_sink), 256) == hipSuccess;
@@ -350,6 +367,8 @@ void bvc_destroy(bvc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    if (ctx->side_b) { (void)hipStreamSynchronize(ctx->side_b); (void)hipStreamDestroy(ctx->side_b); }
+    if (ctx->side_c) { (void)hipStreamSynchronize(ctx->side_c); (void)hipStreamDestroy(ctx->side_c); }
     if (ctx->copy) { (void)hipStreamSynchronize(ctx->copy); (void)hipStreamDestroy(ctx->copy); }
     for (int b = 0; b < bvc_ctx::kRing; ++b) {
         if (ctx->ev_hist_done[b]) (void)hipEventDestroy(ctx->ev_hist_done[b]);
@@ -377,6 +396,8 @@ int bvc_set_stream(bvc_ctx *ctx, void *hip_stream)
     if (!ctx) return BVC_ERR_ARG;
     BVC_HIP(ctx, hipSetDevice(ctx->device));
     BVC_HIP(ctx, hipStreamSynchronize(ctx->side));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->side_b));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->side_c));
     for (bool &p : ctx->em_pending) p = false;
     BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -388,6 +409,8 @@ int bvc_synchronize(bvc_ctx *ctx)
     if (!ctx) return BVC_ERR_ARG;
     BVC_HIP(ctx, hipSetDevice(ctx->device));
     BVC_HIP(ctx, hipStreamSynchronize(ctx->side));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->side_b));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->side_c));
     for (bool &p : ctx->em_pending) p = false;
     BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BVC_OK;
@@ -422,6 +445,8 @@ int bvc_get_profile(bvc_ctx *ctx, bvc_profile *out, int reset)
     if (!ctx || !out) return BVC_ERR_ARG;
     BVC_HIP(ctx, hipSetDevice(ctx->device));
     BVC_HIP(ctx, hipStreamSynchronize(ctx->side));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->side_b));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->side_c));
     BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     reap_timing(ctx, true);
     *out = ctx->prof;
@@ -668,7 +693,7 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
         if (timed) BVC_HIP_T(hipEventRecord(t.b, ctx->stream));
         hipStream_t s2 = ctx->stream;
         if (ctx->overlap) {
-            s2 = ctx->side;
+                s2 = em_stream(ctx, n_samples >= 200000);
             BVC_HIP_T(hipEventRecord(ctx->ev_hist_done[buf], ctx->stream));
             BVC_HIP_T(hipStreamWaitEvent(s2, ctx->ev_hist_done[buf], 0));
         }
@@ -746,6 +771,12 @@ int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value)
     if (std::strcmp(key, "em_wpb") == 0 && (value == 1 || value == 4)) { ctx->ls.em_wpb = value; return BVC_OK; }
     if (std::strcmp(key, "hist_split") == 0 && value >= 0 && value <= 64) { ctx->ls.hist_split = value; return BVC_OK; }
     if (std::strcmp(key, "group_pipe") == 0 && (value == 0 || value == 1)) { ctx->ls.group_pipe = value; return BVC_OK; }
+    if (std::strcmp(key, "em_streams") == 0 && value >= 0 && value <= 3) {
+        int rcj = join_side(ctx);
+        if (rcj != BVC_OK) return rcj;
+        ctx->ls.em_streams = value;
+        return BVC_OK;
+    }
     if (std::strcmp(key, "host_chunk_kib") == 0 && value >= 1 && value <= (1 << 21)) { ctx->ls.host_chunk_bytes = (int64_t)value << 10; return BVC_OK; }
     return fail(ctx, BVC_ERR_ARG, "unknown tuning key or value out of range");
 }

@@ -15,6 +15,7 @@ struct LaunchState {
     int em_wpb = 4;            // waves per EM workgroup: 4, or 1 (A/B runs)
     int hist_split = 0;        // 0 = by tile shape; 1..64 workgroups sharing a site in the dense histogram pass
     int64_t host_chunk_bytes = (int64_t)1 << 29;   // BVC_PTR_HOST calls: bytes per array and staging chunk
+    int em_streams = 0;        // overlap mode: side streams stage 2 alternates between: 0 = by row length, 1, 2
     int group_pipe = 1;        // any-order group histogram: issue the next chunk's loads before counting the current one
     uint32_t attr_done = 0;    // kernels whose dynamic-LDS attribute has been raised on this context's device
 };

@@ -181,13 +181,15 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
  *   "em_waves_per_cu"  0 = default policy, 1..32 resident EM wavefronts per CU
  *   "em_wpb"           waves per EM workgroup: 4 (default) or 1
  *   "hist_split"       0 = by tile shape, 1..64 workgroups sharing a site in the dense histogram pass
+ *   "em_streams"       overlap mode: stage 2 of consecutive calls on one side stream (1), on two alternating ones (2: the
+ *                      next EM launch fills the previous one's tail), or chosen by row length (0, default)
  *   "group_pipe"       any-order group histogram: 1 (default) issues the next chunk's loads before counting the
  *                      current one, 0 loads two chunks then counts both
  *   "host_chunk_kib"   BVC_PTR_HOST calls stage the tile through device memory in chunks of sites of at most this
  *                      many KiB per array (default 524288 = 512 MiB); the upload of chunk i+1 runs under the kernels
  *                      of chunk i
  * A new context starts from the environment variables BVC_EM_WAVES_PER_CU, BVC_EM_WPB, BVC_HIST_SPLIT,
- * BVC_GROUP_PIPE when they are set. */
+ * BVC_GROUP_PIPE, BVC_EM_STREAMS when they are set. */
 int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value);
 
 /* ---- measurement aid ------------------------------------------------------------------------------- */

@@ -579,7 +579,8 @@ def test_config2_1e4_sites_by_1e4_samples(ctx):
     assert 0.05 * ns < called < 0.5 * ns          # ~20 % polymorphic sites in the mixture
 
 
-@pytest.mark.parametrize("knob,value", [("em_wpb", 1), ("em_waves_per_cu", 3), ("hist_split", 5), ("em_waves_per_cu", 32)])
+@pytest.mark.parametrize("knob,value", [("em_wpb", 1), ("em_waves_per_cu", 3), ("hist_split", 5), ("em_waves_per_cu", 32),
+                                        ("em_streams", 1), ("em_streams", 3)])
 def test_tuning_knobs_are_per_context_and_never_change_a_record(ctx, knob, value):
     """bvc_set_tuning acts on ONE context (no process-wide state) and only moves work around: the records of a tuned
     context equal, byte for byte, those of an untouched one, and both match the oracle."""
@@ -602,6 +603,11 @@ def test_tuning_knobs_are_per_context_and_never_change_a_record(ctx, knob, value
             other = tuned.lrt_dense_device(b, q, r, m)
             tuned.synchronize()
             assert np.array_equal(plain.cpu().numpy(), other.cpu().numpy()), (knob, value, n)
+            tuned.set_overlap(True)                             # several calls in flight (stage 2 on the side streams)
+            outs = [tuned.lrt_dense_device(b, q, r, m) for _ in range(5)]
+            tuned.join(); tuned.synchronize()
+            tuned.set_overlap(False)
+            assert all(np.array_equal(plain.cpu().numpy(), o.cpu().numpy()) for o in outs), (knob, value, n, "overlap")
             res = results_from_tensor(other)
             exp, _ = orc.dense_batch(b.cpu().numpy(), q.cpu().numpy(), r.cpu().numpy(), m, use_hist=True)
             for s in range(ns):
