@@ -130,9 +130,14 @@ int join_side(bvc_ctx *ctx)
 // the previous one's drain: +20-28 % where the EM is the bound (1e4 x 1e4: 1.46e7 -> 1.76e7 sites/s; ragged sites at
 // 10 % coverage: 7.9e6 -> 1.02e7).  Underneath a long histogram pass the EM is not the bound and a second launch only
 // adds to the crowd (-0.4 % on the headline), so long rows keep one stream.  (profiles/r02_sweep_em_streams.txt)
-hipStream_t em_stream(bvc_ctx *ctx, bool long_rows)
+// Group mode's stage 2 IS the bound underneath its long histogram pass (k = 5, labels in any order): there two
+// streams at half the wave budget each (2 x 4 per CU instead of 1 x 8) give +3.8 % (any order) / +1 % (ordered
+// columns) -- the same chip share, the tails covered.  (profiles/r02_sweep_group_em_streams.txt)
+int em_stream_count(const bvc_ctx *ctx, int by_default) { return ctx->ls.em_streams > 0 ? ctx->ls.em_streams : by_default; }
+
+hipStream_t em_stream(bvc_ctx *ctx, int by_default)
 {
-    const int n = ctx->ls.em_streams > 0 ? ctx->ls.em_streams : (long_rows ? 1 : 2);
+    const int n = em_stream_count(ctx, by_default);
     const int k = ctx->side_flip++ % n;
     return k == 0 ? ctx->side : (k == 1 ? ctx->side_b : ctx->side_c);
 }
@@ -182,7 +187,7 @@ int run_two_stages(bvc_ctx *ctx, int64_t n_sites, bool zero_counts, bool long_ro
     // stage 2: same stream, or the side stream behind an event
     hipStream_t s2 = ctx->stream;
     if (ctx->overlap) {
-        s2 = em_stream(ctx, long_rows);
+        s2 = em_stream(ctx, long_rows ? 1 : 2);
         BVC_HIP_T(hipEventRecord(ctx->ev_hist_done[buf], ctx->stream));
         BVC_HIP_T(hipStreamWaitEvent(s2, ctx->ev_hist_done[buf], 0));
     }
@@ -693,15 +698,16 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
         if (timed) BVC_HIP_T(hipEventRecord(t.b, ctx->stream));
         hipStream_t s2 = ctx->stream;
         if (ctx->overlap) {
-                s2 = em_stream(ctx, n_samples >= 200000);
+            s2 = em_stream(ctx, 2);
             BVC_HIP_T(hipEventRecord(ctx->ev_hist_done[buf], ctx->stream));
             BVC_HIP_T(hipStreamWaitEvent(s2, ctx->ev_hist_done[buf], 0));
         }
         if (timed) BVC_HIP_T(hipEventRecord(t.c, s2));
         BVC_HIP_T(launch_sum_groups(s2, ns, n_hist, *gp, *cp));
         const bool shared = ctx->overlap && n_samples >= 200000;
-        BVC_HIP_T(launch_lrt(ctx->ls, s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared, 8 /* = kGroupSharedWavesPerCu, em_kernel.hip */));
-        BVC_HIP_T(launch_lrt_groups(ctx->ls, s2, ns, n_groups, *gp, r, min_af, ctx->d_lut, res, gres, shared));
+        const int per_launch = kGroupSharedWavesPerCu / em_stream_count(ctx, 2) > 2 ? kGroupSharedWavesPerCu / em_stream_count(ctx, 2) : 2;
+        BVC_HIP_T(launch_lrt(ctx->ls, s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared, per_launch));
+        BVC_HIP_T(launch_lrt_groups(ctx->ls, s2, ns, n_groups, *gp, r, min_af, ctx->d_lut, res, gres, shared, per_launch));
         if (timed) {
             BVC_HIP_T(hipEventRecord(t.d, s2));
             ctx->ev_pending.push_back(t);

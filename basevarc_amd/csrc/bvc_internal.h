@@ -15,7 +15,7 @@ struct LaunchState {
     int em_wpb = 4;            // waves per EM workgroup: 4, or 1 (A/B runs)
     int hist_split = 0;        // 0 = by tile shape; 1..64 workgroups sharing a site in the dense histogram pass
     int64_t host_chunk_bytes = (int64_t)1 << 29;   // BVC_PTR_HOST calls: bytes per array and staging chunk
-    int em_streams = 0;        // overlap mode: side streams stage 2 alternates between: 0 = by row length, 1, 2
+    int em_streams = 0;        // overlap mode: side streams stage 2 alternates between: 0 = by call shape, 1..3
     int group_pipe = 1;        // any-order group histogram: issue the next chunk's loads before counting the current one
     uint32_t attr_done = 0;    // kernels whose dynamic-LDS attribute has been raised on this context's device
 };
@@ -57,7 +57,11 @@ hipError_t launch_lrt(const LaunchState &st, hipStream_t stream, int64_t n_sites
 
 hipError_t launch_lrt_groups(const LaunchState &st, hipStream_t stream, int64_t n_sites, int n_groups,
                              const uint32_t *grp_counts, const int8_t *ref_base, double min_af, const QualLut *lut,
-                             const bvc_site_result *overall, bvc_group_result *grp_results, bool shared = false);
+                             const bvc_site_result *overall, bvc_group_result *grp_results, bool shared = false,
+                             int shared_waves_per_cu = 0);
+// EM wavefronts per CU the stage-2 launches of group calls keep in flight underneath a long histogram pass, summed
+// over the stage-2 streams in use (em_kernel.hip, em_grid_cap).
+constexpr int kGroupSharedWavesPerCu = 8;
 
 // Sum the per-group histograms (+ the "no group" one) into the overall histogram of each site.
 hipError_t launch_sum_groups(hipStream_t stream, int64_t n_sites, int n_hist, const uint32_t *grp_counts,

@@ -589,8 +589,9 @@ __global__ void sum_groups_kernel(int64_t total, int n_hist, const uint32_t *__r
 // takes 24 per CU.  The context's em_waves_per_cu (bvc_set_tuning / BVC_EM_WAVES_PER_CU) overrides both.
 //
 // Group mode's stage 2 (sum, overall LRT, per-group LRT) is a third longer and its histogram pass slower than the
-// plain call's; swept 8..24 on MI355X (k = 5, N = 1e6, round 2 kernels): 8 waves per CU is as good as any (2.68e6 sites/s at 8, 2.58-2.65e6 at 12-24).
-constexpr int kGroupSharedWavesPerCu = 8;
+// plain call's; swept 8..24 on MI355X (k = 5, N = 1e6, round 2 kernels): 8 waves per CU in flight is as good as any
+// (2.68e6 sites/s at 8, 2.58-2.65e6 at 12-24) -- and since group calls alternate between two stage-2 streams
+// (bvc_api.hip, em_stream) each launch takes half of that: kGroupSharedWavesPerCu in bvc_internal.h.
 
 static int64_t em_grid_cap(const LaunchState &st, bool shared, int shared_waves_per_cu = 0)
 {
@@ -645,10 +646,11 @@ static void launch_group_variants(hipStream_t stream, int64_t want_waves, int64_
 
 hipError_t launch_lrt_groups(const LaunchState &st, hipStream_t stream, int64_t n_sites, int n_groups,
                              const uint32_t *grp_counts, const int8_t *ref_base, double min_af, const QualLut *lut,
-                             const bvc_site_result *overall, bvc_group_result *grp_results, bool shared)
+                             const bvc_site_result *overall, bvc_group_result *grp_results, bool shared,
+                             int shared_waves_per_cu)
 {
     if (n_sites <= 0 || n_groups <= 0) return hipSuccess;
-    const int64_t cap = em_grid_cap(st, shared, kGroupSharedWavesPerCu);
+    const int64_t cap = em_grid_cap(st, shared, shared_waves_per_cu);
     const int64_t n_work = n_sites * n_groups;
     const int64_t want_waves = n_work < cap ? n_work : cap;
     if (st.em_wpb == 1) launch_group_variants<1>(stream, want_waves, n_sites, n_groups, grp_counts, ref_base, min_af, lut, overall, grp_results);

@@ -39,3 +39,4 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for name in ("config1_1e4x1e4", "config4_groups5_interleaved", "config4_groups5_ordered", "csr_coverage10pct"):
         assert legs[name]["value"] > 0 and 0 < legs[name]["roofline"]["frac"] < 1, name
     assert legs["config1_1e4x1e4"]["roofline"]["bound"] == "fp64_valu_issue"
+    assert legs["csr_coverage10pct"]["roofline"]["bound"] == "fp64_valu_issue" and legs["csr_coverage10pct"]["hist_roofline"]["bound"] == "hbm"
