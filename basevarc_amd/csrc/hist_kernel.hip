@@ -59,6 +59,18 @@ __device__ __forceinline__ void lds_add_one(uint32_t lds_byte_address)
     __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)lds_byte_address, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Workgroup barrier that orders LDS traffic only: the wave's LDS operations have completed (lgkmcnt) but its global
+// loads may still be in flight, which __syncthreads() -- a fence over all memory -- would wait for.  Used where loads
+// for the next work item are issued ahead of the fold of the current one.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// (Tried: a scheduling fence after each batch of independent loads, so that all 2 * kUnroll loads issue back to back --
+// the compiler otherwise hoists the first use of the first load above the last two.  The compiler's order measures 1 %
+// FASTER on the headline, 0.5 % slower on the column-range kernel: profiles/r02_hist_load_scheduling.txt.)
+
 // The any-order group kernel's sample loop: each trip issues the loads of the next D chunks (of three 16-byte
 // streams) before it counts the current D, so that a wave has bytes in flight while it works through its LDS atomics.
 // Chunk c belongs to thread c mod kHistThreads; an out-of-range chunk reads nothing and carries base bytes 0xFF, which
@@ -129,6 +141,31 @@ __device__ __forceinline__ void count_chunk(uint32_t *__restrict__ hist, const u
     }
 }
 
+// The last, partial block of a run of 16-sample chunks [.., c1): lanes past the end load nothing and carry base bytes
+// 0xFF, which the counting skips, so every wave that lies wholly inside the run still takes count_chunk's fast path
+// (only the one wave that straddles c1 tests its samples one by one, and waves wholly outside do nothing).
+__device__ __forceinline__ void count_partial_block(uint32_t *__restrict__ hist, const u32x4 *__restrict__ bv,
+                                                    const u32x4 *__restrict__ qv, int64_t cb, int64_t c1, int tid,
+                                                    uint32_t lane_off)
+{
+    u32x4 b[kUnroll], q[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+        const int64_t c = cb + tid + (int64_t)u * kHistThreads;
+        b[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        q[u] = u32x4{0u, 0u, 0u, 0u};
+        if (c < c1) {
+            b[u] = __builtin_nontemporal_load(&bv[c]);
+            q[u] = __builtin_nontemporal_load(&qv[c]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+        const int64_t wave_first = cb + (tid & ~63) + (int64_t)u * kHistThreads;     // wave-uniform
+        if (wave_first < c1) count_chunk(hist, b[u], q[u], lane_off);
+    }
+}
+
 // One workgroup per (site, split).  ALIGNED: row starts and n16 chunks are 16-byte aligned.
 template <bool ALIGNED>
 __global__ __launch_bounds__(kHistThreads) void hist_dense_kernel(
@@ -175,13 +212,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_kernel(
 #pragma unroll
                     for (int u = 0; u < kUnroll; ++u) count_chunk(hist, b[u], q[u], lane_off);
                 } else {
-                    for (int64_t ct = c; ct < n16; ct += kHistThreads) {
-                        const u32x4 b = __builtin_nontemporal_load(&bv[ct]);
-                        const u32x4 q = __builtin_nontemporal_load(&qv[ct]);
-                        // not every lane of the wave is here: per-sample test, no wave-wide vote
-                        count_word_checked(hist, b.x, q.x, lane_off); count_word_checked(hist, b.y, q.y, lane_off);
-                        count_word_checked(hist, b.z, q.z, lane_off); count_word_checked(hist, b.w, q.w, lane_off);
-                    }
+                    count_partial_block(hist, bv, qv, cb, n16, tid, lane_off);
                 }
             }
         } else {
@@ -403,9 +434,30 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_ranges_kernel(
     const int tid = threadIdx.x;
     const uint32_t lane_off = (uint32_t)(tid & (kCopies - 1));
     __builtin_amdgcn_s_setprio(3);
+    // Work items are the NON-EMPTY column ranges only.  An empty one (typically "no group", when every sample has a
+    // group) costs nothing but would still take a turn in the round-robin of items over workgroups -- and workgroups go
+    // round-robin over the 8 XCDs, so with n_hist even the empty turns all fall on the same XCDs, which then run out of
+    // work early (k = 5: four XCDs with 2/3 of the others' bytes, 1.34 ms instead of 1.23; k = 1: four XCDs idle, 1.63 ms).
+    __shared__ uint8_t real_h[BVC_MAX_GROUPS + 1];
+    __shared__ int n_real_s;
+    if (tid == 0) {
+        int c = 0;
+        for (int h = 0; h < n_hist; ++h)
+            if (scratch[1 + h] < scratch[2 + h]) real_h[c++] = (uint8_t)h;
+        n_real_s = c;
+    }
     for (int i = tid * 4; i < kLdsWords; i += kHistThreads * 4)
         *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
+    const int n_real = n_real_s;
+    if (n_real < n_hist) {                               // the empty ranges' histograms: zeros, no LDS involved
+        for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x)
+            for (int h = 0; h < n_hist; ++h)
+                if (scratch[1 + h] >= scratch[2 + h])
+                    for (int key = tid; key < BVC_NCLASS; key += kHistThreads)
+                        grp_counts[(site * n_hist + h) * BVC_NCLASS + key] = 0;
+    }
+    if (n_real == 0) return;
 
     auto scalar = [&](const int8_t *brow, const int8_t *qrow, int64_t i0, int64_t i1) {
         for (int64_t i = i0 + tid; i < i1; i += kHistThreads) {
@@ -415,22 +467,54 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_ranges_kernel(
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
-    const int64_t n_work = n_sites * n_hist;
-    for (int64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
-        const int64_t site = w / n_hist;
-        const int h = (int)(w % n_hist);
-        const int8_t *brow = bases + site * row_stride;
-        const int8_t *qrow = quals + site * row_stride;
-        const int64_t s0 = scratch[1 + h], s1 = scratch[2 + h];
-        // [s0, s1) = unaligned head, whole 16-sample chunks [c0, c1), unaligned tail
-        const int64_t c0 = (s0 + 15) >> 4, c1 = s1 >> 4;
-        if (ALIGNED && c0 < c1) {
-            scalar(brow, qrow, s0, c0 << 4);
+    // A work item is one (site, histogram) = one column range of one row.  The loads of the NEXT item's first block are
+    // issued before the barrier that ends the current one, so the workgroup has bytes in flight while it folds its
+    // copies: with k = 5 a range is a fifth of a row and the fold comes five times as often as in hist_dense_kernel.
+    struct Range { const int8_t *brow, *qrow; int64_t s0, s1, c0, c1, out; };
+    auto range_of = [&](int64_t w) {
+        const int64_t site = w / n_real;
+        const int h = real_h[w % n_real];
+        Range r;
+        r.out = (site * n_hist + h) * BVC_NCLASS;
+        r.brow = bases + site * row_stride;
+        r.qrow = quals + site * row_stride;
+        r.s0 = scratch[1 + h]; r.s1 = scratch[2 + h];
+        r.c0 = (r.s0 + 15) >> 4; r.c1 = r.s1 >> 4;      // [s0, s1) = unaligned head, whole chunks [c0, c1), unaligned tail
+        return r;
+    };
+    constexpr int64_t kBlockChunks = (int64_t)kUnroll * kHistThreads;
+    u32x4 pb[kUnroll], pq[kUnroll];
+    bool have = false;                                   // pb/pq hold chunks [c0, c0 + kBlockChunks) of the item
+    auto prefetch = [&](const Range &r) {
+        have = ALIGNED && r.c0 + kBlockChunks <= r.c1;
+        if (have) {
+            const u32x4 *bv = reinterpret_cast<const u32x4 *>(r.brow);
+            const u32x4 *qv = reinterpret_cast<const u32x4 *>(r.qrow);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                pb[u] = __builtin_nontemporal_load(&bv[r.c0 + tid + (int64_t)u * kHistThreads]);
+                pq[u] = __builtin_nontemporal_load(&qv[r.c0 + tid + (int64_t)u * kHistThreads]);
+            }
+        }
+    };
+    const int64_t n_work = n_sites * n_real;
+    // (Dealing each XCD a contiguous eighth of the item sequence instead of every eighth item measures the same:
+    // profiles/r02_ranges_item_mapping.txt.)
+    int64_t w = blockIdx.x;
+    Range r{nullptr, nullptr, 0, 0, 0, 0, 0};
+    if (w < n_work) { r = range_of(w); prefetch(r); }
+    while (w < n_work) {
+        const int8_t *brow = r.brow, *qrow = r.qrow;
+        if (ALIGNED && r.c0 < r.c1) {
             const u32x4 *bv = reinterpret_cast<const u32x4 *>(brow);
             const u32x4 *qv = reinterpret_cast<const u32x4 *>(qrow);
-            constexpr int64_t kBlockChunks = (int64_t)kUnroll * kHistThreads;
-            int64_t cb = c0;
-            for (; cb + kBlockChunks <= c1; cb += kBlockChunks) {
+            int64_t cb = r.c0;
+            if (have) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) count_chunk(hist, pb[u], pq[u], lane_off);
+                cb += kBlockChunks;
+            }
+            for (; cb + kBlockChunks <= r.c1; cb += kBlockChunks) {
                 u32x4 b[kUnroll], q[kUnroll];
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
@@ -440,17 +524,17 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_ranges_kernel(
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) count_chunk(hist, b[u], q[u], lane_off);
             }
-            for (int64_t ct = cb + tid; ct < c1; ct += kHistThreads) {
-                const u32x4 b = __builtin_nontemporal_load(&bv[ct]);
-                const u32x4 q = __builtin_nontemporal_load(&qv[ct]);
-                count_word_checked(hist, b.x, q.x, lane_off); count_word_checked(hist, b.y, q.y, lane_off);
-                count_word_checked(hist, b.z, q.z, lane_off); count_word_checked(hist, b.w, q.w, lane_off);
-            }
-            scalar(brow, qrow, c1 << 4, s1);
+            if (cb < r.c1) count_partial_block(hist, bv, qv, cb, r.c1, tid, lane_off);
+            scalar(brow, qrow, r.s0, r.c0 << 4);
+            scalar(brow, qrow, r.c1 << 4, r.s1);
         } else {
-            scalar(brow, qrow, s0, s1);
+            scalar(brow, qrow, r.s0, r.s1);
         }
-        __syncthreads();
+        const int64_t wn = w + gridDim.x;
+        const int64_t out = r.out;
+        have = false;
+        if (wn < n_work) { r = range_of(wn); prefetch(r); }
+        lds_barrier();
         for (int key = tid; key < BVC_NCLASS; key += kHistThreads) {
             uint32_t sum = 0;
 #pragma unroll
@@ -461,9 +545,10 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_ranges_kernel(
                 sum += x.x + x.y + x.z + x.w;
                 *p = u32x4{0u, 0u, 0u, 0u};
             }
-            grp_counts[w * BVC_NCLASS + key] = sum;
+            grp_counts[out + key] = sum;
         }
-        __syncthreads();
+        lds_barrier();
+        w = wn;
     }
 }
 
@@ -590,12 +675,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_csr_block_kernel(
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) count_chunk(hist, b[u], q[u], lane_off);
             }
-            for (int64_t ct = cb + tid; ct < c1; ct += kHistThreads) {
-                const u32x4 b = __builtin_nontemporal_load(&bv[ct]);
-                const u32x4 q = __builtin_nontemporal_load(&qv[ct]);
-                count_word_checked(hist, b.x, q.x, lane_off); count_word_checked(hist, b.y, q.y, lane_off);
-                count_word_checked(hist, b.z, q.z, lane_off); count_word_checked(hist, b.w, q.w, lane_off);
-            }
+            if (cb < c1) count_partial_block(hist, bv, qv, cb, c1, tid, lane_off);
             scalar(c1 << 4, s1);
         } else {
             scalar(s0, s1);

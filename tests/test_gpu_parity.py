@@ -930,3 +930,54 @@ def test_error_behaviour_of_the_c_abi(ctx):
     # the context is still good, and a site without a call is a record, not an error
     rec = ctx.lrt_dense(np.full((1, 50), 2, dtype=np.int8), np.full((1, 50), 30, dtype=np.int8), [2], 0.001)
     assert int(rec[0]["called"]) == 0 and int(rec[0]["status"]) == 0 and rec[0]["depth"].tolist() == [0, 0, 50, 0]
+
+
+def test_tiles_beyond_4_gib_are_addressed_with_64_bits(ctx):
+    """Maximum sizes: one call over a tile whose arrays are larger than 2^32 bytes (4,400 sites x 1e6 samples = 4.4 GB
+    each; the bench's own tiles stop at 4.0e9).  Every byte offset inside the kernels is 64-bit: the records of the
+    sites that lie beyond the 4 GiB mark must be the records the same rows give as a tile of their own, their histograms
+    must match the oracle's, and every histogram of the big call must sum to N.  The same tile as ragged (CSR) sites
+    (element offsets up to 4.4e9) and in group mode (both kernels)."""
+    import torch
+    from basevarc_amd.lib import GROUP_DTYPE, results_from_tensor
+    ns, n, k = 4400, 1_000_000, 5
+    m = caller_min_af(n)
+    b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    r = torch.empty(ns, dtype=torch.int8, device="cuda")
+    ctx.synth_dense_device(7, 0, b, q, r)
+    first_beyond = (1 << 32) // n + 1                              # first row that starts past the 4 GiB mark
+    assert first_beyond < ns - 8
+    tail = slice(ns - 8, ns)
+
+    counts = ctx.hist_dense_device(b, q)
+    assert bool((counts.view(torch.int32).sum(dim=1) == n).all())
+    hb, hq = b[tail].cpu().numpy(), q[tail].cpu().numpy()
+    ct = counts[tail].cpu().numpy().view(np.uint32)
+    for i in range(8):
+        assert np.array_equal(ct[i], orc.dense_hist(hb[i], hq[i])), i
+
+    big = results_from_tensor(ctx.lrt_dense_device(b, q, r, m))
+    small = results_from_tensor(ctx.lrt_dense_device(b[tail], q[tail], r[tail], m))
+    assert big[tail].tobytes() == small.tobytes()
+    assert (big["depth_total"] == n).all()
+    hr = r[tail].cpu().numpy()
+    for i in range(8):
+        assert_site_matches(small[i], orc.hist_lrt(ct[i], hr[i], m), where=f"beyond 4 GiB site {i}", path_strict=False)
+
+    # ragged form of the same bytes: site s = elements [s * n, (s + 1) * n) of the concatenated arrays
+    offs = (torch.arange(ns + 1, dtype=torch.int64) * n).cuda()
+    csr = results_from_tensor(ctx.lrt_csr_device(offs, b.reshape(-1), q.reshape(-1), r, m))
+    assert csr.tobytes() == big.tobytes()
+
+    # group mode, labels in any order and ordered by group
+    for layout in ("interleaved", "ordered"):
+        g = torch.from_numpy(_group_labels(n, k, layout)).cuda()
+        res_t, gres_t = ctx.lrt_dense_groups_device(b, q, r, m, g, k)
+        res_s, gres_s = ctx.lrt_dense_groups_device(b[tail], q[tail], r[tail], m, g, k)
+        ctx.synchronize()
+        assert results_from_tensor(res_t).tobytes() == big.tobytes(), layout
+        gb = gres_t.cpu().numpy().view(GROUP_DTYPE).reshape(ns, k)
+        gs = gres_s.cpu().numpy().view(GROUP_DTYPE).reshape(8, k)
+        assert gb[tail].tobytes() == gs.tobytes(), layout
+        assert (gb["depth"].sum(axis=(1, 2)) == n).all(), layout
