@@ -40,3 +40,29 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert legs[name]["value"] > 0 and 0 < legs[name]["roofline"]["frac"] < 1, name
     assert legs["config1_1e4x1e4"]["roofline"]["bound"] == "fp64_valu_issue"
     assert legs["csr_coverage10pct"]["roofline"]["bound"] == "fp64_valu_issue" and legs["csr_coverage10pct"]["hist_roofline"]["bound"] == "hbm"
+
+
+def test_bench_under_the_drivers_multi_gpu_launcher_two_ranks_sharing_the_card():
+    """The driver's N > 1 command line (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...) with N = 2 on this one-GPU box: BVC_BENCH_BACKEND=gloo lets the
+    ranks share device 0 (a rehearsal of the launch, rendezvous, sharding, barrier and max-over-ranks path -- not a
+    scaling measurement).  configs[3] as written: ONE workload split by site (strong scaling), rank 0 prints the line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BVC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--samples", "200000", "--total-sites", "8000",
+                        "--tile-sites", "2000", "--cpu-sites", "0", "--no-legs"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong"
+    # the whole job's 8000 sites per step, 4000 on each rank
+    assert d["config"]["sites_per_step"] == 8000
+    assert d["value"] == pytest.approx(8000 / (d["ms_per_step"] / 1e3), rel=1e-3)
+    assert "gloo" in d["config"]["sharding"] and "strong" in d["config"]["sharding"]

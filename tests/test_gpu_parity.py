@@ -981,3 +981,67 @@ def test_tiles_beyond_4_gib_are_addressed_with_64_bits(ctx):
         gs = gres_s.cpu().numpy().view(GROUP_DTYPE).reshape(8, k)
         assert gb[tail].tobytes() == gs.tobytes(), layout
         assert (gb["depth"].sum(axis=(1, 2)) == n).all(), layout
+
+
+def _fuzz_histogram(rng):
+    """A random (base, qual) count histogram with the features the EM kernel's variants key on: the number of distinct
+    quality values per base (slot count 1..8, with the variant edges 16/17, 32/33, 48/49, 64/65, 96/97 over-sampled),
+    the depth (1 .. 2e9), the number of alleles and how far their fractions sit from min_af."""
+    nq = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 95, 96, 97, 127, 128, int(rng.integers(1, 129))]))
+    quals = np.sort(rng.choice(128, size=nq, replace=False))
+    if quals[0] == 0 and rng.random() < 0.8:
+        quals = quals[1:] if len(quals) > 1 else np.array([1])         # Q = 0 is the NaN path; keep it rare
+    depth = int(10 ** rng.uniform(0, 9.3))
+    ref = int(rng.integers(0, 4))
+    n_alt = int(rng.choice([0, 1, 1, 2, 3]))
+    fr = np.zeros(4)
+    alts = rng.permutation([b for b in range(4) if b != ref])[:n_alt]
+    for a in alts:
+        fr[a] = 10 ** rng.uniform(-7, -0.3)
+    fr[ref] = max(1.0 - fr.sum(), 0.0) if rng.random() < 0.9 else 0.0   # sometimes no reference observation at all
+    if fr.sum() == 0:
+        fr[ref] = 1.0
+    fr /= fr.sum()
+    per_base = rng.multinomial(min(depth, 2_000_000_000), fr) if depth < 2 ** 31 else None
+    counts = np.zeros((4, 128), dtype=np.uint32)
+    for b in range(4):
+        nb = int(per_base[b])
+        if nb == 0:
+            continue
+        use = quals if rng.random() < 0.7 else quals[rng.random(len(quals)) < 0.5]
+        if len(use) == 0:
+            use = quals[:1]
+        w = rng.dirichlet(np.full(len(use), 0.7))
+        counts[b, use] = rng.multinomial(nb, w).astype(np.uint32)
+    return counts.reshape(512), ref
+
+
+def test_fuzz_random_histograms_against_the_oracle(ctx):
+    """3,000 random histograms through bvc_lrt_hist (stage 2 alone) against the oracle's histogram form: every kernel
+    variant (2 / 4 / 8 register slots per lane and their narrow forms), depths from 1 to 2e9, fractions on both sides
+    of min_af, candidate lists from SetBase."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(20261004)
+    n = 3000
+    hs, refs, combs, ncs = [], [], [], []
+    for i in range(n):
+        h, r = _fuzz_histogram(rng)
+        hs.append(h); refs.append(r)
+        if i % 3 == 0:                                              # SetBase: the reference base plus a random subset
+            others = [b for b in range(4) if b != r and rng.random() < 0.6]
+            cb = [r] + others
+        else:
+            cb = [0, 1, 2, 3]
+        combs.append(cb + [0] * (4 - len(cb))); ncs.append(len(cb))
+    H = np.stack(hs); R = np.array(refs, dtype=np.int8)
+    CB = np.array(combs, dtype=np.int8); NC = np.array(ncs, dtype=np.uint8)
+    for min_af in (1e-4, 0.001):
+        got = ctx.lrt_hist(H, R, min_af, CB, NC)
+        with ThreadPoolExecutor(8) as pool:
+            exp = list(pool.map(lambda i: orc.hist_lrt(H[i], int(R[i]), min_af, base_comb=CB[i][:NC[i]]), range(n)))
+        ties = 0
+        for i in range(n):
+            assert_site_matches(got[i], exp[i], where=f"fuzz {i} min_af {min_af}", path_strict=False)
+            ties += assert_path_difference_is_a_tie(got[i], exp[i], where=f"fuzz {i}")
+        assert ties <= 0.02 * n, ties
+        assert sum(e["called"] for e in exp) > n // 10
