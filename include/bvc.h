@@ -99,11 +99,13 @@ const char *bvc_last_error(const bvc_ctx *ctx);
 int  bvc_set_stream(bvc_ctx *ctx, void *hip_stream);
 int  bvc_synchronize(bvc_ctx *ctx);
 /*
- * Overlap mode (off by default).  With it on, bvc_lrt_dense on device pointers runs its second stage
- * (EM/LRT, FP64-bound) on an internal side stream, so that it executes underneath the first stage
- * (histogram, HBM-bound) of the NEXT call.  Results of a call are then complete only after bvc_join
- * (makes the context's stream wait for all side work) or bvc_synchronize; the caller must keep the
- * ref_base and results buffers of a call alive and untouched until then.
+ * Overlap mode (off by default).  With it on, every entry point that takes device pointers (bvc_lrt_dense,
+ * bvc_lrt_dense_groups, bvc_lrt_csr[_comb]) runs its second stage (EM/LRT, FP64-bound) on internal side streams,
+ * so that it executes underneath the first stage (histogram, HBM-bound) of the NEXT call.  Results of a call are
+ * then complete only after bvc_join (makes the context's stream wait for all side work) or bvc_synchronize; the
+ * caller must keep the ref_base and results buffers of a call alive and untouched until then, and give calls
+ * that may be in flight together DIFFERENT results buffers: the second stages of consecutive calls may run
+ * side by side (two side streams), so which of two writers of one buffer comes last is not defined.
  */
 int  bvc_set_overlap(bvc_ctx *ctx, int on);
 int  bvc_join(bvc_ctx *ctx);

@@ -1,11 +1,9 @@
 cd $GRAFT_REPO_ROOT
-run() {
-  for k in 5 16 2; do
-  python bench.py --groups $k --group-layout ordered --steps 8 --warmup 1 --cpu-sites 0 --no-verify --no-legs --total-sites 40000 --no-overlap --profile-every 1 2>/dev/null | python tools/bench_line.py "$1" serial ordered k $k
+for shape in "100000 40000 160000" "10000 100000 400000" "10000 40000 160000"; do
+  set -- $shape
+  for pair in 0 1; do
+   for ov in "" "--no-overlap"; do
+    BVC_EM_PAIR=$pair python bench.py --samples $1 --tile-sites $2 --total-sites $3 --steps 3 --warmup 1 --cpu-sites 0 --no-verify --no-legs $ov 2>/dev/null | python tools/bench_line.py N $1 tile $2 pair $pair $ov
+   done
   done
-  python bench.py --groups 5 --group-layout ordered --steps 8 --warmup 1 --cpu-sites 0 --no-verify --no-legs --total-sites 40000 2>/dev/null | python tools/bench_line.py "$1" overlap ordered k 5
-}
-for rep in 1 2; do
-  BVC_EXTRA_FLAGS="-DBVC_RANGES_SWIZZLE" python -c "from basevarc_amd import build; build.build(force=True)" && run swizzle
-  python -c "from basevarc_amd import build; build.build(force=True)" && run plain
 done
