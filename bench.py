@@ -52,6 +52,7 @@ def parse():
     p.add_argument("--cpu-sites", type=int, default=-1, help="sites for the CPU baseline (-1: one per core, 0: skip)")
     p.add_argument("--no-verify", action="store_true", help="CPU leg: time the baseline only, skip the wider check")
     p.add_argument("--no-legs", action="store_true", help="skip the configs[1] / configs[4] / CSR legs")
+    p.add_argument("--csr-sites", type=int, default=0, help="sites per call of the ragged (CSR) leg (0 = --tile-sites)")
     p.add_argument("--verify-all", action="store_true",
                    help="after the run, check EVERY resident site against the oracle's histogram form (about a minute)")
     p.add_argument("--no-overlap", action="store_true", help="run the two kernels of a call back to back on one stream")
@@ -335,7 +336,8 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
 
     # ---- ragged (CSR) entry point at 10 % coverage: what a real low-coverage pileup looks like at N = 1e6
     cov = 0.1
-    n_csr_tiles, csr_sites = 2, a.tile_sites
+    # (sites per call: --csr-sites; the leg's rate is the same at 4000, 16,000 and 40,000)
+    n_csr_tiles, csr_sites = 2, a.csr_sites or a.tile_sites
     csr = []
     slice_sites = 500                                            # generate + compact in slices: 1 GB of scratch
     tmp_b = torch.empty((slice_sites, stride), dtype=torch.int8, device=dev)
@@ -365,7 +367,7 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
     def fn_csr(j):
         o, b, q, r = csr[j % len(csr)]
         ctx.lrt_csr_device(o, b, q, r, min_af, res[j % len(csr)])
-    n_calls = 40
+    n_calls = max(8, 160000 // csr_sites)
     dt, prof = timed_calls(ctx, fn_csr, n_calls)
     hist_ms = prof["hist_ms"] / max(1, prof["hist_launches"])
     em_ms = prof["em_ms"] / max(1, prof["em_launches"])
