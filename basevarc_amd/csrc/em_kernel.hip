@@ -83,6 +83,7 @@ struct Freq {
 };
 
 constexpr int kDppRor8 = 0x128;                 // row_ror:8
+constexpr int kDppRowBcast15 = 0x142;           // row_bcast:15 (GFX9 family): lane 15 of each row to every lane of the next row
 template <int L> constexpr int dpp_newbcast() { return 0x150 + L; }   // row_newbcast:L (lane L of each row)
 
 struct PassOut {
@@ -162,10 +163,11 @@ __device__ __forceinline__ PassOut em_pass(Slots<NS> &S, const Freq f, double in
     v += dpp_f64<kDppXor2>(v);
     v += dpp_f64<kDppHalfMirror>(v);
     const double drow = dpp_f64<dpp_newbcast<0>()>(v);          // lanes 0-7 of the row: D of the row's base
-    const DPair w = swap16(v, v);
-    const double t = w.a + w.b;                                  // lanes 8-15: rows 0,1 -> E, rows 2,3 -> A
-    const double etot = lane_value<8>(t);
-    const uint32_t a_hi = (uint32_t)__builtin_amdgcn_readlane(__double2hiint(t), 40);
+    // rows 1 and 3 add the z of the row before them (row_bcast:15 hands lane 15 of a row to the next row): lanes 24-31
+    // then hold E, lanes 56-63 A.  (Two instructions fewer than copying v and swapping rows with v_permlane16_swap.)
+    const double t = v + dpp_f64<kDppRowBcast15>(v);
+    const double etot = lane_value<24>(t);
+    const uint32_t a_hi = (uint32_t)__builtin_amdgcn_readlane(__double2hiint(t), 56);
     PassOut o;
     o.converged = a_hi < kSureBelowHi;
     if (a_hi >= kSureBelowHi && a_hi < kSureAboveHi) {           // rare: the bracket straddles eps
