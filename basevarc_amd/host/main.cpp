@@ -229,8 +229,16 @@ struct TileRunner {
     int32_t n_samples = 0;
     double min_af = 0;
     BgzfWriter *fvcf = nullptr, *fcvg = nullptr;
+    // the tile's positions: slots [0, n_used) of `sites` (the slots and their vectors are reused from tile to tile)
     std::vector<SiteColumn> sites;
+    size_t n_used = 0;
+    size_t entries = 0;                  // observations held by the slots in use
     std::vector<int8_t> refs;
+    SiteColumn &slot()
+    {
+        if (n_used == sites.size()) sites.emplace_back();
+        return sites[n_used];
+    }
 
     // tile buffers live as long as the runner: a flush refills them, it does not reallocate them
     std::vector<bvc_site_result> res;
@@ -240,7 +248,7 @@ struct TileRunner {
 
     void flush()
     {
-        const int64_t ns = (int64_t)sites.size();
+        const int64_t ns = (int64_t)n_used;
         if (ns == 0) return;
         res.resize((size_t)ns);
         const int ng = groups ? (int)groups->names.size() : 0;
@@ -250,8 +258,8 @@ struct TileRunner {
             // ragged form: exactly the vectors bt_f builds (src/BaseVarC.cpp:550-559)
             offsets.assign(1, 0);
             bases.clear(); quals.clear();
-            for (auto const &s : sites) {
-                for (auto const &a : s.aiv)
+            for (int64_t i = 0; i < ns; ++i) {
+                for (auto const &a : sites[(size_t)i].aiv)
                     if (a.is_indel == 0) { bases.push_back((int8_t)a.base); quals.push_back((int8_t)a.qual); }
                 offsets.push_back((int64_t)bases.size());
             }
@@ -296,7 +304,8 @@ struct TileRunner {
                 t1 = StageClock::now(); clk.write += t1 - t0; t0 = t1;
             }
         }
-        sites.clear();
+        n_used = 0;
+        entries = 0;
         refs.clear();
     }
 };
@@ -355,10 +364,14 @@ struct BatchInput {
 static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32_t> &pv, const std::string &refseq,
                  const std::string &chr, int32_t rg_s, int32_t N, int thread, int ithread, int device)
 {
+    const double t_start = StageClock::now();
     BgzfWriter fpv(opt::output + "." + std::to_string(ithread) + ".vcf.gz");
     BgzfWriter fpc(opt::output + "." + std::to_string(ithread) + ".cvg.gz");
     std::vector<BatchInput *> fpiv;
     for (auto const &f : ftmp_v) fpiv.push_back(new BatchInput(f));
+    // (BVC_HOST_PROFILE: on a GPU box the first ~0.5 s of every worker thread go to process-wide stalls while the HIP
+    // runtime, started by bvc_device_count in main, finishes coming up -- whatever the thread does first pays them.)
+    const double t_opened = StageClock::now();
     std::string sams, line;
     for (auto fp : fpiv) sams += fp->names;
     if (!sams.empty()) sams.pop_back();                                 // names are tab-terminated
@@ -389,8 +402,11 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
         fpv.write(vcf_header(groups, opt::reference, names));
     }
     std::cerr << "begin to load data and run basetype" << std::endl;
+    const double t_header = StageClock::now();
     TileRunner tr;
+    const double t_create = StageClock::now();
     if (bvc_create(&tr.ctx, device) != BVC_OK) throw std::runtime_error("ERROR: no usable gfx950 device for libbvc");
+    const double create_s = StageClock::now() - t_create;
     tr.groups = groups.empty() ? nullptr : &groups;
     tr.chr = chr;
     tr.n_samples = N;
@@ -406,9 +422,10 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
     size_t lo, hi;
     thread_window(pv.size(), thread, ithread, lo, hi);
     int32_t count = 0;
-    SiteColumn site;
+    const double t_loop = StageClock::now();
     for (size_t ip = lo; ip < hi; ++ip) {
         const int32_t p = pv[ip];
+        SiteColumn &site = tr.slot();                                   // parsed in place: no copy into the tile
         site.clear();
         site.pos = p;
         int32_t j = 0;
@@ -416,18 +433,24 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
         if (!site.aiv.empty()) {
             const char rc = refseq[(size_t)(p - rg_s)];
             const int8_t ref_base = rc == 'A' ? 0 : rc == 'C' ? 1 : rc == 'G' ? 2 : rc == 'T' ? 3 : -1;
-            tr.sites.push_back(site);
+            ++tr.n_used;
+            tr.entries += site.aiv.size();
             tr.refs.push_back(ref_base);
-            if ((int64_t)tr.sites.size() >= tile) tr.flush();
+            // a tile is full at --tile positions or at 4M observations (64 MB of per-sample records held for the
+            // CVG/VCF lines): at 1e5 samples that is a few hundred positions, still far more than the device needs
+            if ((int64_t)tr.n_used >= tile || tr.entries >= ((size_t)1 << 22)) tr.flush();
             if (!(++count % 1000)) std::cerr << "basetype completed " << count << " sites -- thread" << ithread << std::endl;
         }
     }
     tr.flush();
+    const double loop_s = StageClock::now() - t_loop, setup_s = t_loop - t_start;
     if (getenv("BVC_HOST_PROFILE")) {
         const StageClock &c = tr.clk;
         std::cerr << "[profile] thread " << ithread << ": read+inflate " << c.read << " s, parse " << c.parse << " s, pack "
                   << c.pack << " s, libbvc " << c.gpu << " s, cvg lines " << c.cvg << " s, vcf lines " << c.vcf
-                  << " s, compress+write " << c.write << " s" << std::endl;
+                  << " s, compress+write " << c.write << " s; setup (open batches " << t_opened - t_start << " s, names + header "
+                  << t_header - t_opened << " s, bvc_create " << create_s << " s) " << setup_s << " s, position loop " << loop_s << " s, thread total "
+                  << StageClock::now() - t_start << " s" << std::endl;
     }
     bvc_destroy(tr.ctx);
     if (!fpv.close()) std::cerr << "warning: file cannot be closed" << std::endl;
@@ -505,6 +528,7 @@ static void run_basetype(int argc, char **argv)                          // src/
         run_pool(nb - first_batch, thread, [&](int t) { bt_r(bams, pv, refseq, chr, rg_s, rg_e, nb, bc, first_batch + t, thread); });
     }
     time_t tim1 = time(0);
+    const double t_loaded = StageClock::now();
     std::cout << "basetype loading done -- " << ctime(&tim1);
     if (opt::load) std::exit(EXIT_SUCCESS);
     int gpus = bvc_device_count();
@@ -522,6 +546,7 @@ static void run_basetype(int argc, char **argv)                          // src/
         // Every worker is joined BEFORE anything can throw: unwinding past a joinable std::thread is std::terminate,
         // which would lose the error text and leave the other threads in the middle of their device calls.
         for (auto &w : workers) w.join();
+        const double t_joined = StageClock::now();
         {
             std::lock_guard<std::mutex> g(mu);
             if (!werr.empty()) {
@@ -546,6 +571,9 @@ static void run_basetype(int argc, char **argv)                          // src/
         std::cout << "merge subfiles done" << std::endl;
         if (!fov.close()) std::cerr << "warning: file cannot be closed" << std::endl;
         if (!foc.close()) std::cerr << "warning: file cannot be closed" << std::endl;
+        if (getenv("BVC_HOST_PROFILE"))
+            std::cerr << "[profile] main: compute phase (threads) " << t_joined - t_loaded << " s, merge of sub-files "
+                      << StageClock::now() - t_joined << " s" << std::endl;
     }
     for (int i = 0; i < thread; ++i) ::rmdir((opt::output + ".tmp.thread." + std::to_string(i)).c_str());
     time_t tim2 = time(0);

@@ -1,11 +1,26 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "fuzz or random_sites or edge or wide_quality or chi_sweep or set_base or min_af or golden or group" 2>&1 | tail -3 || exit 1
-for rep in 1 2; do
-python bench.py --steps 6 --warmup 1 --cpu-sites 0 --no-verify --no-legs --no-overlap 2>/dev/null | python tools/bench_line.py serial headline
-done
-python bench.py --steps 6 --warmup 1 --cpu-sites 0 --no-verify > gpurun_out/_t.json 2>/dev/null
-python - <<PY
-import json
-d=json.loads(open('gpurun_out/_t.json').read().strip().splitlines()[-1])
-print('headline', round(d['value']), {k: round(v,3) for k,v in d['kernels_ms_per_call'].items()}, ' '.join(f"{k.split('_')[0]}:{round(v['value'])}" for k,v in d['legs'].items()))
+mkdir -p /tmp/hb && cd /tmp/hb
+python - <<'PY'
+import ctypes as C, os, time, sys, glob
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+from basevarc_amd import build as b
+exe, hostlib = b.build_host()
+H=C.CDLL(hostlib)
+H.bvchost_write_synth_batches.restype=C.c_int64
+H.bvchost_write_synth_batches.argtypes=[C.c_char_p,C.c_int32,C.c_int32,C.c_int32,C.c_int32,C.c_int32,C.c_uint64,C.c_int32]
+n,npos,thread,batch=100000,200,4,500
+out='/tmp/hb/o'
+for t in range(thread): os.makedirs(f"{out}.tmp.thread.{t}",exist_ok=True)
+t0=time.time(); print(H.bvchost_write_synth_batches(out.encode(),n,npos,thread,batch,100,11,2), time.time()-t0)
+fs=glob.glob(out+".tmp.thread.*/*")
+t0=time.time()
+for f in fs:
+    with open(f,'rb') as fh: fh.read(16)
+print(len(fs),'opens', time.time()-t0)
+import subprocess
+print(subprocess.run("df /tmp | tail -1; mount | grep -E ' /tmp| / ' | head -3; nproc", shell=True, capture_output=True, text=True).stdout)
 PY
+cd $GRAFT_REPO_ROOT
+g++ -O2 -pthread -o /tmp/t_open tools/_t_open.cpp -ldl
+LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/basevarc_amd:/opt/rocm/lib /tmp/t_open 0
+LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/basevarc_amd:/opt/rocm/lib /tmp/t_open 1

@@ -74,7 +74,9 @@ def main():
             prof = [l for l in r.stderr.splitlines() if l.startswith("[profile]")]
             n_cvg = gzip.decompress(open(out + ".cvg.gz", "rb").read()).count(b"\n") - 3
             n_vcf = sum(1 for l in gzip.decompress(open(out + ".vcf.gz", "rb").read()).split(b"\n") if l and not l.startswith(b"#"))
-            print(json.dumps({"tmp_format": fmt, "n_samples": n, "positions": npos, "threads": thread, "coverage": cov,
+            import re
+            loops = [float(m.group(1)) for m in (re.search(r"position loop ([0-9.e+-]+) s", l) for l in prof) if m]
+            print(json.dumps({"tmp_format": fmt, "positions_per_s_in_the_position_loops": round(npos / max(loops), 1) if loops else None, "n_samples": n, "positions": npos, "threads": thread, "coverage": cov,
                               "entries": entries, "batch_files_MB": round(size / 1e6, 1), "generate_s": round(gen_s, 2),
                               "seconds": round(dt, 3), "positions_per_s": round(npos / dt, 1),
                               "entries_per_s": round(entries / dt), "cvg_lines": n_cvg, "vcf_lines": n_vcf, "profile": prof}))
