@@ -36,7 +36,7 @@ struct bvc_ctx {
     bool em_pending[kRing] = {false, false, false};
     uint32_t *d_grp[kRing] = {nullptr, nullptr, nullptr};   // [sites][groups + 1][512] in group mode
     size_t grp_cap[kRing] = {0, 0, 0};
-    uint32_t *d_sink = nullptr;        // 256-byte sink of the streaming-read measurement kernel (private to it)
+    uint32_t *d_sink = nullptr;        // 256 bytes: sink of the streaming-read measurement kernel; bvc_pack_dense's counter at byte 64
     uint8_t *d_grp_labels = nullptr;   // group mode: the call's group vector clamped to 0..n_groups (hist_kernel.hip)
     size_t grp_labels_cap = 0;
     int64_t *d_grp_scratch = nullptr;  // group mode: "samples ordered by group" flag + column bounds (hist_kernel.hip)
@@ -148,7 +148,7 @@ hipStream_t em_stream(bvc_ctx *ctx, int by_default)
 template <class Stage1>
 int run_two_stages(bvc_ctx *ctx, int64_t n_sites, bool zero_counts, bool long_rows, Stage1 stage1,
                    const int8_t *ref_base, double min_af, const int8_t *comb, const uint8_t *n_comb,
-                   bvc_site_result *results)
+                   bvc_site_result *results, int em_streams_long_rows = 1)
 {
     const size_t cbytes = (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t);
     const int buf = ctx->overlap ? ctx->flip : 0;
@@ -187,7 +187,7 @@ int run_two_stages(bvc_ctx *ctx, int64_t n_sites, bool zero_counts, bool long_ro
     // stage 2: same stream, or the side stream behind an event
     hipStream_t s2 = ctx->stream;
     if (ctx->overlap) {
-        s2 = em_stream(ctx, long_rows ? 1 : 2);
+        s2 = em_stream(ctx, long_rows ? em_streams_long_rows : 2);
         BVC_HIP_T(hipEventRecord(ctx->ev_hist_done[buf], ctx->stream));
         BVC_HIP_T(hipStreamWaitEvent(s2, ctx->ev_hist_done[buf], 0));
     }
@@ -221,6 +221,19 @@ int run_dense_device(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t r
                                                        nullptr, 0, counts, split);
                           },
                           ref_base, min_af, nullptr, nullptr, results);
+}
+
+int run_packed_device(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride, const uint8_t *packed,
+                      const int8_t *ref_base, double min_af, bvc_site_result *results)
+{
+    const int split = choose_hist_split(ctx->ls, n_sites, n_samples);
+    return run_two_stages(ctx, n_sites, split > 1, n_samples >= 200000,
+                          [&](uint32_t *counts) {
+                              return launch_hist_packed(ctx->ls, ctx->stream, n_sites, n_samples, row_stride, packed, counts, split);
+                          },
+                          // at one byte per sample stage 1 is as short as stage 2 and the call is bound by the VALU the
+                          // two share: stage 2 on two streams (4.0e6 -> 4.55e6 sites/s, profiles/r02_packed_sweep.txt)
+                          ref_base, min_af, nullptr, nullptr, results, 2);
 }
 
 int run_csr_device(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets, const int8_t *bases, const int8_t *quals,
@@ -506,6 +519,85 @@ int bvc_lrt_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_
                                         hipMemcpyDeviceToHost, ctx->stream));
             return BVC_OK;
         });
+}
+
+int bvc_lrt_dense_packed(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride, const uint8_t *packed,
+                         const int8_t *ref_base, double min_af, bvc_site_result *results, uint32_t flags)
+{
+    int rc = check_common(ctx, n_sites, n_samples ? (const void *)packed : (const void *)ref_base, ref_base, ref_base, results);
+    if (rc != BVC_OK) return rc;
+    if (n_samples < 0 || row_stride < n_samples) return fail(ctx, BVC_ERR_ARG, "need 0 <= n_samples <= row_stride");
+    if (n_sites == 0) return BVC_OK;
+    if (flags & BVC_PTR_DEVICE) return run_packed_device(ctx, n_sites, n_samples, row_stride, packed, ref_base, min_af, results);
+
+    // host pointers: the chunked staging of bvc_lrt_dense with one array instead of two
+    const int64_t row_bytes = row_stride > 0 ? row_stride : 1;
+    int64_t chunk = ctx->ls.host_chunk_bytes / row_bytes;
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_sites) chunk = n_sites;
+    const size_t arr_al = ((size_t)chunk * (size_t)row_stride + 255) & ~(size_t)255;
+    const size_t ref_al = ((size_t)chunk + 255) & ~(size_t)255;
+    const size_t need = arr_al + ref_al + (size_t)chunk * sizeof(bvc_site_result) + 256;
+    const int n_sets = n_sites > chunk ? 2 : 1;
+    for (int k = 0; k < n_sets; ++k) {
+        rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage[k]), &ctx->stage_cap[k], need);
+        if (rc != BVC_OK) return rc;
+    }
+    auto d_p = [&](int set) { return reinterpret_cast<uint8_t *>(ctx->d_stage[set]); };
+    auto d_r = [&](int set) { return reinterpret_cast<int8_t *>(d_p(set) + arr_al); };
+    auto d_res = [&](int set) { return reinterpret_cast<bvc_site_result *>(d_r(set) + ref_al); };
+    return run_chunks(ctx, n_sites, chunk,
+        [&](int set, int64_t s0, int64_t ns) -> int {
+            const size_t bytes = n_samples ? (size_t)(ns - 1) * (size_t)row_stride + (size_t)n_samples : 0;
+            if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_p(set), packed + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->copy));
+            BVC_HIP(ctx, hipMemcpyAsync(d_r(set), ref_base + s0, (size_t)ns, hipMemcpyHostToDevice, ctx->copy));
+            return BVC_OK;
+        },
+        [&](int set, int64_t s0, int64_t ns, bool download) -> int {
+            if (!download) {
+                int rc2 = run_packed_device(ctx, ns, n_samples, row_stride, d_p(set), d_r(set), min_af, d_res(set));
+                return rc2 == BVC_OK ? join_side(ctx) : rc2;
+            }
+            BVC_HIP(ctx, hipMemcpyAsync(results + s0, d_res(set), (size_t)ns * sizeof(bvc_site_result),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+            return BVC_OK;
+        });
+}
+
+int bvc_pack_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *bases,
+                   const int8_t *quals, int64_t packed_stride, uint8_t *packed, int64_t *n_unrepresentable, uint32_t flags)
+{
+    int rc = check_common(ctx, n_sites, n_samples ? (const void *)bases : (const void *)n_unrepresentable,
+                          n_samples ? (const void *)quals : (const void *)n_unrepresentable,
+                          n_samples ? (const void *)packed : (const void *)n_unrepresentable, n_unrepresentable);
+    if (rc != BVC_OK) return rc;
+    if (!n_unrepresentable) return fail(ctx, BVC_ERR_ARG, "null data pointer");
+    if (n_samples < 0 || row_stride < n_samples || packed_stride < n_samples) return fail(ctx, BVC_ERR_ARG, "need 0 <= n_samples <= row strides");
+    if (!(flags & BVC_PTR_DEVICE)) return fail(ctx, BVC_ERR_ARG, "bvc_pack_dense takes device pointers (a host producer writes base << 6 | qual itself)");
+    *n_unrepresentable = 0;
+    if (n_sites == 0 || n_samples == 0) return BVC_OK;
+    unsigned long long *d_bad = reinterpret_cast<unsigned long long *>(ctx->d_sink) + 8;   // bytes 64..71 of the context's 256-byte sink
+    BVC_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), ctx->stream));
+    BVC_HIP(ctx, launch_pack_dense(ctx->stream, n_sites, n_samples, row_stride, bases, quals, packed_stride, packed, d_bad));
+    unsigned long long bad = 0;
+    BVC_HIP(ctx, hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_unrepresentable = (int64_t)bad;
+    return BVC_OK;
+}
+
+int bvc_hist_dense_packed(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride, const uint8_t *packed,
+                          uint32_t *counts, uint32_t flags)
+{
+    int rc = check_common(ctx, n_sites, n_samples ? (const void *)packed : (const void *)counts, counts, counts, counts);
+    if (rc != BVC_OK) return rc;
+    if (n_samples < 0 || row_stride < n_samples) return fail(ctx, BVC_ERR_ARG, "need 0 <= n_samples <= row_stride");
+    if (!(flags & BVC_PTR_DEVICE)) return fail(ctx, BVC_ERR_ARG, "bvc_hist_dense_packed takes device pointers");
+    if (n_sites == 0) return BVC_OK;
+    const int split = choose_hist_split(ctx->ls, n_sites, n_samples);
+    if (split > 1) BVC_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)n_sites * BVC_NCLASS * sizeof(uint32_t), ctx->stream));
+    BVC_HIP(ctx, launch_hist_packed(ctx->ls, ctx->stream, n_sites, n_samples, row_stride, packed, counts, split));
+    return BVC_OK;
 }
 
 int bvc_hist_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,

@@ -41,6 +41,12 @@ constexpr int kGroupScratchWords = BVC_MAX_GROUPS + 4;
 // Number of sample-range splits per site launch_hist_dense should use for this shape (1 = none).
 int choose_hist_split(const LaunchState &st, int64_t n_sites, int64_t n_samples);
 
+// Stage 1 on packed rows (one byte per sample: base << 6 | qual, qual <= 62; 0xFF = no observation).
+hipError_t launch_hist_packed(LaunchState &st, hipStream_t stream, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                              const uint8_t *packed, uint32_t *counts, int split);
+hipError_t launch_pack_dense(hipStream_t stream, int64_t n_sites, int64_t n_samples, int64_t stride_in, const int8_t *bases,
+                             const int8_t *quals, int64_t stride_out, uint8_t *packed, unsigned long long *bad);
+
 hipError_t launch_stream_read(hipStream_t stream, const void *src, int64_t bytes, uint32_t *sink);
 
 hipError_t launch_hist_csr(LaunchState &st, hipStream_t stream, int64_t n_sites, const int64_t *offsets,

@@ -697,6 +697,128 @@ __global__ __launch_bounds__(kHistThreads) void hist_csr_block_kernel(
     }
 }
 
+// ---- packed rows: ONE byte per sample --------------------------------------------------------------------------
+// The path is HBM-bound at 2 bytes per (site, sample), and the pair (base 0..3, qual 0..62) fits one byte:
+//     packed = base << 6 | qual          0xFF (any byte with qual bits 63) = no observation
+// Half the bytes, half the time of stage 1 -- if the counting keeps up: at one byte per sample the two stages together
+// are bound by VALU issue, not by HBM.  So the byte IS the histogram slot and the counter address is built by ONE
+// instruction: 256 slots x 64 copies (copy = lane: no two lanes of a wave ever share a counter) = 64 KiB of LDS at
+// LDS address 0, counter address = slot << 8 | lane << 2, i.e. the sample's byte dropped into byte 1 of a register
+// that already holds lane << 2 (v_mov_b32_sdwa dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE).  No "covered?" test
+// either: an uncovered sample counts into slot 255, which the fold throws away.  Base qualities of 63 and more
+// (PacBio HiFi reaches 93; Illumina stops at 41) do not fit: such tiles stay on the two-byte entry points
+// (bvc_pack_dense counts them).
+constexpr int kPackedSlots = 256;
+constexpr int kPackedCopies = 64;                                // one per lane
+constexpr int kPackedLdsWords = kPackedSlots * kPackedCopies;    // 16384 words = 64 KiB
+constexpr int kPackedUnroll = 4;                                 // 16-byte loads in flight per lane (one array)
+
+// addr = (addr & ~0xFF00) | byte BYTE of w << 8
+template <int BYTE>
+__device__ __forceinline__ void put_slot(uint32_t &addr, uint32_t w)
+{
+    if (BYTE == 0) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(addr) : "v"(w));
+    if (BYTE == 1) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(addr) : "v"(w));
+    if (BYTE == 2) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(addr) : "v"(w));
+    if (BYTE == 3) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(addr) : "v"(w));
+}
+
+// Four samples; a0..a3 hold the lane's counter address bits outside byte 1 (four registers so that consecutive
+// samples do not wait on one another's register).
+__device__ __forceinline__ void count_packed_word(uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t &a3, uint32_t w)
+{
+    put_slot<0>(a0, w); lds_add_one(a0);
+    put_slot<1>(a1, w); lds_add_one(a1);
+    put_slot<2>(a2, w); lds_add_one(a2);
+    put_slot<3>(a3, w); lds_add_one(a3);
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(kHistThreads) void hist_packed_kernel(
+    int64_t n_sites, int64_t n_samples, int64_t row_stride, const uint8_t *__restrict__ packed,
+    uint32_t *__restrict__ counts, int split)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [slot][copy], the kernel's only LDS: address 0
+    const int tid = threadIdx.x;
+    const uint32_t lane_base = lds_address(hist) + ((uint32_t)(tid & (kPackedCopies - 1)) << 2);
+    // the one-instruction address needs bits 8..15 of the array's address to be zero (they are: see above)
+    const bool at_zero = (lds_address(hist) & 0xFFFFu) == 0u;
+    __builtin_amdgcn_s_setprio(3);
+    for (int i = tid * 4; i < kPackedLdsWords; i += kHistThreads * 4)
+        *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    uint32_t a0 = lane_base, a1 = lane_base, a2 = lane_base, a3 = lane_base;
+    const int64_t n_work = n_sites * split;
+    for (int64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const int64_t site = w / split;
+        const int part = (int)(w % split);
+        const uint8_t *row = packed + site * row_stride;
+        const int64_t n16 = (ALIGNED && at_zero) ? n_samples >> 4 : 0;
+        constexpr int64_t kBlockChunks = (int64_t)kPackedUnroll * kHistThreads;
+        if (ALIGNED && at_zero) {
+            const u32x4 *rv = reinterpret_cast<const u32x4 *>(row);
+            for (int64_t cb = (int64_t)part * kBlockChunks; cb < n16; cb += (int64_t)split * kBlockChunks) {
+                u32x4 v[kPackedUnroll];
+#pragma unroll
+                for (int u = 0; u < kPackedUnroll; ++u) {
+                    const int64_t c = cb + tid + (int64_t)u * kHistThreads;
+                    v[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // past the end: "no observation"
+                    if (cb + kBlockChunks <= n16 || c < n16) v[u] = __builtin_nontemporal_load(&rv[c]);
+                }
+#pragma unroll
+                for (int u = 0; u < kPackedUnroll; ++u) {
+                    count_packed_word(a0, a1, a2, a3, v[u].x); count_packed_word(a0, a1, a2, a3, v[u].y);
+                    count_packed_word(a0, a1, a2, a3, v[u].z); count_packed_word(a0, a1, a2, a3, v[u].w);
+                }
+            }
+        }
+        if (part == split - 1)                                   // the ragged tail (the whole row when not 16-byte aligned)
+            for (int64_t i = (n16 << 4) + tid; i < n_samples; i += kHistThreads)
+                lds_add_one(((uint32_t)row[i] << 8) + lane_base);
+        __syncthreads();
+        // fold the copies, publish in the [base][128 quals] form of the two-byte path, clear for the next site
+        for (int key = tid; key < BVC_NCLASS; key += kHistThreads) {
+            const int q = key & 127;
+            uint32_t sum = 0;
+            if (q < 64) {
+                const int slot = ((key >> 7) << 6) | q;
+#pragma unroll
+                for (int c = 0; c < kPackedCopies; c += 4) {
+                    const int cc = (c + 4 * (slot & 7)) & (kPackedCopies - 1);
+                    u32x4 *p = reinterpret_cast<u32x4 *>(&hist[slot * kPackedCopies + cc]);
+                    const u32x4 x = *p;
+                    sum += x.x + x.y + x.z + x.w;
+                    *p = u32x4{0u, 0u, 0u, 0u};
+                }
+                if (q == 63) sum = 0;                            // qual bits 63: no observation
+            }
+            if (split == 1) counts[site * BVC_NCLASS + key] = sum;
+            else if (sum) atomicAdd(&counts[site * BVC_NCLASS + key], sum);
+        }
+        __syncthreads();
+    }
+}
+
+// (bases, quals) -> packed bytes.  bad += covered samples whose quality does not fit (63..127): written as "no
+// observation", so a caller that finds bad != 0 must not use the packed tile.
+__global__ void pack_dense_kernel(int64_t n_sites, int64_t n_samples, int64_t stride_in, const int8_t *__restrict__ bases,
+                                  const int8_t *__restrict__ quals, int64_t stride_out, uint8_t *__restrict__ packed,
+                                  unsigned long long *__restrict__ bad)
+{
+    const int64_t total = n_sites * n_samples;
+    unsigned long long mine = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / n_samples, k = i - s * n_samples;
+        const uint32_t b = (uint8_t)bases[s * stride_in + k], q = (uint8_t)quals[s * stride_in + k];
+        uint8_t v = 0xFF;
+        if (b < 4u && q < 63u) v = (uint8_t)(b << 6 | q);
+        else if (b < 4u && q < 128u) ++mine;
+        packed[s * stride_out + k] = v;
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
 // Plain streaming read, 16 B per lane, nothing else: the empirical HBM read ceiling the histogram kernel is
 // compared with next to the 8 TB/s spec figure.  The XOR keeps the loads alive.
 __global__ __launch_bounds__(512) void stream_read_kernel(const u32x4 *__restrict__ src, int64_t n16, uint32_t *__restrict__ sink)
@@ -743,6 +865,7 @@ enum KernelSlot : uint32_t {
     kSlotDense0 = 0, kSlotDense1, kSlotRanges0, kSlotRanges1, kSlotCsr0, kSlotCsr1, kSlotGroupByte,
     kSlotGroup = 8,            // + log2c (0..5)
     kSlotGroupPipe = 16,       // + log2c (0..5)
+    kSlotPacked0 = 24, kSlotPacked1 = 25,
 };
 
 static hipError_t raise_lds(LaunchState &st, uint32_t slot, const void *kernel, size_t bytes)
@@ -822,6 +945,30 @@ hipError_t launch_hist_dense(LaunchState &st, hipStream_t stream, int64_t n_site
     const int64_t grid = n_work < 4096 ? n_work : 4096;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kHistThreads), lds, stream, n_sites, n_samples,
                        row_stride, bases, quals, counts, split);
+    return hipGetLastError();
+}
+
+hipError_t launch_hist_packed(LaunchState &st, hipStream_t stream, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                              const uint8_t *packed, uint32_t *counts, int split)
+{
+    if (n_sites <= 0) return hipSuccess;
+    const bool aligned = (reinterpret_cast<uintptr_t>(packed) & 15u) == 0 && (row_stride & 15) == 0;
+    auto kern = aligned ? hist_packed_kernel<true> : hist_packed_kernel<false>;
+    const size_t lds = (size_t)kPackedLdsWords * sizeof(uint32_t);
+    hipError_t e = raise_lds(st, aligned ? kSlotPacked1 : kSlotPacked0, reinterpret_cast<const void *>(kern), lds);
+    if (e != hipSuccess) return e;
+    const int64_t n_work = n_sites * split;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_work < 4096 ? n_work : 4096)), dim3(kHistThreads), lds, stream, n_sites,
+                       n_samples, row_stride, packed, counts, split);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_dense(hipStream_t stream, int64_t n_sites, int64_t n_samples, int64_t stride_in, const int8_t *bases,
+                             const int8_t *quals, int64_t stride_out, uint8_t *packed, unsigned long long *bad)
+{
+    if (n_sites <= 0 || n_samples <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_dense_kernel, dim3(4096), dim3(256), 0, stream, n_sites, n_samples, stride_in, bases, quals,
+                       stride_out, packed, bad);
     return hipGetLastError();
 }
 

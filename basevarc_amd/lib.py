@@ -50,6 +50,7 @@ EXPORTS = [
     "bvc_version", "bvc_device_count", "bvc_create", "bvc_destroy", "bvc_last_error", "bvc_set_stream",
     "bvc_synchronize", "bvc_set_overlap", "bvc_join", "bvc_set_profiling", "bvc_get_profile", "bvc_lrt_dense", "bvc_lrt_dense_groups",
     "bvc_lrt_csr", "bvc_lrt_csr_comb", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense", "bvc_stream_read_ms", "bvc_set_tuning",
+    "bvc_lrt_dense_packed", "bvc_pack_dense", "bvc_hist_dense_packed",
 ]
 
 _lib = None
@@ -101,6 +102,12 @@ def load_library():
     L.bvc_set_tuning.restype = C.c_int; L.bvc_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
     L.bvc_stream_read_ms.restype = C.c_int
     L.bvc_stream_read_ms.argtypes = [vp, vp, i64, C.c_int, C.POINTER(C.c_double)]
+    L.bvc_lrt_dense_packed.restype = C.c_int
+    L.bvc_lrt_dense_packed.argtypes = [vp, i64, i64, i64, vp, vp, dbl, vp, u32]
+    L.bvc_pack_dense.restype = C.c_int
+    L.bvc_pack_dense.argtypes = [vp, i64, i64, i64, vp, vp, i64, vp, C.POINTER(i64), u32]
+    L.bvc_hist_dense_packed.restype = C.c_int
+    L.bvc_hist_dense_packed.argtypes = [vp, i64, i64, i64, vp, vp, u32]
     _lib = L
     return L
 
@@ -288,6 +295,49 @@ class Context:
             counts_t = torch.empty((ns, NCLASS), dtype=torch.int32, device=bases_t.device)
         self._check(self._L.bvc_hist_dense(self._h, ns, n, bases_t.stride(0), _dev_ptr(bases_t), _dev_ptr(quals_t),
                                            _dev_ptr(counts_t), BVC_PTR_DEVICE))
+        return counts_t
+
+    # ---- packed tiles: one byte per sample (base << 6 | qual, qual <= 62; 0xFF = no observation) ----
+    def pack_dense_device(self, bases_t, quals_t, packed_t=None):
+        """Two-byte device tile -> packed device tile.  Returns (packed_t, n_unrepresentable)."""
+        import torch
+        ns, n = bases_t.shape
+        assert bases_t.stride(1) == 1 and quals_t.stride(1) == 1 and quals_t.stride(0) == bases_t.stride(0)
+        if packed_t is None:
+            stride = (n + 127) // 128 * 128
+            packed_t = torch.empty((ns, stride), dtype=torch.uint8, device=bases_t.device)[:, :n]
+        bad = C.c_int64(0)
+        self._check(self._L.bvc_pack_dense(self._h, ns, n, bases_t.stride(0), _dev_ptr(bases_t), _dev_ptr(quals_t),
+                                           packed_t.stride(0), _dev_ptr(packed_t), C.byref(bad), BVC_PTR_DEVICE))
+        return packed_t, int(bad.value)
+
+    def lrt_dense_packed_device(self, packed_t, ref_t, min_af, results_t=None):
+        import torch
+        ns, n = packed_t.shape
+        assert packed_t.stride(1) == 1
+        if results_t is None:
+            results_t = torch.empty(ns * SITE_DTYPE.itemsize, dtype=torch.uint8, device=packed_t.device)
+        self._check(self._L.bvc_lrt_dense_packed(self._h, ns, n, packed_t.stride(0), _dev_ptr(packed_t), _dev_ptr(ref_t),
+                                                 float(min_af), _dev_ptr(results_t), BVC_PTR_DEVICE))
+        return results_t
+
+    def lrt_dense_packed(self, packed, ref_base, min_af):
+        """Host (numpy) packed tile [n_sites, n_samples] uint8."""
+        p = np.ascontiguousarray(packed, dtype=np.uint8)
+        r = np.ascontiguousarray(ref_base, dtype=np.int8)
+        ns, n = p.shape
+        out = np.zeros(ns, dtype=SITE_DTYPE)
+        self._check(self._L.bvc_lrt_dense_packed(self._h, ns, n, n, _np_ptr(p), _np_ptr(r), float(min_af), _np_ptr(out),
+                                                 BVC_PTR_HOST))
+        return out
+
+    def hist_dense_packed_device(self, packed_t, counts_t=None):
+        import torch
+        ns, n = packed_t.shape
+        if counts_t is None:
+            counts_t = torch.empty((ns, NCLASS), dtype=torch.int32, device=packed_t.device)
+        self._check(self._L.bvc_hist_dense_packed(self._h, ns, n, packed_t.stride(0), _dev_ptr(packed_t),
+                                                  _dev_ptr(counts_t), BVC_PTR_DEVICE))
         return counts_t
 
     def synth_dense_device(self, seed, site0, bases_t, quals_t, ref_t, cov_thr16=65536):

@@ -52,6 +52,9 @@ def parse():
     p.add_argument("--cpu-sites", type=int, default=-1, help="sites for the CPU baseline (-1: one per core, 0: skip)")
     p.add_argument("--no-verify", action="store_true", help="CPU leg: time the baseline only, skip the wider check")
     p.add_argument("--no-legs", action="store_true", help="skip the configs[1] / configs[4] / CSR legs")
+    p.add_argument("--packed", action="store_true",
+                   help="headline region on packed tiles (one byte per sample, bvc_lrt_dense_packed): an additive layout, "
+                        "NOT the BASELINE metric's -- for profiling that kernel")
     p.add_argument("--csr-sites", type=int, default=0, help="sites per call of the ragged (CSR) leg (0 = --tile-sites)")
     p.add_argument("--verify-all", action="store_true",
                    help="after the run, check EVERY resident site against the oracle's histogram form (about a minute)")
@@ -63,7 +66,10 @@ def parse():
     p.add_argument("--profile-every", type=int, default=4,
                    help="time the kernels of every K-th call of the timed region with HIP events (four timing events per "
                         "call cost 10-20 us of stream time; 1 = every call)")
-    return p.parse_args()
+    a = p.parse_args()
+    if a.packed:                            # profiling mode: no CPU leg (the checks compare two-byte tiles), no groups
+        a.cpu_sites, a.no_verify, a.verify_all, a.groups = 0, True, False, 0
+    return a
 
 
 def log(msg):
@@ -144,7 +150,13 @@ def main():
         q = torch.empty((ts, stride), dtype=torch.int8, device=dev)
         r = torch.empty(ts, dtype=torch.int8, device=dev)
         ctx.synth_dense_device(a.seed, s0, b[:, :n], q[:, :n], r, cov_thr16=int(round(a.coverage * 65536)))
-        tiles.append((b[:, :n], q[:, :n], r))
+        if a.packed:                        # keep only the packed form of the tile
+            pt, bad = ctx.pack_dense_device(b[:, :n], q[:, :n])
+            assert bad == 0
+            tiles.append((pt, None, r))
+            del b, q
+        else:
+            tiles.append((b[:, :n], q[:, :n], r))
         s0 += ts
     results = [torch.empty(ts * SITE_DTYPE.itemsize, dtype=torch.uint8, device=dev) for ts in tile_sizes]
     torch.cuda.synchronize()
@@ -158,7 +170,9 @@ def main():
 
     def call(i):
         b, q, r = tiles[i]
-        if a.groups > 0:
+        if a.packed:
+            ctx.lrt_dense_packed_device(b, r, min_af, results[i])
+        elif a.groups > 0:
             ctx.lrt_dense_groups_device(b, q, r, min_af, group_t, a.groups, results[i], grp_results[i])
         else:
             ctx.lrt_dense_device(b, q, r, min_af, results[i])
@@ -179,7 +193,7 @@ def main():
         torch.cuda.synchronize()
 
     # empirical read ceiling: one 8 GB tile through a plain 16 B/lane streaming kernel
-    empirical_gbs = ctx.stream_read_gbs(tiles[0][0].as_strided((tile_sizes[0], stride), (stride, 1)))
+    empirical_gbs = ctx.stream_read_gbs(tiles[0][0].as_strided((tile_sizes[0], tiles[0][0].stride(0)), (tiles[0][0].stride(0), 1)))
     for _ in range(a.warmup):
         step()
     barrier()
@@ -212,9 +226,9 @@ def main():
     em_ms_per_site = prof["em_ms"] / max(1, prof["sites"])
     hist_ms = hist_ms_per_site * a.tile_sites
     em_ms = em_ms_per_site * a.tile_sites
-    alg_bytes = 2.0 * a.tile_sites * n                           # 2 B per (site, sample), read once
+    alg_bytes = (1.0 if a.packed else 2.0) * a.tile_sites * n   # 2 B per (site, sample), read once (packed: 1 B)
     achieved = alg_bytes / (hist_ms * 1e-3) / 1e9 if hist_ms > 0 else 0.0
-    kname = hist_kernel_name(a.groups, a.group_layout)
+    kname = "hist_packed_kernel" if a.packed else hist_kernel_name(a.groups, a.group_layout)
     traffic, traffic_source = pmc_traffic(a, n, kname)
 
     out = {
@@ -227,7 +241,8 @@ def main():
             "workload": f"synthetic pileup {a.total_sites} sites x {n} samples (BASELINE configs[2]"
                         f"{'; configs[3]: split by site over the ranks' if world > 1 and a.scaling == 'strong' else ''}), "
                         f"{'dense coverage' if a.coverage >= 1 else f'coverage {a.coverage:g}'}, Q10-40, 20% polymorphic"
-                        f"{f', {a.groups} population groups ({a.group_layout})' if a.groups else ''}; "
+                        f"{f', {a.groups} population groups ({a.group_layout})' if a.groups else ''}"
+                        f"{', PACKED tiles (1 byte per sample: additive layout, not the BASELINE metric)' if a.packed else ''}; "
                         f"step = one pass over the rank's resident sites in calls of {a.tile_sites}",
             "n_samples": n, "sites_per_step": sites_per_step_all, "sites_per_call": a.tile_sites,
             "calls_per_step_per_gpu": n_tiles, "resident_GB_per_gpu": round(2 * res_sites * stride / 1e9, 1),
@@ -251,7 +266,7 @@ def main():
         last = results_from_tensor(results[0])
         out["em_passes_per_site"] = float(last["n_passes"].mean())
         out["called_fraction"] = float(last["called"].mean())
-    if rank == 0 and world == 1 and not a.no_legs and a.groups == 0 and a.coverage >= 1:
+    if rank == 0 and world == 1 and not a.no_legs and a.groups == 0 and a.coverage >= 1 and not a.packed:
         out["legs"] = run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev)
     if rank == 0 and world == 1 and a.cpu_sites != 0:
         # CPU leg (the only place the oracle is used here): the reference path's CPU port timed on a bounded sample
@@ -333,6 +348,41 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
             "stage2_ms_per_call": prof["em_ms"] / max(1, prof["em_launches"]),
         }
         del res, gres
+
+    # ---- additive: packed tiles, one byte per (site, sample) (include/bvc.h, bvc_lrt_dense_packed) -- the same
+    # observations as the headline's tiles in half the bytes; records identical to the two-byte path
+    use = full[:4]
+    packed = []
+    for i in use:
+        b, q, r = tiles[i]
+        pt, bad = ctx.pack_dense_device(b, q)
+        assert bad == 0, "the synthetic qualities (10..40) fit the packed byte"
+        packed.append((pt, r))
+    res = [torch.empty(tile_sizes[i] * SITE_DTYPE.itemsize, dtype=torch.uint8, device=dev) for i in use]
+
+    def fn_packed(j):
+        i = j % len(use)
+        ctx.lrt_dense_packed_device(packed[i][0], packed[i][1], min_af, res[i])
+    n_calls = 12 * len(use)
+    dt, prof = timed_calls(ctx, fn_packed, n_calls)
+    two_byte = ctx.lrt_dense_device(tiles[use[0]][0], tiles[use[0]][1], tiles[use[0]][2], min_af)
+    ctx.join(); torch.cuda.synchronize()
+    same = bool(torch.equal(two_byte, res[0]))
+    hist_ms = prof["hist_ms"] / max(1, prof["hist_launches"])
+    alg = 1.0 * a.tile_sites * n                                 # ONE byte per (site, sample)
+    tr, src = pmc_traffic(a, n, "hist_packed_kernel")
+    legs["packed_1_byte_per_sample"] = {
+        "workload": f"the headline's tiles packed to one byte per sample (base << 6 | qual), N = {n}, "
+                    f"{n_calls} calls of {a.tile_sites} sites over {len(use)} tiles, overlap mode",
+        "value": n_calls * a.tile_sites / dt, "unit": "sites/s", "ms_per_call": dt / n_calls * 1e3,
+        "records_identical_to_two_byte_path": same,
+        "roofline": {"bound": "hbm", "kernel": "hist_packed_kernel", "achieved": alg / (hist_ms * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (hist_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "avg_launch_ms": hist_ms, "launches_timed": int(prof["hist_launches"]),
+                     "algorithmic_bytes_per_launch": alg, "bytes_per_sample": 1, "traffic": tr, "traffic_source": src},
+        "stage2_ms_per_call": prof["em_ms"] / max(1, prof["em_launches"]),
+    }
+    del packed, res, two_byte
 
     # ---- ragged (CSR) entry point at 10 % coverage: what a real low-coverage pileup looks like at N = 1e6
     cov = 0.1

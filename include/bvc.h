@@ -161,10 +161,31 @@ int bvc_lrt_csr_comb(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
                      double min_af, const int8_t *base_comb, const uint8_t *n_comb,
                      bvc_site_result *results, uint32_t flags);
 
+/*
+ * Additive: packed dense tiles, ONE byte per (site, sample) instead of two.  The path is bound by the bytes it reads,
+ * and (base 0..3, qual 0..62) fits a byte:
+ *     packed[s * row_stride + i] = base << 6 | qual        0xFF (any byte whose qual bits are 63) = no observation
+ * Results are those of bvc_lrt_dense on the same observations, bit for bit (the histogram is the same).  Base
+ * qualities of 63 and more cannot be packed: keep such tiles on bvc_lrt_dense.  A producer (the successor of bt_s,
+ * src/BaseVarC.cpp:403-441, which builds the vectors of :550-559) writes the bytes itself; bvc_pack_dense converts a
+ * two-byte tile on the device and reports in *n_unrepresentable how many covered samples did not fit (they are
+ * written as "no observation": a tile with n_unrepresentable != 0 must not be used).
+ */
+int bvc_lrt_dense_packed(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                         const uint8_t *packed, const int8_t *ref_base, double min_af,
+                         bvc_site_result *results, uint32_t flags);
+/* Device pointers only (BVC_PTR_DEVICE); synchronises the context's stream. */
+int bvc_pack_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                   const int8_t *bases, const int8_t *quals, int64_t packed_stride, uint8_t *packed,
+                   int64_t *n_unrepresentable, uint32_t flags);
+
 /* ---- the two stages on their own (used by the parity tests; also valid entry points) -------------- */
 /* Stage 1: counts[s * 512 + base * 128 + qual] = number of covered samples of that class (exact). */
 int bvc_hist_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                    const int8_t *bases, const int8_t *quals, uint32_t *counts, uint32_t flags);
+/* Stage 1 on a packed tile (device pointers only): the same counts[s * 512 + base * 128 + qual]. */
+int bvc_hist_dense_packed(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                          const uint8_t *packed, uint32_t *counts, uint32_t flags);
 /* Stage 2: EM + LRT on per-site class counts.  base_comb (optional): [n_sites][4] candidate bases in
  * SetBase order with n_comb[s] entries used; NULL means the default {A,C,G,T} (src/BaseType.h:79). */
 int bvc_lrt_hist(bvc_ctx *ctx, int64_t n_sites, const uint32_t *counts, const int8_t *ref_base,

@@ -1045,3 +1045,92 @@ def test_fuzz_random_histograms_against_the_oracle(ctx):
             ties += assert_path_difference_is_a_tie(got[i], exp[i], where=f"fuzz {i}")
         assert ties <= 0.02 * n, ties
         assert sum(e["called"] for e in exp) > n // 10
+
+
+def _pack_numpy(b, q):
+    """The packed byte of include/bvc.h: base << 6 | qual for covered samples with qual <= 62, else 0xFF."""
+    b = np.asarray(b).astype(np.uint8); q = np.asarray(q).astype(np.uint8)
+    ok = (b < 4) & (q < 63)
+    return np.where(ok, (b << 6) | q, 0xFF).astype(np.uint8)
+
+
+@pytest.mark.parametrize("ns,n,stride_pad,offset", [(5, 1, 0, 0), (7, 15, 1, 0), (9, 16, 0, 0), (6, 4097, 3, 1),
+                                                     (40, 70001, 15, 0), (3, 262144 + 48, 0, 0), (300, 33000, 128 - 33000 % 128, 0),
+                                                     (2, 2_100_000, 0, 16)])
+def test_packed_tiles_give_the_records_of_the_two_byte_tiles(ctx, ns, n, stride_pad, offset):
+    """bvc_lrt_dense_packed / bvc_hist_dense_packed / bvc_pack_dense (one byte per sample): the same histograms and the
+    same records, bit for bit, as the two-byte entry points -- aligned and unaligned rows, ragged tails, short rows,
+    rows split over several workgroups, uncovered samples, host and device pointers."""
+    import torch
+    from basevarc_amd.lib import results_from_tensor
+    rng = np.random.default_rng(ns * 1000 + n)
+    stride = n + stride_pad
+    flat_b = torch.full((ns * stride + offset + 64,), -1, dtype=torch.int8, device="cuda")
+    flat_q = torch.zeros((ns * stride + offset + 64,), dtype=torch.int8, device="cuda")
+    b = flat_b[offset:offset + ns * stride].view(ns, stride)[:, :n]
+    q = flat_q[offset:offset + ns * stride].view(ns, stride)[:, :n]
+    r = torch.empty(ns, dtype=torch.int8, device="cuda")
+    ctx.synth_dense_device(11, 77, b, q, r, cov_thr16=int(0.8 * 65536))
+    # qualities of the generator are 10..40; add some of 0..62 and sentinels of several kinds
+    hb, hq = b.cpu().numpy().copy(), q.cpu().numpy().copy()
+    m = rng.random(hb.shape) < 0.05
+    hq[m] = rng.integers(0, 63, size=int(m.sum()))
+    hb[rng.random(hb.shape) < 0.02] = 4
+    b.copy_(torch.from_numpy(hb)); q.copy_(torch.from_numpy(hq))
+    m_af = caller_min_af(max(n, 1000))
+    want = results_from_tensor(ctx.lrt_dense_device(b, q, r, m_af))
+    want_counts = ctx.hist_dense_device(b, q).cpu().numpy()
+    # (1) packed on the device by the library, into a tile with its own stride / alignment
+    pflat = torch.empty((ns * stride + offset + 64,), dtype=torch.uint8, device="cuda")
+    p = pflat[offset:offset + ns * stride].view(ns, stride)[:, :n]
+    p2, bad = ctx.pack_dense_device(b, q, p)
+    assert bad == 0
+    assert np.array_equal(p.cpu().numpy(), _pack_numpy(hb, hq))
+    assert np.array_equal(ctx.hist_dense_packed_device(p).cpu().numpy(), want_counts)
+    got = results_from_tensor(ctx.lrt_dense_packed_device(p, r, m_af))
+    assert got.tobytes() == want.tobytes()
+    # (2) host pointers (the producer packs on the host)
+    got_h = ctx.lrt_dense_packed(_pack_numpy(hb, hq), r.cpu().numpy(), m_af)
+    assert got_h.tobytes() == want.tobytes()
+
+
+def test_packing_reports_qualities_that_do_not_fit(ctx):
+    import torch
+    b = torch.zeros((3, 1000), dtype=torch.int8, device="cuda")
+    q = torch.full((3, 1000), 30, dtype=torch.int8, device="cuda")
+    q[1, 10] = 63; q[2, 999] = 93; q[0, 0] = 62
+    b[0, 5] = -1; q[0, 5] = 100                                    # uncovered: its quality does not matter
+    p, bad = ctx.pack_dense_device(b, q)
+    assert bad == 2
+    hp = p.cpu().numpy()
+    assert hp[1, 10] == 0xFF and hp[2, 999] == 0xFF and hp[0, 0] == 62 and hp[0, 5] == 0xFF and hp[1, 0] == 30
+    # every byte whose quality bits are 63 is "no observation"
+    pp = torch.tensor([[0x3F, 0x7F, 0xBF, 0xFF, 0x40 | 20, 0x80 | 62]], dtype=torch.uint8, device="cuda")
+    c = ctx.hist_dense_packed_device(pp).cpu().numpy().view(np.uint32)[0]
+    assert c.sum() == 2 and c[1 * 128 + 20] == 1 and c[2 * 128 + 62] == 1
+
+
+def test_packed_full_size_and_overlap(ctx):
+    """N = 1e6 (rows split over workgroups when sites are few; long-row overlap mode): packed records == two-byte records."""
+    import torch
+    from basevarc_amd.lib import results_from_tensor
+    n = 1_000_000
+    m = caller_min_af(n)
+    for ns in (3, 600):
+        stride = (n + 127) // 128 * 128
+        b = torch.empty((ns, stride), dtype=torch.int8, device="cuda")[:, :n]
+        q = torch.empty((ns, stride), dtype=torch.int8, device="cuda")[:, :n]
+        r = torch.empty(ns, dtype=torch.int8, device="cuda")
+        ctx.synth_dense_device(5, 4242, b, q, r)
+        want = results_from_tensor(ctx.lrt_dense_device(b, q, r, m))
+        p, bad = ctx.pack_dense_device(b, q)
+        assert bad == 0
+        assert results_from_tensor(ctx.lrt_dense_packed_device(p, r, m)).tobytes() == want.tobytes()
+        ctx.set_overlap(True)
+        try:
+            outs = [ctx.lrt_dense_packed_device(p, r, m) for _ in range(4)]
+            ctx.join(); ctx.synchronize()
+        finally:
+            ctx.set_overlap(False)
+        for o in outs:
+            assert results_from_tensor(o).tobytes() == want.tobytes()

@@ -1,26 +1,17 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p /tmp/hb && cd /tmp/hb
-python - <<'PY'
-import ctypes as C, os, time, sys, glob
-sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
-from basevarc_amd import build as b
-exe, hostlib = b.build_host()
-H=C.CDLL(hostlib)
-H.bvchost_write_synth_batches.restype=C.c_int64
-H.bvchost_write_synth_batches.argtypes=[C.c_char_p,C.c_int32,C.c_int32,C.c_int32,C.c_int32,C.c_int32,C.c_uint64,C.c_int32]
-n,npos,thread,batch=100000,200,4,500
-out='/tmp/hb/o'
-for t in range(thread): os.makedirs(f"{out}.tmp.thread.{t}",exist_ok=True)
-t0=time.time(); print(H.bvchost_write_synth_batches(out.encode(),n,npos,thread,batch,100,11,2), time.time()-t0)
-fs=glob.glob(out+".tmp.thread.*/*")
-t0=time.time()
-for f in fs:
-    with open(f,'rb') as fh: fh.read(16)
-print(len(fs),'opens', time.time()-t0)
-import subprocess
-print(subprocess.run("df /tmp | tail -1; mount | grep -E ' /tmp| / ' | head -3; nproc", shell=True, capture_output=True, text=True).stdout)
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "pack" 2>&1 | tail -3 || exit 1
+show() {
+python - "$1" <<PY
+import json,sys
+d=json.loads(open('gpurun_out/_t.json').read().strip().splitlines()[-1])
+v=d['legs']['packed_1_byte_per_sample']
+print(sys.argv[1], 'packed', round(v['value']), 'ms/call', round(v['ms_per_call'],3), 'hist', round(v['roofline']['avg_launch_ms'],3), 'frac', round(v['roofline']['frac'],3), 'em', round(v['stage2_ms_per_call'],3), 'same', v['records_identical_to_two_byte_path'], '| headline', round(d['value']))
 PY
-cd $GRAFT_REPO_ROOT
-g++ -O2 -pthread -o /tmp/t_open tools/_t_open.cpp -ldl
-LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/basevarc_amd:/opt/rocm/lib /tmp/t_open 0
-LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/basevarc_amd:/opt/rocm/lib /tmp/t_open 1
+}
+for cfg in "0 0" "8 1" "12 1" "6 2" "8 2" "12 2" "8 3"; do
+  set -- $cfg
+  BVC_EM_WAVES_PER_CU=$1 BVC_EM_STREAMS=$2 python bench.py --steps 3 --warmup 1 --cpu-sites 0 --no-verify --total-sites 40000 > gpurun_out/_t.json 2>gpurun_out/_t.err || tail -5 gpurun_out/_t.err
+  show "waves $1 streams $2"
+done
+python bench.py --steps 3 --warmup 1 --cpu-sites 0 --no-verify --total-sites 40000 --no-overlap > gpurun_out/_t.json 2>gpurun_out/_t.err
+show "serial"

@@ -23,7 +23,7 @@ def short(name):
     m = re.search(r"(lrt_groups_kernel|lrt_kernel)<(\d+)", name)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
-    for k in ("hist_dense_slots_kernel", "group_slots_kernel", "hist_dense_groups_bytes_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel", "hist_wave_kernel",
+    for k in ("hist_dense_slots_kernel", "group_slots_kernel", "hist_dense_groups_bytes_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel", "hist_wave_kernel", "hist_packed_kernel", "pack_dense_kernel",
               "hist_dense_kernel", "hist_csr_block_kernel", "group_bounds_kernel", "var_qual_kernel",
               "synth_dense_kernel", "sum_groups_kernel", "stream_read_kernel"):
         if k in name:
@@ -96,8 +96,9 @@ def main():
     doc.update({"hist_kernel_sha16": sha, "commit": commit, "summary": f"profiles/{tag}_pmc_summary.md",
                 "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of 16 B/lane streams), WRITE_SIZE KiB x 1024"})
     doc.setdefault("kernels", {})
-    alg = 2.0 * n_samples * sites
-    for kname in ("hist_dense_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel"):
+    for kname in ("hist_dense_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel", "hist_packed_kernel"):
+        bps = 1 if kname == "hist_packed_kernel" else 2          # bytes per (site, sample) of the kernel's input layout
+        alg = float(bps) * n_samples * sites
         h = summary.get(kname, {})
         if "FETCH_SIZE" not in h or h["FETCH_SIZE"] < 1000:        # the kernel that returned at once has no traffic
             continue
@@ -112,7 +113,7 @@ def main():
         lines += [f"## HBM traffic of {kname} per launch", "",
                   f"- FETCH_SIZE raw {h['FETCH_SIZE']:.1f} KiB -> read bytes (x1024 x2) = {fetch:.4g}",
                   f"- WRITE_SIZE raw {h.get('WRITE_SIZE', 0):.1f} KiB -> write bytes = {write:.4g}",
-                  f"- algorithmic bytes (2 B x {sites} sites x {n_samples} samples) = {alg:.4g}",
+                  f"- algorithmic bytes ({bps} B x {sites} sites x {n_samples} samples) = {alg:.4g}",
                   f"- traffic / algorithmic = {(fetch + write) / alg:.4f}", ""]
     json.dump(doc, open(path, "w"), indent=1)
     open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.md"), "w").write("\n".join(lines))

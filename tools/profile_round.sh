@@ -3,7 +3,7 @@
 # stats of both, and PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_*) in serial mode for the three histogram kernels of the
 # dense entry points: plain, any-order groups, groups ordered by column.  usage: bash tools/profile_round.sh r02
 # Output under gpurun_out/<tag>/; `python tools/pmc_summary.py <tag> gpurun_out/<tag>/dense,gpurun_out/<tag>/groups_interleaved,gpurun_out/<tag>/groups_ordered`
-# turns the passes into profiles/<tag>_pmc_summary.md and profiles/pmc_traffic.json.
+# (+ gpurun_out/<tag>/packed) turns the passes into profiles/<tag>_pmc_summary.md and profiles/pmc_traffic.json.
 set -e
 TAG=${1:-rXX}
 R=$GRAFT_REPO_ROOT
@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_overlap -- pyth
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_serial -- python3 $R/bench.py --steps 4 --warmup 1 $Q --no-overlap > $O/trace_serial.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_legs -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-sites 0 --no-verify > $O/trace_legs.log 2>&1
 P="--steps 2 --warmup 1 --total-sites 16000 $Q --no-overlap"
-for cfg in "dense:" "groups_interleaved:--groups 5" "groups_ordered:--groups 5 --group-layout ordered"; do
+for cfg in "dense:" "groups_interleaved:--groups 5" "groups_ordered:--groups 5 --group-layout ordered" "packed:--packed"; do
   name=${cfg%%:*}; flags=${cfg#*:}
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$name/pmc_$c -- python3 $R/bench.py $P $flags > $O/${name}_pmc_$c.log 2>&1
