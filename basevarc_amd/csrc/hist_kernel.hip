@@ -743,7 +743,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_packed_kernel(
     const uint32_t lane_base = lds_address(hist) + ((uint32_t)(tid & (kPackedCopies - 1)) << 2);
     // the one-instruction address needs bits 8..15 of the array's address to be zero (they are: see above)
     const bool at_zero = (lds_address(hist) & 0xFFFFu) == 0u;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);                // as in hist_dense_kernel; priorities 0 and 1 measure 12 % and 1 % slower under the EM (profiles/r02_packed_sweep.txt)
     for (int i = tid * 4; i < kPackedLdsWords; i += kHistThreads * 4)
         *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
