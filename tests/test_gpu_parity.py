@@ -1134,3 +1134,64 @@ def test_packed_full_size_and_overlap(ctx):
             ctx.set_overlap(False)
         for o in outs:
             assert results_from_tensor(o).tobytes() == want.tobytes()
+
+
+def test_overlap_ring_shared_by_every_entry_point(ctx):
+    """One context in overlap mode, calls of all four device-pointer entry points (dense, packed, ragged, groups) and of
+    growing and shrinking sizes interleaved: they share the ring of histogram buffers and the side streams, scratch is
+    re-allocated while earlier calls are still in flight, and every call must return the bytes it returns on its own."""
+    import torch
+    from basevarc_amd import Context
+    from basevarc_amd.lib import GROUP_DTYPE, SITE_DTYPE
+    n, k = 210_000, 3
+    m = caller_min_af(n)
+    g = torch.from_numpy((np.arange(n) % k).astype(np.uint8)).cuda()
+    sizes = [64, 300, 32, 520, 128, 700, 16, 256]
+    work = []
+    for t, ns in enumerate(sizes):
+        b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+        q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+        r = torch.empty(ns, dtype=torch.int8, device="cuda")
+        ctx.synth_dense_device(13, 9000 * t, b, q, r)
+        kind = ("dense", "packed", "csr", "groups")[t % 4]
+        extra = None
+        if kind == "packed":
+            extra, bad = ctx.pack_dense_device(b, q)
+            assert bad == 0
+        if kind == "csr":
+            extra = (torch.arange(ns + 1, dtype=torch.int64) * n).cuda()
+        work.append((kind, b, q, r, extra))
+    ctx.synchronize()
+
+    def run(c, item, out, gout):
+        kind, b, q, r, extra = item
+        if kind == "dense":
+            c.lrt_dense_device(b, q, r, m, out)
+        elif kind == "packed":
+            c.lrt_dense_packed_device(extra, r, m, out)
+        elif kind == "csr":
+            c.lrt_csr_device(extra, b.reshape(-1), q.reshape(-1), r, m, out)
+        else:
+            c.lrt_dense_groups_device(b, q, r, m, g, k, out, gout)
+
+    def buffers():
+        outs = [torch.zeros(it[1].shape[0] * SITE_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for it in work]
+        gouts = [torch.zeros(it[1].shape[0] * k * GROUP_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for it in work]
+        return outs, gouts
+
+    plain, gplain = buffers()
+    for it, o, go in zip(work, plain, gplain):
+        run(ctx, it, o, go)
+        ctx.synchronize()
+    with Context(0) as fresh:                      # fresh context: every scratch buffer starts empty
+        fresh.set_overlap(True)
+        for rep in range(2):
+            outs, gouts = buffers()
+            for it, o, go in zip(work, outs, gouts):
+                run(fresh, it, o, go)
+            fresh.join()
+            fresh.synchronize()
+            for i, (it, o, go) in enumerate(zip(work, outs, gouts)):
+                assert torch.equal(o, plain[i]), (rep, i, it[0])
+                if it[0] == "groups":
+                    assert torch.equal(go, gplain[i]), (rep, i)
