@@ -1195,3 +1195,26 @@ def test_overlap_ring_shared_by_every_entry_point(ctx):
                 assert torch.equal(o, plain[i]), (rep, i, it[0])
                 if it[0] == "groups":
                     assert torch.equal(go, gplain[i]), (rep, i)
+
+
+@pytest.mark.parametrize("k", [1, 7, 31, 32])
+def test_group_counts_up_to_the_maximum(ctx, k):
+    """1 .. BVC_MAX_GROUPS = 32 population groups (33 histograms of one LDS copy each at the top: 66 KiB), labels in any
+    order and ordered, rows of 3008 samples (16-byte aligned: the fast kernels) and of 3000 (the byte kernels): the
+    records of the oracle's group loop."""
+    rng = np.random.default_rng(100 + k)
+    ns, m = 6, 0.001
+    for n in (3008, 3000):
+        sites = [random_site(rng, n, af=0.2) for _ in range(ns)]
+        B, Q, R = pad_rows(sites)
+        for layout in ("any", "ordered"):
+            g = rng.integers(0, k + 1, size=n).astype(np.uint8)   # k = "no group" for some samples
+            if layout == "ordered":
+                g = np.sort(g)
+            g[g == k] = 255
+            res, gres = ctx.lrt_dense_groups(B, Q, R, m, g, k)
+            for s in range(ns):
+                o, gd, ga, ran, pres = orc.dense_site_groups(B[s], Q[s], int(R[s]), m, g, k, use_hist=True)
+                assert_site_matches(res[s], o, where=f"k={k} {layout} n={n} site {s}", path_strict=False)
+                assert np.array_equal(gres[s]["depth"], gd) and np.array_equal(gres[s]["ran"], ran), (k, layout, n, s)
+                np.testing.assert_allclose(gres[s]["af"], ga, rtol=0, atol=AF_ATOL)
