@@ -10,6 +10,18 @@ SOURCES = ["bvc_api.hip", "hist_kernel.hip", "em_kernel.hip", "synth_kernel.hip"
 DEPS = ["bvc_device.h", "bvc_internal.h", "synth_tables.inc", os.path.join("..", "..", "include", "bvc.h")]
 
 
+def code_sha16(path=None):
+    """sha256 (16 hex digits) of a kernel source with its // comments and blank space removed: the stamp that ties a
+    committed counter pass (profiles/pmc_traffic.json) to the code it was taken on, indifferent to comment edits."""
+    import hashlib
+    import re
+    path = path or os.path.join(CSRC, "hist_kernel.hip")
+    text = open(path, encoding="utf-8").read()
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"\s+", " ", text)
+    return hashlib.sha256(text.encode()).hexdigest()[:16]
+
+
 def _hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 

@@ -263,8 +263,8 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_kernel(
 // What bounds it (rocprofv3 counters, profiles/r02_pmc_groups.md): NOT a third load stream -- the group bytes are
 // served by L2 and HBM traffic is 1.007 x the algorithmic bytes -- but issue: per sample one LDS atomic with ~3-way
 // bank conflicts plus the VALU instructions that build its address, and under the EM kernels of the previous call
-// the VALU is the shared resource.  Hence the fast kernel below spends five VALU instructions per sample (the
-// compiler's selection for the same expression needs more than eight).
+// the VALU is the shared resource.  Hence the fast kernel below spends 3.25 VALU instructions per sample (the
+// compiler's selection for the plain expression needs more than eight).
 
 // Generic form: any alignment, group vector as the caller gave it (labels >= n_groups mean "no group").
 __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_bytes_kernel(
@@ -305,8 +305,6 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_bytes_kernel(
 
 // Four covered samples of one lane in group mode: counter byte address =
 //   hist << (11 + L) | base << (9 + L) | qual << (2 + L) | copy << 2      (L = log2 of the copies)
-// glane = (group byte << (11 + L)) + lane_base is shared by ... one sample only, but costs two instructions; the
-// base and qual terms one SDWA shift each, and one three-operand add joins them: five VALU instructions per sample.
 template <int LOG2C>
 __device__ __forceinline__ void count_group_word(uint32_t lane_base, uint32_t bw, uint32_t qw, uint32_t gw)
 {

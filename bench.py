@@ -510,7 +510,8 @@ def pmc_traffic(a, n, kernel):
     except Exception:
         return None, "no profiles/pmc_traffic.json"
     src = os.path.join(ROOT, "basevarc_amd", "csrc", "hist_kernel.hip")
-    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    from basevarc_amd.build import code_sha16
+    sha = code_sha16(src)                                        # comments and blank space do not count
     e = d.get("kernels", {}).get(kernel)
     if not e:
         return None, f"no PMC pass for {kernel} in profiles/pmc_traffic.json"

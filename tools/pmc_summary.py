@@ -81,7 +81,9 @@ def main():
     # kernel and stamped with the sha256 of hist_kernel.hip (bench.py drops the figure when the source has changed)
     import hashlib
     import subprocess
-    sha = hashlib.sha256(open(os.path.join(ROOT, "basevarc_amd", "csrc", "hist_kernel.hip"), "rb").read()).hexdigest()[:16]
+    sys.path.insert(0, ROOT)
+    from basevarc_amd.build import code_sha16
+    sha = code_sha16(os.path.join(ROOT, "basevarc_amd", "csrc", "hist_kernel.hip"))
     try:
         commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
     except Exception:
