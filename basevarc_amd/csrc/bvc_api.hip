@@ -739,11 +739,14 @@ int bvc_lrt_csr(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
     return bvc_lrt_csr_comb(ctx, n_sites, offsets, bases, quals, ref_base, min_af, nullptr, nullptr, results, flags);
 }
 
-int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
-                         const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
-                         double min_af, const uint8_t *group_of_sample, int32_t n_groups,
-                         bvc_site_result *results, bvc_group_result *grp_results, uint32_t flags)
+// bvc_lrt_dense_groups and bvc_lrt_dense_groups_packed: `packed` = the tile is one byte per sample in `bases`
+// (base << 6 | qual, include/bvc.h) and `quals` is not used.
+static int lrt_groups_impl(bvc_ctx *ctx, bool packed, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                           const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
+                           double min_af, const uint8_t *group_of_sample, int32_t n_groups,
+                           bvc_site_result *results, bvc_group_result *grp_results, uint32_t flags)
 {
+    if (packed) quals = bases;
     // rows of zero samples carry no data: their pointers may be null
     int rc = check_common(ctx, n_sites, n_samples ? bases : ref_base, n_samples ? quals : ref_base, ref_base, results);
     if (rc != BVC_OK) return rc;
@@ -786,7 +789,11 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
         if (e__ != hipSuccess) return bail(fail(ctx, BVC_ERR_DEVICE, #call, e__));          \
     } while (0)
         if (timed) BVC_HIP_T(hipEventRecord(t.a, ctx->stream));
-        BVC_HIP_T(launch_hist_dense(ctx->ls, ctx->stream, ns, n_samples, row_stride, b, q, g, n_groups, *gp, 1, ctx->d_grp_scratch, ctx->d_grp_labels));
+        if (packed)
+            BVC_HIP_T(launch_hist_packed_groups(ctx->ls, ctx->stream, ns, n_samples, row_stride, reinterpret_cast<const uint8_t *>(b),
+                                                g, n_groups, *gp, ctx->d_grp_scratch, ctx->d_grp_labels));
+        else
+            BVC_HIP_T(launch_hist_dense(ctx->ls, ctx->stream, ns, n_samples, row_stride, b, q, g, n_groups, *gp, 1, ctx->d_grp_scratch, ctx->d_grp_labels));
         if (timed) BVC_HIP_T(hipEventRecord(t.b, ctx->stream));
         hipStream_t s2 = ctx->stream;
         if (ctx->overlap) {
@@ -825,14 +832,14 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
     const size_t ref_al = ((size_t)chunk + 255) & ~(size_t)255;
     const size_t g_al = ((size_t)n_samples + 255) & ~(size_t)255;
     const size_t res_al = ((size_t)chunk * sizeof(bvc_site_result) + 255) & ~(size_t)255;
-    const size_t need = 2 * arr_al + ref_al + g_al + res_al + (size_t)chunk * n_groups * sizeof(bvc_group_result) + 256;
+    const size_t need = (packed ? 1 : 2) * arr_al + ref_al + g_al + res_al + (size_t)chunk * n_groups * sizeof(bvc_group_result) + 256;
     const int n_sets = n_sites > chunk ? 2 : 1;
     for (int k = 0; k < n_sets; ++k) {
         rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage[k]), &ctx->stage_cap[k], need);
         if (rc != BVC_OK) return rc;
     }
     auto d_b = [&](int set) { return reinterpret_cast<int8_t *>(ctx->d_stage[set]); };
-    auto d_q = [&](int set) { return d_b(set) + arr_al; };
+    auto d_q = [&](int set) { return packed ? d_b(set) : d_b(set) + arr_al; };
     auto d_r = [&](int set) { return d_q(set) + arr_al; };
     auto d_g = [&](int set) { return reinterpret_cast<uint8_t *>(d_r(set) + ref_al); };
     auto d_res = [&](int set) { return reinterpret_cast<bvc_site_result *>(d_g(set) + g_al); };
@@ -844,7 +851,7 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
             if (s0 < 2 * chunk && n_samples)
                 BVC_HIP(ctx, hipMemcpyAsync(d_g(set), group_of_sample, (size_t)n_samples, hipMemcpyHostToDevice, ctx->copy));
             if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_b(set), bases + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->copy));
-            if (bytes) BVC_HIP(ctx, hipMemcpyAsync(d_q(set), quals + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->copy));
+            if (bytes && !packed) BVC_HIP(ctx, hipMemcpyAsync(d_q(set), quals + s0 * row_stride, bytes, hipMemcpyHostToDevice, ctx->copy));
             BVC_HIP(ctx, hipMemcpyAsync(d_r(set), ref_base + s0, (size_t)ns, hipMemcpyHostToDevice, ctx->copy));
             return BVC_OK;
         },
@@ -859,6 +866,24 @@ int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64
                                         hipMemcpyDeviceToHost, ctx->stream));
             return BVC_OK;
         });
+}
+
+int bvc_lrt_dense_groups(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                         const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
+                         double min_af, const uint8_t *group_of_sample, int32_t n_groups,
+                         bvc_site_result *results, bvc_group_result *grp_results, uint32_t flags)
+{
+    return lrt_groups_impl(ctx, false, n_sites, n_samples, row_stride, bases, quals, ref_base, min_af, group_of_sample, n_groups,
+                           results, grp_results, flags);
+}
+
+int bvc_lrt_dense_groups_packed(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                                const uint8_t *packed, const int8_t *ref_base, double min_af,
+                                const uint8_t *group_of_sample, int32_t n_groups,
+                                bvc_site_result *results, bvc_group_result *grp_results, uint32_t flags)
+{
+    return lrt_groups_impl(ctx, true, n_sites, n_samples, row_stride, reinterpret_cast<const int8_t *>(packed), nullptr, ref_base,
+                           min_af, group_of_sample, n_groups, results, grp_results, flags);
 }
 
 int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value)

@@ -17,7 +17,7 @@ struct LaunchState {
     int64_t host_chunk_bytes = (int64_t)1 << 29;   // BVC_PTR_HOST calls: bytes per array and staging chunk
     int em_streams = 0;        // overlap mode: side streams stage 2 alternates between: 0 = by call shape, 1..3
     int group_pipe = 1;        // any-order group histogram: issue the next chunk's loads before counting the current one
-    uint32_t attr_done = 0;    // kernels whose dynamic-LDS attribute has been raised on this context's device
+    uint64_t attr_done = 0;    // kernels whose dynamic-LDS attribute has been raised on this context's device
 };
 
 // Base-quality -> likelihood table, built on the HOST with the same libm exp() the CPU path uses
@@ -44,6 +44,10 @@ int choose_hist_split(const LaunchState &st, int64_t n_sites, int64_t n_samples)
 // Stage 1 on packed rows (one byte per sample: base << 6 | qual, qual <= 62; 0xFF = no observation).
 hipError_t launch_hist_packed(LaunchState &st, hipStream_t stream, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                               const uint8_t *packed, uint32_t *counts, int split);
+// Group mode on packed rows: counts = [site][n_groups + 1][512]; scratch and labels as for launch_hist_dense.
+hipError_t launch_hist_packed_groups(LaunchState &st, hipStream_t stream, int64_t n_sites, int64_t n_samples,
+                                     int64_t row_stride, const uint8_t *packed, const uint8_t *group_of_sample, int n_groups,
+                                     uint32_t *counts, int64_t *group_scratch, uint8_t *hist_of_sample);
 hipError_t launch_pack_dense(hipStream_t stream, int64_t n_sites, int64_t n_samples, int64_t stride_in, const int8_t *bases,
                              const int8_t *quals, int64_t stride_out, uint8_t *packed, unsigned long long *bad);
 

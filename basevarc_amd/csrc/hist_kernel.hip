@@ -803,6 +803,184 @@ __global__ __launch_bounds__(kHistThreads) void hist_packed_kernel(
     }
 }
 
+// ---- packed rows in group mode ---------------------------------------------------------------------------------
+// Samples ordered by group: a (site, group) histogram is the packed histogram of a column range -- hist_packed_kernel's
+// counting (one VALU instruction per sample, 64 conflict-free copies) over hist_dense_ranges_kernel's work items (the
+// non-empty ranges only).  scratch as written by group_bounds_kernel.
+template <bool ALIGNED>
+__global__ __launch_bounds__(kHistThreads) void hist_packed_ranges_kernel(
+    int64_t n_sites, int64_t row_stride, const uint8_t *__restrict__ packed, int n_hist,
+    const int64_t *__restrict__ scratch, uint32_t *__restrict__ grp_counts)
+{
+    // [slot][copy] at LDS address 0 (the one-instruction counter address needs that: no static LDS in this kernel),
+    // followed by the table of non-empty ranges
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    if (scratch[0] != 0) return;                                  // labels in any order: hist_packed_groups_kernel has the call
+    uint8_t *real_h = reinterpret_cast<uint8_t *>(&hist[kPackedLdsWords]);
+    int &n_real_s = *reinterpret_cast<int *>(&hist[kPackedLdsWords + 16]);
+    const int tid = threadIdx.x;
+    const uint32_t lane_base = lds_address(hist) + ((uint32_t)(tid & (kPackedCopies - 1)) << 2);
+    const bool at_zero = (lds_address(hist) & 0xFFFFu) == 0u;     // the one-instruction address (hist_packed_kernel)
+    __builtin_amdgcn_s_setprio(3);
+    if (tid == 0) {
+        int c = 0;
+        for (int h = 0; h < n_hist; ++h)
+            if (scratch[1 + h] < scratch[2 + h]) real_h[c++] = (uint8_t)h;
+        n_real_s = c;
+    }
+    for (int i = tid * 4; i < kPackedLdsWords; i += kHistThreads * 4)
+        *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    const int n_real = n_real_s;
+    if (n_real < n_hist)                                          // the empty ranges' histograms: zeros
+        for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x)
+            for (int h = 0; h < n_hist; ++h)
+                if (scratch[1 + h] >= scratch[2 + h])
+                    for (int key = tid; key < BVC_NCLASS; key += kHistThreads)
+                        grp_counts[(site * n_hist + h) * BVC_NCLASS + key] = 0;
+    if (n_real == 0) return;
+
+    uint32_t a0 = lane_base, a1 = lane_base, a2 = lane_base, a3 = lane_base;
+    const int64_t n_work = n_sites * n_real;
+    for (int64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const int64_t site = w / n_real;
+        const int h = real_h[w % n_real];
+        const uint8_t *row = packed + site * row_stride;
+        const int64_t s0 = scratch[1 + h], s1 = scratch[2 + h];
+        auto scalar = [&](int64_t i0, int64_t i1) {
+            for (int64_t i = i0 + tid; i < i1; i += kHistThreads) lds_add_one(((uint32_t)row[i] << 8) + lane_base);
+        };
+        const int64_t c0 = (s0 + 15) >> 4, c1 = s1 >> 4;          // [s0, s1) = head, whole 16-sample chunks [c0, c1), tail
+        if (ALIGNED && at_zero && c0 < c1) {
+            scalar(s0, c0 << 4);
+            const u32x4 *rv = reinterpret_cast<const u32x4 *>(row);
+            constexpr int64_t kBlockChunks = (int64_t)kPackedUnroll * kHistThreads;
+            for (int64_t cb = c0; cb < c1; cb += kBlockChunks) {
+                u32x4 v[kPackedUnroll];
+#pragma unroll
+                for (int u = 0; u < kPackedUnroll; ++u) {
+                    const int64_t c = cb + tid + (int64_t)u * kHistThreads;
+                    v[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                    if (cb + kBlockChunks <= c1 || c < c1) v[u] = __builtin_nontemporal_load(&rv[c]);
+                }
+#pragma unroll
+                for (int u = 0; u < kPackedUnroll; ++u) {
+                    count_packed_word(a0, a1, a2, a3, v[u].x); count_packed_word(a0, a1, a2, a3, v[u].y);
+                    count_packed_word(a0, a1, a2, a3, v[u].z); count_packed_word(a0, a1, a2, a3, v[u].w);
+                }
+            }
+            scalar(c1 << 4, s1);
+        } else {
+            scalar(s0, s1);
+        }
+        __syncthreads();
+        const int64_t out = (site * n_hist + h) * BVC_NCLASS;
+        for (int key = tid; key < BVC_NCLASS; key += kHistThreads) {
+            const int q = key & 127;
+            uint32_t sum = 0;
+            if (q < 64) {
+                const int slot = ((key >> 7) << 6) | q;
+#pragma unroll
+                for (int c = 0; c < kPackedCopies; c += 4) {
+                    const int cc = (c + 4 * (slot & 7)) & (kPackedCopies - 1);
+                    u32x4 *p = reinterpret_cast<u32x4 *>(&hist[slot * kPackedCopies + cc]);
+                    const u32x4 x = *p;
+                    sum += x.x + x.y + x.z + x.w;
+                    *p = u32x4{0u, 0u, 0u, 0u};
+                }
+                if (q == 63) sum = 0;
+            }
+            grp_counts[out + key] = sum;
+        }
+        __syncthreads();
+    }
+}
+
+// src1 (16-bit half HALF of w) << shift in one instruction (SDWA word select).
+template <int HALF>
+__device__ __forceinline__ uint32_t shl_half(uint32_t w, uint32_t shift)
+{
+    uint32_t r;
+    if (HALF == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(shift), "v"(w));
+    if (HALF == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(shift), "v"(w));
+    return r;
+}
+
+// Labels in any order on packed rows: LDS [hist][256 slots][copies], copies = 1 << LOG2C as many as fit 64 KiB (8 at
+// k = 5, against 4 of the two-byte kernel: half the bank conflicts), counter byte address =
+// (label << 8 | packed byte) << (2 + LOG2C) | copy << 2.  The 16-bit (label, byte) pairs of two samples are put
+// together by one v_perm_b32, each sample then takes one SDWA shift and one add: 2.5 VALU instructions per sample, two
+// load streams instead of three, no "covered?" test (0xFF counts into slot 255 of its histogram and is dropped).
+template <int LOG2C, bool ALIGNED>
+__global__ __launch_bounds__(kHistThreads) void hist_packed_groups_kernel(
+    int64_t n_sites, int64_t n_samples, int64_t row_stride, const uint8_t *__restrict__ packed,
+    const uint8_t *__restrict__ hist_of_sample, int n_groups, uint32_t *__restrict__ grp_counts,
+    const int64_t *__restrict__ bounds)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    if (bounds[0] == 0) return;                                   // ordered by group: hist_packed_ranges_kernel has the call
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    const int n_hist = n_groups + 1;
+    const int words = (n_hist * kPackedSlots) << LOG2C;
+    const uint32_t lane_off = (uint32_t)tid & ((1u << LOG2C) - 1u);
+    const uint32_t lane_base = lds_address(hist) + (lane_off << 2);
+    for (int i = tid * 4; i < words; i += kHistThreads * 4)
+        *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    constexpr uint32_t SH = 2 + LOG2C;
+    auto count_word = [&](uint32_t pw, uint32_t gw) {
+        const uint32_t lo = __builtin_amdgcn_perm(gw, pw, 0x05010400u);   // [g1 p1 g0 p0]
+        const uint32_t hi = __builtin_amdgcn_perm(gw, pw, 0x07030602u);   // [g3 p3 g2 p2]
+        lds_add_one(shl_half<0>(lo, SH) + lane_base);
+        lds_add_one(shl_half<1>(lo, SH) + lane_base);
+        lds_add_one(shl_half<0>(hi, SH) + lane_base);
+        lds_add_one(shl_half<1>(hi, SH) + lane_base);
+    };
+    const int64_t n16 = ALIGNED ? n_samples >> 4 : 0;
+    const u32x4 *gv = reinterpret_cast<const u32x4 *>(hist_of_sample);
+    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
+        const uint8_t *row = packed + site * row_stride;
+        if (ALIGNED) {
+            const u32x4 *rv = reinterpret_cast<const u32x4 *>(row);
+            constexpr int64_t kBlockChunks = 2 * (int64_t)kHistThreads;
+            for (int64_t cb = 0; cb < n16; cb += kBlockChunks) {
+                u32x4 p[2], g[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int64_t c = cb + tid + (int64_t)u * kHistThreads;
+                    p[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // past the end: slot 255 ...
+                    g[u] = u32x4{0u, 0u, 0u, 0u};                                       // ... of histogram 0
+                    if (c < n16) { p[u] = __builtin_nontemporal_load(&rv[c]); g[u] = gv[c]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    count_word(p[u].x, g[u].x); count_word(p[u].y, g[u].y);
+                    count_word(p[u].z, g[u].z); count_word(p[u].w, g[u].w);
+                }
+            }
+        }
+        for (int64_t i = (n16 << 4) + tid; i < n_samples; i += kHistThreads)
+            lds_add_one(((((uint32_t)hist_of_sample[i] << 8) | row[i]) << SH) + lane_base);
+        __syncthreads();
+        for (int key = tid; key < n_hist * BVC_NCLASS; key += kHistThreads) {
+            const int h = key >> 9, cls = key & 511, q = cls & 127;
+            uint32_t sum = 0;
+            if (q < 64) {
+                const int slot = (h << 8) | ((cls >> 7) << 6) | q;
+#pragma unroll
+                for (int v = 0; v < (1 << LOG2C); ++v) {
+                    sum += hist[(slot << LOG2C) + v];
+                    hist[(slot << LOG2C) + v] = 0;
+                }
+                if (q == 63) sum = 0;
+            }
+            grp_counts[site * n_hist * BVC_NCLASS + key] = sum;
+        }
+        __syncthreads();
+    }
+}
+
 // (bases, quals) -> packed bytes.  bad += covered samples whose quality does not fit (63..127): written as "no
 // observation", so a caller that finds bad != 0 must not use the packed tile.
 __global__ void pack_dense_kernel(int64_t n_sites, int64_t n_samples, int64_t stride_in, const int8_t *__restrict__ bases,
@@ -868,14 +1046,15 @@ enum KernelSlot : uint32_t {
     kSlotDense0 = 0, kSlotDense1, kSlotRanges0, kSlotRanges1, kSlotCsr0, kSlotCsr1, kSlotGroupByte,
     kSlotGroup = 8,            // + log2c (0..5)
     kSlotGroupPipe = 16,       // + log2c (0..5)
-    kSlotPacked0 = 24, kSlotPacked1 = 25,
+    kSlotPacked0 = 24, kSlotPacked1 = 25, kSlotPackedRanges0 = 26, kSlotPackedRanges1 = 27,
+    kSlotPackedGroups = 32,    // + 6 * aligned + log2c (0..5)
 };
 
 static hipError_t raise_lds(LaunchState &st, uint32_t slot, const void *kernel, size_t bytes)
 {
-    if (st.attr_done & (1u << slot)) return hipSuccess;
+    if (st.attr_done & ((uint64_t)1 << slot)) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess) st.attr_done |= 1u << slot;
+    if (e == hipSuccess) st.attr_done |= (uint64_t)1 << slot;
     return e;
 }
 
@@ -965,6 +1144,46 @@ hipError_t launch_hist_packed(LaunchState &st, hipStream_t stream, int64_t n_sit
     const int64_t n_work = n_sites * split;
     hipLaunchKernelGGL(kern, dim3((unsigned)(n_work < 4096 ? n_work : 4096)), dim3(kHistThreads), lds, stream, n_sites,
                        n_samples, row_stride, packed, counts, split);
+    return hipGetLastError();
+}
+
+hipError_t launch_hist_packed_groups(LaunchState &st, hipStream_t stream, int64_t n_sites, int64_t n_samples,
+                                     int64_t row_stride, const uint8_t *packed, const uint8_t *group_of_sample, int n_groups,
+                                     uint32_t *counts, int64_t *group_scratch, uint8_t *hist_of_sample)
+{
+    if (n_sites <= 0) return hipSuccess;
+    const int n_hist = n_groups + 1;
+    if (n_samples <= 0)
+        return hipMemsetAsync(counts, 0, (size_t)n_sites * n_hist * BVC_NCLASS * sizeof(uint32_t), stream);
+    if (!group_scratch || !hist_of_sample) return hipErrorInvalidValue;
+    const bool aligned = (reinterpret_cast<uintptr_t>(packed) & 15u) == 0 && (row_stride & 15) == 0;
+    // as launch_hist_dense in group mode: the bounds kernel decides on the device which of the two kernels has the call
+    hipError_t e = hipMemsetAsync(group_scratch, 0, (size_t)kGroupScratchWords * sizeof(int64_t), stream);
+    if (e != hipSuccess) return e;
+    const int64_t bgrid = (n_samples + 255) / 256;
+    hipLaunchKernelGGL(group_bounds_kernel, dim3((unsigned)(bgrid < 1024 ? bgrid : 1024)), dim3(256), 0, stream,
+                       group_of_sample, n_samples, n_groups, group_scratch, hist_of_sample);
+    auto rk = aligned ? hist_packed_ranges_kernel<true> : hist_packed_ranges_kernel<false>;
+    const size_t lds = (size_t)kPackedLdsWords * sizeof(uint32_t);
+    e = raise_lds(st, aligned ? kSlotPackedRanges1 : kSlotPackedRanges0, reinterpret_cast<const void *>(rk), lds + 256);
+    if (e != hipSuccess) return e;
+    const int64_t n_work = n_sites * n_hist;
+    hipLaunchKernelGGL(rk, dim3((unsigned)(n_work < 4096 ? n_work : 4096)), dim3(kHistThreads), lds + 256, stream, n_sites,
+                       row_stride, packed, n_hist, group_scratch, counts);
+    int log2c = 0;
+    while (log2c < 5 && (size_t)n_hist * kPackedSlots * (2u << log2c) <= (size_t)kLdsWords) ++log2c;
+    const size_t glds = ((size_t)n_hist * kPackedSlots << log2c) * sizeof(uint32_t);
+    using GK = void (*)(int64_t, int64_t, int64_t, const uint8_t *, const uint8_t *, int, uint32_t *, const int64_t *);
+    static const GK gk[2][6] = {
+        {hist_packed_groups_kernel<0, false>, hist_packed_groups_kernel<1, false>, hist_packed_groups_kernel<2, false>,
+         hist_packed_groups_kernel<3, false>, hist_packed_groups_kernel<4, false>, hist_packed_groups_kernel<5, false>},
+        {hist_packed_groups_kernel<0, true>, hist_packed_groups_kernel<1, true>, hist_packed_groups_kernel<2, true>,
+         hist_packed_groups_kernel<3, true>, hist_packed_groups_kernel<4, true>, hist_packed_groups_kernel<5, true>}};
+    const GK k = gk[aligned ? 1 : 0][log2c];
+    e = raise_lds(st, kSlotPackedGroups + (aligned ? 6 : 0) + log2c, reinterpret_cast<const void *>(k), (size_t)kLdsWords * sizeof(uint32_t));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3((unsigned)(n_sites < 4096 ? n_sites : 4096)), dim3(kHistThreads), glds, stream, n_sites,
+                       n_samples, row_stride, packed, hist_of_sample, n_groups, counts, group_scratch);
     return hipGetLastError();
 }
 

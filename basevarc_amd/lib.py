@@ -50,7 +50,7 @@ EXPORTS = [
     "bvc_version", "bvc_device_count", "bvc_create", "bvc_destroy", "bvc_last_error", "bvc_set_stream",
     "bvc_synchronize", "bvc_set_overlap", "bvc_join", "bvc_set_profiling", "bvc_get_profile", "bvc_lrt_dense", "bvc_lrt_dense_groups",
     "bvc_lrt_csr", "bvc_lrt_csr_comb", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense", "bvc_stream_read_ms", "bvc_set_tuning",
-    "bvc_lrt_dense_packed", "bvc_pack_dense", "bvc_hist_dense_packed",
+    "bvc_lrt_dense_packed", "bvc_pack_dense", "bvc_hist_dense_packed", "bvc_lrt_dense_groups_packed",
 ]
 
 _lib = None
@@ -106,6 +106,8 @@ def load_library():
     L.bvc_lrt_dense_packed.argtypes = [vp, i64, i64, i64, vp, vp, dbl, vp, u32]
     L.bvc_pack_dense.restype = C.c_int
     L.bvc_pack_dense.argtypes = [vp, i64, i64, i64, vp, vp, i64, vp, C.POINTER(i64), u32]
+    L.bvc_lrt_dense_groups_packed.restype = C.c_int
+    L.bvc_lrt_dense_groups_packed.argtypes = [vp, i64, i64, i64, vp, vp, dbl, vp, i32, vp, vp, u32]
     L.bvc_hist_dense_packed.restype = C.c_int
     L.bvc_hist_dense_packed.argtypes = [vp, i64, i64, i64, vp, vp, u32]
     _lib = L
@@ -320,6 +322,30 @@ class Context:
         self._check(self._L.bvc_lrt_dense_packed(self._h, ns, n, packed_t.stride(0), _dev_ptr(packed_t), _dev_ptr(ref_t),
                                                  float(min_af), _dev_ptr(results_t), BVC_PTR_DEVICE))
         return results_t
+
+    def lrt_dense_groups_packed_device(self, packed_t, ref_t, min_af, group_t, n_groups, results_t=None, grp_results_t=None):
+        import torch
+        ns, n = packed_t.shape
+        assert packed_t.stride(1) == 1
+        if results_t is None:
+            results_t = torch.empty(ns * SITE_DTYPE.itemsize, dtype=torch.uint8, device=packed_t.device)
+        if grp_results_t is None:
+            grp_results_t = torch.empty(ns * n_groups * GROUP_DTYPE.itemsize, dtype=torch.uint8, device=packed_t.device)
+        self._check(self._L.bvc_lrt_dense_groups_packed(self._h, ns, n, packed_t.stride(0), _dev_ptr(packed_t), _dev_ptr(ref_t),
+                                                        float(min_af), _dev_ptr(group_t), int(n_groups),
+                                                        _dev_ptr(results_t), _dev_ptr(grp_results_t), BVC_PTR_DEVICE))
+        return results_t, grp_results_t
+
+    def lrt_dense_groups_packed(self, packed, ref_base, min_af, group_of_sample, n_groups):
+        p = np.ascontiguousarray(packed, dtype=np.uint8)
+        r = np.ascontiguousarray(ref_base, dtype=np.int8)
+        g = np.ascontiguousarray(group_of_sample, dtype=np.uint8)
+        out = np.zeros(p.shape[0], dtype=SITE_DTYPE)
+        gout = np.zeros((p.shape[0], n_groups), dtype=GROUP_DTYPE)
+        self._check(self._L.bvc_lrt_dense_groups_packed(self._h, p.shape[0], p.shape[1], p.shape[1], _np_ptr(p), _np_ptr(r),
+                                                        float(min_af), _np_ptr(g), int(n_groups), _np_ptr(out), _np_ptr(gout),
+                                                        BVC_PTR_HOST))
+        return out, gout
 
     def lrt_dense_packed(self, packed, ref_base, min_af):
         """Host (numpy) packed tile [n_sites, n_samples] uint8."""

@@ -68,7 +68,7 @@ def parse():
                         "call cost 10-20 us of stream time; 1 = every call)")
     a = p.parse_args()
     if a.packed:                            # profiling mode: no CPU leg (the checks compare two-byte tiles), no groups
-        a.cpu_sites, a.no_verify, a.verify_all, a.groups = 0, True, False, 0
+        a.cpu_sites, a.no_verify, a.verify_all = 0, True, False
     return a
 
 
@@ -170,7 +170,9 @@ def main():
 
     def call(i):
         b, q, r = tiles[i]
-        if a.packed:
+        if a.packed and a.groups > 0:
+            ctx.lrt_dense_groups_packed_device(b, r, min_af, group_t, a.groups, results[i], grp_results[i])
+        elif a.packed:
             ctx.lrt_dense_packed_device(b, r, min_af, results[i])
         elif a.groups > 0:
             ctx.lrt_dense_groups_device(b, q, r, min_af, group_t, a.groups, results[i], grp_results[i])
@@ -228,7 +230,7 @@ def main():
     em_ms = em_ms_per_site * a.tile_sites
     alg_bytes = (1.0 if a.packed else 2.0) * a.tile_sites * n   # 2 B per (site, sample), read once (packed: 1 B)
     achieved = alg_bytes / (hist_ms * 1e-3) / 1e9 if hist_ms > 0 else 0.0
-    kname = "hist_packed_kernel" if a.packed else hist_kernel_name(a.groups, a.group_layout)
+    kname = hist_kernel_name(a.groups, a.group_layout).replace("hist_dense_kernel", "hist_packed_kernel").replace("hist_dense_", "hist_packed_") if a.packed else hist_kernel_name(a.groups, a.group_layout)
     traffic, traffic_source = pmc_traffic(a, n, kname)
 
     out = {
@@ -382,6 +384,33 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
                      "algorithmic_bytes_per_launch": alg, "bytes_per_sample": 1, "traffic": tr, "traffic_source": src},
         "stage2_ms_per_call": prof["em_ms"] / max(1, prof["em_launches"]),
     }
+    # ... and the same in group mode (k = 5, both label orders): bvc_lrt_dense_groups_packed
+    for layout in ("interleaved", "ordered"):
+        g = torch.from_numpy(group_labels(np, n, k, layout)).to(dev)
+        gres = [torch.empty(tile_sizes[i] * k * GROUP_DTYPE.itemsize, dtype=torch.uint8, device=dev) for i in use]
+
+        def fn_pg(j, g=g, gres=gres):
+            i = j % len(use)
+            ctx.lrt_dense_groups_packed_device(packed[i][0], packed[i][1], min_af, g, k, res[i], gres[i])
+        n_calls = 10 * len(use)
+        dt, prof = timed_calls(ctx, fn_pg, n_calls)
+        w_res, w_gres = ctx.lrt_dense_groups_device(tiles[use[0]][0], tiles[use[0]][1], tiles[use[0]][2], min_af, g, k)
+        ctx.join(); torch.cuda.synchronize()
+        same = bool(torch.equal(w_res, res[0]) and torch.equal(w_gres, gres[0]))
+        hist_ms = prof["hist_ms"] / max(1, prof["hist_launches"])
+        kname = "hist_packed_ranges_kernel" if layout == "ordered" else "hist_packed_groups_kernel"
+        tr, src = pmc_traffic(a, n, kname)
+        legs[f"packed_groups5_{layout}"] = {
+            "workload": f"configs[4] (k = 5 groups, {layout}) on packed tiles, N = {n}, {n_calls} calls of {a.tile_sites} sites",
+            "value": n_calls * a.tile_sites / dt, "unit": "sites/s", "ms_per_call": dt / n_calls * 1e3,
+            "records_identical_to_two_byte_path": same,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": alg / (hist_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": alg / (hist_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": hist_ms,
+                         "launches_timed": int(prof["hist_launches"]), "algorithmic_bytes_per_launch": alg,
+                         "bytes_per_sample": 1, "traffic": tr, "traffic_source": src},
+            "stage2_ms_per_call": prof["em_ms"] / max(1, prof["em_launches"]),
+        }
+        del gres, w_res, w_gres
     del packed, res, two_byte
 
     # ---- ragged (CSR) entry point at 10 % coverage: what a real low-coverage pileup looks like at N = 1e6

@@ -174,6 +174,11 @@ int bvc_lrt_csr_comb(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
 int bvc_lrt_dense_packed(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                          const uint8_t *packed, const int8_t *ref_base, double min_af,
                          bvc_site_result *results, uint32_t flags);
+/* Group mode on a packed tile: bvc_lrt_dense_groups with the one-byte layout (same records, bit for bit). */
+int bvc_lrt_dense_groups_packed(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
+                                const uint8_t *packed, const int8_t *ref_base, double min_af,
+                                const uint8_t *group_of_sample, int32_t n_groups,
+                                bvc_site_result *results, bvc_group_result *grp_results, uint32_t flags);
 /* Device pointers only (BVC_PTR_DEVICE); synchronises the context's stream. */
 int bvc_pack_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                    const int8_t *bases, const int8_t *quals, int64_t packed_stride, uint8_t *packed,

@@ -41,6 +41,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     # the additive packed layout (one byte per sample) rides along too, and must give the two-byte path's records
     pk = legs["packed_1_byte_per_sample"]
     assert pk["value"] > 0 and pk["records_identical_to_two_byte_path"] is True and pk["roofline"]["bytes_per_sample"] == 1
+    for name in ("packed_groups5_interleaved", "packed_groups5_ordered"):
+        assert legs[name]["value"] > 0 and legs[name]["records_identical_to_two_byte_path"] is True, name
     assert legs["config1_1e4x1e4"]["roofline"]["bound"] == "fp64_valu_issue"
     assert legs["csr_coverage10pct"]["roofline"]["bound"] == "fp64_valu_issue" and legs["csr_coverage10pct"]["hist_roofline"]["bound"] == "hbm"
 

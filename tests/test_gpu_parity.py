@@ -1218,3 +1218,67 @@ def test_group_counts_up_to_the_maximum(ctx, k):
                 assert_site_matches(res[s], o, where=f"k={k} {layout} n={n} site {s}", path_strict=False)
                 assert np.array_equal(gres[s]["depth"], gd) and np.array_equal(gres[s]["ran"], ran), (k, layout, n, s)
                 np.testing.assert_allclose(gres[s]["af"], ga, rtol=0, atol=AF_ATOL)
+
+
+@pytest.mark.parametrize("k", [1, 5, 7, 32])
+def test_packed_group_mode_gives_the_records_of_the_two_byte_group_mode(ctx, k):
+    """bvc_lrt_dense_groups_packed == bvc_lrt_dense_groups on the same observations, byte for byte (site records and
+    group records): labels in any order and ordered by group, with and without samples in no group, rows of 6016
+    samples (16-byte aligned: the vector kernels), 6000 (byte kernels) and 70,000; host and device pointers."""
+    import torch
+    from basevarc_amd.lib import GROUP_DTYPE, results_from_tensor
+    rng = np.random.default_rng(500 + k)
+    for n, ns in ((6016, 9), (6000, 5), (70000, 40)):
+        b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+        q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+        r = torch.empty(ns, dtype=torch.int8, device="cuda")
+        ctx.synth_dense_device(17, 31 * n + k, b, q, r, cov_thr16=int(0.9 * 65536))
+        p, bad = ctx.pack_dense_device(b, q, torch.empty((ns, n), dtype=torch.uint8, device="cuda"))
+        assert bad == 0
+        m = caller_min_af(max(n, 20000))
+        for layout in ("any", "ordered"):
+            g = rng.integers(0, k + 1, size=n).astype(np.uint8)
+            if layout == "ordered":
+                g = np.sort(g)
+            g[g == k] = 255
+            gt = torch.from_numpy(g).cuda()
+            want, gwant = ctx.lrt_dense_groups_device(b, q, r, m, gt, k)
+            got, ggot = ctx.lrt_dense_groups_packed_device(p, r, m, gt, k)
+            ctx.synchronize()
+            assert torch.equal(got, want), (k, n, layout)
+            assert torch.equal(ggot, gwant), (k, n, layout)
+            if n <= 6016:
+                hres, hg = ctx.lrt_dense_groups_packed(p.cpu().numpy(), r.cpu().numpy(), m, g, k)
+                assert hres.tobytes() == results_from_tensor(want).tobytes()
+                assert hg.tobytes() == gwant.cpu().numpy().tobytes()
+
+
+def test_packed_group_mode_at_1e6_samples(ctx):
+    """N = 1e6, k = 5, both label orders, overlap mode: packed group records == two-byte group records."""
+    import torch
+    ns, n, k = 65, 1_000_000, 5
+    m = caller_min_af(n)
+    stride = (n + 127) // 128 * 128
+    b = torch.empty((ns, stride), dtype=torch.int8, device="cuda")[:, :n]
+    q = torch.empty((ns, stride), dtype=torch.int8, device="cuda")[:, :n]
+    r = torch.empty(ns, dtype=torch.int8, device="cuda")
+    ctx.synth_dense_device(3, 12345, b, q, r)
+    p, bad = ctx.pack_dense_device(b, q)
+    assert bad == 0
+    for layout in ("interleaved", "ordered"):
+        g = _group_labels(n, k, layout)
+        g[::97] = 255
+        if layout == "ordered":
+            g = np.sort(np.minimum(g, k)).astype(np.uint8)
+            g[g == k] = 255
+        gt = torch.from_numpy(g).cuda()
+        want, gwant = ctx.lrt_dense_groups_device(b, q, r, m, gt, k)
+        ctx.synchronize()
+        ctx.set_overlap(True)
+        try:
+            outs = [ctx.lrt_dense_groups_packed_device(p, r, m, gt, k) for _ in range(3)]
+            ctx.join(); ctx.synchronize()
+        finally:
+            ctx.set_overlap(False)
+        for got, ggot in outs:
+            assert torch.equal(got, want) and torch.equal(ggot, gwant), layout

@@ -1,11 +1,11 @@
 cd $GRAFT_REPO_ROOT
-python - <<'PY'
-import torch
-p=torch.cuda.get_device_properties(0)
-print('sharedMemPerBlock', getattr(p,'shared_memory_per_block',None), 'optin', getattr(p,'shared_memory_per_block_optin',None), 'per multiprocessor', getattr(p,'shared_memory_per_multiprocessor',None))
+python bench.py --steps 3 --warmup 1 --cpu-sites 0 --no-verify --total-sites 40000 > gpurun_out/_t.json 2>gpurun_out/_t.err || tail -5 gpurun_out/_t.err
+python - <<PY
+import json
+d=json.loads(open('gpurun_out/_t.json').read().strip().splitlines()[-1])
+for k,v in d['legs'].items(): print(k, round(v['value']), 'ms/call', round(v['ms_per_call'],3), 'hist', round(v['roofline'].get('avg_launch_ms',0),3), 'frac', round(v['roofline']['frac'],3), 'stage2', v.get('stage2_ms_per_call'), v.get('records_identical_to_two_byte_path'))
 PY
-for kib in 0 96 128 160; do
-python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "group_kernel_variants" 2>&1 | tail -1
-BVC_GROUP_LDS_KIB=$kib python bench.py --groups 5 --steps 4 --warmup 1 --cpu-sites 0 --no-verify --no-legs --total-sites 40000 2>/dev/null | python tools/bench_line.py lds $kib overlap interleaved
-BVC_GROUP_LDS_KIB=$kib python bench.py --groups 5 --steps 4 --warmup 1 --cpu-sites 0 --no-verify --no-legs --total-sites 40000 --no-overlap 2>/dev/null | python tools/bench_line.py lds $kib serial interleaved
+for lay in interleaved ordered; do
+python bench.py --packed --groups 5 --group-layout $lay --steps 4 --warmup 1 --total-sites 40000 --no-overlap 2>/dev/null | python tools/bench_line.py packed groups $lay serial
+python bench.py --packed --groups 5 --group-layout $lay --steps 4 --warmup 1 --total-sites 40000 2>/dev/null | python tools/bench_line.py packed groups $lay overlap
 done

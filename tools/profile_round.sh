@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_overlap -- pyth
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_serial -- python3 $R/bench.py --steps 4 --warmup 1 $Q --no-overlap > $O/trace_serial.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_legs -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-sites 0 --no-verify > $O/trace_legs.log 2>&1
 P="--steps 2 --warmup 1 --total-sites 16000 $Q --no-overlap"
-for cfg in "dense:" "groups_interleaved:--groups 5" "groups_ordered:--groups 5 --group-layout ordered" "packed:--packed"; do
+for cfg in "dense:" "groups_interleaved:--groups 5" "groups_ordered:--groups 5 --group-layout ordered" "packed:--packed" "packed_groups_interleaved:--packed --groups 5" "packed_groups_ordered:--packed --groups 5 --group-layout ordered"; do
   name=${cfg%%:*}; flags=${cfg#*:}
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$name/pmc_$c -- python3 $R/bench.py $P $flags > $O/${name}_pmc_$c.log 2>&1
