@@ -245,6 +245,7 @@ struct TileRunner {
     std::vector<bvc_group_result> gres;
     std::vector<int64_t> offsets;
     std::vector<int8_t> bases, quals;
+    std::vector<uint8_t> packed;
 
     void flush()
     {
@@ -268,24 +269,46 @@ struct TileRunner {
             rc = bvc_lrt_csr(ctx, ns, offsets.data(), bases.empty() ? &none : bases.data(), quals.empty() ? &none : quals.data(),
                              refs.data(), min_af, res.data(), BVC_PTR_HOST);
         } else {
-            // dense [site][column] tile with -1 for "no observation"; columns are the samples ordered by group
-            // (Groups::order_columns), the group of each column is shared by all sites
+            // dense [site][column] tile; columns are the samples ordered by group (Groups::order_columns), the group of
+            // each column is shared by all sites.  One byte per sample (base << 6 | qual, 0xFF = no observation:
+            // bvc_lrt_dense_groups_packed) as long as every base quality of the tile is below 63; otherwise the
+            // two-byte tile (-1 / 0 for "no observation").  BVC_HOST_TWO_BYTE_TILES=1 forces the latter.
             const int64_t stride = ((int64_t)n_samples + 127) / 128 * 128;
-            bases.assign((size_t)(ns * stride), (int8_t)-1);
-            quals.assign((size_t)(ns * stride), (int8_t)0);
-            for (int64_t s = 0; s < ns; ++s)
-                for (size_t k = 0; k < sites[s].aiv.size(); ++k) {
-                    const AlleleInfo &a = sites[s].aiv[k];
-                    if (a.is_indel == 0) {
-                        const int64_t col = groups->column_of[(size_t)sites[s].sample[k]];
-                        bases[(size_t)(s * stride + col)] = (int8_t)a.base;
-                        quals[(size_t)(s * stride + col)] = (int8_t)a.qual;
+            static const bool two_byte_only = getenv("BVC_HOST_TWO_BYTE_TILES") != nullptr;
+            bool fits = !two_byte_only;
+            if (fits) {
+                packed.assign((size_t)(ns * stride), (uint8_t)0xFF);
+                for (int64_t s = 0; s < ns && fits; ++s)
+                    for (size_t k = 0; k < sites[s].aiv.size(); ++k) {
+                        const AlleleInfo &a = sites[s].aiv[k];
+                        if (a.is_indel == 0) {
+                            if (a.base > 3u) continue;             // not A/C/G/T: no observation, as in the two-byte tile
+                            if (a.qual > 62u) { fits = false; break; }
+                            packed[(size_t)(s * stride + groups->column_of[(size_t)sites[s].sample[k]])] = (uint8_t)((a.base << 6) | a.qual);
+                        }
                     }
-                }
+            }
             gres.resize((size_t)(ns * ng));
-            t1 = StageClock::now(); clk.pack += t1 - t0; t0 = t1;
-            rc = bvc_lrt_dense_groups(ctx, ns, n_samples, stride, bases.data(), quals.data(), refs.data(), min_af,
-                                      groups->of_column.data(), ng, res.data(), gres.data(), BVC_PTR_HOST);
+            if (fits) {
+                t1 = StageClock::now(); clk.pack += t1 - t0; t0 = t1;
+                rc = bvc_lrt_dense_groups_packed(ctx, ns, n_samples, stride, packed.data(), refs.data(), min_af,
+                                                 groups->of_column.data(), ng, res.data(), gres.data(), BVC_PTR_HOST);
+            } else {
+                bases.assign((size_t)(ns * stride), (int8_t)-1);
+                quals.assign((size_t)(ns * stride), (int8_t)0);
+                for (int64_t s = 0; s < ns; ++s)
+                    for (size_t k = 0; k < sites[s].aiv.size(); ++k) {
+                        const AlleleInfo &a = sites[s].aiv[k];
+                        if (a.is_indel == 0) {
+                            const int64_t col = groups->column_of[(size_t)sites[s].sample[k]];
+                            bases[(size_t)(s * stride + col)] = (int8_t)a.base;
+                            quals[(size_t)(s * stride + col)] = (int8_t)a.qual;
+                        }
+                    }
+                t1 = StageClock::now(); clk.pack += t1 - t0; t0 = t1;
+                rc = bvc_lrt_dense_groups(ctx, ns, n_samples, stride, bases.data(), quals.data(), refs.data(), min_af,
+                                          groups->of_column.data(), ng, res.data(), gres.data(), BVC_PTR_HOST);
+            }
         }
         if (rc != BVC_OK) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(ctx));
         t1 = StageClock::now(); clk.gpu += t1 - t0; t0 = t1;

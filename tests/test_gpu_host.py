@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("thread,grouped,tmp_format", [(1, False, "text"), (4, False, "text"), (2, True, "text"),
-                                                       (3, False, "bin"), (2, True, "bin"), (2, False, "raw")])
+                                                       (3, False, "bin"), (2, True, "bin"), (2, False, "raw"),
+                                                       (2, True, "two_byte_tiles")])
 def test_basetype_command_on_reference_test_data(tmp_path, thread, grouped, tmp_format):
     from basevarc_amd import build as b
     from tests import hostref
@@ -21,7 +22,11 @@ def test_basetype_command_on_reference_test_data(tmp_path, thread, grouped, tmp_
     pipe = hostref.Pipeline(mapq=20, batch=10, thread=thread)
     cmd = [exe, "basetype", "--rerun", "-q", "20", "-t", str(thread), "-b", "10", "-i", lst, "-s", hostref.REGION,
            "-r", fa, "-o", out]
-    if tmp_format != "text":                                      # additive: binary temp batches, same outputs
+    env = None
+    if tmp_format == "two_byte_tiles":                            # --group tiles go to libbvc packed (one byte per sample)
+        import os                                                 # unless a quality does not fit; this forces the two-byte tiles
+        env = dict(os.environ, BVC_HOST_TWO_BYTE_TILES="1")
+    elif tmp_format != "text":                                    # additive: binary temp batches, same outputs
         cmd += ["--tmp-format", tmp_format]
     group_of = None
     if grouped:                                                   # --group <SampleID Group>; 7 samples left ungrouped
@@ -29,7 +34,7 @@ def test_basetype_command_on_reference_test_data(tmp_path, thread, grouped, tmp_
         gf = tmp_path / "groups.txt"
         gf.write_text("".join(f"{k} {v}\n" for k, v in group_of.items()))
         cmd += ["-g", str(gf)]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "basetype done" in r.stdout
     vcf_body, cvg_body = pipe.outputs(group_of)
