@@ -927,6 +927,19 @@ def test_error_behaviour_of_the_c_abi(ctx):
         ctx.set_tuning("no_such_knob", 1)
     with pytest.raises(BvcError):
         ctx.set_tuning("em_waves_per_cu", 1000)
+    # packed entry points: the same argument rules; packing and the packed histogram take device pointers only
+    P = np.full((2, 8), 0x40 | 30, dtype=np.uint8)
+    bad = C.c_int64(-1)
+    assert L.bvc_lrt_dense_packed(hh, 2, 8, 4, vp(P), vp(R), 0.001, vp(out), 0) == -1
+    assert L.bvc_lrt_dense_packed(hh, 2, 8, 8, None, vp(R), 0.001, vp(out), 0) == -1
+    assert L.bvc_lrt_dense_packed(hh, 0, 8, 8, None, None, 0.001, None, 0) == 0
+    assert L.bvc_lrt_dense_packed(hh, 2, 8, 8, vp(P), vp(R), 0.001, vp(out), 0) == 0 and out["depth"].tolist() == [[0, 8, 0, 0]] * 2
+    for k in (0, 33):
+        assert L.bvc_lrt_dense_groups_packed(hh, 2, 8, 8, vp(P), vp(R), 0.001, vp(g), k, vp(out), vp(gout), 0) == -1
+    assert L.bvc_lrt_dense_groups_packed(hh, 2, 8, 8, vp(P), vp(R), 0.001, None, 2, vp(out), vp(gout), 0) == -1
+    assert L.bvc_pack_dense(hh, 2, 8, 8, vp(B), vp(B), 8, vp(P), C.byref(bad), 0) == -1 and b"device pointers" in L.bvc_last_error(hh)
+    assert L.bvc_pack_dense(hh, 2, 8, 8, vp(B), vp(B), 4, vp(P), C.byref(bad), 1) == -1     # packed stride < n_samples
+    assert L.bvc_hist_dense_packed(hh, 2, 8, 8, vp(P), vp(cnt), 0) == -1
     # the context is still good, and a site without a call is a record, not an error
     rec = ctx.lrt_dense(np.full((1, 50), 2, dtype=np.int8), np.full((1, 50), 30, dtype=np.int8), [2], 0.001)
     assert int(rec[0]["called"]) == 0 and int(rec[0]["status"]) == 0 and rec[0]["depth"].tolist() == [0, 0, 50, 0]
