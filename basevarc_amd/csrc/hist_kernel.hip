@@ -80,25 +80,33 @@ template <int D, class Load, class Count>
 __device__ __forceinline__ void stream_chunks(int64_t n16, int tid, Load load, Count count)
 {
     u32x4 b[D], q[D], g[D], nb[D], nq[D], ng[D];
+    // c0 = chunk of lane 0 (workgroup-uniform).  A trip whose D chunks all lie inside the row -- every trip but the last
+    // one or two of a row -- loads without a test and without first filling the registers with the "skip me" pattern
+    // (twelve moves per chunk that the common case used to pay for the rare one).
     auto fetch = [&](int64_t c0, u32x4 (&xb)[D], u32x4 (&xq)[D], u32x4 (&xg)[D]) {
+        if (c0 + (int64_t)D * kHistThreads <= n16) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int64_t c = c0 + (int64_t)d * kHistThreads;
-            xb[d] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            xq[d] = u32x4{0u, 0u, 0u, 0u}; xg[d] = xq[d];
-            if (c < n16) load(c, xb[d], xq[d], xg[d]);
+            for (int d = 0; d < D; ++d) load(c0 + tid + (int64_t)d * kHistThreads, xb[d], xq[d], xg[d]);
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int64_t c = c0 + tid + (int64_t)d * kHistThreads;
+                xb[d] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                xq[d] = u32x4{0u, 0u, 0u, 0u}; xg[d] = xq[d];
+                if (c < n16) load(c, xb[d], xq[d], xg[d]);
+            }
         }
     };
-    int64_t c = tid;
-    fetch(c, b, q, g);
-    while (c < n16) {
-        const int64_t cn = c + (int64_t)D * kHistThreads;
+    int64_t c0 = 0;
+    fetch(c0, b, q, g);
+    while (c0 < n16) {
+        const int64_t cn = c0 + (int64_t)D * kHistThreads;
         fetch(cn, nb, nq, ng);
 #pragma unroll
         for (int d = 0; d < D; ++d) count(b[d], q[d], g[d]);
 #pragma unroll
         for (int d = 0; d < D; ++d) { b[d] = nb[d]; q[d] = nq[d]; g[d] = ng[d]; }
-        c = cn;
+        c0 = cn;
     }
 }
 
@@ -763,11 +771,16 @@ __global__ __launch_bounds__(kHistThreads) void hist_packed_kernel(
             const u32x4 *rv = reinterpret_cast<const u32x4 *>(row);
             for (int64_t cb = (int64_t)part * kBlockChunks; cb < n16; cb += (int64_t)split * kBlockChunks) {
                 u32x4 v[kPackedUnroll];
+                if (cb + kBlockChunks <= n16) {                  // a whole block: plain loads
 #pragma unroll
-                for (int u = 0; u < kPackedUnroll; ++u) {
-                    const int64_t c = cb + tid + (int64_t)u * kHistThreads;
-                    v[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // past the end: "no observation"
-                    if (cb + kBlockChunks <= n16 || c < n16) v[u] = __builtin_nontemporal_load(&rv[c]);
+                    for (int u = 0; u < kPackedUnroll; ++u) v[u] = __builtin_nontemporal_load(&rv[cb + tid + (int64_t)u * kHistThreads]);
+                } else {                                         // the last, partial block: lanes past the end count "no observation"
+#pragma unroll
+                    for (int u = 0; u < kPackedUnroll; ++u) {
+                        const int64_t c = cb + tid + (int64_t)u * kHistThreads;
+                        v[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                        if (c < n16) v[u] = __builtin_nontemporal_load(&rv[c]);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < kPackedUnroll; ++u) {
@@ -857,11 +870,16 @@ __global__ __launch_bounds__(kHistThreads) void hist_packed_ranges_kernel(
             constexpr int64_t kBlockChunks = (int64_t)kPackedUnroll * kHistThreads;
             for (int64_t cb = c0; cb < c1; cb += kBlockChunks) {
                 u32x4 v[kPackedUnroll];
+                if (cb + kBlockChunks <= c1) {
 #pragma unroll
-                for (int u = 0; u < kPackedUnroll; ++u) {
-                    const int64_t c = cb + tid + (int64_t)u * kHistThreads;
-                    v[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                    if (cb + kBlockChunks <= c1 || c < c1) v[u] = __builtin_nontemporal_load(&rv[c]);
+                    for (int u = 0; u < kPackedUnroll; ++u) v[u] = __builtin_nontemporal_load(&rv[cb + tid + (int64_t)u * kHistThreads]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kPackedUnroll; ++u) {
+                        const int64_t c = cb + tid + (int64_t)u * kHistThreads;
+                        v[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                        if (c < c1) v[u] = __builtin_nontemporal_load(&rv[c]);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < kPackedUnroll; ++u) {
@@ -946,12 +964,20 @@ __global__ __launch_bounds__(kHistThreads) void hist_packed_groups_kernel(
             constexpr int64_t kBlockChunks = 2 * (int64_t)kHistThreads;
             for (int64_t cb = 0; cb < n16; cb += kBlockChunks) {
                 u32x4 p[2], g[2];
+                if (cb + kBlockChunks <= n16) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int64_t c = cb + tid + (int64_t)u * kHistThreads;
-                    p[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // past the end: slot 255 ...
-                    g[u] = u32x4{0u, 0u, 0u, 0u};                                       // ... of histogram 0
-                    if (c < n16) { p[u] = __builtin_nontemporal_load(&rv[c]); g[u] = gv[c]; }
+                    for (int u = 0; u < 2; ++u) {
+                        const int64_t c = cb + tid + (int64_t)u * kHistThreads;
+                        p[u] = __builtin_nontemporal_load(&rv[c]); g[u] = gv[c];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int64_t c = cb + tid + (int64_t)u * kHistThreads;
+                        p[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // past the end: slot 255 ...
+                        g[u] = u32x4{0u, 0u, 0u, 0u};                                       // ... of histogram 0
+                        if (c < n16) { p[u] = __builtin_nontemporal_load(&rv[c]); g[u] = gv[c]; }
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
