@@ -1295,3 +1295,56 @@ def test_packed_group_mode_at_1e6_samples(ctx):
             ctx.set_overlap(False)
         for got, ggot in outs:
             assert torch.equal(got, want) and torch.equal(ggot, gwant), layout
+
+
+def test_four_host_threads_with_their_own_contexts(ctx):
+    """include/bvc.h, "Threading": one context per host thread, no process-wide mutable state.  Four threads, each with
+    its own context and HIP stream, hammer different entry points (dense, packed, ragged, groups) at the same time on
+    the one device; every call returns what the same call returns alone."""
+    import threading
+    import torch
+    from basevarc_amd import Context
+    from basevarc_amd.lib import GROUP_DTYPE, SITE_DTYPE
+    n, ns, k = 120_000, 200, 4
+    m = caller_min_af(n)
+    b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    r = torch.empty(ns, dtype=torch.int8, device="cuda")
+    ctx.synth_dense_device(23, 600, b, q, r, cov_thr16=int(0.7 * 65536))
+    p, bad = ctx.pack_dense_device(b, q)
+    assert bad == 0
+    g = torch.from_numpy((np.arange(n) % k).astype(np.uint8)).cuda()
+    offs = (torch.arange(ns + 1, dtype=torch.int64) * n).cuda()
+    want = ctx.lrt_dense_device(b, q, r, m).clone()
+    want_g = ctx.lrt_dense_groups_device(b, q, r, m, g, k)[1].clone()
+    ctx.synchronize()
+    errors = []
+
+    def worker(kind):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream), Context(0, stream=stream) as c:
+                c.set_overlap(kind in ("dense", "packed"))
+                for rep in range(12):
+                    out = torch.zeros(ns * SITE_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+                    gout = torch.zeros(ns * k * GROUP_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+                    if kind == "dense":
+                        c.lrt_dense_device(b, q, r, m, out)
+                    elif kind == "packed":
+                        c.lrt_dense_packed_device(p, r, m, out)
+                    elif kind == "csr":
+                        c.lrt_csr_device(offs, b.reshape(-1), q.reshape(-1), r, m, out)
+                    else:
+                        c.lrt_dense_groups_packed_device(p, r, m, g, k, out, gout)
+                    c.join(); c.synchronize()
+                    if not torch.equal(out, want) or (kind == "groups" and not torch.equal(gout, want_g)):
+                        errors.append((kind, rep))
+        except Exception as e:                                     # noqa: BLE001 -- reported by the main thread
+            errors.append((kind, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(kind,)) for kind in ("dense", "packed", "csr", "groups")]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
