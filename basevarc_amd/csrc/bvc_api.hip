@@ -36,6 +36,12 @@ struct bvc_ctx {
     bool em_pending[kRing] = {false, false, false};
     uint32_t *d_grp[kRing] = {nullptr, nullptr, nullptr};   // [sites][groups + 1][512] in group mode
     size_t grp_cap[kRing] = {0, 0, 0};
+    // item-engine scratch of stage 2 (em_items.hip), one per ring buffer (the stage 2 of consecutive calls may run
+    // side by side); the last one serves bvc_lrt_hist on the context's own stream
+    void *d_em[kRing + 1] = {nullptr, nullptr, nullptr, nullptr};
+    size_t em_cap[kRing + 1] = {0, 0, 0, 0};
+    void *d_emg[kRing] = {nullptr, nullptr, nullptr};      // the same for the (site, group) pseudo-sites of group calls
+    size_t emg_cap[kRing] = {0, 0, 0};
     uint32_t *d_sink = nullptr;        // 256 bytes: sink of the streaming-read measurement kernel; bvc_pack_dense's counter at byte 64
     uint8_t *d_grp_labels = nullptr;   // group mode: the call's group vector clamped to 0..n_groups (hist_kernel.hip)
     size_t grp_labels_cap = 0;
@@ -142,6 +148,26 @@ hipStream_t em_stream(bvc_ctx *ctx, int by_default)
     return k == 0 ? ctx->side : (k == 1 ? ctx->side_b : ctx->side_c);
 }
 
+// Device scratch of the item engine for a stage 2 of n_sites sites on ring buffer `slot` (null when the call will not
+// use the engine: launch_lrt's rule).  Growing it waits for whatever may still be using the old one.
+int em_scratch_for(bvc_ctx *ctx, int slot, int64_t n_sites, double min_af, void **out, int n_groups = 0)
+{
+    *out = nullptr;
+    const int64_t n_work = n_groups > 0 ? n_sites * n_groups : n_sites;
+    if (ctx->ls.em_engine == 1 || !(min_af > 0.0)) return BVC_OK;
+    const size_t need = n_groups > 0 ? em_group_scratch_bytes(n_sites, n_groups) : em_items_scratch_bytes(n_sites);
+    void **buf = n_groups > 0 ? &ctx->d_emg[slot] : &ctx->d_em[slot];
+    size_t *cap = n_groups > 0 ? &ctx->emg_cap[slot] : &ctx->em_cap[slot];
+    if (need > *cap) {
+        int rcj = join_side(ctx);
+        if (rcj != BVC_OK) return rcj;
+    }
+    int rc = ensure(ctx, buf, cap, need);
+    if (rc != BVC_OK) return rc;
+    *out = *buf;
+    return BVC_OK;
+}
+
 // The two stages on device pointers.  `stage1(counts)` launches the histogram pass of the call (dense, ragged, ...)
 // on the context's stream into a [n_sites][512] buffer of the ring; stage 2 (EM/LRT) follows on the same stream, or
 // on the side stream behind an event in overlap mode.
@@ -162,6 +188,9 @@ int run_two_stages(bvc_ctx *ctx, int64_t n_sites, bool zero_counts, bool long_ro
     int rc = ensure(ctx, reinterpret_cast<void **>(counts_p), cap_p, cbytes);
     if (rc != BVC_OK) return rc;
     uint32_t *counts = *counts_p;
+    void *em_scratch = nullptr;
+    rc = em_scratch_for(ctx, buf, n_sites, min_af, &em_scratch);
+    if (rc != BVC_OK) return rc;
     bvc_ctx::Triple t{nullptr, nullptr, nullptr, nullptr, n_sites};
     const bool timed = ctx->profiling && take_timing_events(ctx, t);
     auto bail = [&](int code) {                 // an early exit returns the timing events to the pool
@@ -195,7 +224,8 @@ int run_two_stages(bvc_ctx *ctx, int64_t n_sites, bool zero_counts, bool long_ro
     // underneath a long streaming pass the EM kernel keeps to a few wave slots; with short rows it is the longer
     // kernel and takes the chip
     const bool shared = ctx->overlap && long_rows;
-    BVC_HIP_T(launch_lrt(ctx->ls, s2, n_sites, counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut, comb, n_comb, results, shared));
+    BVC_HIP_T(launch_lrt(ctx->ls, s2, n_sites, counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut, comb, n_comb, results, shared, 0,
+                         em_scratch));
     if (timed) {
         BVC_HIP_T(hipEventRecord(t.d, s2));
         ctx->ev_pending.push_back(t);
@@ -349,6 +379,7 @@ int bvc_create(bvc_ctx **out, int device)
     ctx->ls.hist_split = env_int("BVC_HIST_SPLIT", 1, 64, 0);
     ctx->ls.group_pipe = env_int("BVC_GROUP_PIPE", 0, 1, 1);
     ctx->ls.em_streams = env_int("BVC_EM_STREAMS", 0, 3, 0);
+    ctx->ls.em_engine = env_int("BVC_EM_ENGINE", 0, 1, 0);
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return BVC_ERR_DEVICE; }
     // likelihood table from the host's exp(), as the CPU path computes it (src/BaseType.cpp:13,15)
     QualLut lut;
@@ -394,6 +425,10 @@ void bvc_destroy(bvc_ctx *ctx)
         if (ctx->d_cnt[b]) (void)hipFree(ctx->d_cnt[b]);
         if (ctx->d_grp[b]) (void)hipFree(ctx->d_grp[b]);
     }
+    for (int b = 0; b <= bvc_ctx::kRing; ++b)
+        if (ctx->d_em[b]) (void)hipFree(ctx->d_em[b]);
+    for (int b = 0; b < bvc_ctx::kRing; ++b)
+        if (ctx->d_emg[b]) (void)hipFree(ctx->d_emg[b]);
     for (int b = 0; b < 2; ++b) {
         if (ctx->ev_upload[b]) (void)hipEventDestroy(ctx->ev_upload[b]);
         if (ctx->d_stage[b]) (void)hipFree(ctx->d_stage[b]);
@@ -649,9 +684,12 @@ int bvc_lrt_hist(bvc_ctx *ctx, int64_t n_sites, const uint32_t *counts, const in
     if (rc != BVC_OK) return rc;
     if ((base_comb == nullptr) != (n_comb == nullptr)) return fail(ctx, BVC_ERR_ARG, "base_comb and n_comb go together");
     if (n_sites == 0) return BVC_OK;
+    void *em_scratch = nullptr;
+    rc = em_scratch_for(ctx, bvc_ctx::kRing, n_sites, min_af, &em_scratch);
+    if (rc != BVC_OK) return rc;
     if (flags & BVC_PTR_DEVICE) {
         BVC_HIP(ctx, launch_lrt(ctx->ls, ctx->stream, n_sites, counts, BVC_NCLASS, ref_base, min_af, ctx->d_lut, base_comb,
-                                n_comb, results));
+                                n_comb, results, false, 0, em_scratch));
         return BVC_OK;
     }
     if (base_comb && (rc = check_comb_host(ctx, n_sites, base_comb, n_comb)) != BVC_OK) return rc;
@@ -673,7 +711,7 @@ int bvc_lrt_hist(bvc_ctx *ctx, int64_t n_sites, const uint32_t *counts, const in
         BVC_HIP(ctx, hipMemcpyAsync(d_cb, base_comb, (size_t)n_sites * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     BVC_HIP(ctx, launch_lrt(ctx->ls, ctx->stream, n_sites, d_c, BVC_NCLASS, d_r, min_af, ctx->d_lut,
-                            base_comb ? d_cb : nullptr, base_comb ? d_nc : nullptr, d_res));
+                            base_comb ? d_cb : nullptr, base_comb ? d_nc : nullptr, d_res, false, 0, em_scratch));
     BVC_HIP(ctx, hipMemcpyAsync(results, d_res, (size_t)n_sites * sizeof(bvc_site_result), hipMemcpyDeviceToHost,
                                 ctx->stream));
     BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -776,6 +814,11 @@ static int lrt_groups_impl(bvc_ctx *ctx, bool packed, int64_t n_sites, int64_t n
         if (lbytes > ctx->grp_labels_cap) { int rj = join_side(ctx); if (rj != BVC_OK) return rj; }
         rc2 = ensure(ctx, reinterpret_cast<void **>(&ctx->d_grp_labels), &ctx->grp_labels_cap, lbytes);
         if (rc2 != BVC_OK) return rc2;
+        void *em_scratch = nullptr, *emg_scratch = nullptr;
+        rc2 = em_scratch_for(ctx, buf, ns, min_af, &em_scratch);
+        if (rc2 != BVC_OK) return rc2;
+        rc2 = em_scratch_for(ctx, buf, ns, min_af, &emg_scratch, n_groups);
+        if (rc2 != BVC_OK) return rc2;
         if (ctx->overlap && ctx->em_pending[buf]) {
             BVC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_em_done[buf], 0));
             ctx->em_pending[buf] = false;
@@ -805,8 +848,8 @@ static int lrt_groups_impl(bvc_ctx *ctx, bool packed, int64_t n_sites, int64_t n
         BVC_HIP_T(launch_sum_groups(s2, ns, n_hist, *gp, *cp));
         const bool shared = ctx->overlap && n_samples >= 200000;
         const int per_launch = kGroupSharedWavesPerCu / em_stream_count(ctx, 2) > 2 ? kGroupSharedWavesPerCu / em_stream_count(ctx, 2) : 2;
-        BVC_HIP_T(launch_lrt(ctx->ls, s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared, per_launch));
-        BVC_HIP_T(launch_lrt_groups(ctx->ls, s2, ns, n_groups, *gp, r, min_af, ctx->d_lut, res, gres, shared, per_launch));
+        BVC_HIP_T(launch_lrt(ctx->ls, s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared, per_launch, em_scratch));
+        BVC_HIP_T(launch_lrt_groups(ctx->ls, s2, ns, n_groups, *gp, r, min_af, ctx->d_lut, res, gres, shared, per_launch, emg_scratch));
         if (timed) {
             BVC_HIP_T(hipEventRecord(t.d, s2));
             ctx->ev_pending.push_back(t);
@@ -894,6 +937,7 @@ int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value)
     if (std::strcmp(key, "em_wpb") == 0 && (value == 1 || value == 4)) { ctx->ls.em_wpb = value; return BVC_OK; }
     if (std::strcmp(key, "hist_split") == 0 && value >= 0 && value <= 64) { ctx->ls.hist_split = value; return BVC_OK; }
     if (std::strcmp(key, "group_pipe") == 0 && (value == 0 || value == 1)) { ctx->ls.group_pipe = value; return BVC_OK; }
+    if (std::strcmp(key, "em_engine") == 0 && value >= 0 && value <= 1) { ctx->ls.em_engine = value; return BVC_OK; }
     if (std::strcmp(key, "em_streams") == 0 && value >= 0 && value <= 3) {
         int rcj = join_side(ctx);
         if (rcj != BVC_OK) return rcj;

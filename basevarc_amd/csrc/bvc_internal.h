@@ -17,6 +17,10 @@ struct LaunchState {
     int64_t host_chunk_bytes = (int64_t)1 << 29;   // BVC_PTR_HOST calls: bytes per array and staging chunk
     int em_streams = 0;        // overlap mode: side streams stage 2 alternates between: 0 = by call shape, 1..3
     int group_pipe = 1;        // any-order group histogram: issue the next chunk's loads before counting the current one
+    int em_engine = 0;         // stage 2: 0 = item engine (em_items.hip; em_kernel.hip takes the sites it leaves),
+                               // 1 = one wavefront per site for every site (em_kernel.hip): A/B runs.  The two agree to
+                               // rounding (1e-15 on AF), not bit for bit: a call's records never depend on the call's
+                               // size or neighbours with either, but they depend on this choice
     uint64_t attr_done = 0;    // kernels whose dynamic-LDS attribute has been raised on this context's device
 };
 
@@ -60,15 +64,29 @@ hipError_t launch_hist_csr(LaunchState &st, hipStream_t stream, int64_t n_sites,
 //   hist_stride: uint32 elements between consecutive sites' histograms.
 //   comb/n_comb: optional per-site candidate list (SetBase).
 //   shared: the launch runs underneath a streaming histogram kernel (overlap mode) and keeps to a few wave slots.
+//   scratch: em_items_scratch_bytes(n_sites) of device memory for the item engine (em_items.hip), or null: every
+//            site then takes the one-wavefront-per-site kernels.
 hipError_t launch_lrt(const LaunchState &st, hipStream_t stream, int64_t n_sites, const uint32_t *counts,
                       int64_t hist_stride, const int8_t *ref_base, double min_af, const QualLut *lut,
                       const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results, bool shared = false,
-                      int shared_waves_per_cu = 0);   // 0 = default cap when shared
+                      int shared_waves_per_cu = 0,   // 0 = default cap when shared
+                      void *scratch = nullptr);
+
+// Item engine (em_items.hip): the EM fits of the call as work items, 8 or 16 to a wavefront.  Writes the records of
+// the sites it takes and flags them in *taken_out ([n_sites] bytes inside scratch) for the kernels of em_kernel.hip.
+// n_groups > 0: pseudo-site p = (site, group) on the per-group histograms [site][n_groups + 1][512].
+size_t em_items_scratch_bytes(int64_t n_sites);
+hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n_sites, int n_groups,
+                            const uint32_t *counts, int64_t hist_stride, const int8_t *ref_base, double min_af,
+                            const QualLut *lut, const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results,
+                            void *scratch, const uint8_t **taken_out);
 
 hipError_t launch_lrt_groups(const LaunchState &st, hipStream_t stream, int64_t n_sites, int n_groups,
                              const uint32_t *grp_counts, const int8_t *ref_base, double min_af, const QualLut *lut,
                              const bvc_site_result *overall, bvc_group_result *grp_results, bool shared = false,
-                             int shared_waves_per_cu = 0);
+                             int shared_waves_per_cu = 0, void *scratch = nullptr);
+// scratch: em_group_scratch_bytes(n_sites, n_groups) for the item engine on the (site, group) pseudo-sites, or null
+size_t em_group_scratch_bytes(int64_t n_sites, int n_groups);
 // EM wavefronts per CU the stage-2 launches of group calls keep in flight underneath a long histogram pass, summed
 // over the stage-2 streams in use (em_kernel.hip, em_grid_cap).
 constexpr int kGroupSharedWavesPerCu = 8;

@@ -1,0 +1,825 @@
+// em_items.hip -- stage 2 of the basetype path on gfx950, "item engine": the EM fits of a call are the work items,
+// several of them share a wavefront, and the likelihood-ratio control flow of a site runs between launches.
+//
+// Follows (paths under /root/reference), with the per-sample sums regrouped by class as in em_kernel.hip:
+//   BaseType::SetAlleleFreq  src/BaseType.cpp:25-39     -> emit_items
+//   BaseType::UpdateF        src/BaseType.cpp:41-71     -> one FitItem per subset: fit_kernel (EM), decide_kernel (log-likelihood)
+//   BaseType::LRT            src/BaseType.cpp:73-139    -> classes_kernel (:75-88), decide_kernel (one level of :93-110 per launch)
+//   combs_                   src/BaseType.cpp:237-255   -> subset_masks
+//   singleEM / EM / delta    src/Algorithm.cpp:69-130   -> fit_kernel
+//
+// Why: with one wavefront per site (em_kernel.hip) 39 of the 63 vector instructions of an EM pass are cross-lane
+// reduction and control, paid once per fit-pass.  Here a fit ("item") owns 2 lanes per allele: lane (unit u, half h)
+// keeps 16 of the <= 32 quality classes of one allele in registers, so
+//   * D_b (the allele's own sum) needs one DPP step, E one swap per level of the 2x2 row tree, shared by the 8 (four
+//     alleles per item) or 16 (two alleles per item) items of the wavefront;
+//   * alleles outside the fitted subset have f = 0: their classes have marginal e, add exactly their depth to E and
+//     nothing to the stop rule, so they take no lanes at all -- the nested levels with two alleles
+//     (src/BaseType.cpp:93-110, k = 2 and 1) run 16 items per wavefront;
+//   * the stop rule needs no per-class work: m' - m = (f' - f) d for every class of an allele, hence
+//        sum_c n_c |m'_c / m_c - 1| = sum_b |f'_b - f_b| * D_b(previous pass)          (d > 0: quality >= 2)
+//     and delta = sum_c n_c |log m'_c - log m_c| < 1e-3 is decided from that bracket exactly as in em_kernel.hip
+//     (delta itself is evaluated only when the bracket straddles 1e-3);
+//   * 16 independent classes per lane hide the FP64 latency that one dependency chain per wavefront exposes;
+//   * a = 1 - 3e, so the class marginal f a + (1 - f) e is f + (1 - 4 f) e: one FMA on e alone, and with
+//     Y = sum n / m the allele's own sum is D = Y - 4 E_own -- a lane keeps n and e per class, nothing else;
+//   * the 16 reciprocals of a lane come from ONE v_rcp_f64 (16 issue cycles, four FMAs' worth): 1 / (m_0 ... m_15)
+//     refined once, times the other fifteen marginals by a product tree, 2.8 multiplications per class.
+// The items of a wavefront run in lockstep passes (each with its own pass counter; one that has stopped keeps its
+// state until the wavefront's last one stops), and the hardware dispatches the wavefronts dynamically.  Fits differ
+// 7x in passes at N = 1e4, so what shares a wavefront matters: the fits of one site converge alike except the subset
+// that leaves out the site's deepest allele (always slow), which is why a site's items are placed together and the
+// "deepest allele left out" items go to lists of their own.
+// Sites the engine does not take (more than 32 quality values on one allele, a class of quality 0 or 1 -- d < 0 --,
+// min_af <= 0, duplicate candidates) stay with em_kernel.hip's one-wavefront-per-site kernels, flagged per site.
+// FP64 throughout; no MFMA (nothing here is a dense contraction).
+#include "bvc_device.h"
+#include "bvc_internal.h"
+
+namespace bvc {
+namespace {
+
+constexpr double kLrtThreshold = 24.0;    // LRT_THRESHOLD, src/BaseType.h:9
+constexpr int kEmIters = 100;             // src/BaseType.cpp:46
+constexpr double kEmEpsilon = 0.001;      // src/BaseType.cpp:45
+constexpr double kVarQualPending = -1.0;  // as in em_kernel.hip: var_qual_kernel finishes these records
+
+constexpr int kClassesPerBase = 32;        // quality classes of one allele the engine holds
+constexpr int kPlane = 4 * kClassesPerBase;           // doubles per plane of a site's table
+constexpr int kSiteTable = 2 * kPlane;                // planes n | e, each [base][class]
+
+constexpr double kEmptyE = 0.25;           // e of an empty class place
+constexpr uint32_t hi_word(double x) { return (uint32_t)(__builtin_bit_cast(uint64_t, x) >> 32); }
+constexpr uint32_t kSureBelowHi = hi_word(kEmEpsilon / (1.0 + 0.00390625));        // hi(A) <  this: converged
+constexpr uint32_t kSureAboveHi = hi_word(kEmEpsilon / (1.0 - 0.00390625)) + 1u;   // hi(A) >= this: not converged
+
+// One fit: the alleles of a subset in candidate order ("units"), their starting frequencies, and what the alleles
+// outside the subset add to E (a constant of the fit).  64 bytes.
+struct FitItem {
+    int32_t site;
+    uint8_t base[4];        // allele of unit u; 0xFF = no such unit
+    double f0[4];           // SetAlleleFreq: depth / depth of the subset
+    double e_excl;          // sum of the depths of the alleles outside the subset
+    double inv_n;           // 1 / depth_total
+    double pad;
+};
+static_assert(sizeof(FitItem) == 64, "FitItem layout");
+
+struct FitOut {
+    double ex[4];           // expect_allele_prob of the last pass, per unit
+    double fl[4];           // the frequencies the last pass ran on, per unit (the log-likelihood's, UpdateF :58-62)
+    int32_t passes;
+    int32_t pad;
+};
+static_assert(sizeof(FitOut) == 72, "FitOut layout");
+
+// Per-site state between the launches of a call.
+struct ItemSite {
+    double lr_alt, chi;
+    double base_frq[4];
+    int32_t depth[4];
+    int32_t passes, fits;
+    int32_t item[5];        // pending items: list << 28 | index in the list
+    uint32_t blist;         // candidates in order, 4 bits each
+    int8_t n;               // candidates
+    int8_t k;               // subset size of the pending level
+    uint8_t state;          // 0 = left to em_kernel.hip, 1 = running here, 2 = record written
+    uint8_t first;          // the pending level is the first one: full model + its (n-1)-subsets
+};
+
+// list 0 / 1: items of 3-4 units (four rows per item), fast / slow; list 2 / 3: items of 1-2 units, fast / slow
+// ("slow" = the subset leaves out the deepest candidate: such fits run to the iteration cap)
+constexpr int kLists = 4;
+constexpr int kLevels = 3;
+constexpr int kSitesPerBlock = 16;        // classes_kernel / decide_kernel: one wavefront per site
+
+// k-subsets of positions 0..n-1 in lexicographic order (what combs_ yields), as 4-bit position masks packed
+// least-significant first; count returned through `cnt`.
+__device__ __forceinline__ uint32_t subset_masks(int n, int k, int &cnt)
+{
+    switch (n * 8 + k) {
+    case 1 * 8 + 1: cnt = 1; return 0x1u;
+    case 2 * 8 + 2: cnt = 1; return 0x3u;
+    case 2 * 8 + 1: cnt = 2; return 0x21u;
+    case 3 * 8 + 3: cnt = 1; return 0x7u;
+    case 3 * 8 + 2: cnt = 3; return 0x653u;
+    case 3 * 8 + 1: cnt = 3; return 0x421u;
+    case 4 * 8 + 4: cnt = 1; return 0xFu;
+    case 4 * 8 + 3: cnt = 4; return 0xEDB7u;
+    case 4 * 8 + 2: cnt = 6; return 0xCA6953u;
+    case 4 * 8 + 1: cnt = 4; return 0x8421u;
+    default: cnt = 0; return 0u;
+    }
+}
+
+__device__ __forceinline__ int pick4i(const int32_t (&v)[4], int j)
+{
+    return j == 0 ? v[0] : (j == 1 ? v[1] : (j == 2 ? v[2] : v[3]));
+}
+
+// Histogram of pseudo-site p: plain calls have one histogram per site; group calls run one pseudo-site per
+// (site, group) on the per-group histograms [site][n_groups + 1][512].
+__device__ __forceinline__ int64_t hist_index(int64_t p, int n_groups)
+{
+    return n_groups > 0 ? (p / n_groups) * (n_groups + 1) + p % n_groups : p;
+}
+
+// What a level's launch reads and writes (chosen by the host per level: nothing here is indexed dynamically).
+// Lists are laid out by REGION: the 16 sites of a classes/decide workgroup own kSitesPerBlock * per_site[l] places
+// of list l, filled from the front and counted in count_next[l * n_regions + region] -- no atomics, and the fits of
+// a site stay side by side in site order.
+struct LevelIo {
+    const FitOut *outs_prev[kLists];   // fits of the pending level
+    FitItem *items_next[kLists];       // next level's items
+    uint32_t *count_next;              // [kLists][n_regions]
+    int per_site_next[kLists];         // places per site and list at the next level
+    int n_regions;
+};
+
+template <class T>
+__device__ __forceinline__ T sel4(const T (&v)[kLists], int l)
+{
+    return l == 0 ? v[0] : (l == 1 ? v[1] : (l == 2 ? v[2] : v[3]));
+}
+
+// List of a fit: four rows per item for 3-4 alleles, two for 1-2; "slow" when it leaves out the deepest candidate.
+__device__ __forceinline__ int list_of(uint32_t pm, int p_deepest)
+{
+    return (__popc(pm) >= 3 ? 0 : 2) + (((pm >> p_deepest) & 1u) ? 0 : 1);
+}
+
+// Position (in the candidate list) of the deepest candidate, first one on ties.
+__device__ __forceinline__ int deepest_position(const int32_t (&depth)[4], uint32_t blist, int n)
+{
+    int best = 0, best_depth = -1;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int dp = pick4i(depth, (int)((blist >> (4 * p)) & 3u));
+        if (p < n && dp > best_depth) { best_depth = dp; best = p; }
+    }
+    return best;
+}
+
+// Places of a site's new items inside its workgroup's region of each list; the region's counts go to count_next.
+__device__ __forceinline__ void place_items(int wave, int lane, const int (&want)[kLists], const LevelIo &io,
+                                            uint32_t (&at)[kLists])
+{
+    __shared__ int s_want[kSitesPerBlock][kLists];
+    if (lane < kLists) s_want[wave][lane] = sel4(want, lane);
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < kLists; ++l) {
+        uint32_t a = (uint32_t)blockIdx.x * (uint32_t)(kSitesPerBlock * io.per_site_next[l]);
+        for (int w = 0; w < wave; ++w) a += (uint32_t)s_want[w][l];
+        at[l] = a;
+    }
+    if (io.count_next && threadIdx.x < kLists) {
+        int tot = 0;
+        for (int w = 0; w < kSitesPerBlock; ++w) tot += s_want[w][threadIdx.x];
+        io.count_next[threadIdx.x * io.n_regions + blockIdx.x] = (uint32_t)tot;
+    }
+}
+
+__device__ __forceinline__ void count_wanted(uint32_t sets, int n_emit, int p_deepest, int (&want)[kLists])
+{
+    want[0] = want[1] = want[2] = want[3] = 0;
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+        if (c < n_emit) {
+            const int l = list_of((sets >> (4 * c)) & 0xFu, p_deepest);
+            want[0] += l == 0; want[1] += l == 1; want[2] += l == 2; want[3] += l == 3;
+        }
+}
+
+// Emits the fits `sets` (4-bit position masks over S.blist, packed; n_emit of them) of site `site` (wave-uniform).
+__device__ __forceinline__ void emit_items(int64_t site, int lane, ItemSite &S, uint32_t sets, int n_emit, int p_deepest,
+                                           const uint32_t (&at_in)[kLists], const LevelIo &io)
+{
+    const int total_i = S.depth[0] + S.depth[1] + S.depth[2] + S.depth[3];
+    const double inv_n = 1.0 / (double)total_i;
+    uint32_t at0 = at_in[0], at1 = at_in[1], at2 = at_in[2], at3 = at_in[3];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        if (c >= n_emit) break;
+        const uint32_t pm = (sets >> (4 * c)) & 0xFu;
+        const int l = list_of(pm, p_deepest);
+        const uint32_t idx = l == 0 ? at0 : (l == 1 ? at1 : (l == 2 ? at2 : at3));
+        at0 += l == 0; at1 += l == 1; at2 += l == 2; at3 += l == 3;
+        FitItem fi;
+        fi.site = (int32_t)site;
+        int depth_sum = 0, u = 0;
+        uint32_t bases = 0xFFFFFFFFu;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if ((pm >> p) & 1u) {
+                const int b = (S.blist >> (4 * p)) & 3u;
+                bases = (bases & ~(0xFFu << (8 * u))) | ((uint32_t)b << (8 * u));
+                depth_sum += pick4i(S.depth, b);
+                ++u;
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                            // SetAlleleFreq (:25-39)
+            const int b = (bases >> (8 * q)) & 0xFFu;
+            fi.base[q] = (uint8_t)b;
+            fi.f0[q] = q < u ? (double)pick4i(S.depth, b & 3) / (double)depth_sum : 0.0;
+        }
+        fi.e_excl = (double)(total_i - depth_sum);
+        fi.inv_n = inv_n;
+        fi.pad = 0.0;
+        if (lane == 0) sel4(io.items_next, l)[idx] = fi;
+        S.item[c] = (int32_t)((uint32_t)l << 28 | idx);
+    }
+}
+
+__device__ __forceinline__ void store_record(bvc_site_result *dst, const ItemSite &S, int ref, int n, uint32_t blist)
+{
+    bvc_site_result r;
+    const int total_i = S.depth[0] + S.depth[1] + S.depth[2] + S.depth[3];
+    const double depth_total = (double)total_i;
+    r.var_qual = 0.0; r.chi = S.chi; r.depth_total = depth_total; r.lr_alt = S.lr_alt;
+    int n_alt = 0;
+    int a0 = 0, a1 = 0, a2 = 0;
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {                                // src/BaseType.cpp:111-116
+        const int b = (blist >> (4 * p)) & 3;
+        if (p < n && b != ref && n_alt < 3) {
+            const double fr = b == 0 ? S.base_frq[0] : (b == 1 ? S.base_frq[1] : (b == 2 ? S.base_frq[2] : S.base_frq[3]));
+            if (n_alt == 0) { a0 = b; g0 = fr; } else if (n_alt == 1) { a1 = b; g1 = fr; } else { a2 = b; g2 = fr; }
+            ++n_alt;
+        }
+    }
+    r.alt_base[0] = (int8_t)a0; r.alt_base[1] = (int8_t)a1; r.alt_base[2] = (int8_t)a2;
+    r.af[0] = g0; r.af[1] = g1; r.af[2] = g2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r.base_frq[j] = S.base_frq[j];
+        r.depth[j] = S.depth[j];
+        r.kept[j] = (j < n) ? (int8_t)((blist >> (4 * j)) & 3u) : 0;
+    }
+    r.n_passes = S.passes; r.n_alt = (uint8_t)n_alt; r.called = 0;
+    r.n_kept = (uint8_t)n; r.status = 0; r.n_fits = (uint8_t)S.fits;
+    if (n_alt > 0) {                                             // src/BaseType.cpp:117-135
+        const double rr = (double)pick4i(S.depth, (int)(blist & 3u)) / depth_total;
+        if (n == 1 && depth_total > 10 && rr > 0.5) r.var_qual = 5000.0;
+        else if (S.chi <= 0) r.var_qual = 0.0;
+        else r.var_qual = kVarQualPending;                       // chisf(chi, 1): finished by var_qual_kernel
+        r.called = 1;
+    }
+    *dst = r;
+}
+
+// ---- classes_kernel: one wavefront per site -------------------------------------------------------------------
+// Compacts the non-empty classes of each allele (ascending quality) into the site's table for fit_kernel: class c of
+// allele b at [b][c] of the planes n and e = eps / 3 (empty places: n = 0, e = 1/4, whose marginal f + (1 - 4 f) e
+// is 1/4 whatever f: weight 0 in every sum and harmless in the product of a lane's marginals).  Then the head of BaseType::LRT
+// (src/BaseType.cpp:75-88): candidates by min_af, and the first level's items: the full model and, because they
+// depend on nothing but the candidate list, its (n-1)-subsets.
+__global__ __launch_bounds__(64 * kSitesPerBlock) void classes_kernel(
+    int64_t n_sites, int n_groups, const uint32_t *__restrict__ counts, int64_t hist_stride,
+    const QualLut *__restrict__ lut, const int8_t *__restrict__ ref_base, double min_af,
+    const int8_t *__restrict__ comb, const uint8_t *__restrict__ n_comb, ItemSite *__restrict__ sites,
+    double *__restrict__ cls, uint8_t *__restrict__ taken, LevelIo io, bvc_site_result *__restrict__ results)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t site = (int64_t)blockIdx.x * kSitesPerBlock + wave;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int row = lane >> 4, t = lane & 15;
+    const bool in_range = site < n_sites;
+    ItemSite S{};
+    uint32_t sets = 0;
+    int n_emit = 0, p_deepest = 0;
+    bool mine = false, finished = false;
+
+    if (in_range) {
+        const uint32_t *hist = counts + hist_index(site, n_groups) * hist_stride;
+        double *tab = cls + site * kSiteTable + row * kClassesPerBase;
+        int cnt_row = 0, depth_lane = 0;
+        bool low_q = false;
+#pragma unroll
+        for (int lvl = 0; lvl < 8; ++lvl) {
+            const int q = t + 16 * lvl;
+            const uint32_t c = hist[row * 128 + q];
+            const uint64_t nzmask = __ballot(c != 0);
+            const uint32_t rowbits = (uint32_t)(nzmask >> (16 * row)) & 0xFFFFu;
+            if (c != 0) {
+                const int pos = cnt_row + __popc(rowbits & ((1u << t) - 1u));
+                if (pos < kClassesPerBase) {
+                    tab[pos] = (double)c;
+                    tab[kPlane + pos] = lut->e[q];
+                }
+                low_q |= q < 2;
+            }
+            cnt_row += __popc(rowbits);
+            depth_lane += (int)c;
+        }
+        // the places this allele leaves empty
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int pos = t + 16 * half;
+            if (pos >= cnt_row) {
+                tab[pos] = 0.0;
+                tab[kPlane + pos] = kEmptyE;
+            }
+        }
+        const int depth_row = row_sum(depth_lane);
+        S.depth[0] = __builtin_amdgcn_readlane(depth_row, 0);
+        S.depth[1] = __builtin_amdgcn_readlane(depth_row, 16);
+        S.depth[2] = __builtin_amdgcn_readlane(depth_row, 32);
+        S.depth[3] = __builtin_amdgcn_readlane(depth_row, 48);
+        const bool too_wide = __ballot(cnt_row > kClassesPerBase) != 0;
+        const bool any_low = __ballot(low_q) != 0;
+
+        const int total_i = S.depth[0] + S.depth[1] + S.depth[2] + S.depth[3];
+        const double depth_total = (double)total_i;
+        uint32_t blist = 0;
+        int n = 0;
+        bool dup = false;
+        if (total_i > 0) {                                       // src/BaseType.cpp:75
+            uint32_t list = 0x3210u;                             // default base_comb, src/BaseType.h:79
+            int nc = 4;
+            if (comb) {
+                const int want_c = min((int)n_comb[site], 4);
+                list = 0; nc = 0;
+                for (int c = 0; c < want_c; ++c) {
+                    const int b = comb[site * 4 + c];
+                    if ((unsigned)b < 4u) { list |= (uint32_t)b << (4 * nc); ++nc; }
+                }
+            }
+            uint32_t seen = 0;
+            for (int c = 0; c < nc; ++c) {                       // src/BaseType.cpp:77-83
+                const int b = (list >> (4 * c)) & 3;
+                if ((double)pick4i(S.depth, b) / depth_total >= min_af) {
+                    dup |= ((seen >> b) & 1u) != 0;
+                    seen |= 1u << b;
+                    blist |= (uint32_t)b << (4 * n);
+                    ++n;
+                }
+            }
+        }
+        mine = !(too_wide || any_low || dup);
+        S.blist = blist; S.n = (int8_t)n; S.k = (int8_t)n; S.first = 1;
+        S.state = mine ? 1 : 0;
+        if (mine) {
+            if (n == 0) {
+                finished = true;                                 // :75, :84
+            } else {
+                int cnt = 0;
+                sets = (1u << n) - 1u;                           // the full model (:88)
+                n_emit = 1;
+                if (n >= 2) {
+                    const uint32_t masks = subset_masks(n, n - 1, cnt);
+                    sets |= masks << 4;
+                    n_emit += cnt;
+                }
+                p_deepest = deepest_position(S.depth, blist, n);
+            }
+        }
+    }
+
+    int want[kLists];
+    count_wanted(sets, n_emit, p_deepest, want);
+    uint32_t at[kLists];
+    place_items(wave, lane, want, io, at);
+    if (!in_range) return;
+    if (mine && n_emit > 0) emit_items(site, lane, S, sets, n_emit, p_deepest, at, io);
+    if (lane == 0) {
+        if (finished) {
+            store_record(results + site, S, (int)ref_base[n_groups > 0 ? site / n_groups : site], S.n, S.blist);
+            S.state = 2;
+        }
+        sites[site] = S;
+        taken[site] = mine ? 1 : 0;
+    }
+}
+
+// ---- fit_kernel: 64 / (ROWS * G) items per wavefront ------------------------------------------------------------------
+// An item takes ROWS DPP rows x G lanes: unit (allele) = row (ROWS = 4) or row & 1 (ROWS = 2: the row pairs (0,1) and
+// (2,3) hold items of their own); the G = 2^LOG2G lanes of a unit split the allele's 32 class places, 32 / G each.
+
+// 1 / x: v_rcp_f64 (about 2^-26) and one third-order step, y (1 + t + t^2) with t = 1 - x y: residual t^3.
+__device__ __forceinline__ double rcp_cubic(double x)
+{
+    const double y = __builtin_amdgcn_rcp(x);
+    const double t = fma(-x, y, 1.0);
+    return fma(y, fma(t, t, t), y);
+}
+
+// y[i] = 1 / m[i] for N positive values from one reciprocal: products up a binary tree, 1 / (m_0 ... m_{N-1}), and
+// down again each node's reciprocal = parent's reciprocal x sibling.  3 (N - 1) multiplications + one rcp_cubic.
+template <int N>
+__device__ __forceinline__ void rcp_all(const double (&m)[N], double (&y)[N])
+{
+    if constexpr (N == 1) {
+        y[0] = rcp_cubic(m[0]);
+    } else {
+        double p[N / 2], q[N / 2];
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) p[i] = m[2 * i] * m[2 * i + 1];
+        rcp_all<N / 2>(p, q);
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            y[2 * i] = q[i] * m[2 * i + 1];
+            y[2 * i + 1] = q[i] * m[2 * i];
+        }
+    }
+}
+
+// Sum over the G lanes of a unit, result in each of them.
+template <int LOG2G>
+__device__ __forceinline__ double unit_sum(double v)
+{
+    v += dpp_f64<kDppXor1>(v);
+    if (LOG2G >= 2) v += dpp_f64<kDppXor2>(v);
+    if (LOG2G >= 3) v += dpp_f64<kDppHalfMirror>(v);
+    return v;
+}
+
+// Sum over the lanes of an item of x, and of y, both delivered to every lane of the item.
+template <int ROWS, int LOG2G>
+__device__ __forceinline__ void item_sum2(double &x, double &y)
+{
+    double v;
+    if (ROWS == 4) {
+        const DPair h = swap32(x, y);          // lower half: x over rows (r, r + 2); upper half: y
+        v = h.a + h.b;
+        const DPair g = swap16(v, v);          // + the neighbouring row
+        v = g.a + g.b;
+    } else {
+        const DPair g = swap16(x, y);          // even rows: x over the row pair; odd rows: y
+        v = g.a + g.b;
+    }
+    v = unit_sum<LOG2G>(v);
+    const DPair b = ROWS == 4 ? swap32(v, v) : swap16(v, v);
+    x = b.a;
+    y = b.b;
+}
+
+template <int ROWS, int LOG2G>
+__device__ __forceinline__ double item_sum(double x)
+{
+    if (ROWS == 4) {
+        const DPair h = swap32(x, x);
+        x = h.a + h.b;
+    }
+    const DPair g = swap16(x, x);
+    x = g.a + g.b;
+    return unit_sum<LOG2G>(x);
+}
+
+template <int ROWS, int LOG2G>
+__device__ __forceinline__ void fit_body(int64_t item0, int64_t item_end, const FitItem *__restrict__ items,
+                                         FitOut *__restrict__ outs, const double *__restrict__ cls)
+{
+    constexpr int G = 1 << LOG2G, kSlots = kClassesPerBase / G;
+    constexpr int kGroupsPerRow = 16 / G;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int row = lane >> 4, sub = lane & (G - 1), grp = (lane & 15) >> LOG2G;
+    const int unit = ROWS == 4 ? row : (row & 1);
+    const int64_t item = item0 + (ROWS == 4 ? grp : (row >> 1) * kGroupsPerRow + grp);
+    const bool valid = item < item_end;
+
+    double n[kSlots], e[kSlots];
+    double fb = 0.0, e_excl = 0.0, fb_scale = 0.0;
+    bool active = false;
+    if (valid) {
+        const FitItem *fi = items + item;
+        const int base = fi->base[unit];
+        e_excl = fi->e_excl;
+        fb_scale = fi->inv_n;
+        if (base != 0xFF) {
+            active = true;
+            fb = fi->f0[unit];
+            const double *tab = cls + (int64_t)fi->site * kSiteTable + base * kClassesPerBase + sub;
+#pragma unroll
+            for (int k = 0; k < kSlots; ++k) {
+                n[k] = tab[k * G];
+                e[k] = tab[kPlane + k * G];
+            }
+        }
+    }
+    if (!active) {
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) { n[k] = 0.0; e[k] = kEmptyE; }
+    }
+
+    // EM (src/Algorithm.cpp:115-130): pass 0, then at most kEmIters passes each followed by the stop rule.  An item
+    // that stops writes its fit at once and runs on (its lanes are not masked: the passes of a converged fit are
+    // ordinary arithmetic, and nothing of it is read again).
+    double fprev = fb, dprev = 0.0;
+    int it = 0;
+    bool done = !valid;
+    while (true) {
+        // stop-rule bracket of THIS pass: A = sum_b |f_b - f_b(previous pass)| D_b(previous pass), lane partial
+        double ta = fabs(fb - fprev) * dprev;
+        const double g = fma(-4.0, fb, 1.0);
+        double m[kSlots], y[kSlots];
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) m[k] = fma(g, e[k], fb);      // class marginal f + (1 - 4 f) e
+        rcp_all<kSlots>(m, y);
+        double ysum0 = 0.0, ysum1 = 0.0, acc_e0 = 0.0, acc_e1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < kSlots; k += 2) {
+            const double r0 = n[k] * y[k], r1 = n[k + 1] * y[k + 1];
+            ysum0 += r0; ysum1 += r1;
+            acc_e0 = fma(r0, e[k], acc_e0); acc_e1 = fma(r1, e[k + 1], acc_e1);
+        }
+        const double acc_e = acc_e0 + acc_e1;
+        const double acc_d = fma(-4.0, acc_e, ysum0 + ysum1);   // sum n d / m with d = 1 - 4 e
+        double etot = acc_e;
+        item_sum2<ROWS, LOG2G>(etot, ta);
+        const double dunit = unit_sum<LOG2G>(acc_d);            // D of the lane's allele
+        const double ex = (fb * fb_scale) * (dunit + (etot + e_excl));   // expect_allele_prob (src/Algorithm.cpp:84-91)
+        const uint32_t a_hi = (uint32_t)__double2hiint(ta);
+        bool conv = it > 0 && a_hi < kSureBelowHi;
+        const bool straddle = !done && it > 0 && a_hi >= kSureBelowHi && a_hi < kSureAboveHi;
+        if (__ballot(straddle) != 0) {
+            // rare: delta itself.  u = m' / m - 1 = (f' - f) d / m per class, log1p as a cubic (|u| < 2^-9 here)
+            double dl = 0.0;
+            const double df = fb - fprev, gp = fma(-4.0, fprev, 1.0);
+#pragma unroll
+            for (int k = 0; k < kSlots; ++k) {
+                const double mo = fma(gp, e[k], fprev);
+                const double u = df * fma(-4.0, e[k], 1.0) * rcp_cubic(mo);
+                double p = fma(-0.25, u, 1.0 / 3.0);
+                p = fma(p, u, -0.5);
+                p = fma(p, u, 1.0);
+                dl = fma(n[k], fabs(u * p), dl);
+            }
+            dl = item_sum<ROWS, LOG2G>(dl);
+            conv = conv || (straddle && dl < kEmEpsilon);
+        }
+        const bool stop = !done && (conv || it == kEmIters);
+        if (__ballot(stop) != 0) {
+            if (stop && sub == 0) {                              // fb is the frequency this last pass ran on
+                FitOut *o = outs + item;
+                o->ex[unit] = active ? ex : 0.0;
+                o->fl[unit] = active ? fb : 0.0;
+                if (ROWS == 2) { o->ex[unit + 2] = 0.0; o->fl[unit + 2] = 0.0; }
+                if (unit == 0) { o->passes = it + 1; o->pad = 0; }
+            }
+            done = done || stop;
+            if (__ballot(!done) == 0) break;
+        }
+        fprev = fb;
+        dprev = acc_d;
+        fb = ex;
+        ++it;
+    }
+}
+
+// Lanes per allele of the two item shapes, and the wavefronts a region of 16 sites needs per list and level
+// (kCaps places per site, 64 / (ROWS G) items per wavefront).
+constexpr int kLog2G4 = 1, kLog2G2 = 1;
+constexpr int kPerWave4 = 16 >> kLog2G4, kPerWave2 = 2 * (16 >> kLog2G2);
+// places a site can have per level and list: level A = full model + (n-1)-subsets, B and C = the nested levels
+constexpr int kCaps[kLevels][kLists] = {{4, 1, 2, 1}, {0, 0, 2, 1}, {0, 0, 1, 1}};
+constexpr int region_waves(int level, int l)
+{
+    return (kSitesPerBlock * kCaps[level][l] + (l < 2 ? kPerWave4 : kPerWave2) - 1) / (l < 2 ? kPerWave4 : kPerWave2);
+}
+
+struct FitLists {
+    const uint32_t *count;               // [kLists][n_regions]
+    const FitItem *items[kLists];
+    FitOut *outs[kLists];
+    int wave_end[kLists];                // wavefronts per region, exclusive prefix over the lists
+    int per_site[kLists];
+    int n_regions;
+};
+
+// All lists of a level in one launch: wavefront w serves region w / waves_per_region, and within it one list.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void fit_kernel(FitLists fl, const double *__restrict__ cls)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+    const int per_region = fl.wave_end[kLists - 1];
+    const int region = (int)(w / per_region), slot = (int)(w % per_region);
+    if (region >= fl.n_regions) return;
+    const int l = slot < fl.wave_end[0] ? 0 : (slot < fl.wave_end[1] ? 1 : (slot < fl.wave_end[2] ? 2 : 3));
+    const int in_list = slot - (l == 0 ? 0 : (l == 1 ? fl.wave_end[0] : (l == 2 ? fl.wave_end[1] : fl.wave_end[2])));
+    const int64_t base = (int64_t)region * (kSitesPerBlock * sel4(fl.per_site, l));
+    const int64_t first = base + (int64_t)in_list * (l < 2 ? kPerWave4 : kPerWave2);
+    const int64_t end = base + fl.count[l * fl.n_regions + region];
+    if (first >= end) return;
+    if (l < 2) fit_body<4, kLog2G4>(first, end, sel4(fl.items, l), sel4(fl.outs, l), cls);
+    else fit_body<2, kLog2G2>(first, end, sel4(fl.items, l), sel4(fl.outs, l), cls);
+}
+
+// ---- decide_kernel: one wavefront per site, one level of BaseType::LRT per launch -----------------------------------
+// Reads the fits of the pending level, sums their log-likelihoods (UpdateF, src/BaseType.cpp:58-62: all 128 class
+// places of the site, the alleles outside a subset with f = 0), takes the reference's decision (:93-110) and either
+// emits the next level's items or writes the record.
+__global__ __launch_bounds__(64 * kSitesPerBlock) void decide_kernel(
+    int64_t n_sites, int n_groups, const int8_t *__restrict__ ref_base, ItemSite *__restrict__ sites,
+    const double *__restrict__ cls, LevelIo io, bvc_site_result *__restrict__ results)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t site = (int64_t)blockIdx.x * kSitesPerBlock + wave;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int row = lane >> 4, t = lane & 15;
+    const bool in_range = site < n_sites;
+    ItemSite S{};
+    if (in_range) S = sites[site];
+    const bool running = in_range && S.state == 1;
+    uint32_t sets = 0;
+    int n_emit = 0, p_deepest = 0;
+    bool finished = false;
+
+    if (running) {
+        // the lane's two classes of allele `row`: places t and t + 16
+        const double *tab = cls + site * kSiteTable + row * kClassesPerBase + t;
+        const double n0 = tab[0], e0 = tab[kPlane];
+        const double n1 = tab[16], e1 = tab[kPlane + 16];
+        // position of allele `row` in the candidate list (or none)
+        int my_pos = -1;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (p < S.n && (int)((S.blist >> (4 * p)) & 3u) == row) my_pos = p;
+
+        auto fit_loglik = [&](int enc, uint32_t pm, double (&ex)[4], int &passes) -> double {
+            const FitOut *o = sel4(io.outs_prev, (enc >> 28) & 3) + (enc & 0x0FFFFFFF);
+            double fl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ex[u] = o->ex[u]; fl[u] = o->fl[u]; }
+            passes = o->passes;
+            // the lane's allele: unit = rank of its position among the subset's positions
+            double f = 0.0;
+            if (my_pos >= 0 && ((pm >> my_pos) & 1u)) {
+                const int u = __popc(pm & ((1u << my_pos) - 1u));
+                f = u == 0 ? fl[0] : (u == 1 ? fl[1] : (u == 2 ? fl[2] : fl[3]));
+            }
+            const double g = fma(-4.0, f, 1.0);                  // class marginal as fit_kernel forms it
+            double l = n0 * log_pos(fma(g, e0, f));
+            l = fma(n1, log_pos(fma(g, e1, f)), l);
+            return rows_total(row_sum(l));
+        };
+        // expect_allele_prob by allele from the per-unit values of a fit
+        auto by_base = [&](uint32_t pm, const double (&ex)[4], double (&bp)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bp[j] = 0.0;
+            int u = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if ((pm >> p) & 1u) {
+                    const int b = (S.blist >> (4 * p)) & 3u;
+                    const double v = u == 0 ? ex[0] : (u == 1 ? ex[1] : (u == 2 ? ex[2] : ex[3]));
+                    bp[0] = b == 0 ? v : bp[0]; bp[1] = b == 1 ? v : bp[1];
+                    bp[2] = b == 2 ? v : bp[2]; bp[3] = b == 3 ? v : bp[3];
+                    ++u;
+                }
+        };
+
+        int first_sub = 0;
+        if (S.first) {                                           // the full model (:88-90)
+            double ex[4];
+            int passes = 0;
+            S.lr_alt = fit_loglik(S.item[0], (1u << S.n) - 1u, ex, passes);
+            by_base((1u << S.n) - 1u, ex, S.base_frq);
+            S.passes += passes; S.fits += 1;
+            first_sub = 1;
+            S.k = (int8_t)(S.n - 1);
+            S.first = 0;
+        }
+        const int n = S.n, k = S.k;
+        if (k < 1) {
+            finished = true;                                     // n == 1: no nested level
+        } else {
+            int cnt = 0;
+            const uint32_t masks = subset_masks(n, k, cnt);
+            int i_min = 0;
+            double best_chi = 0.0, best_lr = 0.0, best_bp[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c >= cnt) break;
+                const uint32_t pm = (masks >> (4 * c)) & 0xFu;
+                const int enc = first_sub ? S.item[c + 1] : S.item[c];
+                double ex[4];
+                int passes = 0;
+                const double ll = fit_loglik(enc, pm, ex, passes);
+                S.passes += passes; S.fits += 1;
+                const double chi_c = 2.0 * (S.lr_alt - ll);
+                if (c == 0 || chi_c < best_chi) {                // std::min_element: first minimum, '<'
+                    best_chi = chi_c; best_lr = ll; i_min = c;
+                    by_base(pm, ex, best_bp);
+                }
+            }
+            S.lr_alt = best_lr;                                  // overwritten before the threshold test (:100-101)
+            S.chi = best_chi;
+            if (best_chi < kLrtThreshold) {
+                const uint32_t pm = (masks >> (4 * i_min)) & 0xFu;
+                uint32_t nl = 0;
+                int nn = 0;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if ((pm >> p) & 1u) { nl |= ((S.blist >> (4 * p)) & 3u) << (4 * nn); ++nn; }
+                S.blist = nl;
+                S.n = (int8_t)k;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) S.base_frq[j] = best_bp[j];
+                S.k = (int8_t)(k - 1);
+                if (k - 1 >= 1) {
+                    sets = subset_masks(k, k - 1, n_emit);
+                    p_deepest = deepest_position(S.depth, nl, k);
+                } else {
+                    finished = true;
+                }
+            } else {
+                finished = true;
+            }
+        }
+    }
+
+    int want[kLists];
+    count_wanted(sets, n_emit, p_deepest, want);
+    uint32_t at[kLists];
+    place_items(wave, lane, want, io, at);
+    if (!running) return;
+    if (n_emit > 0 && io.count_next) emit_items(site, lane, S, sets, n_emit, p_deepest, at, io);
+    if (lane == 0) {
+        if (finished) {
+            store_record(results + site, S, (int)ref_base[n_groups > 0 ? site / n_groups : site], S.n, S.blist);
+            S.state = 2;
+        }
+        sites[site] = S;
+    }
+}
+
+}  // namespace
+
+static int64_t item_regions(int64_t n_sites) { return (n_sites + kSitesPerBlock - 1) / kSitesPerBlock; }
+
+size_t em_items_scratch_bytes(int64_t n_sites)
+{
+    // region counters | ItemSite | taken | class tables | items and outputs of the three levels
+    const size_t regions = (size_t)item_regions(n_sites), padded = regions * kSitesPerBlock;
+    size_t b = regions * kLevels * kLists * sizeof(uint32_t) + 256;
+    b += (size_t)n_sites * sizeof(ItemSite) + 256;
+    b += (size_t)n_sites + 256;
+    b += (size_t)n_sites * kSiteTable * sizeof(double) + 256;
+    size_t per_site_items = 0;
+    for (int lv = 0; lv < kLevels; ++lv)
+        for (int l = 0; l < kLists; ++l) per_site_items += kCaps[lv][l];
+    b += padded * per_site_items * (sizeof(FitItem) + sizeof(FitOut)) + 2 * 256 * kLevels * kLists;
+    return b;
+}
+
+// Stage 2 with the item engine.  `scratch` holds em_items_scratch_bytes(n_sites).  Sites it does not take are left
+// to the one-wavefront-per-site kernels, which skip the others (`taken`).
+hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n_sites, int n_groups,
+                            const uint32_t *counts, int64_t hist_stride, const int8_t *ref_base, double min_af,
+                            const QualLut *lut, const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results,
+                            void *scratch, const uint8_t **taken_out)
+{
+    (void)st;
+    const int64_t regions = item_regions(n_sites);
+    char *p = static_cast<char *>(scratch);
+    auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
+    uint32_t *count = reinterpret_cast<uint32_t *>(take((size_t)regions * kLevels * kLists * sizeof(uint32_t)));
+    ItemSite *sites = reinterpret_cast<ItemSite *>(take((size_t)n_sites * sizeof(ItemSite)));
+    uint8_t *taken = reinterpret_cast<uint8_t *>(take((size_t)n_sites));
+    double *cls = reinterpret_cast<double *>(take((size_t)n_sites * kSiteTable * sizeof(double)));
+    FitItem *items[kLevels][kLists];
+    FitOut *outs[kLevels][kLists];
+    for (int lv = 0; lv < kLevels; ++lv)
+        for (int l = 0; l < kLists; ++l) {
+            const size_t n = (size_t)regions * kSitesPerBlock * kCaps[lv][l];
+            items[lv][l] = reinterpret_cast<FitItem *>(take(n * sizeof(FitItem)));
+            outs[lv][l] = reinterpret_cast<FitOut *>(take(n * sizeof(FitOut)));
+        }
+    auto level_io = [&](int level) {                              // what the launch after `level` fit levels reads and writes
+        LevelIo io{};
+        for (int l = 0; l < kLists; ++l) {
+            io.outs_prev[l] = level > 0 ? outs[level - 1][l] : nullptr;
+            io.items_next[l] = level < kLevels ? items[level][l] : nullptr;
+            io.per_site_next[l] = level < kLevels ? kCaps[level][l] : 0;
+        }
+        io.count_next = level < kLevels ? count + (size_t)level * kLists * regions : nullptr;
+        io.n_regions = (int)regions;
+        return io;
+    };
+    const dim3 sgrid((unsigned)regions), sblock(64 * kSitesPerBlock);
+    hipLaunchKernelGGL(classes_kernel, sgrid, sblock, 0, stream, n_sites, n_groups, counts, hist_stride, lut, ref_base,
+                       min_af, comb, n_comb, sites, cls, taken, level_io(0), results);
+    for (int level = 0; level < kLevels; ++level) {
+        FitLists fl{};
+        fl.count = count + (size_t)level * kLists * regions;
+        fl.n_regions = (int)regions;
+        int end = 0;
+        for (int l = 0; l < kLists; ++l) {
+            end += region_waves(level, l);
+            fl.wave_end[l] = end;
+            fl.per_site[l] = kCaps[level][l];
+            fl.items[l] = items[level][l];
+            fl.outs[l] = outs[level][l];
+        }
+        const int64_t waves = regions * end;
+        hipLaunchKernelGGL(fit_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, fl, cls);
+        hipLaunchKernelGGL(decide_kernel, sgrid, sblock, 0, stream, n_sites, n_groups, ref_base, sites, cls,
+                           level_io(level + 1), results);
+    }
+    *taken_out = taken;
+    return hipGetLastError();
+}
+
+}  // namespace bvc

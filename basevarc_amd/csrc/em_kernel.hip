@@ -248,7 +248,8 @@ __device__ __forceinline__ void wave_lds_sync()
 // The whole per-site computation for one wavefront.  `hist` points at 512 class counts.
 // comb_list: candidate bases packed 4 bits each in SetBase order; n_comb entries.
 // Returns false (and leaves `out` untouched) when the site needs a different NS variant.
-template <int NS, int WPB>
+// ANY: the variant takes every site whatever its quality spectrum (the remainder launch behind the item engine).
+template <int NS, int WPB, bool ANY = false>
 __device__ bool lrt_site(const uint32_t *__restrict__ hist, int ref, double min_af,
                          uint32_t comb_list, int n_comb, const QualLut *__restrict__ lut,
                          uint32_t *s_n, uint8_t *s_q, SiteOut &out)
@@ -282,7 +283,7 @@ __device__ bool lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
                      max(__builtin_amdgcn_readlane(cnt_row, 32), __builtin_amdgcn_readlane(cnt_row, 48)));
     const int nslots = (maxcnt + 15) >> 4;
     // variant gate (wave-uniform): NS = 2 takes 0..2 slots, NS = 4 takes 3..4, NS = 8 takes 5..8
-    if (nslots > NS || (NS > 2 && nslots <= NS / 2)) return false;
+    if (nslots > NS || (!ANY && NS > 2 && nslots <= NS / 2)) return false;
     wave_lds_sync<WPB>();                      // the wave's own LDS writes above, read back below
 
     Slots<NS> S;
@@ -445,12 +446,13 @@ __device__ __forceinline__ void store_result(bvc_site_result *dst, const SiteOut
 // 0.57 -> 0.48 ms per 4000 sites alone, 1.25 -> 1.19 ms underneath the histogram kernel at 8 waves per CU.
 // The wave index is made scalar (readfirstlane): the site state then lives in SGPRs and branches stay scalar;
 // derived from threadIdx directly it is "divergent" to the compiler and the kernel needs 116 instead of 76 VGPRs.
-template <int NS, int WPB>
+template <int NS, int WPB, bool ANY = false>
 __global__ __launch_bounds__(64 * WPB) void lrt_kernel(int64_t n_sites, const uint32_t *__restrict__ counts,
                                                  int64_t hist_stride, const int8_t *__restrict__ ref_base,
                                                  double min_af, const QualLut *__restrict__ lut,
                                                  const int8_t *__restrict__ comb,
                                                  const uint8_t *__restrict__ n_comb,
+                                                 const uint8_t *__restrict__ taken,
                                                  bvc_site_result *__restrict__ results)
 {
     __shared__ uint32_t s_n_all[WPB][512];
@@ -461,6 +463,7 @@ __global__ __launch_bounds__(64 * WPB) void lrt_kernel(int64_t n_sites, const ui
     // holds only a few wave slots per SIMD and the HBM-bound histogram kernel of the next tile, which runs
     // at the same time in overlap mode, keeps its occupancy.
     for (int64_t site = (int64_t)blockIdx.x * WPB + wave; site < n_sites; site += (int64_t)gridDim.x * WPB) {
+        if (taken && taken[site]) continue;                      // the item engine (em_items.hip) has this site
         uint32_t *s_n = s_n_all[wave];
         uint8_t *s_q = s_q_all[wave];
         uint32_t list = 0x3210u;                                 // default base_comb, src/BaseType.h:79
@@ -476,19 +479,20 @@ __global__ __launch_bounds__(64 * WPB) void lrt_kernel(int64_t n_sites, const ui
             }
         }
         SiteOut o;
-        const bool mine = lrt_site<NS, WPB>(counts + site * hist_stride, ref_base[site], min_af, list, nc, lut, s_n, s_q, o);
+        const bool mine = lrt_site<NS, WPB, ANY>(counts + site * hist_stride, ref_base[site], min_af, list, nc, lut, s_n, s_q, o);
         if (mine && (threadIdx.x & 63) == 0) store_result(results + site, o);
         wave_lds_sync<WPB>();                                    // s_n / s_q are reused by the next site
     }
 }
 
 // Caller's --group loop (src/BaseVarC.cpp:617-661): one wavefront per (site, group).
-template <int NS, int WPB>
+template <int NS, int WPB, bool ANY = false>
 __global__ __launch_bounds__(64 * WPB) void lrt_groups_kernel(int64_t n_sites, int n_groups,
                                                         const uint32_t *__restrict__ grp_counts,
                                                         const int8_t *__restrict__ ref_base, double min_af,
                                                         const QualLut *__restrict__ lut,
                                                         const bvc_site_result *__restrict__ overall,
+                                                        const uint8_t *__restrict__ taken,
                                                         bvc_group_result *__restrict__ grp_results)
 {
     __shared__ uint32_t s_n_all[WPB][512];
@@ -499,6 +503,7 @@ __global__ __launch_bounds__(64 * WPB) void lrt_groups_kernel(int64_t n_sites, i
     uint8_t *s_q = s_q_all[wave];
     const int64_t n_work = n_sites * n_groups;
     for (int64_t w = (int64_t)blockIdx.x * WPB + wave; w < n_work; w += (int64_t)gridDim.x * WPB) {
+        if (taken && taken[w]) continue;                         // the item engine (em_items.hip) has this (site, group)
         const int64_t site = w / n_groups;
         const int g = (int)(w % n_groups);
         const uint32_t *hist = grp_counts + (site * (n_groups + 1) + g) * BVC_NCLASS;
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(64 * WPB) void lrt_groups_kernel(int64_t n_sites, i
             // Not called overall: no group run at all (:633-636), only the depth columns na:nc:ng:nt (:640).  One
             // variant writes them from a plain sum of the histogram rows; the others have nothing to do here.  (Four
             // sites in five are like this: no compaction, no ballots, and two of the three variants touch no memory.)
-            if (NS == 2) {
+            if (NS == 2 || ANY) {
                 const int lane = threadIdx.x & 63, row = lane >> 4, t = lane & 15;
                 int d = 0;
 #pragma unroll
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(64 * WPB) void lrt_groups_kernel(int64_t n_sites, i
             if (i < ov.n_alt) { list |= (uint32_t)(ov.alt_base[i] & 3) << (4 * nc); ++nc; }
         SiteOut o;
         // called overall: the group's own LRT, when it has covered samples (:641; lrt_site returns at once otherwise)
-        const bool mine = lrt_site<NS, WPB>(hist, ref, min_af, list, nc, lut, s_n, s_q, o);
+        const bool mine = lrt_site<NS, WPB, ANY>(hist, ref, min_af, list, nc, lut, s_n, s_q, o);
         if (mine && (threadIdx.x & 63) == 0) {
             bvc_group_result r;
             for (int j = 0; j < 4; ++j) r.depth[j] = o.depth[j];
@@ -583,6 +588,53 @@ __global__ void sum_groups_kernel(int64_t total, int n_hist, const uint32_t *__r
     counts[i] = s;
 }
 
+// Group mode through the item engine: every (site, group) is a pseudo-site with SetBase({ref} + alt_bases) when the
+// site was called overall (src/BaseVarC.cpp:614-615, 642-644) and no candidate at all otherwise (:633-636).
+__global__ void group_comb_kernel(int64_t n_pseudo, int n_groups, const int8_t *__restrict__ ref_base,
+                                  const bvc_site_result *__restrict__ overall, int8_t *__restrict__ comb,
+                                  uint8_t *__restrict__ n_comb)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pseudo) return;
+    const int64_t site = p / n_groups;
+    int nc = 0;
+    int8_t list[4] = {0, 0, 0, 0};
+    if (overall[site].called) {
+        const int ref = ref_base[site];
+        if ((unsigned)ref < 4u) list[nc++] = (int8_t)ref;
+        const int n_alt = overall[site].n_alt;
+        for (int i = 0; i < 3; ++i)
+            if (i < n_alt) list[nc++] = (int8_t)(overall[site].alt_base[i] & 3);
+    }
+    for (int c = 0; c < 4; ++c) comb[p * 4 + c] = list[c];
+    n_comb[p] = (uint8_t)nc;
+}
+
+// The group record of a pseudo-site the item engine took, from its site-style record (:640-652).
+__global__ void group_records_kernel(int64_t n_pseudo, int n_groups, const bvc_site_result *__restrict__ overall,
+                                     const bvc_site_result *__restrict__ pseudo, const uint8_t *__restrict__ taken,
+                                     bvc_group_result *__restrict__ grp_results)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pseudo || !taken[p]) return;
+    const int64_t site = p / n_groups;
+    const bvc_site_result t = pseudo[p];
+    bvc_group_result r;
+    for (int j = 0; j < 4; ++j) r.depth[j] = t.depth[j];
+    for (int j = 0; j < 6; ++j) r.pad[j] = 0;
+    for (int j = 0; j < 3; ++j) r.af[j] = 0.0;
+    r.ran = 0; r.present = 0;
+    if (overall[site].called) {
+        r.ran = t.depth_total > 0 ? 1 : 0;
+        const int n_alt = overall[site].n_alt;
+        for (int i = 0; i < 3; ++i)
+            if (r.ran && i < n_alt)
+                for (int tt = 0; tt < 3; ++tt)
+                    if (tt < t.n_alt && t.alt_base[tt] == overall[site].alt_base[i]) { r.af[i] = t.af[tt]; r.present |= (uint8_t)(1u << i); }
+    }
+    grp_results[p] = r;
+}
+
 }  // namespace
 
 // Waves the EM kernels keep on the chip.  `shared` = the launch runs underneath a streaming histogram kernel
@@ -605,29 +657,44 @@ static int64_t em_grid_cap(const LaunchState &st, bool shared, int shared_waves_
 template <int WPB>
 static void launch_lrt_variants(hipStream_t stream, int64_t want_waves, int64_t n_sites,
                                 const uint32_t *counts, int64_t hist_stride, const int8_t *ref_base, double min_af,
-                                const QualLut *lut, const int8_t *comb, const uint8_t *n_comb,
+                                const QualLut *lut, const int8_t *comb, const uint8_t *n_comb, const uint8_t *taken,
                                 bvc_site_result *results)
 {
-    // Every variant visits every site; a wave skips a site at once when it belongs to another variant.
     const dim3 grid((unsigned)((want_waves + WPB - 1) / WPB)), block(64 * WPB);
+    if (taken) {
+        // behind the item engine: the few sites it left (wide quality spectra, qualities 0 and 1, ...) in ONE launch of
+        // the widest variant, which narrows itself to the slots a site fills
+        hipLaunchKernelGGL((lrt_kernel<8, WPB, true>), grid, block, 0, stream, n_sites, counts, hist_stride, ref_base,
+                           min_af, lut, comb, n_comb, taken, results);
+        return;
+    }
+    // Every variant visits every site; a wave skips a site at once when it belongs to another variant.
     hipLaunchKernelGGL((lrt_kernel<2, WPB>), grid, block, 0, stream, n_sites, counts, hist_stride, ref_base,
-                       min_af, lut, comb, n_comb, results);
+                       min_af, lut, comb, n_comb, taken, results);
     hipLaunchKernelGGL((lrt_kernel<4, WPB>), grid, block, 0, stream, n_sites, counts, hist_stride, ref_base, min_af,
-                       lut, comb, n_comb, results);
+                       lut, comb, n_comb, taken, results);
     hipLaunchKernelGGL((lrt_kernel<8, WPB>), grid, block, 0, stream, n_sites, counts, hist_stride, ref_base, min_af,
-                       lut, comb, n_comb, results);
+                       lut, comb, n_comb, taken, results);
 }
 
 hipError_t launch_lrt(const LaunchState &st, hipStream_t stream, int64_t n_sites, const uint32_t *counts,
                       int64_t hist_stride, const int8_t *ref_base, double min_af, const QualLut *lut,
                       const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results, bool shared,
-                      int shared_waves_per_cu)
+                      int shared_waves_per_cu, void *scratch)
 {
     if (n_sites <= 0) return hipSuccess;
+    // The item engine takes the sites it can (em_items.hip); the kernels below take the rest.  min_af <= 0 lets
+    // zero-depth alleles through the filter and UpdateF skip subsets (src/BaseType.cpp:54): left to lrt_site.
+    const uint8_t *taken = nullptr;
+    if (scratch && st.em_engine != 1 && min_af > 0.0) {
+        const hipError_t e = launch_lrt_items(st, stream, n_sites, 0, counts, hist_stride, ref_base, min_af, lut, comb, n_comb,
+                                              results, scratch, &taken);
+        if (e != hipSuccess) return e;
+    }
     const int64_t cap = em_grid_cap(st, shared, shared_waves_per_cu);
     const int64_t want_waves = n_sites < cap ? n_sites : cap;
-    if (st.em_wpb == 1) launch_lrt_variants<1>(stream, want_waves, n_sites, counts, hist_stride, ref_base, min_af, lut, comb, n_comb, results);
-    else launch_lrt_variants<4>(stream, want_waves, n_sites, counts, hist_stride, ref_base, min_af, lut, comb, n_comb, results);
+    if (st.em_wpb == 1) launch_lrt_variants<1>(stream, want_waves, n_sites, counts, hist_stride, ref_base, min_af, lut, comb, n_comb, taken, results);
+    else launch_lrt_variants<4>(stream, want_waves, n_sites, counts, hist_stride, ref_base, min_af, lut, comb, n_comb, taken, results);
     hipLaunchKernelGGL(var_qual_kernel, dim3((unsigned)((n_sites + 255) / 256)), dim3(256), 0, stream, n_sites, results);
     return hipGetLastError();
 }
@@ -635,28 +702,56 @@ hipError_t launch_lrt(const LaunchState &st, hipStream_t stream, int64_t n_sites
 template <int WPB>
 static void launch_group_variants(hipStream_t stream, int64_t want_waves, int64_t n_sites, int n_groups,
                                   const uint32_t *grp_counts, const int8_t *ref_base, double min_af,
-                                  const QualLut *lut, const bvc_site_result *overall, bvc_group_result *grp_results)
+                                  const QualLut *lut, const bvc_site_result *overall, const uint8_t *taken,
+                                  bvc_group_result *grp_results)
 {
     const dim3 grid((unsigned)((want_waves + WPB - 1) / WPB)), block(64 * WPB);
+    if (taken) {                                                 // behind the item engine: what it left, in one launch
+        hipLaunchKernelGGL((lrt_groups_kernel<8, WPB, true>), grid, block, 0, stream, n_sites, n_groups, grp_counts,
+                           ref_base, min_af, lut, overall, taken, grp_results);
+        return;
+    }
     hipLaunchKernelGGL((lrt_groups_kernel<2, WPB>), grid, block, 0, stream, n_sites, n_groups, grp_counts, ref_base,
-                       min_af, lut, overall, grp_results);
+                       min_af, lut, overall, taken, grp_results);
     hipLaunchKernelGGL((lrt_groups_kernel<4, WPB>), grid, block, 0, stream, n_sites, n_groups, grp_counts, ref_base,
-                       min_af, lut, overall, grp_results);
+                       min_af, lut, overall, taken, grp_results);
     hipLaunchKernelGGL((lrt_groups_kernel<8, WPB>), grid, block, 0, stream, n_sites, n_groups, grp_counts, ref_base,
-                       min_af, lut, overall, grp_results);
+                       min_af, lut, overall, taken, grp_results);
+}
+
+size_t em_group_scratch_bytes(int64_t n_sites, int n_groups)
+{
+    const size_t n_pseudo = (size_t)n_sites * (size_t)n_groups;
+    return ((n_pseudo * 4 + 255) & ~(size_t)255) + ((n_pseudo + 255) & ~(size_t)255) +
+           ((n_pseudo * sizeof(bvc_site_result) + 255) & ~(size_t)255) + em_items_scratch_bytes((int64_t)n_pseudo);
 }
 
 hipError_t launch_lrt_groups(const LaunchState &st, hipStream_t stream, int64_t n_sites, int n_groups,
                              const uint32_t *grp_counts, const int8_t *ref_base, double min_af, const QualLut *lut,
                              const bvc_site_result *overall, bvc_group_result *grp_results, bool shared,
-                             int shared_waves_per_cu)
+                             int shared_waves_per_cu, void *scratch)
 {
     if (n_sites <= 0 || n_groups <= 0) return hipSuccess;
     const int64_t cap = em_grid_cap(st, shared, shared_waves_per_cu);
     const int64_t n_work = n_sites * n_groups;
     const int64_t want_waves = n_work < cap ? n_work : cap;
-    if (st.em_wpb == 1) launch_group_variants<1>(stream, want_waves, n_sites, n_groups, grp_counts, ref_base, min_af, lut, overall, grp_results);
-    else launch_group_variants<4>(stream, want_waves, n_sites, n_groups, grp_counts, ref_base, min_af, lut, overall, grp_results);
+    const uint8_t *taken = nullptr;
+    if (scratch && st.em_engine != 1 && min_af > 0.0) {
+        // every (site, group) a pseudo-site of the item engine; its records become group records afterwards
+        char *p = static_cast<char *>(scratch);
+        auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
+        int8_t *comb = reinterpret_cast<int8_t *>(take((size_t)n_work * 4));
+        uint8_t *n_comb = reinterpret_cast<uint8_t *>(take((size_t)n_work));
+        bvc_site_result *pseudo = reinterpret_cast<bvc_site_result *>(take((size_t)n_work * sizeof(bvc_site_result)));
+        const dim3 tgrid((unsigned)((n_work + 255) / 256)), tblock(256);
+        hipLaunchKernelGGL(group_comb_kernel, tgrid, tblock, 0, stream, n_work, n_groups, ref_base, overall, comb, n_comb);
+        const hipError_t e = launch_lrt_items(st, stream, n_work, n_groups, grp_counts, BVC_NCLASS, ref_base, min_af, lut, comb,
+                                              n_comb, pseudo, p, &taken);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(group_records_kernel, tgrid, tblock, 0, stream, n_work, n_groups, overall, pseudo, taken, grp_results);
+    }
+    if (st.em_wpb == 1) launch_group_variants<1>(stream, want_waves, n_sites, n_groups, grp_counts, ref_base, min_af, lut, overall, taken, grp_results);
+    else launch_group_variants<4>(stream, want_waves, n_sites, n_groups, grp_counts, ref_base, min_af, lut, overall, taken, grp_results);
     return hipGetLastError();
 }
 

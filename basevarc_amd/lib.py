@@ -290,6 +290,16 @@ class Context:
                                                  _dev_ptr(results_t), _dev_ptr(grp_results_t), BVC_PTR_DEVICE))
         return results_t, grp_results_t
 
+    def lrt_hist_device(self, counts_t, ref_t, min_af, results_t=None):
+        """Stage 2 alone on device tensors: counts_t int32/uint32 [n_sites, 512]; asynchronous on the stream."""
+        import torch
+        ns = counts_t.shape[0]
+        if results_t is None:
+            results_t = torch.empty(ns * SITE_DTYPE.itemsize, dtype=torch.uint8, device=counts_t.device)
+        self._check(self._L.bvc_lrt_hist(self._h, ns, _dev_ptr(counts_t), _dev_ptr(ref_t), float(min_af), None, None,
+                                         _dev_ptr(results_t), BVC_PTR_DEVICE))
+        return results_t
+
     def hist_dense_device(self, bases_t, quals_t, counts_t=None):
         import torch
         ns, n = bases_t.shape

@@ -35,7 +35,12 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6
 N_SIMD = 1024                # 256 CUs x 4 SIMDs
 ENGINE_CLOCK_HZ = 2.4e9      # MI355X peak engine clock
 VALU_CYCLES_PER_WAVE_INST = 4     # wave64 FP64 / 32-bit VALU instruction (tools/micro/valu_rate.hip)
-EM_VALU_INST_PER_PASS = 63        # SQ_INSTS_VALU per E+M pass of lrt_kernel, everything included (profiles/*pmc_summary*)
+# Issue slots (4 cycles each; v_rcp_f64 and the lane swaps count for what they cost, 4 and 2) the item engine needs per
+# E+M pass of ONE fit when every lane group of its wavefronts works: fit_kernel's pass is 150 slots for 8 four-allele
+# items or 16 two-allele items (ISA of em_items.hip, fit_body<4,1> / <2,1>); a site's passes are about 64 % four-allele
+# (full model + 3-subsets) and 36 % two-allele (the nested levels) on the synthetic workload: 0.64 * 18.75 + 0.36 * 9.4.
+# (Round 2's one-wavefront-per-site kernel: 63 instructions per pass, 82 slots all told.)
+EM_ISSUE_SLOTS_PER_PASS = 15.4
 
 
 def parse():
@@ -259,7 +264,7 @@ def main():
             "empirical_stream_read_GBs": empirical_gbs, "frac_of_empirical": achieved / empirical_gbs if empirical_gbs else None,
         },
         "kernels_ms_per_call": {kname: hist_ms,
-                                ("sum_groups + lrt + lrt_groups kernels" if a.groups > 0 else "lrt_kernel"): em_ms},
+                                ("sum_groups + lrt + lrt_groups kernels" if a.groups > 0 else "stage 2 (classes + fit + decide kernels)"): em_ms},
     }
     if res_sites < my_sites:
         out["config"]["note"] = f"only {res_sites} of this rank's {my_sites} sites fit in device memory; a step covers those"
@@ -468,7 +473,7 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
         "workload": f"ragged (CSR) sites, bvc_lrt_csr: N = {n} samples at {cov:.0%} coverage = {covered / csr_sites:.0f} "
                     f"observations per site on average, {n_calls} calls of {csr_sites} sites over {len(csr)} tiles",
         "value": n_calls * csr_sites / dt, "unit": "sites/s", "ms_per_call": dt / n_calls * 1e3,
-        "bound_by": "lrt_kernel (FP64 VALU)",
+        "bound_by": "stage 2: fit_kernel (FP64 VALU issue)",
         "roofline": em_roofline(rec, em_ms, dt / n_calls * 1e3),
         "hist_roofline": {"bound": "hbm", "kernel": "hist_csr_block_kernel", "achieved": alg / (hist_ms * 1e-3) / 1e9,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (hist_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -504,7 +509,7 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
         "workload": f"BASELINE configs[1]: synthetic pileup {ns1} sites x {n1} samples, EM to convergence, "
                     f"{n_calls} calls of {ns1} sites",
         "value": n_calls * ns1 / dt, "unit": "sites/s", "ms_per_call": dt / n_calls * 1e3,
-        "bound_by": "lrt_kernel (FP64 VALU)",
+        "bound_by": "stage 2: fit_kernel (FP64 VALU issue)",
         "roofline": em_roofline(rec, em_ms, dt / n_calls * 1e3),
         "hist_wave_kernel_ms_per_call_under_the_em": hist_ms,     # 0.05 ms alone (profiles/r02_kernel_stats_legs.csv)
     }
@@ -512,18 +517,19 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
 
 
 def em_roofline(rec, em_launch_ms, call_ms):
-    """FP64-VALU issue roofline of the EM/LRT kernels where they are the bound: wave-instructions x 4 cycles against
-    1024 SIMDs x 2.4 GHz.  Instructions = E+M passes of a call x 63 VALU instructions per pass (PMC-measured).  The
-    denominator is the wall time per call: consecutive EM launches run on two streams and overlap (the next one fills
-    the previous one's tail), so a launch's own event-to-event duration is longer than its share of the chip."""
+    """FP64-VALU issue roofline of stage 2 where it is the bound: issue slots x 4 cycles against 1024 SIMDs x 2.4 GHz.
+    Numerator = E+M passes of a call (singleEM calls, as the reference counts them) x the slots a pass NEEDS in
+    fit_kernel with every lane group busy (EM_ISSUE_SLOTS_PER_PASS) -- so lockstep idling (a wavefront runs until its
+    slowest fit stops), the small kernels between the levels and launch tails all show up as lost fraction.  The
+    denominator is the wall time per call: the stage 2 of consecutive calls runs on two streams side by side."""
     passes = float(rec["n_passes"].astype("int64").sum())
-    inst = passes * EM_VALU_INST_PER_PASS
+    inst = passes * EM_ISSUE_SLOTS_PER_PASS
     peak = N_SIMD * ENGINE_CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST          # wave-instructions per second, whole chip
     ach = inst / (call_ms * 1e-3) if call_ms > 0 else 0.0
-    return {"bound": "fp64_valu_issue", "kernel": "lrt_kernel<2,4>/<4,4>/<8,4>", "achieved": ach / 1e9, "peak": peak / 1e9,
-            "unit": "G wave-instructions/s", "frac": ach / peak, "ms_per_call": call_ms,
+    return {"bound": "fp64_valu_issue", "kernel": "fit_kernel (em_items.hip)", "achieved": ach / 1e9, "peak": peak / 1e9,
+            "unit": "G issue slots/s", "frac": ach / peak, "ms_per_call": call_ms,
             "avg_launch_ms": em_launch_ms, "launches_overlap": True,
-            "em_passes_per_site": passes / max(1, len(rec)), "valu_inst_per_pass": EM_VALU_INST_PER_PASS,
+            "em_passes_per_site": passes / max(1, len(rec)), "issue_slots_per_pass": EM_ISSUE_SLOTS_PER_PASS,
             "note": "no MFMA: the EM is a scalar recurrence per class, not a contraction; peak = 1024 SIMDs x 2.4 GHz / 4 cycles "
                     "(the chip holds about 2.17 GHz under this load)"}
 
