@@ -153,7 +153,6 @@ hipStream_t em_stream(bvc_ctx *ctx, int by_default)
 int em_scratch_for(bvc_ctx *ctx, int slot, int64_t n_sites, double min_af, void **out, int n_groups = 0)
 {
     *out = nullptr;
-    const int64_t n_work = n_groups > 0 ? n_sites * n_groups : n_sites;
     if (ctx->ls.em_engine == 1 || !(min_af > 0.0)) return BVC_OK;
     const size_t need = n_groups > 0 ? em_group_scratch_bytes(n_sites, n_groups) : em_items_scratch_bytes(n_sites);
     void **buf = n_groups > 0 ? &ctx->d_emg[slot] : &ctx->d_em[slot];
@@ -388,6 +387,7 @@ int bvc_create(bvc_ctx **out, int device)
         lut.a[q] = 1.0 - eps;
         lut.e[q] = eps / 3.0;
     }
+    lut.e_empty = 0.25;
     if (hipMalloc(reinterpret_cast<void **>(&ctx->d_lut), sizeof(QualLut)) != hipSuccess ||
         hipMemcpy(ctx->d_lut, &lut, sizeof(QualLut), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipGetLastError();

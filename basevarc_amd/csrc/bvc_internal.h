@@ -31,6 +31,7 @@ struct LaunchState {
 struct QualLut {
     double a[128];
     double e[128];
+    double e_empty;            // e[128]: the "empty class place" of the item engine (em_items.hip), 1/4
 };
 
 // Stage 1: dense pileup rows -> per-site class counts.  counts must be zeroed by the caller when split > 1.
@@ -79,7 +80,7 @@ size_t em_items_scratch_bytes(int64_t n_sites);
 hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n_sites, int n_groups,
                             const uint32_t *counts, int64_t hist_stride, const int8_t *ref_base, double min_af,
                             const QualLut *lut, const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results,
-                            void *scratch, const uint8_t **taken_out);
+                            void *scratch, const uint8_t **taken_out, bool shared = false);
 
 hipError_t launch_lrt_groups(const LaunchState &st, hipStream_t stream, int64_t n_sites, int n_groups,
                              const uint32_t *grp_counts, const int8_t *ref_base, double min_af, const QualLut *lut,

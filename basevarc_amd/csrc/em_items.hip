@@ -1,12 +1,14 @@
 // em_items.hip -- stage 2 of the basetype path on gfx950, "item engine": the EM fits of a call are the work items,
-// several of them share a wavefront, and the likelihood-ratio control flow of a site runs between launches.
+// several of them share a wavefront, and a workgroup takes a REGION of 8 sites through the whole likelihood-ratio
+// test in one launch: classes -> fits of the first level -> decisions -> fits of the next level -> ... with workgroup
+// barriers between the phases and every intermediate (class tables, fit descriptors and results, site state) in LDS.
 //
 // Follows (paths under /root/reference), with the per-sample sums regrouped by class as in em_kernel.hip:
-//   BaseType::SetAlleleFreq  src/BaseType.cpp:25-39     -> emit_items
-//   BaseType::UpdateF        src/BaseType.cpp:41-71     -> one FitItem per subset: fit_kernel (EM), decide_kernel (log-likelihood)
-//   BaseType::LRT            src/BaseType.cpp:73-139    -> classes_kernel (:75-88), decide_kernel (one level of :93-110 per launch)
+//   BaseType::SetAlleleFreq  src/BaseType.cpp:25-39     -> site_emit
+//   BaseType::UpdateF        src/BaseType.cpp:41-71     -> one FitItem per subset: fit_body (EM), site_decide (log-likelihood)
+//   BaseType::LRT            src/BaseType.cpp:73-139    -> site_classes (:75-88), site_decide (one level of :93-110 per phase)
 //   combs_                   src/BaseType.cpp:237-255   -> subset_masks
-//   singleEM / EM / delta    src/Algorithm.cpp:69-130   -> fit_kernel
+//   singleEM / EM / delta    src/Algorithm.cpp:69-130   -> fit_body
 //
 // Why: with one wavefront per site (em_kernel.hip) 39 of the 63 vector instructions of an EM pass are cross-lane
 // reduction and control, paid once per fit-pass.  Here a fit ("item") owns 2 lanes per allele: lane (unit u, half h)
@@ -25,14 +27,16 @@
 //     Y = sum n / m the allele's own sum is D = Y - 4 E_own -- a lane keeps n and e per class, nothing else;
 //   * the 16 reciprocals of a lane come from ONE v_rcp_f64 (16 issue cycles, four FMAs' worth): 1 / (m_0 ... m_15)
 //     refined once, times the other fifteen marginals by a product tree, 2.8 multiplications per class.
-// The items of a wavefront run in lockstep passes (each with its own pass counter; one that has stopped keeps its
-// state until the wavefront's last one stops), and the hardware dispatches the wavefronts dynamically.  Fits differ
-// 7x in passes at N = 1e4, so what shares a wavefront matters: the fits of one site converge alike except the subset
-// that leaves out the site's deepest allele (always slow), which is why a site's items are placed together and the
-// "deepest allele left out" items go to lists of their own.
+// The items of a wavefront run in lockstep passes (each with its own pass counter), the wavefronts of a region meet
+// at a barrier after every level, and the hardware dispatches the regions dynamically.  Fits differ 7x in passes at
+// N = 1e4, so what shares a wavefront matters: the fits of one site converge alike except the subset that leaves out
+// the site's deepest allele (always slow), which is why a site's items are placed together and the "deepest allele
+// left out" items go to lists (wavefronts) of their own.
 // Sites the engine does not take (more than 32 quality values on one allele, a class of quality 0 or 1 -- d < 0 --,
 // min_af <= 0, duplicate candidates) stay with em_kernel.hip's one-wavefront-per-site kernels, flagged per site.
 // FP64 throughout; no MFMA (nothing here is a dense contraction).
+#include <cstdlib>
+
 #include "bvc_device.h"
 #include "bvc_internal.h"
 
@@ -45,10 +49,11 @@ constexpr double kEmEpsilon = 0.001;      // src/BaseType.cpp:45
 constexpr double kVarQualPending = -1.0;  // as in em_kernel.hip: var_qual_kernel finishes these records
 
 constexpr int kClassesPerBase = 32;        // quality classes of one allele the engine holds
-constexpr int kPlane = 4 * kClassesPerBase;           // doubles per plane of a site's table
-constexpr int kSiteTable = 2 * kPlane;                // planes n | e, each [base][class]
+constexpr int kPlane = 4 * kClassesPerBase;           // class places of a site
+// A site's table (LDS): counts uint32 [base][class] and then quality indices uint8 [base][class], 640 bytes.
+constexpr int kSiteTable = kPlane * 5;
 
-constexpr double kEmptyE = 0.25;           // e of an empty class place
+constexpr int kEmptyQ = 128;               // quality index of an empty class place: QualLut::e_empty = 1/4
 constexpr uint32_t hi_word(double x) { return (uint32_t)(__builtin_bit_cast(uint64_t, x) >> 32); }
 constexpr uint32_t kSureBelowHi = hi_word(kEmEpsilon / (1.0 + 0.00390625));        // hi(A) <  this: converged
 constexpr uint32_t kSureAboveHi = hi_word(kEmEpsilon / (1.0 - 0.00390625)) + 1u;   // hi(A) >= this: not converged
@@ -56,30 +61,33 @@ constexpr uint32_t kSureAboveHi = hi_word(kEmEpsilon / (1.0 - 0.00390625)) + 1u;
 // One fit: the alleles of a subset in candidate order ("units"), their starting frequencies, and what the alleles
 // outside the subset add to E (a constant of the fit).  64 bytes.
 struct FitItem {
-    int32_t site;
+    int32_t site;           // site of the region (0 .. kRegionSites - 1)
     uint8_t base[4];        // allele of unit u; 0xFF = no such unit
     double f0[4];           // SetAlleleFreq: depth / depth of the subset
     double e_excl;          // sum of the depths of the alleles outside the subset
     double inv_n;           // 1 / depth_total
-    double pad;
+    double ll_excl;         // what their classes add to the log-likelihood: sum n log e (their marginal is e)
 };
 static_assert(sizeof(FitItem) == 64, "FitItem layout");
 
 struct FitOut {
     double ex[4];           // expect_allele_prob of the last pass, per unit
-    double fl[4];           // the frequencies the last pass ran on, per unit (the log-likelihood's, UpdateF :58-62)
+    double ll;              // log-likelihood at the frequencies the last pass ran on (UpdateF, src/BaseType.cpp:58-62)
     int32_t passes;
     int32_t pad;
 };
-static_assert(sizeof(FitOut) == 72, "FitOut layout");
+static_assert(sizeof(FitOut) == 48, "FitOut layout");
 
-// Per-site state between the launches of a call.
+// Per-site state between the phases.
 struct ItemSite {
     double lr_alt, chi;
     double base_frq[4];
+    double lle[4];          // per allele: sum over its classes of n log e
     int32_t depth[4];
     int32_t passes, fits;
-    int32_t item[5];        // pending items: list << 28 | index in the list
+    int32_t item[5];        // pending items: index into the region's item / result arrays
+    uint32_t sets;          // fits to emit next: 4-bit position masks over blist, packed
+    int8_t n_emit, p_deepest;
     uint32_t blist;         // candidates in order, 4 bits each
     int8_t n;               // candidates
     int8_t k;               // subset size of the pending level
@@ -91,7 +99,10 @@ struct ItemSite {
 // ("slow" = the subset leaves out the deepest candidate: such fits run to the iteration cap)
 constexpr int kLists = 4;
 constexpr int kLevels = 3;
-constexpr int kSitesPerBlock = 16;        // classes_kernel / decide_kernel: one wavefront per site
+constexpr int kRegionSites = 6;           // sites of a workgroup: 6 x (full model + 4 subsets) = 24 + 6 items in 3 + 1 wavefronts
+constexpr int kRegionWaves = 4;
+// places of the region's item arrays per list: a site has at most 4 / 1 / 2 / 1 items in lists 0..3 at any level
+constexpr int kListAt[kLists + 1] = {0, 4 * kRegionSites, 5 * kRegionSites, 7 * kRegionSites, 8 * kRegionSites};
 
 // k-subsets of positions 0..n-1 in lexicographic order (what combs_ yields), as 4-bit position masks packed
 // least-significant first; count returned through `cnt`.
@@ -124,18 +135,6 @@ __device__ __forceinline__ int64_t hist_index(int64_t p, int n_groups)
     return n_groups > 0 ? (p / n_groups) * (n_groups + 1) + p % n_groups : p;
 }
 
-// What a level's launch reads and writes (chosen by the host per level: nothing here is indexed dynamically).
-// Lists are laid out by REGION: the 16 sites of a classes/decide workgroup own kSitesPerBlock * per_site[l] places
-// of list l, filled from the front and counted in count_next[l * n_regions + region] -- no atomics, and the fits of
-// a site stay side by side in site order.
-struct LevelIo {
-    const FitOut *outs_prev[kLists];   // fits of the pending level
-    FitItem *items_next[kLists];       // next level's items
-    uint32_t *count_next;              // [kLists][n_regions]
-    int per_site_next[kLists];         // places per site and list at the next level
-    int n_regions;
-};
-
 template <class T>
 __device__ __forceinline__ T sel4(const T (&v)[kLists], int l)
 {
@@ -160,26 +159,6 @@ __device__ __forceinline__ int deepest_position(const int32_t (&depth)[4], uint3
     return best;
 }
 
-// Places of a site's new items inside its workgroup's region of each list; the region's counts go to count_next.
-__device__ __forceinline__ void place_items(int wave, int lane, const int (&want)[kLists], const LevelIo &io,
-                                            uint32_t (&at)[kLists])
-{
-    __shared__ int s_want[kSitesPerBlock][kLists];
-    if (lane < kLists) s_want[wave][lane] = sel4(want, lane);
-    __syncthreads();
-#pragma unroll
-    for (int l = 0; l < kLists; ++l) {
-        uint32_t a = (uint32_t)blockIdx.x * (uint32_t)(kSitesPerBlock * io.per_site_next[l]);
-        for (int w = 0; w < wave; ++w) a += (uint32_t)s_want[w][l];
-        at[l] = a;
-    }
-    if (io.count_next && threadIdx.x < kLists) {
-        int tot = 0;
-        for (int w = 0; w < kSitesPerBlock; ++w) tot += s_want[w][threadIdx.x];
-        io.count_next[threadIdx.x * io.n_regions + blockIdx.x] = (uint32_t)tot;
-    }
-}
-
 __device__ __forceinline__ void count_wanted(uint32_t sets, int n_emit, int p_deepest, int (&want)[kLists])
 {
     want[0] = want[1] = want[2] = want[3] = 0;
@@ -191,43 +170,62 @@ __device__ __forceinline__ void count_wanted(uint32_t sets, int n_emit, int p_de
         }
 }
 
-// Emits the fits `sets` (4-bit position masks over S.blist, packed; n_emit of them) of site `site` (wave-uniform).
-__device__ __forceinline__ void emit_items(int64_t site, int lane, ItemSite &S, uint32_t sets, int n_emit, int p_deepest,
-                                           const uint32_t (&at_in)[kLists], const LevelIo &io)
+// What a region keeps in LDS.
+struct Region {
+    ItemSite site[kRegionSites];
+    FitItem items[kListAt[kLists]];
+    FitOut outs[kListAt[kLists]];
+    int want[kRegionSites][kLists];
+    int count[kLists];
+    alignas(8) uint8_t tab[kRegionSites][kSiteTable];
+};
+
+// Emits the fits S.sets of site `ls` of the region (wave-uniform): places from the prefix of `want` over the sites.
+__device__ __forceinline__ void site_emit(Region &R, int ls, int lane)
 {
+    ItemSite &S = R.site[ls];
+    const uint32_t sets = S.sets;
+    const int n_emit = S.n_emit, p_deepest = S.p_deepest;
+    if (S.state != 1 || n_emit <= 0) return;
+    int at0 = kListAt[0], at1 = kListAt[1], at2 = kListAt[2], at3 = kListAt[3];
+    for (int w = 0; w < ls; ++w) { at0 += R.want[w][0]; at1 += R.want[w][1]; at2 += R.want[w][2]; at3 += R.want[w][3]; }
     const int total_i = S.depth[0] + S.depth[1] + S.depth[2] + S.depth[3];
     const double inv_n = 1.0 / (double)total_i;
-    uint32_t at0 = at_in[0], at1 = at_in[1], at2 = at_in[2], at3 = at_in[3];
+    const uint32_t blist = S.blist;
+    int depth[4] = {S.depth[0], S.depth[1], S.depth[2], S.depth[3]};
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
         if (c >= n_emit) break;
         const uint32_t pm = (sets >> (4 * c)) & 0xFu;
         const int l = list_of(pm, p_deepest);
-        const uint32_t idx = l == 0 ? at0 : (l == 1 ? at1 : (l == 2 ? at2 : at3));
+        const int idx = l == 0 ? at0 : (l == 1 ? at1 : (l == 2 ? at2 : at3));
         at0 += l == 0; at1 += l == 1; at2 += l == 2; at3 += l == 3;
         FitItem fi;
-        fi.site = (int32_t)site;
+        fi.site = ls;
         int depth_sum = 0, u = 0;
-        uint32_t bases = 0xFFFFFFFFu;
+        uint32_t bases = 0xFFFFFFFFu, in_set = 0;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             if ((pm >> p) & 1u) {
-                const int b = (S.blist >> (4 * p)) & 3u;
+                const int b = (blist >> (4 * p)) & 3u;
                 bases = (bases & ~(0xFFu << (8 * u))) | ((uint32_t)b << (8 * u));
-                depth_sum += pick4i(S.depth, b);
+                in_set |= 1u << b;
+                depth_sum += pick4i(depth, b);
                 ++u;
             }
+        double ll_excl = 0.0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) ll_excl += ((in_set >> b) & 1u) ? 0.0 : S.lle[b];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                            // SetAlleleFreq (:25-39)
             const int b = (bases >> (8 * q)) & 0xFFu;
             fi.base[q] = (uint8_t)b;
-            fi.f0[q] = q < u ? (double)pick4i(S.depth, b & 3) / (double)depth_sum : 0.0;
+            fi.f0[q] = q < u ? (double)pick4i(depth, b & 3) / (double)depth_sum : 0.0;
         }
         fi.e_excl = (double)(total_i - depth_sum);
         fi.inv_n = inv_n;
-        fi.pad = 0.0;
-        if (lane == 0) sel4(io.items_next, l)[idx] = fi;
-        S.item[c] = (int32_t)((uint32_t)l << 28 | idx);
+        fi.ll_excl = ll_excl;
+        if (lane == 0) { R.items[idx] = fi; S.item[c] = idx; }
     }
 }
 
@@ -269,131 +267,127 @@ __device__ __forceinline__ void store_record(bvc_site_result *dst, const ItemSit
     *dst = r;
 }
 
-// ---- classes_kernel: one wavefront per site -------------------------------------------------------------------
-// Compacts the non-empty classes of each allele (ascending quality) into the site's table for fit_kernel: class c of
-// allele b at [b][c] of the planes n and e = eps / 3 (empty places: n = 0, e = 1/4, whose marginal f + (1 - 4 f) e
-// is 1/4 whatever f: weight 0 in every sum and harmless in the product of a lane's marginals).  Then the head of BaseType::LRT
-// (src/BaseType.cpp:75-88): candidates by min_af, and the first level's items: the full model and, because they
-// depend on nothing but the candidate list, its (n-1)-subsets.
-__global__ __launch_bounds__(64 * kSitesPerBlock) void classes_kernel(
-    int64_t n_sites, int n_groups, const uint32_t *__restrict__ counts, int64_t hist_stride,
-    const QualLut *__restrict__ lut, const int8_t *__restrict__ ref_base, double min_af,
-    const int8_t *__restrict__ comb, const uint8_t *__restrict__ n_comb, ItemSite *__restrict__ sites,
-    double *__restrict__ cls, uint8_t *__restrict__ taken, LevelIo io, bvc_site_result *__restrict__ results)
+// ---- site_classes: one wavefront per site ------------------------------------------------------------------------
+// Compacts the non-empty classes of each allele (ascending quality) into the site's table: class c of allele b at
+// [b][c], its count and its quality (e = eps / 3 comes from the context's table; empty places: n = 0 and the index of
+// e = 1/4, whose marginal f + (1 - 4 f) e is 1/4 whatever f: weight 0 in every sum and harmless in the product of a
+// lane's marginals).  Then the head of BaseType::LRT (src/BaseType.cpp:75-88): candidates by min_af, and the first
+// level's fits: the full model and, because they depend on nothing but the candidate list, its (n-1)-subsets.
+__device__ __forceinline__ void site_classes(Region &R, int ls, int lane, int64_t site, int n_groups,
+                                             const uint32_t *__restrict__ counts, int64_t hist_stride,
+                                             const QualLut *__restrict__ lut,
+                                             const int8_t *__restrict__ ref_base, double min_af,
+                                             const int8_t *__restrict__ comb, const uint8_t *__restrict__ n_comb,
+                                             uint8_t *__restrict__ taken, bvc_site_result *__restrict__ results)
 {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t site = (int64_t)blockIdx.x * kSitesPerBlock + wave;
-    const int lane = threadIdx.x & (kWave - 1);
     const int row = lane >> 4, t = lane & 15;
-    const bool in_range = site < n_sites;
     ItemSite S{};
     uint32_t sets = 0;
     int n_emit = 0, p_deepest = 0;
-    bool mine = false, finished = false;
-
-    if (in_range) {
-        const uint32_t *hist = counts + hist_index(site, n_groups) * hist_stride;
-        double *tab = cls + site * kSiteTable + row * kClassesPerBase;
-        int cnt_row = 0, depth_lane = 0;
-        bool low_q = false;
+    bool finished = false;
+    const uint32_t *hist = counts + hist_index(site, n_groups) * hist_stride;
+    uint32_t *tab_n = reinterpret_cast<uint32_t *>(R.tab[ls]) + row * kClassesPerBase;
+    uint8_t *tab_q = R.tab[ls] + 4 * kPlane + row * kClassesPerBase;
+    int cnt_row = 0, depth_lane = 0;
+    double lle = 0.0;
+    bool low_q = false;
 #pragma unroll
-        for (int lvl = 0; lvl < 8; ++lvl) {
-            const int q = t + 16 * lvl;
-            const uint32_t c = hist[row * 128 + q];
-            const uint64_t nzmask = __ballot(c != 0);
-            const uint32_t rowbits = (uint32_t)(nzmask >> (16 * row)) & 0xFFFFu;
-            if (c != 0) {
-                const int pos = cnt_row + __popc(rowbits & ((1u << t) - 1u));
-                if (pos < kClassesPerBase) {
-                    tab[pos] = (double)c;
-                    tab[kPlane + pos] = lut->e[q];
-                }
-                low_q |= q < 2;
+    for (int lvl = 0; lvl < 8; ++lvl) {
+        const int q = t + 16 * lvl;
+        const uint32_t c = hist[row * 128 + q];
+        const uint64_t nzmask = __ballot(c != 0);
+        const uint32_t rowbits = (uint32_t)(nzmask >> (16 * row)) & 0xFFFFu;
+        if (c != 0) {
+            const int pos = cnt_row + __popc(rowbits & ((1u << t) - 1u));
+            if (pos < kClassesPerBase) {
+                tab_n[pos] = c;
+                tab_q[pos] = (uint8_t)q;
             }
-            cnt_row += __popc(rowbits);
-            depth_lane += (int)c;
+            lle = fma((double)c, log_pos(lut->e[q]), lle);
+            low_q |= q < 2;
         }
-        // the places this allele leaves empty
+        cnt_row += __popc(rowbits);
+        depth_lane += (int)c;
+    }
+    // the places this allele leaves empty
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int pos = t + 16 * half;
-            if (pos >= cnt_row) {
-                tab[pos] = 0.0;
-                tab[kPlane + pos] = kEmptyE;
-            }
+    for (int half = 0; half < 2; ++half) {
+        const int pos = t + 16 * half;
+        if (pos >= cnt_row) {
+            tab_n[pos] = 0u;
+            tab_q[pos] = (uint8_t)kEmptyQ;
         }
-        const int depth_row = row_sum(depth_lane);
-        S.depth[0] = __builtin_amdgcn_readlane(depth_row, 0);
-        S.depth[1] = __builtin_amdgcn_readlane(depth_row, 16);
-        S.depth[2] = __builtin_amdgcn_readlane(depth_row, 32);
-        S.depth[3] = __builtin_amdgcn_readlane(depth_row, 48);
-        const bool too_wide = __ballot(cnt_row > kClassesPerBase) != 0;
-        const bool any_low = __ballot(low_q) != 0;
+    }
+    const int depth_row = row_sum(depth_lane);
+    lle = row_sum(lle);
+    S.lle[0] = lane_value<0>(lle); S.lle[1] = lane_value<16>(lle); S.lle[2] = lane_value<32>(lle); S.lle[3] = lane_value<48>(lle);
+    S.depth[0] = __builtin_amdgcn_readlane(depth_row, 0);
+    S.depth[1] = __builtin_amdgcn_readlane(depth_row, 16);
+    S.depth[2] = __builtin_amdgcn_readlane(depth_row, 32);
+    S.depth[3] = __builtin_amdgcn_readlane(depth_row, 48);
+    const bool too_wide = __ballot(cnt_row > kClassesPerBase) != 0;
+    const bool any_low = __ballot(low_q) != 0;
 
-        const int total_i = S.depth[0] + S.depth[1] + S.depth[2] + S.depth[3];
-        const double depth_total = (double)total_i;
-        uint32_t blist = 0;
-        int n = 0;
-        bool dup = false;
-        if (total_i > 0) {                                       // src/BaseType.cpp:75
-            uint32_t list = 0x3210u;                             // default base_comb, src/BaseType.h:79
-            int nc = 4;
-            if (comb) {
-                const int want_c = min((int)n_comb[site], 4);
-                list = 0; nc = 0;
-                for (int c = 0; c < want_c; ++c) {
-                    const int b = comb[site * 4 + c];
-                    if ((unsigned)b < 4u) { list |= (uint32_t)b << (4 * nc); ++nc; }
-                }
-            }
-            uint32_t seen = 0;
-            for (int c = 0; c < nc; ++c) {                       // src/BaseType.cpp:77-83
-                const int b = (list >> (4 * c)) & 3;
-                if ((double)pick4i(S.depth, b) / depth_total >= min_af) {
-                    dup |= ((seen >> b) & 1u) != 0;
-                    seen |= 1u << b;
-                    blist |= (uint32_t)b << (4 * n);
-                    ++n;
-                }
+    const int total_i = S.depth[0] + S.depth[1] + S.depth[2] + S.depth[3];
+    const double depth_total = (double)total_i;
+    uint32_t blist = 0;
+    int n = 0;
+    bool dup = false;
+    if (total_i > 0) {                                           // src/BaseType.cpp:75
+        uint32_t list = 0x3210u;                                 // default base_comb, src/BaseType.h:79
+        int nc = 4;
+        if (comb) {
+            const int want_c = min((int)n_comb[site], 4);
+            list = 0; nc = 0;
+            for (int c = 0; c < want_c; ++c) {
+                const int b = comb[site * 4 + c];
+                if ((unsigned)b < 4u) { list |= (uint32_t)b << (4 * nc); ++nc; }
             }
         }
-        mine = !(too_wide || any_low || dup);
-        S.blist = blist; S.n = (int8_t)n; S.k = (int8_t)n; S.first = 1;
-        S.state = mine ? 1 : 0;
-        if (mine) {
-            if (n == 0) {
-                finished = true;                                 // :75, :84
-            } else {
-                int cnt = 0;
-                sets = (1u << n) - 1u;                           // the full model (:88)
-                n_emit = 1;
-                if (n >= 2) {
-                    const uint32_t masks = subset_masks(n, n - 1, cnt);
-                    sets |= masks << 4;
-                    n_emit += cnt;
-                }
-                p_deepest = deepest_position(S.depth, blist, n);
+        uint32_t seen = 0;
+        for (int c = 0; c < nc; ++c) {                           // src/BaseType.cpp:77-83
+            const int b = (list >> (4 * c)) & 3;
+            if ((double)pick4i(S.depth, b) / depth_total >= min_af) {
+                dup |= ((seen >> b) & 1u) != 0;
+                seen |= 1u << b;
+                blist |= (uint32_t)b << (4 * n);
+                ++n;
             }
         }
     }
-
+    const bool mine = !(too_wide || any_low || dup);
+    S.blist = blist; S.n = (int8_t)n; S.k = (int8_t)n; S.first = 1;
+    S.state = mine ? 1 : 0;
+    if (mine) {
+        if (n == 0) {
+            finished = true;                                     // :75, :84
+        } else {
+            int cnt = 0;
+            sets = (1u << n) - 1u;                               // the full model (:88)
+            n_emit = 1;
+            if (n >= 2) {
+                const uint32_t masks = subset_masks(n, n - 1, cnt);
+                sets |= masks << 4;
+                n_emit += cnt;
+            }
+            p_deepest = deepest_position(S.depth, blist, n);
+        }
+    }
+    S.sets = sets; S.n_emit = (int8_t)n_emit; S.p_deepest = (int8_t)p_deepest;
     int want[kLists];
     count_wanted(sets, n_emit, p_deepest, want);
-    uint32_t at[kLists];
-    place_items(wave, lane, want, io, at);
-    if (!in_range) return;
-    if (mine && n_emit > 0) emit_items(site, lane, S, sets, n_emit, p_deepest, at, io);
     if (lane == 0) {
         if (finished) {
             store_record(results + site, S, (int)ref_base[n_groups > 0 ? site / n_groups : site], S.n, S.blist);
             S.state = 2;
         }
-        sites[site] = S;
+        R.site[ls] = S;
+        R.want[ls][0] = want[0]; R.want[ls][1] = want[1]; R.want[ls][2] = want[2]; R.want[ls][3] = want[3];
         taken[site] = mine ? 1 : 0;
     }
 }
 
-// ---- fit_kernel: 64 / (ROWS * G) items per wavefront ------------------------------------------------------------------
+// ---- the fits: 64 / (ROWS * G) items per wavefront -----------------------------------------------------------------
 // An item takes ROWS DPP rows x G lanes: unit (allele) = row (ROWS = 4) or row & 1 (ROWS = 2: the row pairs (0,1) and
 // (2,3) hold items of their own); the G = 2^LOG2G lanes of a unit split the allele's 32 class places, 32 / G each.
 
@@ -468,15 +462,15 @@ __device__ __forceinline__ double item_sum(double x)
 }
 
 template <int ROWS, int LOG2G>
-__device__ __forceinline__ void fit_body(int64_t item0, int64_t item_end, const FitItem *__restrict__ items,
-                                         FitOut *__restrict__ outs, const double *__restrict__ cls)
+__device__ __forceinline__ void fit_body(int item0, int item_end, const FitItem *items, FitOut *outs, const uint8_t *cls,
+                                         const double *lut_e)
 {
     constexpr int G = 1 << LOG2G, kSlots = kClassesPerBase / G;
     constexpr int kGroupsPerRow = 16 / G;
     const int lane = threadIdx.x & (kWave - 1);
     const int row = lane >> 4, sub = lane & (G - 1), grp = (lane & 15) >> LOG2G;
     const int unit = ROWS == 4 ? row : (row & 1);
-    const int64_t item = item0 + (ROWS == 4 ? grp : (row >> 1) * kGroupsPerRow + grp);
+    const int item = item0 + (ROWS == 4 ? grp : (row >> 1) * kGroupsPerRow + grp);
     const bool valid = item < item_end;
 
     double n[kSlots], e[kSlots];
@@ -490,23 +484,25 @@ __device__ __forceinline__ void fit_body(int64_t item0, int64_t item_end, const 
         if (base != 0xFF) {
             active = true;
             fb = fi->f0[unit];
-            const double *tab = cls + (int64_t)fi->site * kSiteTable + base * kClassesPerBase + sub;
+            const uint8_t *tab = cls + fi->site * kSiteTable;
+            const uint32_t *tab_n = reinterpret_cast<const uint32_t *>(tab) + base * kClassesPerBase + sub;
+            const uint8_t *tab_q = tab + 4 * kPlane + base * kClassesPerBase + sub;
 #pragma unroll
             for (int k = 0; k < kSlots; ++k) {
-                n[k] = tab[k * G];
-                e[k] = tab[kPlane + k * G];
+                n[k] = (double)tab_n[k * G];
+                e[k] = lut_e[tab_q[k * G]];
             }
         }
     }
     if (!active) {
 #pragma unroll
-        for (int k = 0; k < kSlots; ++k) { n[k] = 0.0; e[k] = kEmptyE; }
+        for (int k = 0; k < kSlots; ++k) { n[k] = 0.0; e[k] = 0.25; }
     }
 
     // EM (src/Algorithm.cpp:115-130): pass 0, then at most kEmIters passes each followed by the stop rule.  An item
     // that stops writes its fit at once and runs on (its lanes are not masked: the passes of a converged fit are
     // ordinary arithmetic, and nothing of it is read again).
-    double fprev = fb, dprev = 0.0;
+    double fprev = fb, dprev = 0.0, fl = fb;
     int it = 0;
     bool done = !valid;
     while (true) {
@@ -551,11 +547,11 @@ __device__ __forceinline__ void fit_body(int64_t item0, int64_t item_end, const 
         }
         const bool stop = !done && (conv || it == kEmIters);
         if (__ballot(stop) != 0) {
-            if (stop && sub == 0) {                              // fb is the frequency this last pass ran on
+            if (stop) fl = fb;                                   // the frequency this last pass ran on
+            if (stop && sub == 0) {
                 FitOut *o = outs + item;
                 o->ex[unit] = active ? ex : 0.0;
-                o->fl[unit] = active ? fb : 0.0;
-                if (ROWS == 2) { o->ex[unit + 2] = 0.0; o->fl[unit + 2] = 0.0; }
+                if (ROWS == 2) o->ex[unit + 2] = 0.0;
                 if (unit == 0) { o->passes = it + 1; o->pad = 0; }
             }
             done = done || stop;
@@ -566,202 +562,217 @@ __device__ __forceinline__ void fit_body(int64_t item0, int64_t item_end, const 
         fb = ex;
         ++it;
     }
+    // UpdateF's log-likelihood (src/BaseType.cpp:58-62) at the frequencies of each item's last pass: the lane's
+    // classes here, the alleles outside the subset from the item's constant
+    {
+        const double g = fma(-4.0, fl, 1.0);
+        double ll = 0.0;
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) ll = fma(n[k], log_pos(fma(g, e[k], fl)), ll);
+        ll = item_sum<ROWS, LOG2G>(ll);
+        if (valid && unit == 0 && sub == 0) outs[item].ll = ll + items[item].ll_excl;
+    }
 }
 
-// Lanes per allele of the two item shapes, and the wavefronts a region of 16 sites needs per list and level
-// (kCaps places per site, 64 / (ROWS G) items per wavefront).
-constexpr int kLog2G4 = 1, kLog2G2 = 1;
+// Lanes per allele of the two item shapes: two for four-row items (8 per wavefront), four for two-row items (8 per
+// wavefront: the nested levels have few items per region, so they are spread over more wavefronts).
+constexpr int kLog2G4 = 1, kLog2G2 = 2;
 constexpr int kPerWave4 = 16 >> kLog2G4, kPerWave2 = 2 * (16 >> kLog2G2);
-// places a site can have per level and list: level A = full model + (n-1)-subsets, B and C = the nested levels
-constexpr int kCaps[kLevels][kLists] = {{4, 1, 2, 1}, {0, 0, 2, 1}, {0, 0, 1, 1}};
-constexpr int region_waves(int level, int l)
-{
-    return (kSitesPerBlock * kCaps[level][l] + (l < 2 ? kPerWave4 : kPerWave2) - 1) / (l < 2 ? kPerWave4 : kPerWave2);
-}
 
-struct FitLists {
-    const uint32_t *count;               // [kLists][n_regions]
-    const FitItem *items[kLists];
-    FitOut *outs[kLists];
-    int wave_end[kLists];                // wavefronts per region, exclusive prefix over the lists
-    int per_site[kLists];
-    int n_regions;
-};
-
-// All lists of a level in one launch: wavefront w serves region w / waves_per_region, and within it one list.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void fit_kernel(FitLists fl, const double *__restrict__ cls)
+// ---- site_decide: one wavefront per site, one level of BaseType::LRT -------------------------------------------------
+// Reads the fits of the pending level, takes the reference's decision (src/BaseType.cpp:93-110) and either sets up
+// the next level's fits or writes the record.
+__device__ __forceinline__ void site_decide(Region &R, int ls, int lane, int64_t site, int n_groups,
+                                            const int8_t *__restrict__ ref_base, bvc_site_result *__restrict__ results)
 {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
-    const int per_region = fl.wave_end[kLists - 1];
-    const int region = (int)(w / per_region), slot = (int)(w % per_region);
-    if (region >= fl.n_regions) return;
-    const int l = slot < fl.wave_end[0] ? 0 : (slot < fl.wave_end[1] ? 1 : (slot < fl.wave_end[2] ? 2 : 3));
-    const int in_list = slot - (l == 0 ? 0 : (l == 1 ? fl.wave_end[0] : (l == 2 ? fl.wave_end[1] : fl.wave_end[2])));
-    const int64_t base = (int64_t)region * (kSitesPerBlock * sel4(fl.per_site, l));
-    const int64_t first = base + (int64_t)in_list * (l < 2 ? kPerWave4 : kPerWave2);
-    const int64_t end = base + fl.count[l * fl.n_regions + region];
-    if (first >= end) return;
-    if (l < 2) fit_body<4, kLog2G4>(first, end, sel4(fl.items, l), sel4(fl.outs, l), cls);
-    else fit_body<2, kLog2G2>(first, end, sel4(fl.items, l), sel4(fl.outs, l), cls);
-}
-
-// ---- decide_kernel: one wavefront per site, one level of BaseType::LRT per launch -----------------------------------
-// Reads the fits of the pending level, sums their log-likelihoods (UpdateF, src/BaseType.cpp:58-62: all 128 class
-// places of the site, the alleles outside a subset with f = 0), takes the reference's decision (:93-110) and either
-// emits the next level's items or writes the record.
-__global__ __launch_bounds__(64 * kSitesPerBlock) void decide_kernel(
-    int64_t n_sites, int n_groups, const int8_t *__restrict__ ref_base, ItemSite *__restrict__ sites,
-    const double *__restrict__ cls, LevelIo io, bvc_site_result *__restrict__ results)
-{
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t site = (int64_t)blockIdx.x * kSitesPerBlock + wave;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int row = lane >> 4, t = lane & 15;
-    const bool in_range = site < n_sites;
-    ItemSite S{};
-    if (in_range) S = sites[site];
-    const bool running = in_range && S.state == 1;
+    ItemSite S = R.site[ls];
+    if (S.state != 1) {
+        if (lane == 0) { R.want[ls][0] = 0; R.want[ls][1] = 0; R.want[ls][2] = 0; R.want[ls][3] = 0; R.site[ls].n_emit = 0; }
+        return;
+    }
     uint32_t sets = 0;
     int n_emit = 0, p_deepest = 0;
     bool finished = false;
 
-    if (running) {
-        // the lane's two classes of allele `row`: places t and t + 16
-        const double *tab = cls + site * kSiteTable + row * kClassesPerBase + t;
-        const double n0 = tab[0], e0 = tab[kPlane];
-        const double n1 = tab[16], e1 = tab[kPlane + 16];
-        // position of allele `row` in the candidate list (or none)
-        int my_pos = -1;
+    auto fit_loglik = [&](int idx, uint32_t pm, double (&ex)[4], int &passes) -> double {
+        (void)pm;
+        const FitOut &o = R.outs[idx];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ex[u] = o.ex[u];
+        passes = o.passes;
+        return o.ll;
+    };
+    // expect_allele_prob by allele from the per-unit values of a fit
+    auto by_base = [&](uint32_t pm, const double (&ex)[4], double (&bp)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bp[j] = 0.0;
+        int u = 0;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            if (p < S.n && (int)((S.blist >> (4 * p)) & 3u) == row) my_pos = p;
-
-        auto fit_loglik = [&](int enc, uint32_t pm, double (&ex)[4], int &passes) -> double {
-            const FitOut *o = sel4(io.outs_prev, (enc >> 28) & 3) + (enc & 0x0FFFFFFF);
-            double fl[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { ex[u] = o->ex[u]; fl[u] = o->fl[u]; }
-            passes = o->passes;
-            // the lane's allele: unit = rank of its position among the subset's positions
-            double f = 0.0;
-            if (my_pos >= 0 && ((pm >> my_pos) & 1u)) {
-                const int u = __popc(pm & ((1u << my_pos) - 1u));
-                f = u == 0 ? fl[0] : (u == 1 ? fl[1] : (u == 2 ? fl[2] : fl[3]));
+            if ((pm >> p) & 1u) {
+                const int b = (S.blist >> (4 * p)) & 3u;
+                const double v = u == 0 ? ex[0] : (u == 1 ? ex[1] : (u == 2 ? ex[2] : ex[3]));
+                bp[0] = b == 0 ? v : bp[0]; bp[1] = b == 1 ? v : bp[1];
+                bp[2] = b == 2 ? v : bp[2]; bp[3] = b == 3 ? v : bp[3];
+                ++u;
             }
-            const double g = fma(-4.0, f, 1.0);                  // class marginal as fit_kernel forms it
-            double l = n0 * log_pos(fma(g, e0, f));
-            l = fma(n1, log_pos(fma(g, e1, f)), l);
-            return rows_total(row_sum(l));
-        };
-        // expect_allele_prob by allele from the per-unit values of a fit
-        auto by_base = [&](uint32_t pm, const double (&ex)[4], double (&bp)[4]) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bp[j] = 0.0;
-            int u = 0;
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                if ((pm >> p) & 1u) {
-                    const int b = (S.blist >> (4 * p)) & 3u;
-                    const double v = u == 0 ? ex[0] : (u == 1 ? ex[1] : (u == 2 ? ex[2] : ex[3]));
-                    bp[0] = b == 0 ? v : bp[0]; bp[1] = b == 1 ? v : bp[1];
-                    bp[2] = b == 2 ? v : bp[2]; bp[3] = b == 3 ? v : bp[3];
-                    ++u;
-                }
-        };
+    };
 
-        int first_sub = 0;
-        if (S.first) {                                           // the full model (:88-90)
+    int first_sub = 0;
+    if (S.first) {                                               // the full model (:88-90)
+        double ex[4];
+        int passes = 0;
+        S.lr_alt = fit_loglik(S.item[0], (1u << S.n) - 1u, ex, passes);
+        by_base((1u << S.n) - 1u, ex, S.base_frq);
+        S.passes += passes; S.fits += 1;
+        first_sub = 1;
+        S.k = (int8_t)(S.n - 1);
+        S.first = 0;
+    }
+    const int n = S.n, k = S.k;
+    if (k < 1) {
+        finished = true;                                         // n == 1: no nested level
+    } else {
+        int cnt = 0;
+        const uint32_t masks = subset_masks(n, k, cnt);
+        int i_min = 0;
+        double best_chi = 0.0, best_lr = 0.0, best_bp[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c >= cnt) break;
+            const uint32_t pm = (masks >> (4 * c)) & 0xFu;
+            const int idx = first_sub ? S.item[c + 1] : S.item[c];
             double ex[4];
             int passes = 0;
-            S.lr_alt = fit_loglik(S.item[0], (1u << S.n) - 1u, ex, passes);
-            by_base((1u << S.n) - 1u, ex, S.base_frq);
+            const double ll = fit_loglik(idx, pm, ex, passes);
             S.passes += passes; S.fits += 1;
-            first_sub = 1;
-            S.k = (int8_t)(S.n - 1);
-            S.first = 0;
-        }
-        const int n = S.n, k = S.k;
-        if (k < 1) {
-            finished = true;                                     // n == 1: no nested level
-        } else {
-            int cnt = 0;
-            const uint32_t masks = subset_masks(n, k, cnt);
-            int i_min = 0;
-            double best_chi = 0.0, best_lr = 0.0, best_bp[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c >= cnt) break;
-                const uint32_t pm = (masks >> (4 * c)) & 0xFu;
-                const int enc = first_sub ? S.item[c + 1] : S.item[c];
-                double ex[4];
-                int passes = 0;
-                const double ll = fit_loglik(enc, pm, ex, passes);
-                S.passes += passes; S.fits += 1;
-                const double chi_c = 2.0 * (S.lr_alt - ll);
-                if (c == 0 || chi_c < best_chi) {                // std::min_element: first minimum, '<'
-                    best_chi = chi_c; best_lr = ll; i_min = c;
-                    by_base(pm, ex, best_bp);
-                }
+            const double chi_c = 2.0 * (S.lr_alt - ll);
+            if (c == 0 || chi_c < best_chi) {                    // std::min_element: first minimum, '<'
+                best_chi = chi_c; best_lr = ll; i_min = c;
+                by_base(pm, ex, best_bp);
             }
-            S.lr_alt = best_lr;                                  // overwritten before the threshold test (:100-101)
-            S.chi = best_chi;
-            if (best_chi < kLrtThreshold) {
-                const uint32_t pm = (masks >> (4 * i_min)) & 0xFu;
-                uint32_t nl = 0;
-                int nn = 0;
+        }
+        S.lr_alt = best_lr;                                      // overwritten before the threshold test (:100-101)
+        S.chi = best_chi;
+        if (best_chi < kLrtThreshold) {
+            const uint32_t pm = (masks >> (4 * i_min)) & 0xFu;
+            uint32_t nl = 0;
+            int nn = 0;
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    if ((pm >> p) & 1u) { nl |= ((S.blist >> (4 * p)) & 3u) << (4 * nn); ++nn; }
-                S.blist = nl;
-                S.n = (int8_t)k;
+            for (int p = 0; p < 4; ++p)
+                if ((pm >> p) & 1u) { nl |= ((S.blist >> (4 * p)) & 3u) << (4 * nn); ++nn; }
+            S.blist = nl;
+            S.n = (int8_t)k;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) S.base_frq[j] = best_bp[j];
-                S.k = (int8_t)(k - 1);
-                if (k - 1 >= 1) {
-                    sets = subset_masks(k, k - 1, n_emit);
-                    p_deepest = deepest_position(S.depth, nl, k);
-                } else {
-                    finished = true;
-                }
+            for (int j = 0; j < 4; ++j) S.base_frq[j] = best_bp[j];
+            S.k = (int8_t)(k - 1);
+            if (k - 1 >= 1) {
+                sets = subset_masks(k, k - 1, n_emit);
+                p_deepest = deepest_position(S.depth, nl, k);
             } else {
                 finished = true;
             }
+        } else {
+            finished = true;
         }
     }
-
+    S.sets = sets; S.n_emit = (int8_t)n_emit; S.p_deepest = (int8_t)p_deepest;
     int want[kLists];
     count_wanted(sets, n_emit, p_deepest, want);
-    uint32_t at[kLists];
-    place_items(wave, lane, want, io, at);
-    if (!running) return;
-    if (n_emit > 0 && io.count_next) emit_items(site, lane, S, sets, n_emit, p_deepest, at, io);
     if (lane == 0) {
         if (finished) {
             store_record(results + site, S, (int)ref_base[n_groups > 0 ? site / n_groups : site], S.n, S.blist);
             S.state = 2;
         }
-        sites[site] = S;
+        R.site[ls] = S;
+        R.want[ls][0] = want[0]; R.want[ls][1] = want[1]; R.want[ls][2] = want[2]; R.want[ls][3] = want[3];
     }
+}
+
+// ---- region_kernel: one workgroup of five wavefronts per region of eight sites ---------------------------------------
+template <bool WALK>
+__device__ __forceinline__ void region_body(
+    Region &R, int64_t n_sites, int n_groups, const uint32_t *__restrict__ counts, int64_t hist_stride,
+    const QualLut *__restrict__ lut, const int8_t *__restrict__ ref_base, double min_af,
+    const int8_t *__restrict__ comb, const uint8_t *__restrict__ n_comb, uint8_t *__restrict__ taken,
+    bvc_site_result *__restrict__ results, int dbg_levels)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t n_regions = (n_sites + kRegionSites - 1) / kRegionSites;
+    // one region per workgroup when the launch has the chip to itself (the dispatcher balances them); underneath a
+    // streaming histogram pass the launcher bounds the grid and a workgroup walks several regions
+    for (int64_t region = blockIdx.x; region < n_regions; region += WALK ? (int64_t)gridDim.x : n_regions) {
+    const int64_t site0 = region * kRegionSites;
+    for (int ls = wave; ls < kRegionSites; ls += kRegionWaves) {
+        if (site0 + ls < n_sites) {
+            site_classes(R, ls, lane, site0 + ls, n_groups, counts, hist_stride, lut, ref_base, min_af, comb, n_comb, taken, results);
+        } else if (lane == 0) {
+            R.site[ls].state = 2; R.site[ls].n_emit = 0;
+            R.want[ls][0] = 0; R.want[ls][1] = 0; R.want[ls][2] = 0; R.want[ls][3] = 0;
+        }
+    }
+    __syncthreads();
+    for (int level = 0; level < kLevels && level < (dbg_levels >> 1); ++level) {
+        // the fits of this level, side by side in site order in each list
+        for (int ls = wave; ls < kRegionSites; ls += kRegionWaves) site_emit(R, ls, lane);
+        if (threadIdx.x < kLists) {
+            int tot = 0;
+            for (int w = 0; w < kRegionSites; ++w) tot += R.want[w][threadIdx.x];
+            R.count[threadIdx.x] = tot;
+        }
+        __syncthreads();
+        const int c0 = R.count[0], c1 = R.count[1], c2 = R.count[2], c3 = R.count[3];
+        if (c0 + c1 + c2 + c3 == 0) break;                       // (uniform over the workgroup)
+        const int w0 = (c0 + kPerWave4 - 1) / kPerWave4, w1 = w0 + (c1 + kPerWave4 - 1) / kPerWave4;
+        const int w2 = w1 + (c2 + kPerWave2 - 1) / kPerWave2, w3 = w2 + (c3 + kPerWave2 - 1) / kPerWave2;
+        // (the wavefront that takes slot 0 rotates with the region: a level with fewer slots than wavefronts would
+        // otherwise load the same SIMDs in every workgroup of the CU)
+        for (int slot = (wave + (int)region) % kRegionWaves; slot < w3; slot += kRegionWaves) {
+            const int l = slot < w0 ? 0 : (slot < w1 ? 1 : (slot < w2 ? 2 : 3));
+            const int in_list = slot - (l == 0 ? 0 : (l == 1 ? w0 : (l == 2 ? w1 : w2)));
+            const int base = l == 0 ? kListAt[0] : (l == 1 ? kListAt[1] : (l == 2 ? kListAt[2] : kListAt[3]));
+            const int cnt = l == 0 ? c0 : (l == 1 ? c1 : (l == 2 ? c2 : c3));
+            if (l < 2) fit_body<4, kLog2G4>(base + in_list * kPerWave4, base + cnt, R.items, R.outs, &R.tab[0][0], lut->e);
+            else fit_body<2, kLog2G2>(base + in_list * kPerWave2, base + cnt, R.items, R.outs, &R.tab[0][0], lut->e);
+        }
+        __syncthreads();
+        if (level + 1 == (dbg_levels >> 1) && (dbg_levels & 1)) break;
+        for (int ls = wave; ls < kRegionSites; ls += kRegionWaves)
+            if (site0 + ls < n_sites) site_decide(R, ls, lane, site0 + ls, n_groups, ref_base, results);
+        __syncthreads();
+    }
+    __syncthreads();                                             // the region's LDS is reused by the next one
+    }
+}
+
+// One region per workgroup: three workgroups (12 wavefronts) per CU.
+__global__ __launch_bounds__(64 * kRegionWaves) __attribute__((amdgpu_waves_per_eu(3, 3))) void region_kernel(
+    int64_t n_sites, int n_groups, const uint32_t *__restrict__ counts, int64_t hist_stride,
+    const QualLut *__restrict__ lut, const int8_t *__restrict__ ref_base, double min_af,
+    const int8_t *__restrict__ comb, const uint8_t *__restrict__ n_comb, uint8_t *__restrict__ taken,
+    bvc_site_result *__restrict__ results, int dbg_levels)
+{
+    __shared__ Region R;
+    region_body<false>(R, n_sites, n_groups, counts, hist_stride, lut, ref_base, min_af, comb, n_comb, taken, results, dbg_levels);
+}
+
+// A bounded grid whose workgroups walk the regions (underneath a streaming histogram pass: two workgroups per CU).
+__global__ __launch_bounds__(64 * kRegionWaves) void region_walk_kernel(
+    int64_t n_sites, int n_groups, const uint32_t *__restrict__ counts, int64_t hist_stride,
+    const QualLut *__restrict__ lut, const int8_t *__restrict__ ref_base, double min_af,
+    const int8_t *__restrict__ comb, const uint8_t *__restrict__ n_comb, uint8_t *__restrict__ taken,
+    bvc_site_result *__restrict__ results, int dbg_levels)
+{
+    __shared__ Region R;
+    region_body<true>(R, n_sites, n_groups, counts, hist_stride, lut, ref_base, min_af, comb, n_comb, taken, results, dbg_levels);
 }
 
 }  // namespace
 
-static int64_t item_regions(int64_t n_sites) { return (n_sites + kSitesPerBlock - 1) / kSitesPerBlock; }
-
 size_t em_items_scratch_bytes(int64_t n_sites)
 {
-    // region counters | ItemSite | taken | class tables | items and outputs of the three levels
-    const size_t regions = (size_t)item_regions(n_sites), padded = regions * kSitesPerBlock;
-    size_t b = regions * kLevels * kLists * sizeof(uint32_t) + 256;
-    b += (size_t)n_sites * sizeof(ItemSite) + 256;
-    b += (size_t)n_sites + 256;
-    b += (size_t)n_sites * kSiteTable * sizeof(double) + 256;
-    size_t per_site_items = 0;
-    for (int lv = 0; lv < kLevels; ++lv)
-        for (int l = 0; l < kLists; ++l) per_site_items += kCaps[lv][l];
-    b += padded * per_site_items * (sizeof(FitItem) + sizeof(FitOut)) + 2 * 256 * kLevels * kLists;
-    return b;
+    return (size_t)n_sites + 256;                                 // the `taken` flags; everything else lives in LDS
 }
 
 // Stage 2 with the item engine.  `scratch` holds em_items_scratch_bytes(n_sites).  Sites it does not take are left
@@ -769,55 +780,24 @@ size_t em_items_scratch_bytes(int64_t n_sites)
 hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n_sites, int n_groups,
                             const uint32_t *counts, int64_t hist_stride, const int8_t *ref_base, double min_af,
                             const QualLut *lut, const int8_t *comb, const uint8_t *n_comb, bvc_site_result *results,
-                            void *scratch, const uint8_t **taken_out)
+                            void *scratch, const uint8_t **taken_out, bool shared)
 {
-    (void)st;
-    const int64_t regions = item_regions(n_sites);
-    char *p = static_cast<char *>(scratch);
-    auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
-    uint32_t *count = reinterpret_cast<uint32_t *>(take((size_t)regions * kLevels * kLists * sizeof(uint32_t)));
-    ItemSite *sites = reinterpret_cast<ItemSite *>(take((size_t)n_sites * sizeof(ItemSite)));
-    uint8_t *taken = reinterpret_cast<uint8_t *>(take((size_t)n_sites));
-    double *cls = reinterpret_cast<double *>(take((size_t)n_sites * kSiteTable * sizeof(double)));
-    FitItem *items[kLevels][kLists];
-    FitOut *outs[kLevels][kLists];
-    for (int lv = 0; lv < kLevels; ++lv)
-        for (int l = 0; l < kLists; ++l) {
-            const size_t n = (size_t)regions * kSitesPerBlock * kCaps[lv][l];
-            items[lv][l] = reinterpret_cast<FitItem *>(take(n * sizeof(FitItem)));
-            outs[lv][l] = reinterpret_cast<FitOut *>(take(n * sizeof(FitOut)));
-        }
-    auto level_io = [&](int level) {                              // what the launch after `level` fit levels reads and writes
-        LevelIo io{};
-        for (int l = 0; l < kLists; ++l) {
-            io.outs_prev[l] = level > 0 ? outs[level - 1][l] : nullptr;
-            io.items_next[l] = level < kLevels ? items[level][l] : nullptr;
-            io.per_site_next[l] = level < kLevels ? kCaps[level][l] : 0;
-        }
-        io.count_next = level < kLevels ? count + (size_t)level * kLists * regions : nullptr;
-        io.n_regions = (int)regions;
-        return io;
-    };
-    const dim3 sgrid((unsigned)regions), sblock(64 * kSitesPerBlock);
-    hipLaunchKernelGGL(classes_kernel, sgrid, sblock, 0, stream, n_sites, n_groups, counts, hist_stride, lut, ref_base,
-                       min_af, comb, n_comb, sites, cls, taken, level_io(0), results);
-    for (int level = 0; level < kLevels; ++level) {
-        FitLists fl{};
-        fl.count = count + (size_t)level * kLists * regions;
-        fl.n_regions = (int)regions;
-        int end = 0;
-        for (int l = 0; l < kLists; ++l) {
-            end += region_waves(level, l);
-            fl.wave_end[l] = end;
-            fl.per_site[l] = kCaps[level][l];
-            fl.items[l] = items[level][l];
-            fl.outs[l] = outs[level][l];
-        }
-        const int64_t waves = regions * end;
-        hipLaunchKernelGGL(fit_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, fl, cls);
-        hipLaunchKernelGGL(decide_kernel, sgrid, sblock, 0, stream, n_sites, n_groups, ref_base, sites, cls,
-                           level_io(level + 1), results);
-    }
+    uint8_t *taken = static_cast<uint8_t *>(scratch);
+    const int64_t regions = (n_sites + kRegionSites - 1) / kRegionSites;
+    // underneath a streaming histogram pass (overlap mode, long rows): ONE workgroup (four wavefronts) per CU.  The
+    // fits are dense FP64 work; at two workgroups per CU they take the histogram kernel from 1.18 to 1.34 ms per call
+    // and the packed one from 0.63 to 0.77, at one they leave both at their stand-alone speed and still finish well
+    // inside the histogram pass (profiles/r03_stage2_cap_under_hist.txt)
+    int64_t grid = regions;
+    const int per_cu = st.em_waves_per_cu > 0 ? (st.em_waves_per_cu + kRegionWaves - 1) / kRegionWaves : (shared ? 1 : 0);
+    if (per_cu > 0 && grid > (int64_t)per_cu * st.n_cu) grid = (int64_t)per_cu * st.n_cu;
+    const int dbg_levels = getenv("BVC_DBG_LEVELS") ? atoi(getenv("BVC_DBG_LEVELS")) : 2 * kLevels;
+    if (grid < regions)
+        hipLaunchKernelGGL(region_walk_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, n_sites, n_groups, counts,
+                           hist_stride, lut, ref_base, min_af, comb, n_comb, taken, results, dbg_levels);
+    else
+        hipLaunchKernelGGL(region_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, n_sites, n_groups, counts,
+                           hist_stride, lut, ref_base, min_af, comb, n_comb, taken, results, dbg_levels);
     *taken_out = taken;
     return hipGetLastError();
 }

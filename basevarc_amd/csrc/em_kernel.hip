@@ -688,7 +688,7 @@ hipError_t launch_lrt(const LaunchState &st, hipStream_t stream, int64_t n_sites
     const uint8_t *taken = nullptr;
     if (scratch && st.em_engine != 1 && min_af > 0.0) {
         const hipError_t e = launch_lrt_items(st, stream, n_sites, 0, counts, hist_stride, ref_base, min_af, lut, comb, n_comb,
-                                              results, scratch, &taken);
+                                              results, scratch, &taken, shared);
         if (e != hipSuccess) return e;
     }
     const int64_t cap = em_grid_cap(st, shared, shared_waves_per_cu);
@@ -746,7 +746,7 @@ hipError_t launch_lrt_groups(const LaunchState &st, hipStream_t stream, int64_t 
         const dim3 tgrid((unsigned)((n_work + 255) / 256)), tblock(256);
         hipLaunchKernelGGL(group_comb_kernel, tgrid, tblock, 0, stream, n_work, n_groups, ref_base, overall, comb, n_comb);
         const hipError_t e = launch_lrt_items(st, stream, n_work, n_groups, grp_counts, BVC_NCLASS, ref_base, min_af, lut, comb,
-                                              n_comb, pseudo, p, &taken);
+                                              n_comb, pseudo, p, &taken, shared);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(group_records_kernel, tgrid, tblock, 0, stream, n_work, n_groups, overall, pseudo, taken, grp_results);
     }
