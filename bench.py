@@ -41,6 +41,10 @@ VALU_CYCLES_PER_WAVE_INST = 4     # wave64 FP64 / 32-bit VALU instruction (tools
 # (full model + 3-subsets) and 36 % two-allele (the nested levels) on the synthetic workload: 0.64 * 18.75 + 0.36 * 9.4.
 # (Round 2's one-wavefront-per-site kernel: 63 instructions per pass, 82 slots all told.)
 EM_ISSUE_SLOTS_PER_PASS = 15.4
+# What it EXECUTES per site-pass (SQ_INSTS_VALU of region_kernel / (sites x passes), profiles/r03_stage2_pmc.txt): a
+# wavefront runs until its slowest fit stops and a region's wavefronts meet at a barrier per level, so the shorter the
+# fits (small N) the more passes run on fits that have already stopped.
+EM_VALU_EXECUTED_PER_PASS = {10_000: 32.3, 100_000: 26.5, 1_000_000: 22.0}
 
 
 def parse():
@@ -264,7 +268,7 @@ def main():
             "empirical_stream_read_GBs": empirical_gbs, "frac_of_empirical": achieved / empirical_gbs if empirical_gbs else None,
         },
         "kernels_ms_per_call": {kname: hist_ms,
-                                ("sum_groups + lrt + lrt_groups kernels" if a.groups > 0 else "stage 2 (classes + fit + decide kernels)"): em_ms},
+                                ("sum_groups + lrt + lrt_groups kernels" if a.groups > 0 else "stage 2 (region_kernel)"): em_ms},
     }
     if res_sites < my_sites:
         out["config"]["note"] = f"only {res_sites} of this rank's {my_sites} sites fit in device memory; a step covers those"
@@ -473,8 +477,8 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
         "workload": f"ragged (CSR) sites, bvc_lrt_csr: N = {n} samples at {cov:.0%} coverage = {covered / csr_sites:.0f} "
                     f"observations per site on average, {n_calls} calls of {csr_sites} sites over {len(csr)} tiles",
         "value": n_calls * csr_sites / dt, "unit": "sites/s", "ms_per_call": dt / n_calls * 1e3,
-        "bound_by": "stage 2: fit_kernel (FP64 VALU issue)",
-        "roofline": em_roofline(rec, em_ms, dt / n_calls * 1e3),
+        "bound_by": "stage 2: region_kernel (FP64 VALU issue)",
+        "roofline": em_roofline(rec, em_ms, dt / n_calls * 1e3, depth=100_000 if abs(covered / csr_sites - 1e5) < 2e4 else 0),
         "hist_roofline": {"bound": "hbm", "kernel": "hist_csr_block_kernel", "achieved": alg / (hist_ms * 1e-3) / 1e9,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (hist_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "avg_launch_ms": hist_ms, "launches_timed": int(prof["hist_launches"]),
@@ -509,14 +513,14 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
         "workload": f"BASELINE configs[1]: synthetic pileup {ns1} sites x {n1} samples, EM to convergence, "
                     f"{n_calls} calls of {ns1} sites",
         "value": n_calls * ns1 / dt, "unit": "sites/s", "ms_per_call": dt / n_calls * 1e3,
-        "bound_by": "stage 2: fit_kernel (FP64 VALU issue)",
-        "roofline": em_roofline(rec, em_ms, dt / n_calls * 1e3),
+        "bound_by": "stage 2: region_kernel (FP64 VALU issue)",
+        "roofline": em_roofline(rec, em_ms, dt / n_calls * 1e3, depth=n1),
         "hist_wave_kernel_ms_per_call_under_the_em": hist_ms,     # 0.05 ms alone (profiles/r02_kernel_stats_legs.csv)
     }
     return legs
 
 
-def em_roofline(rec, em_launch_ms, call_ms):
+def em_roofline(rec, em_launch_ms, call_ms, depth=0):
     """FP64-VALU issue roofline of stage 2 where it is the bound: issue slots x 4 cycles against 1024 SIMDs x 2.4 GHz.
     Numerator = E+M passes of a call (singleEM calls, as the reference counts them) x the slots a pass NEEDS in
     fit_kernel with every lane group busy (EM_ISSUE_SLOTS_PER_PASS) -- so lockstep idling (a wavefront runs until its
@@ -526,10 +530,13 @@ def em_roofline(rec, em_launch_ms, call_ms):
     inst = passes * EM_ISSUE_SLOTS_PER_PASS
     peak = N_SIMD * ENGINE_CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST          # wave-instructions per second, whole chip
     ach = inst / (call_ms * 1e-3) if call_ms > 0 else 0.0
-    return {"bound": "fp64_valu_issue", "kernel": "fit_kernel (em_items.hip)", "achieved": ach / 1e9, "peak": peak / 1e9,
+    executed = EM_VALU_EXECUTED_PER_PASS.get(depth)
+    return {"bound": "fp64_valu_issue", "kernel": "region_kernel (em_items.hip)", "achieved": ach / 1e9, "peak": peak / 1e9,
             "unit": "G issue slots/s", "frac": ach / peak, "ms_per_call": call_ms,
             "avg_launch_ms": em_launch_ms, "launches_overlap": True,
             "em_passes_per_site": passes / max(1, len(rec)), "issue_slots_per_pass": EM_ISSUE_SLOTS_PER_PASS,
+            "valu_executed_per_pass": executed,
+            "frac_executed": (passes * executed / (call_ms * 1e-3) / peak) if executed and call_ms > 0 else None,
             "note": "no MFMA: the EM is a scalar recurrence per class, not a contraction; peak = 1024 SIMDs x 2.4 GHz / 4 cycles "
                     "(the chip holds about 2.17 GHz under this load)"}
 
