@@ -29,7 +29,7 @@ struct bvc_ctx {
     bool overlap = false;
     hipStream_t side = nullptr;        // stage 2 of even calls
     hipStream_t side_b = nullptr, side_c = nullptr;   // further stage-2 streams (two_em_streams below)
-    int side_flip = 0;
+    unsigned side_flip = 0;
     int flip = 0;
     hipEvent_t ev_hist_done[kRing] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_em_done[kRing] = {nullptr, nullptr, nullptr};
@@ -82,7 +82,10 @@ int ensure(bvc_ctx *ctx, void **buf, size_t *cap, size_t need)
 {
     if (need <= *cap) return BVC_OK;
     if (*buf) {
+        // nothing may still be reading or writing the old buffer: the context's stream, and the copy stream (a staging
+        // set may have an upload in flight after a failed host-pointer call)
         BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->copy) BVC_HIP(ctx, hipStreamSynchronize(ctx->copy));
         BVC_HIP(ctx, hipFree(*buf));
         *buf = nullptr; *cap = 0;
     }
@@ -144,7 +147,7 @@ int em_stream_count(const bvc_ctx *ctx, int by_default) { return ctx->ls.em_stre
 hipStream_t em_stream(bvc_ctx *ctx, int by_default)
 {
     const int n = em_stream_count(ctx, by_default);
-    const int k = ctx->side_flip++ % n;
+    const int k = (int)(ctx->side_flip++ % (unsigned)n);
     return k == 0 ? ctx->side : (k == 1 ? ctx->side_b : ctx->side_c);
 }
 
@@ -299,26 +302,41 @@ void reap_timing(bvc_ctx *ctx, bool all)
 template <class Upload, class Compute>
 int run_chunks(bvc_ctx *ctx, int64_t n_sites, int64_t chunk, Upload upload, Compute compute)
 {
+    // an early exit must not leave an upload or a kernel running on the staging sets: the next call may free or refill them
+    auto drained = [&](int code) {
+        if (code != BVC_OK) {
+            (void)hipStreamSynchronize(ctx->copy);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipGetLastError();
+        }
+        return code;
+    };
+#define BVC_HIP_D(call)                                                                   \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) return drained(fail(ctx, BVC_ERR_DEVICE, #call, e__));     \
+    } while (0)
     int set = 0;
     int rc = upload(set, (int64_t)0, n_sites < chunk ? n_sites : chunk);
-    if (rc != BVC_OK) return rc;
-    BVC_HIP(ctx, hipEventRecord(ctx->ev_upload[set], ctx->copy));
+    if (rc != BVC_OK) return drained(rc);
+    BVC_HIP_D(hipEventRecord(ctx->ev_upload[set], ctx->copy));
     for (int64_t s0 = 0; s0 < n_sites; s0 += chunk, set ^= 1) {
         const int64_t ns = n_sites - s0 < chunk ? n_sites - s0 : chunk;
-        BVC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upload[set], 0));
+        BVC_HIP_D(hipStreamWaitEvent(ctx->stream, ctx->ev_upload[set], 0));
         rc = compute(set, s0, ns, /*download=*/false);
-        if (rc != BVC_OK) return rc;
+        if (rc != BVC_OK) return drained(rc);
         const int64_t s1 = s0 + chunk;
         if (s1 < n_sites) {
             // the other set's previous chunk (i-1) has been downloaded synchronously below: it is free
             rc = upload(set ^ 1, s1, n_sites - s1 < chunk ? n_sites - s1 : chunk);
-            if (rc != BVC_OK) return rc;
-            BVC_HIP(ctx, hipEventRecord(ctx->ev_upload[set ^ 1], ctx->copy));
+            if (rc != BVC_OK) return drained(rc);
+            BVC_HIP_D(hipEventRecord(ctx->ev_upload[set ^ 1], ctx->copy));
         }
         rc = compute(set, s0, ns, /*download=*/true);
-        if (rc != BVC_OK) return rc;
-        BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (rc != BVC_OK) return drained(rc);
+        BVC_HIP_D(hipStreamSynchronize(ctx->stream));
     }
+#undef BVC_HIP_D
     return BVC_OK;
 }
 
@@ -464,6 +482,7 @@ int bvc_synchronize(bvc_ctx *ctx)
     BVC_HIP(ctx, hipStreamSynchronize(ctx->side));
     BVC_HIP(ctx, hipStreamSynchronize(ctx->side_b));
     BVC_HIP(ctx, hipStreamSynchronize(ctx->side_c));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->copy));
     for (bool &p : ctx->em_pending) p = false;
     BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BVC_OK;
@@ -770,6 +789,45 @@ int bvc_lrt_csr_comb(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
     return BVC_OK;
 }
 
+int bvc_lrt_csr_packed(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets, const uint8_t *packed,
+                       const int8_t *ref_base, double min_af, bvc_site_result *results, uint32_t flags)
+{
+    int rc = check_common(ctx, n_sites, offsets, ref_base, results, results);
+    if (rc != BVC_OK) return rc;
+    if (n_sites == 0) return BVC_OK;
+    const int8_t *obs = reinterpret_cast<const int8_t *>(packed);
+    if (flags & BVC_PTR_DEVICE) {
+        if (!packed) return fail(ctx, BVC_ERR_ARG, "null data pointer");
+        return run_csr_device(ctx, n_sites, offsets, obs, nullptr, ref_base, min_af, nullptr, nullptr, results);
+    }
+    const int64_t total = offsets[n_sites];
+    if (offsets[0] != 0 || total < 0) return fail(ctx, BVC_ERR_ARG, "offsets must start at 0 and be non-decreasing");
+    for (int64_t s = 0; s < n_sites; ++s)
+        if (offsets[s + 1] < offsets[s]) return fail(ctx, BVC_ERR_ARG, "offsets must start at 0 and be non-decreasing");
+    if (total > 0 && !packed) return fail(ctx, BVC_ERR_ARG, "null data pointer");
+    // one staging set: offsets | observations | ref | records (half the bytes of bvc_lrt_csr over the host link)
+    const size_t ta = ((size_t)total + 255) & ~(size_t)255;
+    const size_t oa = ((size_t)(n_sites + 1) * 8 + 255) & ~(size_t)255;
+    const size_t sa = ((size_t)n_sites + 255) & ~(size_t)255;
+    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage[0]), &ctx->stage_cap[0],
+                oa + ta + sa + (size_t)n_sites * sizeof(bvc_site_result) + 256);
+    if (rc != BVC_OK) return rc;
+    int64_t *d_o = reinterpret_cast<int64_t *>(ctx->d_stage[0]);
+    int8_t *d_p = reinterpret_cast<int8_t *>(ctx->d_stage[0] + oa);
+    int8_t *d_r = d_p + ta;
+    bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(d_r + sa);
+    BVC_HIP(ctx, hipMemcpyAsync(d_o, offsets, (size_t)(n_sites + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (total > 0) BVC_HIP(ctx, hipMemcpyAsync(d_p, packed, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+    BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
+    rc = run_csr_device(ctx, n_sites, d_o, d_p, nullptr, d_r, min_af, nullptr, nullptr, d_res);
+    if (rc == BVC_OK) rc = join_side(ctx);
+    if (rc != BVC_OK) return rc;
+    BVC_HIP(ctx, hipMemcpyAsync(results, d_res, (size_t)n_sites * sizeof(bvc_site_result), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BVC_OK;
+}
+
 int bvc_lrt_csr(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
                 const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
                 double min_af, bvc_site_result *results, uint32_t flags)
@@ -933,6 +991,7 @@ int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value)
 {
     if (!ctx) return BVC_ERR_ARG;
     if (!key) return fail(ctx, BVC_ERR_ARG, "null tuning key");
+    BVC_HIP(ctx, hipSetDevice(ctx->device));                     // "em_streams" joins the side streams of THIS device
     if (std::strcmp(key, "em_waves_per_cu") == 0 && value >= 0 && value <= 32) { ctx->ls.em_waves_per_cu = value; return BVC_OK; }
     if (std::strcmp(key, "em_wpb") == 0 && (value == 1 || value == 4)) { ctx->ls.em_wpb = value; return BVC_OK; }
     if (std::strcmp(key, "hist_split") == 0 && value >= 0 && value <= 64) { ctx->ls.hist_split = value; return BVC_OK; }

@@ -572,6 +572,24 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_ranges_kernel(
 //                          with short rows (BASELINE configs[1]: 1e4 samples per site)
 //   hist_csr_block_kernel  len >= kCsrLong: one workgroup per site with the dense kernel's 32 conflict-free copies,
 //                          16-byte loads over the aligned middle of the range, head and tail sample by sample
+// Ragged sites in the ONE-byte form (bvc_lrt_csr_packed: base << 6 | qual, qual <= 62, qual bits 63 = no observation):
+// four bytes of a word become the base word and the qual word of the two-byte kernels; a "no observation" byte gets
+// base byte 0xFF, which their counting skips.
+__device__ __forceinline__ void unpack_word(uint32_t w, uint32_t &bw, uint32_t &qw)
+{
+    qw = w & 0x3F3F3F3Fu;
+    const uint32_t none = ((qw + 0x01010101u) >> 6) & 0x01010101u;       // 1 in the bytes whose qual bits are 63
+    bw = ((w >> 6) & 0x03030303u) | (none * 0xFFu);
+}
+
+__device__ __forceinline__ void unpack_chunk(const u32x4 p, u32x4 &b, u32x4 &q)
+{
+    uint32_t b0, b1, b2, b3, q0, q1, q2, q3;
+    unpack_word(p.x, b0, q0); unpack_word(p.y, b1, q1); unpack_word(p.z, b2, q2); unpack_word(p.w, b3, q3);
+    b = u32x4{b0, b1, b2, b3};
+    q = u32x4{q0, q1, q2, q3};
+}
+
 constexpr int64_t kCsrLong = 4096;
 constexpr int kCsrWaves = kHistThreads / 64;
 constexpr int kWaveCopies = 2;                     // copies of a wave's private histogram (copy = lane & 1)
@@ -579,7 +597,7 @@ constexpr int kWaveCopies = 2;                     // copies of a wave's private
 // One wavefront counts elements [s0, s1) of the arrays into its private LDS histogram [class][kWaveCopies].
 // ALIGNED: both arrays start on a 16-byte boundary, so whole 16-element chunks of the range load as one dwordx4 per
 // lane; head and tail element by element.
-template <bool ALIGNED>
+template <bool ALIGNED, bool PACKED = false>
 __device__ __forceinline__ void wave_count_range(uint32_t *__restrict__ hist, const int8_t *__restrict__ bases,
                                                  const int8_t *__restrict__ quals, int64_t s0, int64_t s1, int lane)
 {
@@ -589,7 +607,10 @@ __device__ __forceinline__ void wave_count_range(uint32_t *__restrict__ hist, co
             __hip_atomic_fetch_add(&hist[((b << 7) | q) * kWaveCopies + copy], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     auto scalar = [&](int64_t i0, int64_t i1) {
-        for (int64_t i = i0 + lane; i < i1; i += 64) one((uint8_t)bases[i], (uint8_t)quals[i]);
+        for (int64_t i = i0 + lane; i < i1; i += 64) {
+            if (PACKED) { const uint32_t v = (uint8_t)bases[i]; one((v & 63u) == 63u ? 0xFFu : v >> 6, v & 63u); }
+            else one((uint8_t)bases[i], (uint8_t)quals[i]);
+        }
     };
     const int64_t c0 = (s0 + 15) >> 4, c1 = s1 >> 4;
     if (ALIGNED && c0 < c1) {
@@ -597,7 +618,8 @@ __device__ __forceinline__ void wave_count_range(uint32_t *__restrict__ hist, co
         const u32x4 *bv = reinterpret_cast<const u32x4 *>(bases);
         const u32x4 *qv = reinterpret_cast<const u32x4 *>(quals);
         for (int64_t c = c0 + lane; c < c1; c += 64) {
-            const u32x4 b = bv[c], q = qv[c];
+            u32x4 b = bv[c], q;
+            if (PACKED) unpack_chunk(b, b, q); else q = qv[c];
             const uint32_t bw[4] = {b.x, b.y, b.z, b.w}, qw[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int w = 0; w < 4; ++w)
@@ -612,7 +634,7 @@ __device__ __forceinline__ void wave_count_range(uint32_t *__restrict__ hist, co
 
 // One wavefront per site: short ragged sites (DENSE = false: [offsets[s], offsets[s+1]), the long ones are left to
 // hist_csr_block_kernel) or short dense rows (DENSE = true: [s * row_stride, s * row_stride + n_samples)).
-template <bool ALIGNED, bool DENSE>
+template <bool ALIGNED, bool DENSE, bool PACKED = false>
 __global__ __launch_bounds__(kHistThreads) void hist_wave_kernel(
     int64_t n_sites, const int64_t *__restrict__ offsets, int64_t n_samples, int64_t row_stride,
     const int8_t *__restrict__ bases, const int8_t *__restrict__ quals, uint32_t *__restrict__ counts)
@@ -628,7 +650,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_wave_kernel(
         const int64_t o0 = DENSE ? site * row_stride : offsets[site];
         const int64_t o1 = DENSE ? o0 + n_samples : offsets[site + 1];
         if (!DENSE && o1 - o0 >= kCsrLong) continue;             // hist_csr_block_kernel's
-        wave_count_range<ALIGNED>(hist, bases, quals, o0, o1, lane);
+        wave_count_range<ALIGNED, PACKED>(hist, bases, quals, o0, o1, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         uint32_t *dst = counts + site * BVC_NCLASS;
@@ -645,7 +667,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_wave_kernel(
     }
 }
 
-template <bool ALIGNED>
+template <bool ALIGNED, bool PACKED = false>
 __global__ __launch_bounds__(kHistThreads) void hist_csr_block_kernel(
     int64_t n_sites, const int64_t *__restrict__ offsets, const int8_t *__restrict__ bases,
     const int8_t *__restrict__ quals, uint32_t *__restrict__ counts)
@@ -659,7 +681,9 @@ __global__ __launch_bounds__(kHistThreads) void hist_csr_block_kernel(
     __syncthreads();
     auto scalar = [&](int64_t i0, int64_t i1) {
         for (int64_t i = i0 + tid; i < i1; i += kHistThreads) {
-            const uint32_t b = (uint8_t)bases[i], q = (uint8_t)quals[i];
+            uint32_t b = (uint8_t)bases[i], q;
+            if (PACKED) { q = b & 63u; b = q == 63u ? 0xFFu : b >> 6; }
+            else q = (uint8_t)quals[i];
             if (b < 4u && q < 128u)
                 __hip_atomic_fetch_add(&hist[((b << 7) | q) * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -668,6 +692,33 @@ __global__ __launch_bounds__(kHistThreads) void hist_csr_block_kernel(
     for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
         const int64_t s0 = offsets[site], s1 = offsets[site + 1];
         if (s1 - s0 < kCsrLong) continue;                        // hist_wave_kernel's (workgroup-uniform)
+        if (PACKED) {
+            // one array: the chunks of a block loaded, unpacked into the two-byte kernels' base and qual words, counted
+            const int64_t c0 = (s0 + 15) >> 4, c1 = s1 >> 4;
+            if (ALIGNED && c0 < c1) {
+                scalar(s0, c0 << 4);
+                const u32x4 *pv = reinterpret_cast<const u32x4 *>(bases);
+                for (int64_t cb = c0; cb < c1; cb += (int64_t)kUnroll * kHistThreads) {
+                    u32x4 v[kUnroll];
+#pragma unroll
+                    for (int u = 0; u < kUnroll; ++u) {
+                        const int64_t c = cb + tid + (int64_t)u * kHistThreads;
+                        v[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};     // "no observation"
+                        if (c < c1) v[u] = __builtin_nontemporal_load(&pv[c]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kUnroll; ++u) {
+                        const int64_t wave_first = cb + (tid & ~63) + (int64_t)u * kHistThreads;   // wave-uniform
+                        u32x4 b, q;
+                        unpack_chunk(v[u], b, q);
+                        if (wave_first < c1) count_chunk(hist, b, q, lane_off);
+                    }
+                }
+                scalar(c1 << 4, s1);
+            } else {
+                scalar(s0, s1);
+            }
+        } else {
         // [s0, s1) = unaligned head, whole 16-sample chunks [c0, c1) of the concatenated arrays, unaligned tail
         const int64_t c0 = (s0 + 15) >> 4, c1 = s1 >> 4;
         if (ALIGNED && c0 < c1) {
@@ -690,6 +741,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_csr_block_kernel(
             scalar(c1 << 4, s1);
         } else {
             scalar(s0, s1);
+        }
         }
         __syncthreads();
         for (int key = tid; key < BVC_NCLASS; key += kHistThreads) {
@@ -1027,15 +1079,19 @@ __global__ void pack_dense_kernel(int64_t n_sites, int64_t n_samples, int64_t st
 }
 
 // Plain streaming read, 16 B per lane, nothing else: the empirical HBM read ceiling the histogram kernel is
-// compared with next to the 8 TB/s spec figure.  The XOR keeps the loads alive.
+// compared with next to the 8 TB/s spec figure.  The XOR keeps the loads alive.  Shape = the best of
+// tools/micro/read_bw.hip's grid-stride sweeps over a line-aligned 8 GB tile (profiles/r02_read_bw_aligned.txt): four
+// non-temporal loads in flight per lane, 16384 workgroups of 512 (6.80 TB/s; the round-2 shape, 4096 x 512 with two
+// loads, reads 6.38 and was below the kernel it is meant to cap).
 __global__ __launch_bounds__(512) void stream_read_kernel(const u32x4 *__restrict__ src, int64_t n16, uint32_t *__restrict__ sink)
 {
     uint32_t acc = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + stride < n16; i += 2 * stride) {
+    for (; i + 3 * stride < n16; i += 4 * stride) {
         const u32x4 a = __builtin_nontemporal_load(&src[i]), b = __builtin_nontemporal_load(&src[i + stride]);
-        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w;
+        const u32x4 c = __builtin_nontemporal_load(&src[i + 2 * stride]), d = __builtin_nontemporal_load(&src[i + 3 * stride]);
+        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
     }
     for (; i < n16; i += stride) { const u32x4 a = __builtin_nontemporal_load(&src[i]); acc ^= a.x ^ a.y ^ a.z ^ a.w; }
     if (acc == 0x9E3779B9u) sink[0] = acc;       // practically never: the store only makes the result observable
@@ -1047,7 +1103,9 @@ hipError_t launch_stream_read(hipStream_t stream, const void *src, int64_t bytes
 {
     const int64_t n16 = bytes / 16;
     if (n16 <= 0) return hipSuccess;
-    hipLaunchKernelGGL(stream_read_kernel, dim3(4096), dim3(512), 0, stream, reinterpret_cast<const u32x4 *>(src), n16, sink);
+    int64_t blocks = (n16 + 4 * 512 - 1) / (4 * 512);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(stream_read_kernel, dim3((unsigned)blocks), dim3(512), 0, stream, reinterpret_cast<const u32x4 *>(src), n16, sink);
     return hipGetLastError();
 }
 
@@ -1074,6 +1132,7 @@ enum KernelSlot : uint32_t {
     kSlotGroupPipe = 16,       // + log2c (0..5)
     kSlotPacked0 = 24, kSlotPacked1 = 25, kSlotPackedRanges0 = 26, kSlotPackedRanges1 = 27,
     kSlotPackedGroups = 32,    // + 6 * aligned + log2c (0..5)
+    kSlotCsrPacked0 = 44, kSlotCsrPacked1 = 45,
 };
 
 static hipError_t raise_lds(LaunchState &st, uint32_t slot, const void *kernel, size_t bytes)
@@ -1226,14 +1285,18 @@ hipError_t launch_hist_csr(LaunchState &st, hipStream_t stream, int64_t n_sites,
                            const int8_t *bases, const int8_t *quals, uint32_t *counts)
 {
     if (n_sites <= 0) return hipSuccess;
+    const bool packed = quals == nullptr;                        // one byte per observation in `bases`
     // both arrays are indexed by the same element offsets, so one alignment test covers every site
     const bool aligned = ((reinterpret_cast<uintptr_t>(bases) | reinterpret_cast<uintptr_t>(quals)) & 15u) == 0;
     const size_t lds = (size_t)kLdsWords * sizeof(uint32_t);
-    auto bk = aligned ? hist_csr_block_kernel<true> : hist_csr_block_kernel<false>;
-    hipError_t e = raise_lds(st, aligned ? kSlotCsr1 : kSlotCsr0, reinterpret_cast<const void *>(bk), lds);
+    auto bk = packed ? (aligned ? hist_csr_block_kernel<true, true> : hist_csr_block_kernel<false, true>)
+                     : (aligned ? hist_csr_block_kernel<true> : hist_csr_block_kernel<false>);
+    hipError_t e = raise_lds(st, (aligned ? kSlotCsr1 : kSlotCsr0) + (packed ? kSlotCsrPacked0 - kSlotCsr0 : 0),
+                             reinterpret_cast<const void *>(bk), lds);
     if (e != hipSuccess) return e;
     const int64_t wgrid = (n_sites + kCsrWaves - 1) / kCsrWaves;
-    auto wk = aligned ? hist_wave_kernel<true, false> : hist_wave_kernel<false, false>;
+    auto wk = packed ? (aligned ? hist_wave_kernel<true, false, true> : hist_wave_kernel<false, false, true>)
+                     : (aligned ? hist_wave_kernel<true, false> : hist_wave_kernel<false, false>);
     hipLaunchKernelGGL(wk, dim3((unsigned)(wgrid < 8192 ? wgrid : 8192)), dim3(kHistThreads), 0, stream,
                        n_sites, offsets, (int64_t)0, (int64_t)0, bases, quals, counts);
     hipLaunchKernelGGL(bk, dim3((unsigned)(n_sites < 4096 ? n_sites : 4096)), dim3(kHistThreads), lds, stream, n_sites,

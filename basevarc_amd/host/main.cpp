@@ -18,6 +18,8 @@
 #include <fstream>
 #include <iostream>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -221,14 +223,8 @@ struct StageClock {
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 };
 
-struct TileRunner {
-    StageClock clk;
-    bvc_ctx *ctx = nullptr;
-    const Groups *groups = nullptr;
-    std::string chr;
-    int32_t n_samples = 0;
-    double min_af = 0;
-    BgzfWriter *fvcf = nullptr, *fcvg = nullptr;
+// One tile of positions on its way through a runner: parsed (stage 1), handed to libbvc (stage 2), written out (stage 3).
+struct Tile {
     // the tile's positions: slots [0, n_used) of `sites` (the slots and their vectors are reused from tile to tile)
     std::vector<SiteColumn> sites;
     size_t n_used = 0;
@@ -239,97 +235,227 @@ struct TileRunner {
         if (n_used == sites.size()) sites.emplace_back();
         return sites[n_used];
     }
-
-    // tile buffers live as long as the runner: a flush refills them, it does not reallocate them
+    // buffers of the library call and its records: live as long as the tile, refilled, not reallocated
     std::vector<bvc_site_result> res;
     std::vector<bvc_group_result> gres;
     std::vector<int64_t> offsets;
     std::vector<int8_t> bases, quals;
     std::vector<uint8_t> packed;
+    void reset() { n_used = 0; entries = 0; refs.clear(); }
+};
 
+// A runner's three stages on three threads with three tiles in flight: while libbvc works on tile i the thread that
+// reads the temp batches parses tile i + 1 and the writer formats and compresses the lines of tile i - 1 (the
+// reference does all of it position by position on one thread, src/BaseVarC.cpp:403-454, 548-666).  Tiles pass
+// through in order, so the outputs are those of the one-thread loop byte for byte.
+class TileQueue {
+ public:
+    void push(Tile *t) { { std::lock_guard<std::mutex> g(mu_); q_.push_back(t); } cv_.notify_one(); }
+    // nullptr = the queue was closed and is empty
+    Tile *pop()
+    {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return nullptr;
+        Tile *t = q_.front();
+        q_.pop_front();
+        return t;
+    }
+    void close() { { std::lock_guard<std::mutex> g(mu_); closed_ = true; } cv_.notify_all(); }
+ private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Tile *> q_;
+    bool closed_ = false;
+};
+
+struct TileRunner {
+    StageClock clk;                      // stage 1 (the caller's thread): read, parse
+    StageClock clk_dev, clk_out;         // stage 2: pack, gpu; stage 3: cvg, vcf, write
+    bvc_ctx *ctx = nullptr;
+    const Groups *groups = nullptr;
+    std::string chr;
+    int32_t n_samples = 0;
+    double min_af = 0;
+    BgzfWriter *fvcf = nullptr, *fcvg = nullptr;
+
+    static const int kTiles = 3;
+    Tile tiles[kTiles];
+    Tile *cur = nullptr;                 // the tile stage 1 is filling
+    TileQueue free_q, dev_q, out_q;
+    std::thread dev_thread, out_thread;
+    std::mutex err_mu;
+    std::string err;                     // first failure of stage 2 or 3
+    bool started = false;
+    int64_t tiles_one_byte = 0, tiles_two_byte = 0;   // library calls by tile form (stage 2's thread; read after finish())
+
+    void fail(const std::string &what)
+    {
+        { std::lock_guard<std::mutex> g(err_mu); if (err.empty()) err = what; }
+        // let every stage run dry: tiles still flow back to the parser, which sees the error at its next flush
+    }
+    bool failed() { std::lock_guard<std::mutex> g(err_mu); return !err.empty(); }
+
+    void start()
+    {
+        for (int i = 0; i < kTiles; ++i) free_q.push(&tiles[i]);
+        cur = free_q.pop();
+        dev_thread = std::thread([this] {
+            for (Tile *t; (t = dev_q.pop()) != nullptr;) {
+                if (!failed()) { try { run_device(*t); } catch (const std::exception &e) { fail(e.what()); } }
+                out_q.push(t);
+            }
+            out_q.close();
+        });
+        out_thread = std::thread([this] {
+            for (Tile *t; (t = out_q.pop()) != nullptr;) {
+                if (!failed()) { try { write_out(*t); } catch (const std::exception &e) { fail(e.what()); } }
+                t->reset();
+                free_q.push(t);
+            }
+        });
+        started = true;
+    }
+
+    SiteColumn &slot() { return cur->slot(); }
+
+    // stage 1 hands its tile on and takes a free one (waits when both later stages are still busy)
     void flush()
     {
-        const int64_t ns = (int64_t)n_used;
-        if (ns == 0) return;
-        res.resize((size_t)ns);
+        if (cur->n_used == 0) return;
+        dev_q.push(cur);
+        cur = free_q.pop();
+        if (failed()) { std::lock_guard<std::mutex> g(err_mu); throw std::runtime_error(err); }
+    }
+
+    // end of the window: drain the pipeline; rethrows the first failure of a later stage
+    void finish()
+    {
+        if (!started) return;
+        if (cur && cur->n_used) dev_q.push(cur);
+        dev_q.close();
+        dev_thread.join();
+        out_thread.join();
+        started = false;
+        std::lock_guard<std::mutex> g(err_mu);
+        if (!err.empty()) throw std::runtime_error(err);
+    }
+    ~TileRunner()
+    {
+        if (started) { dev_q.close(); dev_thread.join(); out_thread.join(); }
+    }
+
+    // stage 2: the tile in the form libbvc takes, and the call
+    void run_device(Tile &T)
+    {
+        const int64_t ns = (int64_t)T.n_used;
+        std::vector<SiteColumn> &sites = T.sites;
+        T.res.resize((size_t)ns);
         const int ng = groups ? (int)groups->names.size() : 0;
         int rc;
         double t0 = StageClock::now(), t1;
+        static const bool two_byte_only = getenv("BVC_HOST_TWO_BYTE_TILES") != nullptr;
         if (ng == 0) {
-            // ragged form: exactly the vectors bt_f builds (src/BaseVarC.cpp:550-559)
-            offsets.assign(1, 0);
-            bases.clear(); quals.clear();
-            for (int64_t i = 0; i < ns; ++i) {
+            // ragged form: exactly the vectors bt_f builds (src/BaseVarC.cpp:550-559) -- as ONE byte per observation
+            // (base << 6 | qual, bvc_lrt_csr_packed: half the bytes over the host link) while every base quality of the
+            // tile is below 63, as the two vectors otherwise
+            T.offsets.assign(1, 0);
+            T.packed.clear();
+            bool fits = !two_byte_only;
+            for (int64_t i = 0; i < ns && fits; ++i) {
                 for (auto const &a : sites[(size_t)i].aiv)
-                    if (a.is_indel == 0) { bases.push_back((int8_t)a.base); quals.push_back((int8_t)a.qual); }
-                offsets.push_back((int64_t)bases.size());
+                    if (a.is_indel == 0) {
+                        if (a.qual > 62u) { fits = false; break; }
+                        T.packed.push_back(a.base > 3u ? (uint8_t)0xFF : (uint8_t)((a.base << 6) | a.qual));
+                    }
+                T.offsets.push_back((int64_t)T.packed.size());
             }
             static const int8_t none = 0;
-            t1 = StageClock::now(); clk.pack += t1 - t0; t0 = t1;
-            rc = bvc_lrt_csr(ctx, ns, offsets.data(), bases.empty() ? &none : bases.data(), quals.empty() ? &none : quals.data(),
-                             refs.data(), min_af, res.data(), BVC_PTR_HOST);
+            (fits ? tiles_one_byte : tiles_two_byte) += 1;
+            if (fits) {
+                t1 = StageClock::now(); clk_dev.pack += t1 - t0; t0 = t1;
+                rc = bvc_lrt_csr_packed(ctx, ns, T.offsets.data(), T.packed.empty() ? reinterpret_cast<const uint8_t *>(&none) : T.packed.data(),
+                                        T.refs.data(), min_af, T.res.data(), BVC_PTR_HOST);
+            } else {
+                T.offsets.assign(1, 0);
+                T.bases.clear(); T.quals.clear();
+                for (int64_t i = 0; i < ns; ++i) {
+                    for (auto const &a : sites[(size_t)i].aiv)
+                        if (a.is_indel == 0) { T.bases.push_back((int8_t)a.base); T.quals.push_back((int8_t)a.qual); }
+                    T.offsets.push_back((int64_t)T.bases.size());
+                }
+                t1 = StageClock::now(); clk_dev.pack += t1 - t0; t0 = t1;
+                rc = bvc_lrt_csr(ctx, ns, T.offsets.data(), T.bases.empty() ? &none : T.bases.data(),
+                                 T.quals.empty() ? &none : T.quals.data(), T.refs.data(), min_af, T.res.data(), BVC_PTR_HOST);
+            }
         } else {
             // dense [site][column] tile; columns are the samples ordered by group (Groups::order_columns), the group of
             // each column is shared by all sites.  One byte per sample (base << 6 | qual, 0xFF = no observation:
             // bvc_lrt_dense_groups_packed) as long as every base quality of the tile is below 63; otherwise the
             // two-byte tile (-1 / 0 for "no observation").  BVC_HOST_TWO_BYTE_TILES=1 forces the latter.
             const int64_t stride = ((int64_t)n_samples + 127) / 128 * 128;
-            static const bool two_byte_only = getenv("BVC_HOST_TWO_BYTE_TILES") != nullptr;
             bool fits = !two_byte_only;
             if (fits) {
-                packed.assign((size_t)(ns * stride), (uint8_t)0xFF);
+                T.packed.assign((size_t)(ns * stride), (uint8_t)0xFF);
                 for (int64_t s = 0; s < ns && fits; ++s)
                     for (size_t k = 0; k < sites[s].aiv.size(); ++k) {
                         const AlleleInfo &a = sites[s].aiv[k];
                         if (a.is_indel == 0) {
                             if (a.base > 3u) continue;             // not A/C/G/T: no observation, as in the two-byte tile
                             if (a.qual > 62u) { fits = false; break; }
-                            packed[(size_t)(s * stride + groups->column_of[(size_t)sites[s].sample[k]])] = (uint8_t)((a.base << 6) | a.qual);
+                            T.packed[(size_t)(s * stride + groups->column_of[(size_t)sites[s].sample[k]])] = (uint8_t)((a.base << 6) | a.qual);
                         }
                     }
             }
-            gres.resize((size_t)(ns * ng));
+            T.gres.resize((size_t)(ns * ng));
+            (fits ? tiles_one_byte : tiles_two_byte) += 1;
             if (fits) {
-                t1 = StageClock::now(); clk.pack += t1 - t0; t0 = t1;
-                rc = bvc_lrt_dense_groups_packed(ctx, ns, n_samples, stride, packed.data(), refs.data(), min_af,
-                                                 groups->of_column.data(), ng, res.data(), gres.data(), BVC_PTR_HOST);
+                t1 = StageClock::now(); clk_dev.pack += t1 - t0; t0 = t1;
+                rc = bvc_lrt_dense_groups_packed(ctx, ns, n_samples, stride, T.packed.data(), T.refs.data(), min_af,
+                                                 groups->of_column.data(), ng, T.res.data(), T.gres.data(), BVC_PTR_HOST);
             } else {
-                bases.assign((size_t)(ns * stride), (int8_t)-1);
-                quals.assign((size_t)(ns * stride), (int8_t)0);
+                T.bases.assign((size_t)(ns * stride), (int8_t)-1);
+                T.quals.assign((size_t)(ns * stride), (int8_t)0);
                 for (int64_t s = 0; s < ns; ++s)
                     for (size_t k = 0; k < sites[s].aiv.size(); ++k) {
                         const AlleleInfo &a = sites[s].aiv[k];
                         if (a.is_indel == 0) {
                             const int64_t col = groups->column_of[(size_t)sites[s].sample[k]];
-                            bases[(size_t)(s * stride + col)] = (int8_t)a.base;
-                            quals[(size_t)(s * stride + col)] = (int8_t)a.qual;
+                            T.bases[(size_t)(s * stride + col)] = (int8_t)a.base;
+                            T.quals[(size_t)(s * stride + col)] = (int8_t)a.qual;
                         }
                     }
-                t1 = StageClock::now(); clk.pack += t1 - t0; t0 = t1;
-                rc = bvc_lrt_dense_groups(ctx, ns, n_samples, stride, bases.data(), quals.data(), refs.data(), min_af,
-                                          groups->of_column.data(), ng, res.data(), gres.data(), BVC_PTR_HOST);
+                t1 = StageClock::now(); clk_dev.pack += t1 - t0; t0 = t1;
+                rc = bvc_lrt_dense_groups(ctx, ns, n_samples, stride, T.bases.data(), T.quals.data(), T.refs.data(), min_af,
+                                          groups->of_column.data(), ng, T.res.data(), T.gres.data(), BVC_PTR_HOST);
             }
         }
         if (rc != BVC_OK) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(ctx));
-        t1 = StageClock::now(); clk.gpu += t1 - t0; t0 = t1;
+        clk_dev.gpu += StageClock::now() - t0;
+    }
+
+    // stage 3: the CVG line of every position, the VCF line of every called one (bt_f, src/BaseVarC.cpp:548-666)
+    void write_out(Tile &T)
+    {
+        const int64_t ns = (int64_t)T.n_used;
+        const int ng = groups ? (int)groups->names.size() : 0;
+        StageClock &c = clk_out;
+        double t0 = StageClock::now(), t1;
         for (int64_t s = 0; s < ns; ++s) {
-            const bvc_group_result *g = ng ? &gres[(size_t)(s * ng)] : nullptr;
-            const std::string cl = cvg_line(chr, sites[s].pos, refs[s], sites[s], g, ng);
-            t1 = StageClock::now(); clk.cvg += t1 - t0; t0 = t1;
+            const bvc_group_result *g = ng ? &T.gres[(size_t)(s * ng)] : nullptr;
+            const std::string cl = cvg_line(chr, T.sites[s].pos, T.refs[s], T.sites[s], g, ng);
+            t1 = StageClock::now(); c.cvg += t1 - t0; t0 = t1;
             fcvg->write(cl);
-            t1 = StageClock::now(); clk.write += t1 - t0; t0 = t1;
-            if (res[s].called) {
+            t1 = StageClock::now(); c.write += t1 - t0; t0 = t1;
+            if (T.res[s].called) {
                 std::map<std::string, std::string> info;
-                if (ng) group_af_info(res[s], g, *groups, info);
-                const std::string vl = vcf_line(res[s], chr, sites[s].pos, refs[s], sites[s], info, n_samples);
-                t1 = StageClock::now(); clk.vcf += t1 - t0; t0 = t1;
+                if (ng) group_af_info(T.res[s], g, *groups, info);
+                const std::string vl = vcf_line(T.res[s], chr, T.sites[s].pos, T.refs[s], T.sites[s], info, n_samples);
+                t1 = StageClock::now(); c.vcf += t1 - t0; t0 = t1;
                 fvcf->write(vl);
-                t1 = StageClock::now(); clk.write += t1 - t0; t0 = t1;
+                t1 = StageClock::now(); c.write += t1 - t0; t0 = t1;
             }
         }
-        n_used = 0;
-        entries = 0;
-        refs.clear();
     }
 };
 
@@ -365,7 +491,9 @@ struct BatchInput {
         double t0 = StageClock::now();
         if (bin) {
             unsigned char b4[4];
-            if (rd.read(b4, 4) != 4) { clk.read += StageClock::now() - t0; return (int32_t)n_in_batch; }
+            // a temp batch holds one record per position of the thread's window: running out of records before the window
+            // is exhausted means the file was cut short (both forms: the text form below)
+            if (rd.read(b4, 4) != 4) throw std::runtime_error("ERROR: truncated temp batch (it ends before the thread's window does)");
             const uint32_t n = (uint32_t)b4[0] | ((uint32_t)b4[1] << 8) | ((uint32_t)b4[2] << 16) | ((uint32_t)b4[3] << 24);
             rec.resize(n);
             if (n && rd.read(rec.data(), n) != n) throw std::runtime_error("ERROR: truncated temp batch record");
@@ -376,9 +504,10 @@ struct BatchInput {
             return (int32_t)n_in_batch;
         }
         const bool got = rd.getline(line);
+        if (!got) throw std::runtime_error("ERROR: truncated temp batch (it ends before the thread's window does)");
         double t1 = StageClock::now();
         clk.read += t1 - t0;
-        const int32_t adv = got ? parse_pileup_line(line.data(), line.size(), j0, site) : 0;
+        const int32_t adv = parse_pileup_line(line.data(), line.size(), j0, site);
         clk.parse += StageClock::now() - t1;
         return adv;
     }
@@ -439,9 +568,13 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
     tr.min_af = min_af;
     tr.fvcf = &fpv;
     tr.fcvg = &fpc;
+    tr.start();
     int64_t tile = opt::tile > 0 ? opt::tile : 4096;
     if (!groups.empty()) tile = std::max<int64_t>(1, std::min<int64_t>(tile, ((int64_t)256 << 20) / std::max(1, N)));
     reset_parser_carry();
+    // BVC_HOST_QUAL_SHIFT=k (tests only): k is added to every base quality as it is read, so that data whose qualities
+    // stop at 41 can exercise the tiles that do not fit one byte per observation (quality >= 63)
+    const int qual_shift = getenv("BVC_HOST_QUAL_SHIFT") ? atoi(getenv("BVC_HOST_QUAL_SHIFT")) : 0;
     size_t lo, hi;
     thread_window(pv.size(), thread, ithread, lo, hi);
     int32_t count = 0;
@@ -453,25 +586,30 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
         site.pos = p;
         int32_t j = 0;
         for (auto fp : fpiv) j += fp->next(j, site, line, tr.clk);
+        if (qual_shift)                                                 // test hook, see above
+            for (auto &a : site.aiv)
+                if (a.is_indel == 0) a.qual = (uint32_t)std::min(127, (int)a.qual + qual_shift);
         if (!site.aiv.empty()) {
             const char rc = refseq[(size_t)(p - rg_s)];
             const int8_t ref_base = rc == 'A' ? 0 : rc == 'C' ? 1 : rc == 'G' ? 2 : rc == 'T' ? 3 : -1;
-            ++tr.n_used;
-            tr.entries += site.aiv.size();
-            tr.refs.push_back(ref_base);
+            ++tr.cur->n_used;
+            tr.cur->entries += site.aiv.size();
+            tr.cur->refs.push_back(ref_base);
             // a tile is full at --tile positions or at 4M observations (64 MB of per-sample records held for the
             // CVG/VCF lines): at 1e5 samples that is a few hundred positions, still far more than the device needs
-            if ((int64_t)tr.n_used >= tile || tr.entries >= ((size_t)1 << 22)) tr.flush();
+            if ((int64_t)tr.cur->n_used >= tile || tr.cur->entries >= ((size_t)1 << 22)) tr.flush();
             if (!(++count % 1000)) std::cerr << "basetype completed " << count << " sites -- thread" << ithread << std::endl;
         }
     }
-    tr.flush();
+    tr.finish();
     const double loop_s = StageClock::now() - t_loop, setup_s = t_loop - t_start;
     if (getenv("BVC_HOST_PROFILE")) {
-        const StageClock &c = tr.clk;
-        std::cerr << "[profile] thread " << ithread << ": read+inflate " << c.read << " s, parse " << c.parse << " s, pack "
-                  << c.pack << " s, libbvc " << c.gpu << " s, cvg lines " << c.cvg << " s, vcf lines " << c.vcf
-                  << " s, compress+write " << c.write << " s; setup (open batches " << t_opened - t_start << " s, names + header "
+        std::cerr << "[profile] thread " << ithread << ": library calls on one-byte tiles " << tr.tiles_one_byte << ", on two-byte tiles "
+                  << tr.tiles_two_byte << std::endl;
+        const StageClock &c = tr.clk, &d = tr.clk_dev, &o = tr.clk_out;
+        std::cerr << "[profile] thread " << ithread << ": stage 1 read+inflate " << c.read << " s, parse " << c.parse << " s | stage 2 pack "
+                  << d.pack << " s, libbvc " << d.gpu << " s | stage 3 cvg lines " << o.cvg << " s, vcf lines " << o.vcf
+                  << " s, compress+write " << o.write << " s; setup (open batches " << t_opened - t_start << " s, names + header "
                   << t_header - t_opened << " s, bvc_create " << create_s << " s) " << setup_s << " s, position loop " << loop_s << " s, thread total "
                   << StageClock::now() - t_start << " s" << std::endl;
     }

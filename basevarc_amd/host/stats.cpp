@@ -134,6 +134,11 @@ static double rank_r1(const std::vector<double> &x, size_t n1)
         size_t from_first = order[lo] < n1 ? 1 : 0;
         while (hi + 1 < n && x[order[hi + 1]] == x[order[lo]]) { ++hi; from_first += order[hi] < n1 ? 1 : 0; }
         // ranks lo+1 .. hi+1: their sum is an integer, divided once by the run length as the reference does
+        // (src/Algorithm.cpp:41: static_cast<double>(k) / (n + 1)).  DELIBERATE DIVERGENCE: the reference keeps that sum
+        // in an int32_t `k` (:31), which wraps -- undefined behaviour -- once a run of equal values is longer than about
+        // 65,536 (sum of its ranks > 2^31); at CMDB depth (1e5 observations per site, most with mapping quality 60) its
+        // *RankSum fields are then garbage.  Here the sum is exact (size_t), so the two agree wherever the reference is
+        // defined and this one stays the rank-sum statistic beyond (tests/test_host.py).
         const size_t len = hi - lo + 1;
         const double shared = len == 1 ? (double)(lo + 1) : (double)((lo + 1 + hi + 1) * len / 2) / (double)len;
         for (size_t t = 0; t < from_first; ++t) r1 += shared;   // added one member at a time, like the reference's loop

@@ -51,6 +51,7 @@ EXPORTS = [
     "bvc_synchronize", "bvc_set_overlap", "bvc_join", "bvc_set_profiling", "bvc_get_profile", "bvc_lrt_dense", "bvc_lrt_dense_groups",
     "bvc_lrt_csr", "bvc_lrt_csr_comb", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense", "bvc_stream_read_ms", "bvc_set_tuning",
     "bvc_lrt_dense_packed", "bvc_pack_dense", "bvc_hist_dense_packed", "bvc_lrt_dense_groups_packed",
+    "bvc_lrt_csr_packed",
 ]
 
 _lib = None
@@ -110,6 +111,8 @@ def load_library():
     L.bvc_lrt_dense_groups_packed.argtypes = [vp, i64, i64, i64, vp, vp, dbl, vp, i32, vp, vp, u32]
     L.bvc_hist_dense_packed.restype = C.c_int
     L.bvc_hist_dense_packed.argtypes = [vp, i64, i64, i64, vp, vp, u32]
+    L.bvc_lrt_csr_packed.restype = C.c_int
+    L.bvc_lrt_csr_packed.argtypes = [vp, i64, vp, vp, vp, dbl, vp, u32]
     _lib = L
     return L
 
@@ -225,6 +228,25 @@ class Context:
                                              _np_ptr(cb) if cb is not None else None,
                                              _np_ptr(nc) if nc is not None else None, _np_ptr(out), BVC_PTR_HOST))
         return out
+
+    def lrt_csr_packed(self, offsets, packed, ref_base, min_af):
+        """Ragged sites at one byte per observation (base << 6 | qual); host arrays, synchronous."""
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        pk = np.ascontiguousarray(packed, dtype=np.uint8)
+        r = np.ascontiguousarray(ref_base, dtype=np.int8)
+        out = np.zeros(len(o) - 1, dtype=SITE_DTYPE)
+        self._check(self._L.bvc_lrt_csr_packed(self._h, len(o) - 1, _np_ptr(o), _np_ptr(pk), _np_ptr(r), float(min_af),
+                                               _np_ptr(out), BVC_PTR_HOST))
+        return out
+
+    def lrt_csr_packed_device(self, offsets_t, packed_t, ref_t, min_af, results_t=None):
+        import torch
+        ns = offsets_t.numel() - 1
+        if results_t is None:
+            results_t = torch.empty(ns * SITE_DTYPE.itemsize, dtype=torch.uint8, device=packed_t.device)
+        self._check(self._L.bvc_lrt_csr_packed(self._h, ns, _dev_ptr(offsets_t), _dev_ptr(packed_t), _dev_ptr(ref_t),
+                                               float(min_af), _dev_ptr(results_t), BVC_PTR_DEVICE))
+        return results_t
 
     def lrt_csr_device(self, offsets_t, bases_t, quals_t, ref_t, min_af, results_t=None):
         """offsets_t: int64 [n_sites + 1]; bases_t/quals_t: int8 [total] CUDA tensors (asynchronous on the stream)."""

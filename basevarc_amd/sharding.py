@@ -19,6 +19,22 @@ def shard_range(n_sites, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def call_sizes(n_sites, sites_per_call, min_calls=1):
+    """Sites of a rank's range cut into library calls: as few calls of at most `sites_per_call` sites as cover it, but at
+    least `min_calls` (a rank of a multi-GPU run pipelines its calls -- stage 2 of call i under stage 1 of call i + 1 --
+    and the fill and drain of that pipeline cost about one call per pass, so a pass should be >= 8 calls), all of the
+    same size to within one site: no short tail call.  12,500 sites at 4,000 per call and min_calls 8: 4 x 1563 + 4 x 1562."""
+    n_sites, sites_per_call, min_calls = int(n_sites), int(sites_per_call), int(min_calls)
+    if n_sites <= 0:
+        return []
+    if sites_per_call < 1 or min_calls < 1:
+        raise ValueError("sites_per_call and min_calls must be >= 1")
+    calls = max(min_calls, -(-n_sites // sites_per_call))
+    calls = min(calls, n_sites)
+    base, extra = divmod(n_sites, calls)
+    return [base + (1 if i < extra else 0) for i in range(calls)]
+
+
 def gather_records(records, dst=0, group=None):
     """records: numpy structured array of this rank's sites (any fixed-size dtype).
     Returns the concatenation over ranks in rank (= position) order on rank `dst`, None elsewhere."""

@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PCIE_PEAK_GBS = 63.0         # PCIe Gen5 x16, one direction: the bound of callers that hand over HOST pointers
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s is what a copy reaches)
 N_SIMD = 1024                # 256 CUs x 4 SIMDs
 ENGINE_CLOCK_HZ = 2.4e9      # MI355X peak engine clock
@@ -131,7 +132,7 @@ def main():
 
     from basevarc_amd import Context
     from basevarc_amd.lib import SITE_DTYPE, results_from_tensor
-    from basevarc_amd.sharding import shard_range
+    from basevarc_amd.sharding import call_sizes, shard_range
 
     n = a.samples
     stride = (n + a.row_align - 1) // a.row_align * a.row_align
@@ -149,9 +150,11 @@ def main():
     budget = free_b // (world if shared_device else 1) - (16 << 30)         # room for the legs and scratch
     fit_sites = max(a.tile_sites, int(budget // (2 * stride)) // a.tile_sites * a.tile_sites)
     res_sites = min(my_sites, fit_sites)                         # sites actually resident (= my_sites on MI355X)
-    tile_sizes = [min(a.tile_sites, res_sites - s) for s in range(0, res_sites, a.tile_sites)]
+    # calls of a pass: --tile-sites each on one GPU; with several GPUs at least 8 equal calls per rank (the two-stage
+    # pipeline's fill and drain cost about one call per pass: 12,500 sites are 8 x 1,563, not 3 x 4,000 + 500)
+    tile_sizes = call_sizes(res_sites, a.tile_sites, 8 if world > 1 else 1)
     n_tiles = len(tile_sizes)
-    log(f"rank 0: sites [{lo}, {lo + res_sites}) as {n_tiles} tiles x {n} samples ({2 * res_sites * stride / 1e9:.1f} GB) on device")
+    log(f"rank 0: sites [{lo}, {lo + res_sites}) as {n_tiles} tiles x {n} samples ({(1 if a.packed else 2) * res_sites * stride / 1e9:.1f} GB) on device")
     tiles = []
     s0 = lo
     for ts in tile_sizes:
@@ -218,6 +221,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    dt_own = dt
     prof = ctx.profile(reset=True)
     ctx.set_profiling(False)
     if world > 1:
@@ -229,15 +233,26 @@ def main():
         sites_per_step_all = int(st.item())
     else:
         sites_per_step_all = res_sites
+    # every rank's own clock and kernel times, so that a slow rank can be told from a slow path
+    my_hist_ms_site = prof["hist_ms"] / max(1, prof["sites"])
+    mine = [float(rank), dt_own / a.steps * 1e3, float(res_sites), float(n_tiles), my_hist_ms_site, prof["em_ms"] / max(1, prof["sites"])]
+    if world > 1:
+        pr = torch.tensor(mine, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allpr = [torch.zeros_like(pr) for _ in range(world)]
+        dist.all_gather(allpr, pr)
+        per_rank_raw = [[float(x) for x in t.cpu()] for t in allpr]
+    else:
+        per_rank_raw = [mine]
 
     log(f"timed region done: {dt * 1e3:.1f} ms for {a.steps} steps")
     value = a.steps * sites_per_step_all / dt
     # the timed launches are full tiles except possibly the last of a pass: normalise per site
     hist_ms_per_site = prof["hist_ms"] / max(1, prof["sites"])
     em_ms_per_site = prof["em_ms"] / max(1, prof["sites"])
-    hist_ms = hist_ms_per_site * a.tile_sites
-    em_ms = em_ms_per_site * a.tile_sites
-    alg_bytes = (1.0 if a.packed else 2.0) * a.tile_sites * n   # 2 B per (site, sample), read once (packed: 1 B)
+    call_sites = max(tile_sizes)
+    hist_ms = hist_ms_per_site * call_sites
+    em_ms = em_ms_per_site * call_sites
+    alg_bytes = (1.0 if a.packed else 2.0) * call_sites * n   # 2 B per (site, sample), read once (packed: 1 B)
     achieved = alg_bytes / (hist_ms * 1e-3) / 1e9 if hist_ms > 0 else 0.0
     kname = hist_kernel_name(a.groups, a.group_layout).replace("hist_dense_kernel", "hist_packed_kernel").replace("hist_dense_", "hist_packed_") if a.packed else hist_kernel_name(a.groups, a.group_layout)
     traffic, traffic_source = pmc_traffic(a, n, kname)
@@ -246,7 +261,7 @@ def main():
         "metric": "sites/sec at N=1e6 samples; achieved HBM GB/s vs roofline",
         "value": value, "unit": "sites/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-        "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None,
+        "scaling": a.scaling if world > 1 else "none", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": f"synthetic pileup {a.total_sites} sites x {n} samples (BASELINE configs[2]"
@@ -254,9 +269,10 @@ def main():
                         f"{'dense coverage' if a.coverage >= 1 else f'coverage {a.coverage:g}'}, Q10-40, 20% polymorphic"
                         f"{f', {a.groups} population groups ({a.group_layout})' if a.groups else ''}"
                         f"{', PACKED tiles (1 byte per sample: additive layout, not the BASELINE metric)' if a.packed else ''}; "
-                        f"step = one pass over the rank's resident sites in calls of {a.tile_sites}",
-            "n_samples": n, "sites_per_step": sites_per_step_all, "sites_per_call": a.tile_sites,
-            "calls_per_step_per_gpu": n_tiles, "resident_GB_per_gpu": round(2 * res_sites * stride / 1e9, 1),
+                        f"step = one pass over the rank's resident sites in calls of {max(tile_sizes)}",
+            "n_samples": n, "sites_per_step": sites_per_step_all, "sites_per_call": max(tile_sizes),
+            "calls_per_step_per_gpu": n_tiles,
+            "resident_GB_per_gpu": round((1 if a.packed else 2) * res_sites * stride / 1e9, 1),
             "row_stride": stride, "min_af": min_af,
             "sharding": f"sites x{world} ({a.scaling}), no collective; barrier over {backend}" if world > 1 else "1 GPU", "seed": a.seed,
             "overlap": not a.no_overlap,
@@ -266,7 +282,14 @@ def main():
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
             "avg_launch_ms": hist_ms, "launches_timed": int(prof["hist_launches"]), "algorithmic_bytes_per_launch": alg_bytes,
             "empirical_stream_read_GBs": empirical_gbs, "frac_of_empirical": achieved / empirical_gbs if empirical_gbs else None,
+            "traffic_note": "HBM bytes per launch from the COMMITTED rocprofv3 counter passes named in traffic_source (FETCH_SIZE and "
+                            "WRITE_SIZE in separate --pmc runs, corrected as MI355X_MICROARCH.md prescribes), valid for the kernel source "
+                            "hashed there; not re-measured in this run.  achieved / avg_launch_ms ARE measured in this run (HIP events)",
         },
+        "per_rank": [{"rank": int(p[0]), "ms_per_step": p[1], "sites": int(p[2]), "calls_per_step": int(p[3]),
+                      "hist_ms_per_call": p[4] * max(tile_sizes), "stage2_ms_per_call": p[5] * max(tile_sizes),
+                      "hist_frac": ((1.0 if a.packed else 2.0) * n / (p[4] * 1e-3) / 1e9 / HBM_PEAK_GBS) if p[4] > 0 else None}
+                     for p in per_rank_raw],
         "kernels_ms_per_call": {kname: hist_ms,
                                 ("sum_groups + lrt + lrt_groups kernels" if a.groups > 0 else "stage 2 (region_kernel)"): em_ms},
     }
@@ -486,7 +509,41 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
                           "note": "timed underneath the EM launches it shares the chip with (it waits for wave slots); "
                                   "0.20 ms = 3.9 TB/s with the chip to itself (profiles/r02_kernel_stats_legs.csv)"},
     }
-    del csr, res
+    # ---- host-pointer callers (BVC_PTR_HOST): bound by the host link, so they get the one-byte forms.  Never the
+    # reported `value` (inputs are not resident); the roofline of this leg is PCIe, 63 GB/s.
+    hp = {}
+    o, b, q, r = csr[0]
+    pk_h = ((b.to(torch.uint8) << 6) | q.to(torch.uint8)).cpu().numpy()
+    o_h, r_h = o.cpu().numpy(), r.cpu().numpy()
+    ctx.join(); ctx.synchronize()
+    ctx.lrt_csr_packed(o_h, pk_h, r_h, min_af)                   # warm-up: staging buffers
+    t0 = time.perf_counter()
+    for _ in range(3):
+        rec_h = ctx.lrt_csr_packed(o_h, pk_h, r_h, min_af)
+    dth = (time.perf_counter() - t0) / 3
+    moved = pk_h.nbytes + o_h.nbytes + r_h.nbytes + rec_h.nbytes
+    hp["ragged_one_byte"] = {"sites_per_s": csr_sites / dth, "GBs": moved / dth / 1e9, "frac": moved / dth / 1e9 / PCIE_PEAK_GBS,
+                             "ms_per_call": dth * 1e3, "bytes_per_call": int(moved),
+                             "records_identical_to_device_pointer_call": bool(rec_h.tobytes() == results_from_tensor(res[0]).tobytes()),
+                             "workload": f"bvc_lrt_csr_packed, BVC_PTR_HOST, {csr_sites} sites of {covered / csr_sites:.0f} observations"}
+    del pk_h
+    hs = min(1000, tile_sizes[0])
+    tb, tq, tr_ = tiles[full[0]]
+    pt_h = ctx.pack_dense_device(tb[:hs], tq[:hs])[0].cpu().numpy()
+    rr_h = tr_[:hs].cpu().numpy()
+    ctx.lrt_dense_packed(pt_h, rr_h, min_af)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        rec_h = ctx.lrt_dense_packed(pt_h, rr_h, min_af)
+    dth = (time.perf_counter() - t0) / 2
+    moved = pt_h.nbytes + rr_h.nbytes + rec_h.nbytes
+    hp["dense_one_byte"] = {"sites_per_s": hs / dth, "GBs": moved / dth / 1e9, "frac": moved / dth / 1e9 / PCIE_PEAK_GBS,
+                            "ms_per_call": dth * 1e3, "bytes_per_call": int(moved),
+                            "workload": f"bvc_lrt_dense_packed, BVC_PTR_HOST, {hs} sites x {n} samples, pageable host memory, "
+                                        "chunked staging (upload of chunk i + 1 under the kernels of chunk i)"}
+    legs["host_pointer_one_byte"] = {"bound": "pcie", "peak": PCIE_PEAK_GBS, "unit": "GB/s", "value": hp["dense_one_byte"]["sites_per_s"],
+                                     "value_unit": "sites/s (dense, N = 1e6)", **hp}
+    del csr, res, pt_h
 
     # ---- BASELINE configs[1]: 1e4 sites x 1e4 samples, EM to convergence: the EM/LRT kernel is the bound
     ns1, n1 = 10_000, 10_000
@@ -682,10 +739,29 @@ def cpu_model():
     return "unknown"
 
 
+def cgroup_cpu_quota():
+    """CPUs this process may use by the cgroup's quota (cpu.max of cgroup v2, cfs_quota of v1), or None when unlimited."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline(tile, min_af, a, np, gpu_records):
     """The faithful per-sample CPU port (oracle/basetype_oracle.c) on a bounded sample of the same workload: first
     ONE site on one thread (north_star / SURVEY 8d: the reference at --thread 1), then one site per host thread
-    (about 10-20 s each at N = 1e6); its answers are compared with the GPU records of the same sites."""
+    (about 10-20 s each at N = 1e6); its answers are compared with the GPU records of the same sites.  Beside it, as
+    BASELINE.md section 4 asks: the same port at N = 1e4 and the CPU histogram form (the GPU kernels' algorithm) at
+    this N, each on one thread and on all of them, so that the algorithmic and the hardware gain can be told apart.
+    `cores` is the number of threads the run was GIVEN; what it got is `effective_parallelism` (its rate over the
+    one-thread rate) -- a cgroup CPU quota below the visible core count shows up there, and in `cgroup_cpu_quota`."""
     from oracle import orc
     cores = os.cpu_count() or 1
     try:
@@ -696,24 +772,50 @@ def cpu_baseline(tile, min_af, a, np, gpu_records):
     k = a.cpu_sites if a.cpu_sites > 0 else cores
     b, q, r = tile
     k = min(k, b.shape[0])
-    hb, hq, hr = b[:k].cpu().numpy(), q[:k].cpu().numpy(), r[:k].cpu().numpy()
+    n_hist = min(max(64, 16 * cores), b.shape[0])                # rows for the histogram-form leg
+    hb, hq, hr = b[:n_hist].cpu().numpy(), q[:n_hist].cpu().numpy(), r[:n_hist].cpu().numpy()
     log("cpu baseline: 1 site on 1 thread")
     t0 = time.perf_counter()
     orc.dense_batch(hb[:1], hq[:1], hr[:1], min_af, use_hist=False, threads=1)
     dt1 = time.perf_counter() - t0
     log(f"cpu baseline: {k} sites on {min(cores, k)} threads (about 20 s per site per core)")
     t0 = time.perf_counter()
-    exp, used = orc.dense_batch(hb, hq, hr, min_af, use_hist=False, threads=min(cores, k))
+    exp, used = orc.dense_batch(hb[:k], hq[:k], hr[:k], min_af, use_hist=False, threads=min(cores, k))
     dt = time.perf_counter() - t0
     bad = 0
     for s, e in enumerate(exp):
         # the per-sample double sum of the reference drifts by up to N*u*|loglik|
         bad += not record_ok(gpu_records[s], e, floor=1e-6 + 2e-10 * abs(e["lr_alt"]))
+
+    def rate(fn, sites):
+        t = time.perf_counter()
+        fn()
+        return sites / (time.perf_counter() - t)
+    # histogram form at this N (the histogram is built from the rows inside the timed call, as the GPU path does)
+    log("cpu baseline: histogram form, 1 thread and all threads")
+    h1 = rate(lambda: orc.dense_batch(hb[:16], hq[:16], hr[:16], min_af, use_hist=True, threads=1), 16)
+    hall = rate(lambda: orc.dense_batch(hb, hq, hr, min_af, use_hist=True, threads=cores), n_hist)
+    # the faithful port at N = 1e4 (BASELINE configs[1]'s depth): sites of the same generator
+    log("cpu baseline: faithful port at N = 1e4")
+    n4 = 10_000
+    m4 = min(0.001, 100.0 / n4)
+    sb, sq, sr = orc.synth_tile(a.seed, 0, 8 * cores, n4)
+    f1 = rate(lambda: orc.dense_batch(sb[:8], sq[:8], sr[:8], m4, use_hist=False, threads=1), 8)
+    fall = rate(lambda: orc.dense_batch(sb, sq, sr, m4, use_hist=False, threads=cores), 8 * cores)
     return {"value": k / dt, "unit": "sites/s", "cores": int(used), "kind": "port", "cpu_model": cpu_model(),
+            "effective_parallelism": (k / dt) / (1.0 / dt1), "cgroup_cpu_quota": cgroup_cpu_quota(),
+            "visible_cpus": os.cpu_count(),
             "sample": f"first {k} sites of tile 0 at N={a.samples}, one site per thread, faithful per-sample "
                       f"restatement of BaseType ctor+LRT+EM (oracle/basetype_oracle.c), {dt:.1f} s",
             "single_thread": {"value": 1.0 / dt1, "unit": "sites/s", "cores": 1,
                               "sample": f"site 0 of tile 0 at N={a.samples} on one thread, {dt1:.1f} s"},
+            "faithful_port_N1e4": {"one_thread": f1, "all_threads": fall, "threads": cores, "unit": "sites/s",
+                                   "effective_parallelism": fall / f1,
+                                   "sample": f"8 / {8 * cores} sites of the synthetic generator at N=10000"},
+            "histogram_form": {"one_thread": h1, "all_threads": hall, "threads": cores, "unit": "sites/s",
+                               "effective_parallelism": hall / h1,
+                               "sample": f"16 / {n_hist} sites of tile 0 at N={a.samples}: class histogram from the rows, then the "
+                                         "EM/LRT on <= 512 classes (ORC_MODE_HIST: the GPU kernels' algorithm on the CPU)"},
             "calibration": "the reference binary cannot be built here (DESIGN.md section 5), so the port's wall time is not "
                            "calibrated against it; SURVEY.md's 17.3 s/site was measured on another CPU (2.1 GHz Xeon)",
             "gpu_check_same_sites": {"sites": k, "mismatches": int(bad)}}

@@ -162,6 +162,17 @@ int bvc_lrt_csr_comb(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
                      bvc_site_result *results, uint32_t flags);
 
 /*
+ * Additive: the ragged form at ONE byte per observation (the packed byte of bvc_lrt_dense_packed below:
+ * base << 6 | qual, qual 0..62; a byte whose qual bits are 63 is skipped).  Site s owns packed[offsets[s] .. offsets[s+1]).
+ * Same records as bvc_lrt_csr on the same observations, bit for bit.  For host callers this halves what crosses
+ * the host link, which is what bounds them (src/BaseVarC.cpp:550-559 builds the two vectors this replaces; the
+ * successor of bt_s writes the byte directly).  Observations with base quality >= 63 cannot be packed: such tiles
+ * stay on bvc_lrt_csr.
+ */
+int bvc_lrt_csr_packed(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets, const uint8_t *packed,
+                       const int8_t *ref_base, double min_af, bvc_site_result *results, uint32_t flags);
+
+/*
  * Additive: packed dense tiles, ONE byte per (site, sample) instead of two.  The path is bound by the bytes it reads,
  * and (base 0..3, qual 0..62) fits a byte:
  *     packed[s * row_stride + i] = base << 6 | qual        0xFF (any byte whose qual bits are 63) = no observation
@@ -192,7 +203,12 @@ int bvc_hist_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row
 int bvc_hist_dense_packed(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                           const uint8_t *packed, uint32_t *counts, uint32_t flags);
 /* Stage 2: EM + LRT on per-site class counts.  base_comb (optional): [n_sites][4] candidate bases in
- * SetBase order with n_comb[s] entries used; NULL means the default {A,C,G,T} (src/BaseType.h:79). */
+ * SetBase order with n_comb[s] entries used; NULL means the default {A,C,G,T} (src/BaseType.h:79).
+ * base_comb / n_comb contract (also bvc_lrt_csr_comb): with BVC_PTR_HOST an entry outside 0..3 or n_comb[s] > 4 is
+ * rejected with BVC_ERR_ARG before anything runs.  With BVC_PTR_DEVICE the library cannot look at the arrays without
+ * a round trip, so the kernels apply the reference's own rule instead: a candidate that is not A, C, G or T has
+ * depth 0 in BaseType (src/BaseType.cpp:79 reads depth[b]) and falls to the min_af filter, i.e. the entry is
+ * ignored (the record equals the one for the list without it), and n_comb[s] > 4 is read as 4. */
 int bvc_lrt_hist(bvc_ctx *ctx, int64_t n_sites, const uint32_t *counts, const int8_t *ref_base,
                  double min_af, const int8_t *base_comb, const uint8_t *n_comb,
                  bvc_site_result *results, uint32_t flags);
@@ -206,7 +222,8 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
 
 /* ---- tuning (per context; additive, no counterpart in the reference) -------------------------------- */
 /* Launch policy of THIS context; results never depend on it.  Keys:
- *   "em_waves_per_cu"  0 = default policy, 1..32 resident EM wavefronts per CU
+ *   "em_waves_per_cu"  0 = default policy, 1..32 resident stage-2 wavefronts per CU (the region kernel runs in workgroups
+ *                      of four: the value is rounded up to a multiple of 4)
  *   "em_wpb"           waves per EM workgroup: 4 (default) or 1
  *   "hist_split"       0 = by tile shape, 1..64 workgroups sharing a site in the dense histogram pass
  *   "em_streams"       overlap mode: stage 2 of consecutive calls on one side stream (1), on two alternating ones (2: the
@@ -217,7 +234,16 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
  *                      many KiB per array (default 524288 = 512 MiB); the upload of chunk i+1 runs under the kernels
  *                      of chunk i
  * A new context starts from the environment variables BVC_EM_WAVES_PER_CU, BVC_EM_WPB, BVC_HIST_SPLIT,
- * BVC_GROUP_PIPE, BVC_EM_STREAMS when they are set. */
+ * BVC_GROUP_PIPE, BVC_EM_STREAMS when they are set.
+ *
+ * One key is NOT a launch policy:
+ *   "em_engine"        0 (default) = the item engine of stage 2 (fits as work items, csrc/em_items.hip), 1 = one
+ *                      wavefront per site for every site (csrc/em_kernel.hip, the engine of rounds 1-2, which otherwise
+ *                      only takes the sites the item engine leaves).  The two evaluate the same sums in different
+ *                      orders: calls, depths, pass counts and every integer field agree (except where two subsets tie
+ *                      to rounding), AF / chi / var_qual agree to ~1e-15 relative, not bit for
+ *                      bit.  With either engine a site's record never depends on the call's size or on its neighbours.
+ *                      Environment: BVC_EM_ENGINE. */
 int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value);
 
 /* ---- measurement aid ------------------------------------------------------------------------------- */

@@ -22,7 +22,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["scaling"] == "none" and d["vs_baseline"] is None           # one GPU: nothing is scaled and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     # a step is one pass over the whole resident workload (8000 sites here, in calls of 2000)
     assert d["config"]["sites_per_step"] == 8000 and d["config"]["sites_per_call"] == 2000
@@ -34,6 +34,12 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["cpu_model"] and cb["single_thread"]["cores"] == 1 and cb["single_thread"]["value"] > 0
     assert cb["gpu_check_same_sites"]["mismatches"] == 0 and cb["gpu_check_hist_form"]["mismatches"] == 0
+    # the parallelism the CPU leg GOT (not just what it was given), and the rates BASELINE.md section 4 asks for
+    assert 0 < cb["effective_parallelism"] <= cb["cores"] * 1.2 and "cgroup_cpu_quota" in cb
+    for k in ("faithful_port_N1e4", "histogram_form"):
+        assert cb[k]["one_thread"] > 0 and cb[k]["all_threads"] > 0 and cb[k]["threads"] >= 1, k
+    assert rf["frac_of_empirical"] <= 1.02 and "traffic_note" in rf     # the streaming read is a ceiling again
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["sites"] == 8000 and d["per_rank"][0]["calls_per_step"] == 4
     # the other single-GPU configurations ride along as sub-records with their own roofline
     legs = d["legs"]
     for name in ("config1_1e4x1e4", "config4_groups5_interleaved", "config4_groups5_ordered", "csr_coverage10pct"):
@@ -43,6 +49,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert pk["value"] > 0 and pk["records_identical_to_two_byte_path"] is True and pk["roofline"]["bytes_per_sample"] == 1
     for name in ("packed_groups5_interleaved", "packed_groups5_ordered"):
         assert legs[name]["value"] > 0 and legs[name]["records_identical_to_two_byte_path"] is True, name
+    hp = legs["host_pointer_one_byte"]
+    assert hp["bound"] == "pcie" and 0 < hp["ragged_one_byte"]["frac"] < 1 and 0 < hp["dense_one_byte"]["frac"] < 1
+    assert hp["ragged_one_byte"]["records_identical_to_device_pointer_call"] is True
     assert legs["config1_1e4x1e4"]["roofline"]["bound"] == "fp64_valu_issue"
     assert legs["csr_coverage10pct"]["roofline"]["bound"] == "fp64_valu_issue" and legs["csr_coverage10pct"]["hist_roofline"]["bound"] == "hbm"
 
@@ -71,3 +80,7 @@ def test_bench_under_the_drivers_multi_gpu_launcher_two_ranks_sharing_the_card()
     assert d["config"]["sites_per_step"] == 8000
     assert d["value"] == pytest.approx(8000 / (d["ms_per_step"] / 1e3), rel=1e-3)
     assert "gloo" in d["config"]["sharding"] and "strong" in d["config"]["sharding"]
+    # every rank's own clock and kernel times; each rank cuts its 4000 sites into 8 equal calls (no short tail call)
+    pr = d["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1] and all(p["sites"] == 4000 and p["calls_per_step"] == 8 for p in pr)
+    assert all(p["ms_per_step"] > 0 and p["hist_ms_per_call"] > 0 for p in pr) and d["config"]["sites_per_call"] == 500

@@ -124,3 +124,73 @@ def test_more_gpus_requested_than_present_degrades_to_the_devices_there(tmp_path
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([gzip.decompress(open(out + k, "rb").read()) for k in (".vcf.gz", ".cvg.gz")])
     assert outs[0] == outs[1]
+
+
+def _run(exe, out, lst, fa, extra=(), env=None, thread=2, batch=25):
+    from tests import hostref
+    r = subprocess.run([exe, "basetype", "-q", "20", "-t", str(thread), "-b", str(batch), "-i", lst, "-s", hostref.REGION,
+                        "-r", fa, "-o", out] + list(extra), capture_output=True, text=True, env=env)
+    return r
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_tiles_with_qualities_of_63_and_more_fall_back_to_two_bytes_by_themselves(tmp_path, grouped):
+    """The host program sends a tile to libbvc at one byte per observation (bvc_lrt_csr_packed, or
+    bvc_lrt_dense_groups_packed with --group) as long as every base quality of the tile is below 63, and as two bytes
+    otherwise -- tile by tile, without being told.  The test data stop at quality 39 (0.5 % of the observations), so a test
+    hook shifts every quality by 24 as it is read (Q39 becomes 63): with tiles of 32 positions some fit, some do not.  The outputs must be those of a run that is forced onto
+    two-byte tiles throughout (BVC_HOST_TWO_BYTE_TILES=1), byte for byte, and the automatic run must have used both forms."""
+    import os
+    import re
+    from basevarc_amd import build as b
+    from tests import hostref
+    exe, _ = b.build_host()
+    fa = hostref.write_fasta(str(tmp_path / "chr17.fa"))
+    lst = hostref.write_bam_list(str(tmp_path / "bam.list"))
+    extra = ["--tile", "32"]
+    if grouped:
+        names = hostref.Pipeline(mapq=20, batch=25, thread=1).names
+        gf = tmp_path / "groups.txt"
+        gf.write_text("".join(f"{n} {['EAS', 'AFR', 'EUR'][i % 3]}\n" for i, n in enumerate(names) if i % 14 != 5))
+        extra += ["-g", str(gf)]
+    outs = {}
+    for name, env_extra in (("auto", {}), ("two", {"BVC_HOST_TWO_BYTE_TILES": "1"})):
+        out = str(tmp_path / name)
+        env = dict(os.environ, BVC_HOST_QUAL_SHIFT="24", BVC_HOST_PROFILE="1", **env_extra)
+        r = _run(exe, out, lst, fa, extra, env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        forms = [(int(a), int(c)) for a, c in re.findall(r"one-byte tiles (\d+), on two-byte tiles (\d+)", r.stderr)]
+        outs[name] = ([gzip.decompress(open(out + k, "rb").read()) for k in (".vcf.gz", ".cvg.gz")], forms)
+    assert outs["auto"][0] == outs["two"][0]
+    one = sum(a for a, _ in outs["auto"][1]); two = sum(c for _, c in outs["auto"][1])
+    assert one > 0 and two > 0, outs["auto"][1]
+    assert sum(a for a, _ in outs["two"][1]) == 0
+    assert outs["auto"][0][0].count(b"\n") > 30                 # a VCF with records, not an empty run
+
+
+def test_a_temp_batch_cut_short_is_an_error_in_both_forms(tmp_path):
+    """A temp batch holds one record per position of its thread's window.  One that ends early (a valid BGZF file with
+    its EOF block, but fewer records) used to leave the remaining positions without that batch's samples, silently; it
+    is an error now, in the text and in the binary form (exit code 1, message on stderr)."""
+    import os
+    from basevarc_amd import build as b
+    from tests import hostref
+    from tools.host_bench import _bgzf_write
+    exe, _ = b.build_host()
+    fa = hostref.write_fasta(str(tmp_path / "chr17.fa"))
+    lst = hostref.write_bam_list(str(tmp_path / "bam.list"))
+    for fmt in ("text", "bin"):
+        out = str(tmp_path / f"cut_{fmt}")
+        extra = ["--keep_tmp"] + ([] if fmt == "text" else ["--tmp-format", "bin"])
+        r = _run(exe, out, lst, fa, extra + ["--load"])
+        assert r.returncode == 0, r.stderr[-1000:]
+        victim = f"{out}.tmp.thread.1/batch.2"
+        raw = gzip.decompress(open(victim, "rb").read())
+        cut = raw[:raw.rfind(b"\n", 0, len(raw) * 2 // 3) + 1] if fmt == "text" else raw[:16 + (len(raw) - 16) // 2]
+        tmp = str(tmp_path / "cut.raw")
+        open(tmp, "wb").write(cut)
+        _bgzf_write(tmp, victim)
+        r = _run(exe, out, lst, fa, extra + ["--rerun"])
+        assert r.returncode == 1, (fmt, r.returncode, r.stderr[-500:])
+        assert "truncated temp batch" in r.stderr or "malformed temp batch" in r.stderr, r.stderr[-500:]
+        assert os.path.exists(victim)

@@ -1,0 +1,204 @@
+"""GPU parity tests added in round 3 (run with -m gpu on an MI355X): the item engine of stage 2 (csrc/em_items.hip)
+against the one-wavefront-per-site engine and the oracle at its boundaries, the one-byte ragged entry point, the
+device-pointer contract of base_comb, and var_qual through the exp() underflow of chisf."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests.sitegen import caller_min_af, random_site
+from tests.test_gpu_parity import assert_path_difference_is_a_tie, assert_site_matches, pad_rows, _pack_numpy
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from basevarc_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+INT_FIELDS = ("called", "n_alt", "alt_base", "depth", "n_kept", "kept", "status", "depth_total")
+
+
+def _site_with_quals(rng, nind, quals, af=0.02):
+    """A site whose observations take exactly the given quality values (every one of them on every base that occurs
+    often enough)."""
+    b, _, r = random_site(rng, nind, af=af)
+    q = np.asarray(quals, dtype=np.int8)[np.arange(nind) % len(quals)]
+    rng.shuffle(q)
+    return b, q, r
+
+
+def test_item_engine_agrees_with_the_wave_engine_and_the_oracle(ctx):
+    """Stage 2 has two engines (include/bvc.h, "em_engine"): the item engine takes a site when no allele has more than 32
+    quality values and no observation has quality 0 or 1, the one-wavefront-per-site kernels take the rest.  A tile that
+    mixes both kinds, with a site count that fills the last region only partly: every integer field of the two engines'
+    records is identical (pass counts too, unless the oracle shows a tie), AF / chi / var_qual agree to 1e-12 relative,
+    and both match the faithful oracle."""
+    from basevarc_amd import Context
+    rng = np.random.default_rng(31)
+    sites = []
+    for s in range(151):
+        kind = s % 8
+        nind = int(rng.choice([3, 17, 60, 400, 3000, 20000]))
+        af = float(rng.choice([0.0, 0.0, 0.004, 0.03, 0.3]))
+        if kind == 5:
+            sites.append(random_site(rng, max(nind, 3000), af=af, qlo=2, qhi=70))        # > 32 values: wave engine
+        elif kind == 6:
+            sites.append(random_site(rng, nind, af=af, qlo=0, qhi=30))                    # qualities 0 and 1: wave engine
+        elif kind == 7:
+            sites.append(_site_with_quals(rng, max(nind, 2000), list(range(5, 37)), af=af))  # exactly 32 values: item engine
+        else:
+            sites.append(random_site(rng, nind, af=af, second_af=af / 3 if s % 16 == 3 else 0.0))
+    B, Q, R = pad_rows(sites)
+    m = 0.001
+    recs = {}
+    for engine in (0, 1):
+        with Context(0) as c:
+            c.set_tuning("em_engine", engine)
+            recs[engine] = c.lrt_dense(B, Q, R, m)
+    a, b = recs[0], recs[1]
+    ties = 0
+    for s, (sb, sq, sr) in enumerate(sites):
+        exp = orc.basetype_lrt(sb, sq, sr, m)
+        for eng in (0, 1):
+            assert_site_matches(recs[eng][s], exp, where=f"engine {eng} site {s}", path_strict=False)
+            ties += assert_path_difference_is_a_tie(recs[eng][s], exp, where=f"engine {eng} site {s}")
+        for f in INT_FIELDS:
+            assert np.array_equal(a[s][f], b[s][f]), (s, f)
+        for f in ("af", "chi", "var_qual", "lr_alt", "base_frq"):
+            x, y = np.asarray(a[s][f], dtype=float), np.asarray(b[s][f], dtype=float)
+            ok = np.isclose(x, y, rtol=1e-12, atol=1e-9 if f in ("chi", "var_qual") else 1e-14, equal_nan=True)
+            assert ok.all(), (s, f, x, y)
+    assert ties <= 4
+
+
+@pytest.mark.parametrize("n_values,taken", [(32, True), (33, False)])
+def test_thirty_two_quality_values_per_allele_is_the_item_engines_limit(ctx, n_values, taken):
+    """32 quality values on an allele fill the two lanes x 16 classes an item gives it; 33 send the site to the
+    one-wavefront-per-site kernels.  Either way the record is the oracle's."""
+    rng = np.random.default_rng(n_values)
+    sites = [_site_with_quals(rng, 6000, list(range(3, 3 + n_values)), af=af) for af in (0.0, 0.01, 0.2, 0.0, 0.05, 0.5, 0.0)]
+    B, Q, R = pad_rows(sites)
+    m = caller_min_af(6000)
+    got = ctx.lrt_dense(B, Q, R, m)
+    for s, (b, q, r) in enumerate(sites):
+        assert len(np.unique(q[b == r])) == n_values
+        assert_site_matches(got[s], orc.basetype_lrt(b, q, r, m), where=f"{n_values} values, site {s}", path_strict=False)
+    del taken
+
+
+def test_ragged_sites_at_one_byte_per_observation(ctx):
+    """bvc_lrt_csr_packed: the records of bvc_lrt_csr on the same observations, byte for byte, from host and from device
+    pointers; sites shorter and longer than the 4096 observations that separate the two ragged histogram kernels, ranges
+    that start at every alignment, "no observation" bytes inside; a sample of sites against the oracle."""
+    import torch
+    rng = np.random.default_rng(77)
+    lens = [0, 1, 15, 16, 17, 100, 4095, 4096, 4097, 9000, 70001, 3, 20000, 64, 5000]
+    sites = [random_site(rng, n, af=[0.0, 0.02, 0.3][i % 3], qlo=2, qhi=40) for i, n in enumerate(lens)]
+    offs = np.zeros(len(sites) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(lens)
+    bases = np.concatenate([s[0] for s in sites]).astype(np.int8)
+    quals = np.concatenate([s[1] for s in sites]).astype(np.int8)
+    ref = np.array([s[2] for s in sites], dtype=np.int8)
+    hole = rng.random(len(bases)) < 0.01                         # observations the producer marked "none"
+    bases[hole] = -1
+    packed = _pack_numpy(bases, quals)
+    assert (packed[hole] == 0xFF).all()
+    m = 0.001
+    want = ctx.lrt_csr(offs, bases, quals, ref, m)
+    got = ctx.lrt_csr_packed(offs, packed, ref, m)
+    assert got.tobytes() == want.tobytes()
+    for shift in (0, 1, 7):                                      # device pointers, arrays starting off the 16-byte grid
+        buf = torch.zeros(len(packed) + 32, dtype=torch.uint8, device="cuda")
+        buf[shift:shift + len(packed)] = torch.from_numpy(packed).cuda()
+        out = ctx.lrt_csr_packed_device(torch.from_numpy(offs).cuda(), buf[shift:shift + len(packed)], torch.from_numpy(ref).cuda(), m)
+        ctx.synchronize()
+        assert out.cpu().numpy().tobytes() == want.tobytes(), shift
+    for s in (2, 6, 8, 10, 12):
+        keep = ~hole[offs[s]:offs[s + 1]]
+        exp = orc.basetype_lrt(sites[s][0][keep], sites[s][1][keep], sites[s][2], m)
+        assert_site_matches(got[s], exp, where=f"packed ragged site {s}", path_strict=False)
+    # overlap mode keeps the two stages of consecutive packed calls apart like every other entry point
+    ctx.set_overlap(True)
+    outs = [ctx.lrt_csr_packed_device(torch.from_numpy(offs).cuda(), torch.from_numpy(packed).cuda(), torch.from_numpy(ref).cuda(), m)
+            for _ in range(4)]
+    ctx.join(); ctx.synchronize()
+    ctx.set_overlap(False)
+    assert all(o.cpu().numpy().tobytes() == want.tobytes() for o in outs)
+
+
+def test_base_comb_entries_outside_acgt_are_ignored_with_device_pointers(ctx):
+    """include/bvc.h, base_comb contract: with host pointers an entry outside 0..3 is BVC_ERR_ARG; with device pointers
+    the kernels apply the reference's rule -- such a candidate has depth 0 (src/BaseType.cpp:79) and falls to the min_af
+    filter -- so the record equals the one for the list without the entry.  Both stage-2 engines."""
+    import torch
+    from basevarc_amd import Context
+    from basevarc_amd.lib import BVC_PTR_DEVICE, BvcError, SITE_DTYPE, _dev_ptr
+    rng = np.random.default_rng(9)
+    sites = [random_site(rng, 800, af=af, second_af=0.05) for af in (0.0, 0.1, 0.3, 0.02)]
+    counts = np.stack([orc.dense_hist(b, q) for b, q, _ in sites])
+    ref = np.array([r for _, _, r in sites], dtype=np.int8)
+    bad = np.array([[0, 7, 1, 2], [-3, 3, 2, 1], [2, 1, 99, 0], [1, 0, 2, 5]], dtype=np.int8)
+    n_bad = np.array([4, 4, 3, 4], dtype=np.uint8)
+    clean = np.array([[0, 1, 2, 0], [3, 2, 1, 0], [2, 1, 0, 0], [1, 0, 2, 0]], dtype=np.int8)
+    n_clean = np.array([3, 3, 2, 3], dtype=np.uint8)
+    with pytest.raises(BvcError):
+        ctx.lrt_hist(counts, ref, 0.001, bad, n_bad)
+    want = ctx.lrt_hist(counts, ref, 0.001, clean, n_clean)
+    for engine in (0, 1):
+        with Context(0) as c:
+            c.set_tuning("em_engine", engine)
+            want_e = c.lrt_hist(counts, ref, 0.001, clean, n_clean)          # host pointers, the clean lists
+            d = [torch.from_numpy(x).cuda() for x in (counts.astype(np.uint32).view(np.int32), ref, bad, n_bad)]
+            out = torch.empty(len(sites) * SITE_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+            c._check(c._L.bvc_lrt_hist(c._h, len(sites), _dev_ptr(d[0]), _dev_ptr(d[1]), 0.001, _dev_ptr(d[2]), _dev_ptr(d[3]),
+                                       _dev_ptr(out), BVC_PTR_DEVICE))
+            c.synchronize()
+            assert out.cpu().numpy().tobytes() == want_e.tobytes(), engine
+    for s, (b, q, r) in enumerate(sites):
+        exp = orc.basetype_lrt(b, q, r, 0.001, base_comb=clean[s][:n_clean[s]])
+        assert_site_matches(want[s], exp, where=f"comb site {s}", path_strict=False)
+
+
+def test_var_qual_through_the_underflow_of_chisf(ctx):
+    """src/BaseType.cpp:127-132: var_qual = -10 log10(chisf(chi, 1)) while chisf is non-zero, 10000 once it is not.
+    chisf = kf_gammaq(0.5, chi / 2) ends in exp(-chi / 2 - ...), which underflows to 0 near chi = 1490.  Histograms
+    whose chi walks through [1380, 1540]: var_qual equals the oracle's on both sides of the switch, and below it also
+    scipy's regularised upper incomplete gamma function (the arithmetic is a third-party restatement: parity unpinned,
+    not unguarded)."""
+    from scipy.special import gammaincc
+    cands = []
+    for n in range(1900, 2300, 7):
+        for k in range(106, 120):
+            h = np.zeros(512, dtype=np.uint32)
+            h[0 * 128 + 40] = n - k                                 # reference allele A at Q40
+            h[2 * 128 + 40] = k                                     # ALT G at Q40
+            cands.append(h)
+    counts = np.stack(cands)
+    ref = np.zeros(len(cands), dtype=np.int8)
+    got = ctx.lrt_hist(counts, ref, 0.001)
+    sides = {"below": 0, "above": 0}
+    worst = 0.0
+    for s in range(len(cands)):
+        chi = float(got[s]["chi"])
+        if not (1380.0 <= chi <= 1540.0):
+            continue
+        exp = orc.hist_lrt(counts[s], 0, 0.001)
+        assert_site_matches(got[s], exp, where=f"chi {chi:.2f}")
+        vq = float(got[s]["var_qual"])
+        if vq == 10000.0:
+            sides["above"] += 1
+            assert orc.chisf(exp["chi"]) == 0.0
+        else:
+            sides["below"] += 1
+            p = gammaincc(0.5, chi / 2.0)
+            if p > 1e-300:                                       # scipy reaches denormals; compare where it is normal
+                assert vq == pytest.approx(-10.0 * math.log10(p), rel=1e-9), chi
+                worst = max(worst, abs(vq + 10.0 * math.log10(p)) / vq)
+    assert sides["below"] >= 20 and sides["above"] >= 20, sides
+    assert worst < 1e-9

@@ -80,6 +80,21 @@ def test_rank_sum_test(H):
     assert math.isnan(ranksum(H, [], [1.0, 2.0])) and math.isnan(ranksum(H, [3.0], []))
 
 
+
+def test_rank_sum_with_a_tie_run_longer_than_65536(H):
+    """The reference sums a tie run's ranks in an int32 (src/Algorithm.cpp:31-41), which overflows once a run of equal
+    values exceeds about 65,536 members -- the regime of CMDB-depth sites, where most reads share mapping quality 60.
+    The host library keeps the sum exact (a stated divergence: the reference's value is undefined there).  Pinned
+    against the Python restatement, whose integers do not overflow, and against the closed form for one all-equal run."""
+    n1, n2 = 70_000, 50_000
+    x = [60.0] * n1
+    y = [60.0] * (n2 - 3) + [20.0, 30.0, 61.0]
+    got = ranksum(H, x, y)
+    want = eo.rank_sum_test(x, y)
+    assert got == pytest.approx(want, rel=1e-9, abs=1e-9) and 0.0 < got < 10000.0
+    # everything tied: every rank is (n + 1) / 2, R1 equals its expectation, z = 0, phred(1) = 0
+    assert ranksum(H, [60.0] * n1, [60.0] * n2) == 0.0
+
 def random_site_lines(rng, n_samples, batch, ref, cov=0.6):
     """Batch lines of one position in the temp-file format, plus the per-sample truth."""
     toks = []

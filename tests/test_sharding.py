@@ -22,6 +22,24 @@ def test_shard_range_partitions_exactly():
         shard_range(10, 2, 2)
 
 
+def test_call_sizes_give_every_rank_equal_calls_and_no_short_tail():
+    """bench.py --gpus W: rank r owns shard_range(100000, r, W) and cuts it into calls with call_sizes(..., 4000, 8 if W > 1
+    else 1): at least 8 calls per pass on every rank, sizes within one site of each other (round 2 had 3 x 4000 + 500 at
+    W = 8: a quarter of the pass was pipeline fill and drain), never more than the 4000 the single-GPU run uses."""
+    from basevarc_amd.sharding import call_sizes
+    assert call_sizes(100000, 4000, 1) == [4000] * 25                     # the 1-GPU headline: unchanged
+    for w in (2, 4, 8):
+        for r in range(w):
+            lo, hi = shard_range(100000, r, w)
+            sizes = call_sizes(hi - lo, 4000, 8)
+            assert sum(sizes) == hi - lo and len(sizes) >= 8
+            assert max(sizes) - min(sizes) <= 1 and max(sizes) <= 4000
+    assert call_sizes(12500, 4000, 8) == [1563] * 4 + [1562] * 4
+    assert call_sizes(5, 4000, 8) == [1] * 5 and call_sizes(0, 4000, 8) == []
+    with pytest.raises(ValueError):
+        call_sizes(10, 0)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
