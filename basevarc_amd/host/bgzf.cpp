@@ -10,22 +10,41 @@ static const size_t kBlockIn = 0xff00;          // uncompressed bytes per block
 static const unsigned char kEofMarker[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0,
                                              0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-BgzfWriter::BgzfWriter(const std::string &path, int level) : fp_(std::fopen(path.c_str(), "wb")), level_(level), failed_(false)
+BgzfWriter::BgzfWriter(const std::string &path, int level, bool background)
+    : fp_(std::fopen(path.c_str(), "wb")), level_(level), failed_(false), background_(background && fp_ != nullptr)
 {
     buf_.reserve(kBlockIn);
+    if (background_)
+        worker_ = std::thread([this] {
+            for (;;) {
+                std::vector<unsigned char> blk;
+                {
+                    std::unique_lock<std::mutex> g(mu_);
+                    cv_.wait(g, [&] { return !pending_.empty() || closing_; });
+                    if (pending_.empty()) return;
+                    blk.swap(pending_.front());
+                    pending_.pop_front();
+                }
+                cv_.notify_all();                   // room for the producer
+                deflate_and_write(blk);
+            }
+        });
 }
 
 BgzfWriter::~BgzfWriter() { if (fp_) close(); }
 
-void BgzfWriter::flush_block(size_t n)
+// One or more BGZF blocks from `in` (all of it), written to the file.
+void BgzfWriter::deflate_and_write(std::vector<unsigned char> &in)
 {
+    size_t n = in.size();
     if (!fp_ || n == 0) return;
     unsigned char out[0x10000];
+    size_t at = 0;
     for (size_t take = n;;) {                   // shrink the input if the deflated block would not fit 64 KiB
         z_stream zs;
         std::memset(&zs, 0, sizeof zs);
         if (deflateInit2(&zs, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { failed_ = true; return; }
-        zs.next_in = buf_.data();
+        zs.next_in = in.data() + at;
         zs.avail_in = (uInt)take;
         zs.next_out = out + 18;
         zs.avail_out = (uInt)(sizeof out - 18 - 8);
@@ -38,15 +57,37 @@ void BgzfWriter::flush_block(size_t n)
         std::memcpy(out, hdr, 16);
         out[16] = (unsigned char)((bsize - 1) & 0xff);
         out[17] = (unsigned char)((bsize - 1) >> 8);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf_.data(), (uInt)take);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in.data() + at, (uInt)take);
         const uint32_t isize = (uint32_t)take;
         for (int i = 0; i < 4; ++i) { out[18 + clen + i] = (crc >> (8 * i)) & 0xff; out[22 + clen + i] = (isize >> (8 * i)) & 0xff; }
         if (std::fwrite(out, 1, bsize, fp_) != bsize) failed_ = true;
-        buf_.erase(buf_.begin(), buf_.begin() + take);
-        if (take == n) return;
-        n -= take;
-        take = n;
+        at += take;
+        if (at == n) return;
+        take = n - at;
     }
+}
+
+void BgzfWriter::flush_block(size_t n)
+{
+    if (!fp_ || n == 0) return;
+    std::vector<unsigned char> blk(buf_.begin(), buf_.begin() + n);
+    buf_.erase(buf_.begin(), buf_.begin() + n);
+    if (!background_) { deflate_and_write(blk); return; }
+    std::unique_lock<std::mutex> g(mu_);
+    cv_.wait(g, [&] { return pending_.size() < 256; });          // at most 16 MB waiting for the deflater
+    pending_.push_back(std::move(blk));
+    g.unlock();
+    cv_.notify_all();
+}
+
+// Background mode: every block handed over so far has reached the file.
+void BgzfWriter::drain()
+{
+    if (!background_ || !worker_.joinable()) return;
+    { std::lock_guard<std::mutex> g(mu_); closing_ = true; }
+    cv_.notify_all();
+    worker_.join();
+    background_ = false;
 }
 
 void BgzfWriter::write(const char *data, size_t n)
@@ -64,6 +105,7 @@ bool BgzfWriter::append_file(const std::string &path)
 {
     if (!fp_) return false;
     flush_block(buf_.size());
+    drain();
     FILE *in = std::fopen(path.c_str(), "rb");
     if (!in) return false;
     std::fseek(in, 0, SEEK_END);
@@ -92,6 +134,7 @@ bool BgzfWriter::close()
 {
     if (!fp_) return false;
     flush_block(buf_.size());
+    drain();
     if (std::fwrite(kEofMarker, 1, sizeof kEofMarker, fp_) != sizeof kEofMarker) failed_ = true;
     const bool good = std::fclose(fp_) == 0 && !failed_;
     fp_ = nullptr;

@@ -4,16 +4,23 @@
 #ifndef BVC_HOST_BGZF_H
 #define BVC_HOST_BGZF_H
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace bvchost {
 
 class BgzfWriter {
  public:
-    explicit BgzfWriter(const std::string &path, int level = 6);
+    // background = true: full blocks are deflated and written by a thread of the writer's own, in order; write() only
+    // copies bytes.  (The compute phase's outputs: deflating the CVG text was the largest single item of its last stage.)
+    explicit BgzfWriter(const std::string &path, int level = 6, bool background = false);
     ~BgzfWriter();
     bool ok() const { return fp_ != nullptr && !failed_; }
     void write(const char *data, size_t n);
@@ -24,10 +31,19 @@ class BgzfWriter {
     bool append_file(const std::string &path);
  private:
     void flush_block(size_t n);
+    void deflate_and_write(std::vector<unsigned char> &in);
+    void drain();
     FILE *fp_;
     int level_;
-    bool failed_;
+    std::atomic<bool> failed_;      // set by whichever thread deflates
     std::vector<unsigned char> buf_;
+    // background mode
+    bool background_;
+    std::thread worker_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::vector<unsigned char>> pending_;
+    bool closing_ = false;
 };
 
 class BgzfReader {

@@ -517,8 +517,10 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
                  const std::string &chr, int32_t rg_s, int32_t N, int thread, int ithread, int device)
 {
     const double t_start = StageClock::now();
-    BgzfWriter fpv(opt::output + "." + std::to_string(ithread) + ".vcf.gz");
-    BgzfWriter fpc(opt::output + "." + std::to_string(ithread) + ".cvg.gz");
+    // the outputs (a VCF line carries a field per SAMPLE: a megabyte at 1e5 samples) are deflated by threads of their
+    // writers' own
+    BgzfWriter fpv(opt::output + "." + std::to_string(ithread) + ".vcf.gz", 6, true);
+    BgzfWriter fpc(opt::output + "." + std::to_string(ithread) + ".cvg.gz", 6, true);
     std::vector<BatchInput *> fpiv;
     for (auto const &f : ftmp_v) fpiv.push_back(new BatchInput(f));
     // (BVC_HOST_PROFILE: on a GPU box the first ~0.5 s of every worker thread go to process-wide stalls while the HIP
@@ -595,9 +597,10 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
             ++tr.cur->n_used;
             tr.cur->entries += site.aiv.size();
             tr.cur->refs.push_back(ref_base);
-            // a tile is full at --tile positions or at 4M observations (64 MB of per-sample records held for the
-            // CVG/VCF lines): at 1e5 samples that is a few hundred positions, still far more than the device needs
-            if ((int64_t)tr.cur->n_used >= tile || tr.cur->entries >= ((size_t)1 << 22)) tr.flush();
+            // a tile is full at --tile positions or at 1M observations (16 MB of per-sample records held for the
+            // CVG/VCF lines; three tiles are in flight per thread): at 1e5 samples that is a hundred positions, still far
+            // more than the device needs, and short enough for the three stages to overlap within a thread's window
+            if ((int64_t)tr.cur->n_used >= tile || tr.cur->entries >= ((size_t)1 << 20)) tr.flush();
             if (!(++count % 1000)) std::cerr << "basetype completed " << count << " sites -- thread" << ithread << std::endl;
         }
     }
