@@ -211,11 +211,16 @@ std::string vcf_header(const Groups &g, const std::string &reference, const std:
 std::string cvg_line(const std::string &chr, int32_t pos, int8_t ref_base, const SiteColumn &site,
                      const bvc_group_result *grp, int n_groups)
 {
+    // ONE pass over the position's entries: depth per base (non-indel entries), and forward / reverse counts per base
+    // value of EVERY entry -- indel entries take part in the strand tallies with the fields they carry (src/BaseVarC.cpp:
+    // 575-590 reads a.base and a.strand of all of aiv) -- from which the ref and alt columns are picked afterwards.
     int cnt[4] = {0, 0, 0, 0};
+    int fwd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::map<std::string, int> indel_m;    // the reference iterates a hash map here (:570-573): order by key instead
     for (auto const &a : site.aiv) {
         if (a.is_indel == 0) { if (a.base < 4) cnt[a.base] += 1; }
         else indel_m[a.indel] += 1;
+        (a.strand == 1 ? fwd : rev)[a.base & 7u] += a.base < 8u ? 1 : 0;
     }
     std::string indels = ".";
     if (!indel_m.empty()) {
@@ -227,16 +232,11 @@ std::string cvg_line(const std::string &chr, int32_t pos, int8_t ref_base, const
     int didx[4] = {0, 1, 2, 3};
     std::stable_sort(didx, didx + 4, [&cnt](int a, int b) { return cnt[a] > cnt[b]; });
     int alt_base = (didx[0] != ref_base) ? didx[0] : didx[1];
-    int ref_fwd = 0, ref_rev = 0, alt_fwd = 0, alt_rev = 0;
-    for (auto const &a : site.aiv) {                              // indel entries take part with carried fields
-        if (a.strand == 1) {
-            if (a.base == ref_base) ref_fwd += 1;
-            else if (a.base == alt_base) alt_fwd += 1;
-        } else {
-            if (a.base == ref_base) ref_rev += 1;
-            else if (a.base == alt_base) alt_rev += 1;
-        }
-    }
+    // an entry counts as ref when its base equals ref_base, else as alt when it equals alt_base (alt_base != ref_base
+    // unless ref_base is outside 0..3, where no entry matches it)
+    const bool ref_ok = ref_base >= 0 && ref_base < 8;
+    const int ref_fwd = ref_ok ? fwd[ref_base] : 0, ref_rev = ref_ok ? rev[ref_base] : 0;
+    const int alt_fwd = (ref_ok && alt_base == ref_base) ? 0 : fwd[alt_base], alt_rev = (ref_ok && alt_base == ref_base) ? 0 : rev[alt_base];
     const double fs = bt_fisher_exact(ref_fwd, ref_rev, alt_fwd, alt_rev);
     const double sor = (alt_fwd * ref_rev > 0) ? (double)(ref_fwd * alt_rev) / (ref_rev * alt_fwd) : 10000.0;
     const int dep = cnt[0] + cnt[1] + cnt[2] + cnt[3];

@@ -105,14 +105,20 @@ def main():
         h = summary.get(kname, {})
         if "FETCH_SIZE" not in h or h["FETCH_SIZE"] < 1000:        # the kernel that returned at once has no traffic
             continue
-        fetch = h["FETCH_SIZE"] * 1024 * 2          # gfx950: FETCH_SIZE counts 64 B per 128-B request
+        # gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide (16 B/lane) coalesced streaming read -- checked on a
+        # known byte count with tools/micro/read_bw.hip.  The doubling is applied ONLY to the six streaming histogram
+        # kernels listed above, whose input is read that way; the byte-wise kernels, group_bounds_kernel, the stage-2
+        # kernels and everything else appear in the tables above with their raw counter values, uncorrected.
+        fetch = h["FETCH_SIZE"] * 1024 * 2
         write = h.get("WRITE_SIZE", 0.0) * 1024
         doc["kernels"][kname] = {
             "n_samples": n_samples, "sites_per_launch": sites, "row_align": row_align,
             "fetch_size_kib_raw": h["FETCH_SIZE"], "write_size_kib_raw": h.get("WRITE_SIZE"),
             "hbm_read_bytes_per_launch": fetch, "hbm_write_bytes_per_launch": write,
             "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": alg,
-            "traffic_over_algorithmic": (fetch + write) / alg}
+            "traffic_over_algorithmic": (fetch + write) / alg,
+            "correction_applied": "read = FETCH_SIZE KiB x 1024 x 2 (16 B/lane streaming loads: gfx950 counts half, validated "
+                                  "with tools/micro/read_bw.hip); write = WRITE_SIZE KiB x 1024 (as is)"}
         lines += [f"## HBM traffic of {kname} per launch", "",
                   f"- FETCH_SIZE raw {h['FETCH_SIZE']:.1f} KiB -> read bytes (x1024 x2) = {fetch:.4g}",
                   f"- WRITE_SIZE raw {h.get('WRITE_SIZE', 0):.1f} KiB -> write bytes = {write:.4g}",
