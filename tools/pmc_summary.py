@@ -23,7 +23,7 @@ def short(name):
     m = re.search(r"(lrt_groups_kernel|lrt_kernel)<(\d+)", name)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
-    for k in ("hist_dense_slots_kernel", "group_slots_kernel", "hist_dense_groups_bytes_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel", "hist_wave_kernel", "hist_packed_groups_kernel", "hist_packed_ranges_kernel", "hist_packed_kernel", "pack_dense_kernel",
+    for k in ("region_walk_kernel", "region_kernel", "group_comb_kernel", "group_records_kernel", "hist_dense_slots_kernel", "group_slots_kernel", "hist_dense_groups_bytes_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel", "hist_wave_kernel", "hist_packed_groups_kernel", "hist_packed_ranges_kernel", "hist_packed_kernel", "pack_dense_kernel",
               "hist_dense_kernel", "hist_csr_block_kernel", "group_bounds_kernel", "var_qual_kernel",
               "synth_dense_kernel", "sum_groups_kernel", "stream_read_kernel"):
         if k in name:
