@@ -48,10 +48,12 @@ constexpr int kEmIters = 100;             // src/BaseType.cpp:46
 constexpr double kEmEpsilon = 0.001;      // src/BaseType.cpp:45
 constexpr double kVarQualPending = -1.0;  // as in em_kernel.hip: var_qual_kernel finishes these records
 
-constexpr int kClassesPerBase = 32;        // quality classes of one allele the engine holds
-constexpr int kPlane = 4 * kClassesPerBase;           // class places of a site
-// A site's table (LDS): counts uint32 [base][class] and then quality indices uint8 [base][class], 640 bytes.
-constexpr int kSiteTable = kPlane * 5;
+// Quality classes of one allele the engine holds: CPB = 32 (two lanes x 16; 2^5 VGPRs short of three waves per SIMD) for
+// the regions whose sites all fit, CPB = 48 (two lanes x 24, two waves per SIMD) for the regions with a wider site --
+// Illumina's unbinned 41 values.  A site's table (LDS): counts uint32 [base][class], then quality indices uint8
+// [base][class]: 5 * 4 * CPB bytes.
+constexpr int kNarrow = 32, kWide = 48;
+template <int CPB> constexpr int site_table_bytes() { return 4 * CPB * 5; }
 
 constexpr int kEmptyQ = 128;               // quality index of an empty class place: QualLut::e_empty = 1/4
 constexpr uint32_t hi_word(double x) { return (uint32_t)(__builtin_bit_cast(uint64_t, x) >> 32); }
@@ -171,17 +173,20 @@ __device__ __forceinline__ void count_wanted(uint32_t sets, int n_emit, int p_de
 }
 
 // What a region keeps in LDS.
+template <int CPB>
 struct Region {
     ItemSite site[kRegionSites];
     FitItem items[kListAt[kLists]];
     FitOut outs[kListAt[kLists]];
     int want[kRegionSites][kLists];
     int count[kLists];
-    alignas(8) uint8_t tab[kRegionSites][kSiteTable];
+    int wide;                                            // some site of the region needs more than kNarrow class places
+    alignas(8) uint8_t tab[kRegionSites][site_table_bytes<CPB>()];
 };
 
 // Emits the fits S.sets of site `ls` of the region (wave-uniform): places from the prefix of `want` over the sites.
-__device__ __forceinline__ void site_emit(Region &R, int ls, int lane)
+template <class RegionT>
+__device__ __forceinline__ void site_emit(RegionT &R, int ls, int lane)
 {
     ItemSite &S = R.site[ls];
     const uint32_t sets = S.sets;
@@ -273,7 +278,8 @@ __device__ __forceinline__ void store_record(bvc_site_result *dst, const ItemSit
 // e = 1/4, whose marginal f + (1 - 4 f) e is 1/4 whatever f: weight 0 in every sum and harmless in the product of a
 // lane's marginals).  Then the head of BaseType::LRT (src/BaseType.cpp:75-88): candidates by min_af, and the first
 // level's fits: the full model and, because they depend on nothing but the candidate list, its (n-1)-subsets.
-__device__ __forceinline__ void site_classes(Region &R, int ls, int lane, int64_t site, int n_groups,
+template <int CPB>
+__device__ __forceinline__ void site_classes(Region<CPB> &R, int ls, int lane, int64_t site, int n_groups,
                                              const uint32_t *__restrict__ counts, int64_t hist_stride,
                                              const QualLut *__restrict__ lut,
                                              const int8_t *__restrict__ ref_base, double min_af,
@@ -286,8 +292,8 @@ __device__ __forceinline__ void site_classes(Region &R, int ls, int lane, int64_
     int n_emit = 0, p_deepest = 0;
     bool finished = false;
     const uint32_t *hist = counts + hist_index(site, n_groups) * hist_stride;
-    uint32_t *tab_n = reinterpret_cast<uint32_t *>(R.tab[ls]) + row * kClassesPerBase;
-    uint8_t *tab_q = R.tab[ls] + 4 * kPlane + row * kClassesPerBase;
+    uint32_t *tab_n = reinterpret_cast<uint32_t *>(R.tab[ls]) + row * CPB;
+    uint8_t *tab_q = R.tab[ls] + 16 * CPB + row * CPB;
     int cnt_row = 0, depth_lane = 0;
     double lle = 0.0;
     bool low_q = false;
@@ -299,7 +305,7 @@ __device__ __forceinline__ void site_classes(Region &R, int ls, int lane, int64_
         const uint32_t rowbits = (uint32_t)(nzmask >> (16 * row)) & 0xFFFFu;
         if (c != 0) {
             const int pos = cnt_row + __popc(rowbits & ((1u << t) - 1u));
-            if (pos < kClassesPerBase) {
+            if (pos < CPB) {
                 tab_n[pos] = c;
                 tab_q[pos] = (uint8_t)q;
             }
@@ -311,8 +317,8 @@ __device__ __forceinline__ void site_classes(Region &R, int ls, int lane, int64_
     }
     // the places this allele leaves empty
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int pos = t + 16 * half;
+    for (int part = 0; part < CPB / 16; ++part) {
+        const int pos = t + 16 * part;
         if (pos >= cnt_row) {
             tab_n[pos] = 0u;
             tab_q[pos] = (uint8_t)kEmptyQ;
@@ -325,7 +331,8 @@ __device__ __forceinline__ void site_classes(Region &R, int ls, int lane, int64_
     S.depth[1] = __builtin_amdgcn_readlane(depth_row, 16);
     S.depth[2] = __builtin_amdgcn_readlane(depth_row, 32);
     S.depth[3] = __builtin_amdgcn_readlane(depth_row, 48);
-    const bool too_wide = __ballot(cnt_row > kClassesPerBase) != 0;
+    const bool too_wide = __ballot(cnt_row > kWide) != 0;
+    const bool wide = __ballot(cnt_row > kNarrow) != 0;
     const bool any_low = __ballot(low_q) != 0;
 
     const int total_i = S.depth[0] + S.depth[1] + S.depth[2] + S.depth[3];
@@ -356,6 +363,7 @@ __device__ __forceinline__ void site_classes(Region &R, int ls, int lane, int64_
         }
     }
     const bool mine = !(too_wide || any_low || dup);
+    if (mine && wide && lane == 0) R.wide = 1;                   // (every writer writes the same value)
     S.blist = blist; S.n = (int8_t)n; S.k = (int8_t)n; S.first = 1;
     S.state = mine ? 1 : 0;
     if (mine) {
@@ -376,11 +384,9 @@ __device__ __forceinline__ void site_classes(Region &R, int ls, int lane, int64_
     S.sets = sets; S.n_emit = (int8_t)n_emit; S.p_deepest = (int8_t)p_deepest;
     int want[kLists];
     count_wanted(sets, n_emit, p_deepest, want);
+    (void)ref_base; (void)results;
     if (lane == 0) {
-        if (finished) {
-            store_record(results + site, S, (int)ref_base[n_groups > 0 ? site / n_groups : site], S.n, S.blist);
-            S.state = 2;
-        }
+        if (finished) S.state = 3;                               // record pending: written by the kernel that owns the region
         R.site[ls] = S;
         R.want[ls][0] = want[0]; R.want[ls][1] = want[1]; R.want[ls][2] = want[2]; R.want[ls][3] = want[3];
         taken[site] = mine ? 1 : 0;
@@ -406,6 +412,20 @@ __device__ __forceinline__ void rcp_all(const double (&m)[N], double (&y)[N])
 {
     if constexpr (N == 1) {
         y[0] = rcp_cubic(m[0]);
+    } else if constexpr ((N & (N - 1)) != 0) {
+        // not a power of two (24 = 16 + 8, 12 = 8 + 4): a tree and a reciprocal for each part
+        constexpr int P = N >= 32 ? 32 : (N >= 16 ? 16 : (N >= 8 ? 8 : (N >= 4 ? 4 : 2)));
+        double a[P], ya[P], b[N - P], yb[N - P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) a[i] = m[i];
+#pragma unroll
+        for (int i = 0; i < N - P; ++i) b[i] = m[P + i];
+        rcp_all<P>(a, ya);
+        rcp_all<N - P>(b, yb);
+#pragma unroll
+        for (int i = 0; i < P; ++i) y[i] = ya[i];
+#pragma unroll
+        for (int i = 0; i < N - P; ++i) y[P + i] = yb[i];
     } else {
         double p[N / 2], q[N / 2];
 #pragma unroll
@@ -461,11 +481,11 @@ __device__ __forceinline__ double item_sum(double x)
     return unit_sum<LOG2G>(x);
 }
 
-template <int ROWS, int LOG2G>
+template <int ROWS, int LOG2G, int CPB>
 __device__ __forceinline__ void fit_body(int item0, int item_end, const FitItem *items, FitOut *outs, const uint8_t *cls,
                                          const double *lut_e)
 {
-    constexpr int G = 1 << LOG2G, kSlots = kClassesPerBase / G;
+    constexpr int G = 1 << LOG2G, kSlots = CPB / G;
     constexpr int kGroupsPerRow = 16 / G;
     const int lane = threadIdx.x & (kWave - 1);
     const int row = lane >> 4, sub = lane & (G - 1), grp = (lane & 15) >> LOG2G;
@@ -484,9 +504,9 @@ __device__ __forceinline__ void fit_body(int item0, int item_end, const FitItem 
         if (base != 0xFF) {
             active = true;
             fb = fi->f0[unit];
-            const uint8_t *tab = cls + fi->site * kSiteTable;
-            const uint32_t *tab_n = reinterpret_cast<const uint32_t *>(tab) + base * kClassesPerBase + sub;
-            const uint8_t *tab_q = tab + 4 * kPlane + base * kClassesPerBase + sub;
+            const uint8_t *tab = cls + fi->site * site_table_bytes<CPB>();
+            const uint32_t *tab_n = reinterpret_cast<const uint32_t *>(tab) + base * CPB + sub;
+            const uint8_t *tab_q = tab + 16 * CPB + base * CPB + sub;
 #pragma unroll
             for (int k = 0; k < kSlots; ++k) {
                 n[k] = (double)tab_n[k * G];
@@ -582,7 +602,8 @@ constexpr int kPerWave4 = 16 >> kLog2G4, kPerWave2 = 2 * (16 >> kLog2G2);
 // ---- site_decide: one wavefront per site, one level of BaseType::LRT -------------------------------------------------
 // Reads the fits of the pending level, takes the reference's decision (src/BaseType.cpp:93-110) and either sets up
 // the next level's fits or writes the record.
-__device__ __forceinline__ void site_decide(Region &R, int ls, int lane, int64_t site, int n_groups,
+template <class RegionT>
+__device__ __forceinline__ void site_decide(RegionT &R, int ls, int lane, int64_t site, int n_groups,
                                             const int8_t *__restrict__ ref_base, bvc_site_result *__restrict__ results)
 {
     ItemSite S = R.site[ls];
@@ -690,30 +711,62 @@ __device__ __forceinline__ void site_decide(Region &R, int ls, int lane, int64_t
 }
 
 // ---- region_kernel: one workgroup of five wavefronts per region of eight sites ---------------------------------------
-template <bool WALK>
-__device__ __forceinline__ void region_body(
-    Region &R, int64_t n_sites, int n_groups, const uint32_t *__restrict__ counts, int64_t hist_stride,
-    const QualLut *__restrict__ lut, const int8_t *__restrict__ ref_base, double min_af,
-    const int8_t *__restrict__ comb, const uint8_t *__restrict__ n_comb, uint8_t *__restrict__ taken,
-    bvc_site_result *__restrict__ results, int dbg_levels)
+struct RegionArgs {
+    int64_t n_sites;
+    int n_groups;
+    const uint32_t *counts;
+    int64_t hist_stride;
+    const QualLut *lut;
+    const int8_t *ref_base;
+    double min_af;
+    const int8_t *comb;
+    const uint8_t *n_comb;
+    uint8_t *taken;
+    bvc_site_result *results;
+    uint32_t *wide_epoch;        // set to `epoch` by the narrow launch when some region needs the wide one
+    uint32_t epoch;
+    int dbg_levels;
+};
+
+// CPB = kNarrow: the regions whose sites all fit 32 class places per allele; a region with a wider site is left (whole)
+// to the CPB = kWide launch, which takes only those.  Both run the classes phase of every region they look at; the
+// wide launch returns at once when the narrow one has seen no wide region in this call.
+template <bool WALK, int CPB>
+__device__ __forceinline__ void region_body(Region<CPB> &R, const RegionArgs &A)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (kWave - 1);
+    const int64_t n_sites = A.n_sites;
     const int64_t n_regions = (n_sites + kRegionSites - 1) / kRegionSites;
+    if (CPB == kWide && *A.wide_epoch != A.epoch) return;
     // one region per workgroup when the launch has the chip to itself (the dispatcher balances them); underneath a
     // streaming histogram pass the launcher bounds the grid and a workgroup walks several regions
     for (int64_t region = blockIdx.x; region < n_regions; region += WALK ? (int64_t)gridDim.x : n_regions) {
     const int64_t site0 = region * kRegionSites;
+    if (threadIdx.x == 0) R.wide = 0;
+    __syncthreads();
     for (int ls = wave; ls < kRegionSites; ls += kRegionWaves) {
         if (site0 + ls < n_sites) {
-            site_classes(R, ls, lane, site0 + ls, n_groups, counts, hist_stride, lut, ref_base, min_af, comb, n_comb, taken, results);
+            site_classes<CPB>(R, ls, lane, site0 + ls, A.n_groups, A.counts, A.hist_stride, A.lut, A.ref_base, A.min_af, A.comb,
+                              A.n_comb, A.taken, A.results);
         } else if (lane == 0) {
             R.site[ls].state = 2; R.site[ls].n_emit = 0;
             R.want[ls][0] = 0; R.want[ls][1] = 0; R.want[ls][2] = 0; R.want[ls][3] = 0;
         }
     }
     __syncthreads();
-    for (int level = 0; level < kLevels && level < (dbg_levels >> 1); ++level) {
+    const bool wide = R.wide != 0;                               // (uniform over the workgroup)
+    if (CPB == kNarrow && wide && threadIdx.x == 0) *A.wide_epoch = A.epoch;
+    if (wide == (CPB == kWide)) {
+    // records of the sites that ended in the classes phase (no observation, no candidate)
+    for (int ls = wave; ls < kRegionSites; ls += kRegionWaves)
+        if (lane == 0 && R.site[ls].state == 3) {
+            const int64_t site = site0 + ls;
+            store_record(A.results + site, R.site[ls], (int)A.ref_base[A.n_groups > 0 ? site / A.n_groups : site], R.site[ls].n,
+                         R.site[ls].blist);
+            R.site[ls].state = 2;
+        }
+    for (int level = 0; level < kLevels && level < (A.dbg_levels >> 1); ++level) {
         // the fits of this level, side by side in site order in each list
         for (int ls = wave; ls < kRegionSites; ls += kRegionWaves) site_emit(R, ls, lane);
         if (threadIdx.x < kLists) {
@@ -733,46 +786,47 @@ __device__ __forceinline__ void region_body(
             const int in_list = slot - (l == 0 ? 0 : (l == 1 ? w0 : (l == 2 ? w1 : w2)));
             const int base = l == 0 ? kListAt[0] : (l == 1 ? kListAt[1] : (l == 2 ? kListAt[2] : kListAt[3]));
             const int cnt = l == 0 ? c0 : (l == 1 ? c1 : (l == 2 ? c2 : c3));
-            if (l < 2) fit_body<4, kLog2G4>(base + in_list * kPerWave4, base + cnt, R.items, R.outs, &R.tab[0][0], lut->e);
-            else fit_body<2, kLog2G2>(base + in_list * kPerWave2, base + cnt, R.items, R.outs, &R.tab[0][0], lut->e);
+            if (l < 2) fit_body<4, kLog2G4, CPB>(base + in_list * kPerWave4, base + cnt, R.items, R.outs, &R.tab[0][0], A.lut->e);
+            else fit_body<2, kLog2G2, CPB>(base + in_list * kPerWave2, base + cnt, R.items, R.outs, &R.tab[0][0], A.lut->e);
         }
         __syncthreads();
-        if (level + 1 == (dbg_levels >> 1) && (dbg_levels & 1)) break;
+        if (level + 1 == (A.dbg_levels >> 1) && (A.dbg_levels & 1)) break;
         for (int ls = wave; ls < kRegionSites; ls += kRegionWaves)
-            if (site0 + ls < n_sites) site_decide(R, ls, lane, site0 + ls, n_groups, ref_base, results);
+            if (site0 + ls < n_sites) site_decide(R, ls, lane, site0 + ls, A.n_groups, A.ref_base, A.results);
         __syncthreads();
+    }
     }
     __syncthreads();                                             // the region's LDS is reused by the next one
     }
 }
 
 // One region per workgroup: three workgroups (12 wavefronts) per CU.
-__global__ __launch_bounds__(64 * kRegionWaves) __attribute__((amdgpu_waves_per_eu(3, 3))) void region_kernel(
-    int64_t n_sites, int n_groups, const uint32_t *__restrict__ counts, int64_t hist_stride,
-    const QualLut *__restrict__ lut, const int8_t *__restrict__ ref_base, double min_af,
-    const int8_t *__restrict__ comb, const uint8_t *__restrict__ n_comb, uint8_t *__restrict__ taken,
-    bvc_site_result *__restrict__ results, int dbg_levels)
+__global__ __launch_bounds__(64 * kRegionWaves) __attribute__((amdgpu_waves_per_eu(3, 3))) void region_kernel(RegionArgs A)
 {
-    __shared__ Region R;
-    region_body<false>(R, n_sites, n_groups, counts, hist_stride, lut, ref_base, min_af, comb, n_comb, taken, results, dbg_levels);
+    __shared__ Region<kNarrow> R;
+    region_body<false, kNarrow>(R, A);
 }
 
-// A bounded grid whose workgroups walk the regions (underneath a streaming histogram pass: two workgroups per CU).
-__global__ __launch_bounds__(64 * kRegionWaves) void region_walk_kernel(
-    int64_t n_sites, int n_groups, const uint32_t *__restrict__ counts, int64_t hist_stride,
-    const QualLut *__restrict__ lut, const int8_t *__restrict__ ref_base, double min_af,
-    const int8_t *__restrict__ comb, const uint8_t *__restrict__ n_comb, uint8_t *__restrict__ taken,
-    bvc_site_result *__restrict__ results, int dbg_levels)
+// A bounded grid whose workgroups walk the regions (underneath a streaming histogram pass: one workgroup per CU).
+__global__ __launch_bounds__(64 * kRegionWaves) void region_walk_kernel(RegionArgs A)
 {
-    __shared__ Region R;
-    region_body<true>(R, n_sites, n_groups, counts, hist_stride, lut, ref_base, min_af, comb, n_comb, taken, results, dbg_levels);
+    __shared__ Region<kNarrow> R;
+    region_body<true, kNarrow>(R, A);
+}
+
+// The same for the regions with a site of 33..48 quality values on an allele (24 classes per lane: two wavefronts per
+// SIMD); the grid walks the regions.
+__global__ __launch_bounds__(64 * kRegionWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void region_wide_kernel(RegionArgs A)
+{
+    __shared__ Region<kWide> R;
+    region_body<true, kWide>(R, A);
 }
 
 }  // namespace
 
 size_t em_items_scratch_bytes(int64_t n_sites)
 {
-    return (size_t)n_sites + 256;                                 // the `taken` flags; everything else lives in LDS
+    return (size_t)n_sites + 256 + 64;                            // the `taken` flags and the "wide regions seen" word; everything else lives in LDS
 }
 
 // Stage 2 with the item engine.  `scratch` holds em_items_scratch_bytes(n_sites).  Sites it does not take are left
@@ -791,13 +845,18 @@ hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n
     int64_t grid = regions;
     const int per_cu = st.em_waves_per_cu > 0 ? (st.em_waves_per_cu + kRegionWaves - 1) / kRegionWaves : (shared ? 1 : 0);
     if (per_cu > 0 && grid > (int64_t)per_cu * st.n_cu) grid = (int64_t)per_cu * st.n_cu;
-    const int dbg_levels = getenv("BVC_DBG_LEVELS") ? atoi(getenv("BVC_DBG_LEVELS")) : 2 * kLevels;
-    if (grid < regions)
-        hipLaunchKernelGGL(region_walk_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, n_sites, n_groups, counts,
-                           hist_stride, lut, ref_base, min_af, comb, n_comb, taken, results, dbg_levels);
-    else
-        hipLaunchKernelGGL(region_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, n_sites, n_groups, counts,
-                           hist_stride, lut, ref_base, min_af, comb, n_comb, taken, results, dbg_levels);
+    RegionArgs A;
+    A.n_sites = n_sites; A.n_groups = n_groups; A.counts = counts; A.hist_stride = hist_stride; A.lut = lut;
+    A.ref_base = ref_base; A.min_af = min_af; A.comb = comb; A.n_comb = n_comb; A.taken = taken; A.results = results;
+    A.wide_epoch = reinterpret_cast<uint32_t *>(taken + (((size_t)n_sites + 255) & ~(size_t)255));
+    A.epoch = ++st.em_epoch;                                     // never 0; a stale word can only cost the wide launch a scan
+    if (A.epoch == 0) A.epoch = ++st.em_epoch;
+    A.dbg_levels = getenv("BVC_DBG_LEVELS") ? atoi(getenv("BVC_DBG_LEVELS")) : 2 * kLevels;
+    if (grid < regions) hipLaunchKernelGGL(region_walk_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, A);
+    else hipLaunchKernelGGL(region_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, A);
+    int64_t wide_grid = (int64_t)(per_cu > 0 ? per_cu : 2) * st.n_cu;
+    if (wide_grid > regions) wide_grid = regions;
+    hipLaunchKernelGGL(region_wide_kernel, dim3((unsigned)wide_grid), dim3(64 * kRegionWaves), 0, stream, A);
     *taken_out = taken;
     return hipGetLastError();
 }

@@ -77,19 +77,26 @@ def test_item_engine_agrees_with_the_wave_engine_and_the_oracle(ctx):
     assert ties <= 4
 
 
-@pytest.mark.parametrize("n_values,taken", [(32, True), (33, False)])
-def test_thirty_two_quality_values_per_allele_is_the_item_engines_limit(ctx, n_values, taken):
-    """32 quality values on an allele fill the two lanes x 16 classes an item gives it; 33 send the site to the
-    one-wavefront-per-site kernels.  Either way the record is the oracle's."""
+@pytest.mark.parametrize("n_values", [32, 33, 41, 48, 49])
+def test_class_capacity_boundaries_of_the_item_engine(ctx, n_values):
+    """32 quality values on an allele fill the two lanes x 16 classes of the narrow region kernel; 33..48 (Illumina's
+    unbinned 41) send the site's whole REGION to the wide one (two lanes x 24); 49 send the site to the one-wavefront-per-site
+    kernels.  Whichever path: the record is the oracle's.  The tile mixes sites of the tested width with narrow ones, so
+    that regions of both kinds occur in one call."""
     rng = np.random.default_rng(n_values)
-    sites = [_site_with_quals(rng, 6000, list(range(3, 3 + n_values)), af=af) for af in (0.0, 0.01, 0.2, 0.0, 0.05, 0.5, 0.0)]
+    sites = []
+    for i, af in enumerate((0.0, 0.01, 0.2, 0.0, 0.05, 0.5, 0.0, 0.1, 0.0, 0.3, 0.0, 0.02, 0.0, 0.0)):
+        nv = n_values if i % 5 != 4 and i < 8 else 20                 # sites 8.. form a region of narrow sites only
+        sites.append(_site_with_quals(rng, 6000, list(range(3, 3 + nv)), af=af))
+    n_values_of = [n_values if i % 5 != 4 and i < 8 else 20 for i in range(len(sites))]
     B, Q, R = pad_rows(sites)
     m = caller_min_af(6000)
     got = ctx.lrt_dense(B, Q, R, m)
     for s, (b, q, r) in enumerate(sites):
-        assert len(np.unique(q[b == r])) == n_values
-        assert_site_matches(got[s], orc.basetype_lrt(b, q, r, m), where=f"{n_values} values, site {s}", path_strict=False)
-    del taken
+        assert len(np.unique(q[b == r])) == n_values_of[s]
+        exp = orc.basetype_lrt(b, q, r, m)
+        assert_site_matches(got[s], exp, where=f"{n_values} values, site {s}", path_strict=False)
+        assert_path_difference_is_a_tie(got[s], exp, where=f"{n_values} values, site {s}")
 
 
 def test_ragged_sites_at_one_byte_per_observation(ctx):

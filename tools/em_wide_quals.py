@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""EM/LRT kernel speed by quality spectrum (GPU): the number of distinct quality values per base decides which
+"""Stage-2 speed by quality spectrum (GPU): the number of distinct quality values per allele decides the path: <= 32 the
+narrow region kernel (em_items.hip), 33..48 the wide one, more (or qualities 0 / 1) the one-wavefront-per-site kernels, where it decides which
 lrt_kernel<NS> variant a site takes (<= 32: NS = 2, <= 64: NS = 4, <= 128: NS = 8).  The SURVEY's generator draws
 Q from 10..40 (31 values, NS = 2); real Illumina data has ~40 (NS = 4), the int8 range allows 128 (NS = 8).
 Tiles are made with torch on the device; 16 sites per spectrum are checked against the oracle's histogram form.
@@ -23,7 +24,7 @@ ctx = Context(0)
 g = torch.Generator(device=dev); g.manual_seed(7)
 m = caller_min_af(N)
 BINNED = torch.tensor([2, 12, 23, 37], dtype=torch.int8, device=dev)          # NovaSeq-style binned qualities
-for name, qlo, qhi in (("binned Q2/12/23/37 (4 values, NS=2 one slot)", 0, 3), ("Q10-40 (31 values, NS=2)", 10, 40), ("Q2-41 (40 values, NS=4)", 2, 41), ("Q1-93 (93 values, NS=8)", 1, 93)):
+for name, qlo, qhi in (("binned Q2/12/23/37 (4 values)", 0, 3), ("Q10-40 (31 values)", 10, 40), ("Q2-41 (40 values)", 2, 41), ("Q2-93 (92 values)", 2, 93)):
     q = torch.randint(qlo, qhi + 1, (S, N), generator=g, device=dev, dtype=torch.int8)
     if name.startswith("binned"):
         q = BINNED[q.long()]
