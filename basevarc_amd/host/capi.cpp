@@ -164,6 +164,16 @@ size_t bvchost_pileup_tokens(const char *reads, const int32_t *positions, int32_
 // each sample covered with probability cov_permille / 1000 (reference base A, errors at the rate the quality states).
 // Counter-based (splitmix64 of seed, position, sample): the text and the binary form hold the same entries.
 // The directories must exist.  Returns the number of entries written, -1 on an I/O error.
+// Test hook: writes `n` bytes in pieces of `piece` bytes through a BgzfWriter (background = its own deflate thread) and
+// closes it.  Returns 1 when the writer reports success.
+int bvchost_bgzf_write(const char *path, const char *data, int64_t n, int64_t piece, int level, int background)
+{
+    BgzfWriter w(path, level, background != 0);
+    if (!w.ok()) return 0;
+    for (int64_t i = 0; i < n; i += piece) w.write(data + i, (size_t)(n - i < piece ? n - i : piece));
+    return w.close() ? 1 : 0;
+}
+
 int64_t bvchost_write_synth_batches(const char *out_prefix, int32_t n_samples, int32_t n_pos, int32_t thread, int32_t batch,
                                     int32_t cov_permille, uint64_t seed, int32_t bin)
 {

@@ -503,3 +503,29 @@ def test_rerun_resumes_extraction_at_the_first_incomplete_batch(tmp_path):
         os.utime(f, (old, old))
     subprocess.run(base, check=True, capture_output=True)
     assert all(os.path.getmtime(f) > old + 1800 for f in files.values())
+
+
+@pytest.mark.parametrize("background", [0, 1])
+def test_bgzf_writer_with_its_own_deflate_thread_writes_the_same_stream(H, tmp_path, background):
+    """The compute phase's output writers deflate on a thread of their own (BgzfWriter, background mode).  Whatever the
+    piece size of the writes, the file is valid BGZF with the EOF block and inflates to exactly the bytes written; the
+    background and the foreground writer produce identical files (blocks are cut at the same 0xff00-byte marks)."""
+    import gzip
+    rng = np.random.default_rng(3)
+    text = ("\t".join(str(x) for x in rng.integers(0, 50, 400000)) + "\n").encode() * 3          # ~3.4 MB, compressible
+    blob = rng.integers(0, 256, 300000, dtype=np.uint8).tobytes()                                   # incompressible tail
+    data = text + blob
+    H.bvchost_bgzf_write.restype = C.c_int
+    H.bvchost_bgzf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int, C.c_int]
+    files = []
+    for piece in (1 << 20, 70001, 513):
+        f = str(tmp_path / f"w{background}_{piece}.gz")
+        assert H.bvchost_bgzf_write(f.encode(), data, len(data), piece, 6, background) == 1
+        raw = open(f, "rb").read()
+        assert raw[:4] == b"\x1f\x8b\x08\x04" and raw[12:14] == b"BC" and raw[-28:-12] == raw[-28:][:16]
+        assert gzip.decompress(raw) == data
+        files.append(raw)
+    assert files[0] == files[1] == files[2]
+    ref = str(tmp_path / "fg.gz")
+    assert H.bvchost_bgzf_write(ref.encode(), data, len(data), 99999, 6, 0) == 1
+    assert open(ref, "rb").read() == files[0]
