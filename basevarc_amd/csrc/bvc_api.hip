@@ -354,7 +354,7 @@ int check_common(bvc_ctx *ctx, int64_t n_sites, const void *a, const void *b, co
 
 extern "C" {
 
-const char *bvc_version(void) { return "libbvc 0.2.0 (gfx950)"; }
+const char *bvc_version(void) { return "libbvc 0.3.0 (gfx950)"; }
 
 int bvc_device_count(void)
 {

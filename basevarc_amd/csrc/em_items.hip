@@ -35,6 +35,7 @@
 // Sites the engine does not take (more than 32 quality values on one allele, a class of quality 0 or 1 -- d < 0 --,
 // min_af <= 0, duplicate candidates) stay with em_kernel.hip's one-wavefront-per-site kernels, flagged per site.
 // FP64 throughout; no MFMA (nothing here is a dense contraction).
+#include <algorithm>
 #include <cstdlib>
 
 #include "bvc_device.h"
@@ -842,9 +843,11 @@ hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n
     // fits are dense FP64 work; at two workgroups per CU they take the histogram kernel from 1.18 to 1.34 ms per call
     // and the packed one from 0.63 to 0.77, at one they leave both at their stand-alone speed and still finish well
     // inside the histogram pass (profiles/r03_stage2_cap_under_hist.txt)
+    // (the knob counts wavefronts per CU: 4 = one workgroup on every CU, 2 = one on every other CU, 8 = two per CU)
     int64_t grid = regions;
-    const int per_cu = st.em_waves_per_cu > 0 ? (st.em_waves_per_cu + kRegionWaves - 1) / kRegionWaves : (shared ? 1 : 0);
-    if (per_cu > 0 && grid > (int64_t)per_cu * st.n_cu) grid = (int64_t)per_cu * st.n_cu;
+    const int waves_per_cu = st.em_waves_per_cu > 0 ? st.em_waves_per_cu : (shared ? kRegionWaves : 0);
+    const int64_t cap = waves_per_cu > 0 ? std::max<int64_t>(1, (int64_t)waves_per_cu * st.n_cu / kRegionWaves) : 0;
+    if (cap > 0 && grid > cap) grid = cap;
     RegionArgs A;
     A.n_sites = n_sites; A.n_groups = n_groups; A.counts = counts; A.hist_stride = hist_stride; A.lut = lut;
     A.ref_base = ref_base; A.min_af = min_af; A.comb = comb; A.n_comb = n_comb; A.taken = taken; A.results = results;
@@ -854,7 +857,7 @@ hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n
     A.dbg_levels = getenv("BVC_DBG_LEVELS") ? atoi(getenv("BVC_DBG_LEVELS")) : 2 * kLevels;
     if (grid < regions) hipLaunchKernelGGL(region_walk_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, A);
     else hipLaunchKernelGGL(region_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, A);
-    int64_t wide_grid = (int64_t)(per_cu > 0 ? per_cu : 2) * st.n_cu;
+    int64_t wide_grid = cap > 0 ? cap : (int64_t)2 * st.n_cu;
     if (wide_grid > regions) wide_grid = regions;
     hipLaunchKernelGGL(region_wide_kernel, dim3((unsigned)wide_grid), dim3(64 * kRegionWaves), 0, stream, A);
     *taken_out = taken;

@@ -223,7 +223,7 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
 /* ---- tuning (per context; additive, no counterpart in the reference) -------------------------------- */
 /* Launch policy of THIS context; results never depend on it.  Keys:
  *   "em_waves_per_cu"  0 = default policy, 1..32 resident stage-2 wavefronts per CU (the region kernel runs in workgroups
- *                      of four: the value is rounded up to a multiple of 4)
+ *                      of four: 4 = one workgroup on every CU, 2 = on every other CU, 8 = two per CU)
  *   "em_wpb"           waves per EM workgroup: 4 (default) or 1
  *   "hist_split"       0 = by tile shape, 1..64 workgroups sharing a site in the dense histogram pass
  *   "em_streams"       overlap mode: stage 2 of consecutive calls on one side stream (1), on two alternating ones (2: the
