@@ -49,11 +49,12 @@ constexpr int kEmIters = 100;             // src/BaseType.cpp:46
 constexpr double kEmEpsilon = 0.001;      // src/BaseType.cpp:45
 constexpr double kVarQualPending = -1.0;  // as in em_kernel.hip: var_qual_kernel finishes these records
 
-// Quality classes of one allele the engine holds: CPB = 32 (two lanes x 16; 2^5 VGPRs short of three waves per SIMD) for
-// the regions whose sites all fit, CPB = 48 (two lanes x 24, two waves per SIMD) for the regions with a wider site --
-// Illumina's unbinned 41 values.  A site's table (LDS): counts uint32 [base][class], then quality indices uint8
+// Quality classes of one allele the engine holds: CPB = 32 (two lanes x 16, three waves per SIMD) for the regions whose
+// sites all fit; CPB = 48 (two lanes x 24, two waves per SIMD) for the regions with a wider site -- Illumina's unbinned 41
+// values; CPB = 8 (ONE lane per allele: 16 four-allele fits per wavefront) for the regions whose sites all have at most
+// 8 -- binned qualities (NovaSeq: 4).  A site's table (LDS): counts uint32 [base][class], then quality indices uint8
 // [base][class]: 5 * 4 * CPB bytes.
-constexpr int kNarrow = 32, kWide = 48;
+constexpr int kTiny = 8, kNarrow = 32, kWide = 48;
 template <int CPB> constexpr int site_table_bytes() { return 4 * CPB * 5; }
 
 constexpr int kEmptyQ = 128;               // quality index of an empty class place: QualLut::e_empty = 1/4
@@ -181,7 +182,7 @@ struct Region {
     FitOut outs[kListAt[kLists]];
     int want[kRegionSites][kLists];
     int count[kLists];
-    int wide;                                            // some site of the region needs more than kNarrow class places
+    int need;                                            // most class places a taken site of the region needs on an allele
     alignas(8) uint8_t tab[kRegionSites][site_table_bytes<CPB>()];
 };
 
@@ -318,9 +319,9 @@ __device__ __forceinline__ void site_classes(Region<CPB> &R, int ls, int lane, i
     }
     // the places this allele leaves empty
 #pragma unroll
-    for (int part = 0; part < CPB / 16; ++part) {
+    for (int part = 0; part < (CPB + 15) / 16; ++part) {
         const int pos = t + 16 * part;
-        if (pos >= cnt_row) {
+        if (pos >= cnt_row && pos < CPB) {
             tab_n[pos] = 0u;
             tab_q[pos] = (uint8_t)kEmptyQ;
         }
@@ -333,7 +334,9 @@ __device__ __forceinline__ void site_classes(Region<CPB> &R, int ls, int lane, i
     S.depth[2] = __builtin_amdgcn_readlane(depth_row, 32);
     S.depth[3] = __builtin_amdgcn_readlane(depth_row, 48);
     const bool too_wide = __ballot(cnt_row > kWide) != 0;
-    const bool wide = __ballot(cnt_row > kNarrow) != 0;
+    int need = cnt_row;                                          // most class places on an allele of this site
+    need = max(need, __shfl_xor(need, 16, kWave));
+    need = max(need, __shfl_xor(need, 32, kWave));
     const bool any_low = __ballot(low_q) != 0;
 
     const int total_i = S.depth[0] + S.depth[1] + S.depth[2] + S.depth[3];
@@ -364,7 +367,7 @@ __device__ __forceinline__ void site_classes(Region<CPB> &R, int ls, int lane, i
         }
     }
     const bool mine = !(too_wide || any_low || dup);
-    if (mine && wide && lane == 0) R.wide = 1;                   // (every writer writes the same value)
+    if (mine && lane == 0) atomicMax(&R.need, need);
     S.blist = blist; S.n = (int8_t)n; S.k = (int8_t)n; S.first = 1;
     S.state = mine ? 1 : 0;
     if (mine) {
@@ -444,7 +447,7 @@ __device__ __forceinline__ void rcp_all(const double (&m)[N], double (&y)[N])
 template <int LOG2G>
 __device__ __forceinline__ double unit_sum(double v)
 {
-    v += dpp_f64<kDppXor1>(v);
+    if (LOG2G >= 1) v += dpp_f64<kDppXor1>(v);
     if (LOG2G >= 2) v += dpp_f64<kDppXor2>(v);
     if (LOG2G >= 3) v += dpp_f64<kDppHalfMirror>(v);
     return v;
@@ -597,8 +600,10 @@ __device__ __forceinline__ void fit_body(int item0, int item_end, const FitItem 
 
 // Lanes per allele of the two item shapes: two for four-row items (8 per wavefront), four for two-row items (8 per
 // wavefront: the nested levels have few items per region, so they are spread over more wavefronts).
+// (narrow and wide regions; the tiny ones take one lane per allele for four-row items and two for two-row items)
 constexpr int kLog2G4 = 1, kLog2G2 = 2;
-constexpr int kPerWave4 = 16 >> kLog2G4, kPerWave2 = 2 * (16 >> kLog2G2);
+template <int CPB> constexpr int log2g4() { return CPB == kTiny ? 0 : kLog2G4; }
+template <int CPB> constexpr int log2g2() { return CPB == kTiny ? 1 : kLog2G2; }
 
 // ---- site_decide: one wavefront per site, one level of BaseType::LRT -------------------------------------------------
 // Reads the fits of the pending level, takes the reference's decision (src/BaseType.cpp:93-110) and either sets up
@@ -724,14 +729,14 @@ struct RegionArgs {
     const uint8_t *n_comb;
     uint8_t *taken;
     bvc_site_result *results;
-    uint32_t *wide_epoch;        // set to `epoch` by the narrow launch when some region needs the wide one
+    uint32_t *kind_epoch;        // [0] / [1]: set to `epoch` by the narrow launch when some region is the tiny / the wide launch's
     uint32_t epoch;
     int dbg_levels;
 };
 
-// CPB = kNarrow: the regions whose sites all fit 32 class places per allele; a region with a wider site is left (whole)
-// to the CPB = kWide launch, which takes only those.  Both run the classes phase of every region they look at; the
-// wide launch returns at once when the narrow one has seen no wide region in this call.
+// A region belongs to ONE of three launches by the most class places any of its sites needs on an allele: <= 8 tiny,
+// <= 32 narrow, <= 48 wide.  Each runs the classes phase of the regions it looks at and goes on only with its own; the
+// narrow launch comes first, and the other two return at once when it has met no region of theirs in this call.
 template <bool WALK, int CPB>
 __device__ __forceinline__ void region_body(Region<CPB> &R, const RegionArgs &A)
 {
@@ -739,12 +744,14 @@ __device__ __forceinline__ void region_body(Region<CPB> &R, const RegionArgs &A)
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t n_sites = A.n_sites;
     const int64_t n_regions = (n_sites + kRegionSites - 1) / kRegionSites;
-    if (CPB == kWide && *A.wide_epoch != A.epoch) return;
+    // the narrow launch comes first and stamps these words when it meets a region for one of the others
+    if (CPB == kWide && A.kind_epoch[1] != A.epoch) return;
+    if (CPB == kTiny && A.kind_epoch[0] != A.epoch) return;
     // one region per workgroup when the launch has the chip to itself (the dispatcher balances them); underneath a
     // streaming histogram pass the launcher bounds the grid and a workgroup walks several regions
     for (int64_t region = blockIdx.x; region < n_regions; region += WALK ? (int64_t)gridDim.x : n_regions) {
     const int64_t site0 = region * kRegionSites;
-    if (threadIdx.x == 0) R.wide = 0;
+    if (threadIdx.x == 0) R.need = 0;
     __syncthreads();
     for (int ls = wave; ls < kRegionSites; ls += kRegionWaves) {
         if (site0 + ls < n_sites) {
@@ -756,9 +763,12 @@ __device__ __forceinline__ void region_body(Region<CPB> &R, const RegionArgs &A)
         }
     }
     __syncthreads();
-    const bool wide = R.wide != 0;                               // (uniform over the workgroup)
-    if (CPB == kNarrow && wide && threadIdx.x == 0) *A.wide_epoch = A.epoch;
-    if (wide == (CPB == kWide)) {
+    // whose region this is (uniform over the workgroup): tiny when every taken site has at most kTiny class places per
+    // allele, wide when some site has more than kNarrow, narrow otherwise
+    const int need = R.need;
+    const int kind = need <= kTiny ? kTiny : (need <= kNarrow ? kNarrow : kWide);
+    if (CPB == kNarrow && kind != kNarrow && threadIdx.x == 0) A.kind_epoch[kind == kWide ? 1 : 0] = A.epoch;
+    if (kind == CPB) {
     // records of the sites that ended in the classes phase (no observation, no candidate)
     for (int ls = wave; ls < kRegionSites; ls += kRegionWaves)
         if (lane == 0 && R.site[ls].state == 3) {
@@ -778,6 +788,7 @@ __device__ __forceinline__ void region_body(Region<CPB> &R, const RegionArgs &A)
         __syncthreads();
         const int c0 = R.count[0], c1 = R.count[1], c2 = R.count[2], c3 = R.count[3];
         if (c0 + c1 + c2 + c3 == 0) break;                       // (uniform over the workgroup)
+        constexpr int kPerWave4 = 16 >> log2g4<CPB>(), kPerWave2 = 2 * (16 >> log2g2<CPB>());
         const int w0 = (c0 + kPerWave4 - 1) / kPerWave4, w1 = w0 + (c1 + kPerWave4 - 1) / kPerWave4;
         const int w2 = w1 + (c2 + kPerWave2 - 1) / kPerWave2, w3 = w2 + (c3 + kPerWave2 - 1) / kPerWave2;
         // (the wavefront that takes slot 0 rotates with the region: a level with fewer slots than wavefronts would
@@ -787,8 +798,8 @@ __device__ __forceinline__ void region_body(Region<CPB> &R, const RegionArgs &A)
             const int in_list = slot - (l == 0 ? 0 : (l == 1 ? w0 : (l == 2 ? w1 : w2)));
             const int base = l == 0 ? kListAt[0] : (l == 1 ? kListAt[1] : (l == 2 ? kListAt[2] : kListAt[3]));
             const int cnt = l == 0 ? c0 : (l == 1 ? c1 : (l == 2 ? c2 : c3));
-            if (l < 2) fit_body<4, kLog2G4, CPB>(base + in_list * kPerWave4, base + cnt, R.items, R.outs, &R.tab[0][0], A.lut->e);
-            else fit_body<2, kLog2G2, CPB>(base + in_list * kPerWave2, base + cnt, R.items, R.outs, &R.tab[0][0], A.lut->e);
+            if (l < 2) fit_body<4, log2g4<CPB>(), CPB>(base + in_list * kPerWave4, base + cnt, R.items, R.outs, &R.tab[0][0], A.lut->e);
+            else fit_body<2, log2g2<CPB>(), CPB>(base + in_list * kPerWave2, base + cnt, R.items, R.outs, &R.tab[0][0], A.lut->e);
         }
         __syncthreads();
         if (level + 1 == (A.dbg_levels >> 1) && (A.dbg_levels & 1)) break;
@@ -813,6 +824,14 @@ __global__ __launch_bounds__(64 * kRegionWaves) void region_walk_kernel(RegionAr
 {
     __shared__ Region<kNarrow> R;
     region_body<true, kNarrow>(R, A);
+}
+
+// The same for the regions whose sites have at most 8 quality values per allele (binned qualities): one lane per allele,
+// 16 four-allele fits per wavefront; the grid walks the regions.
+__global__ __launch_bounds__(64 * kRegionWaves) void region_tiny_kernel(RegionArgs A)
+{
+    __shared__ Region<kTiny> R;
+    region_body<true, kTiny>(R, A);
 }
 
 // The same for the regions with a site of 33..48 quality values on an allele (24 classes per lane: two wavefronts per
@@ -851,7 +870,7 @@ hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n
     RegionArgs A;
     A.n_sites = n_sites; A.n_groups = n_groups; A.counts = counts; A.hist_stride = hist_stride; A.lut = lut;
     A.ref_base = ref_base; A.min_af = min_af; A.comb = comb; A.n_comb = n_comb; A.taken = taken; A.results = results;
-    A.wide_epoch = reinterpret_cast<uint32_t *>(taken + (((size_t)n_sites + 255) & ~(size_t)255));
+    A.kind_epoch = reinterpret_cast<uint32_t *>(taken + (((size_t)n_sites + 255) & ~(size_t)255));
     A.epoch = ++st.em_epoch;                                     // never 0; a stale word can only cost the wide launch a scan
     if (A.epoch == 0) A.epoch = ++st.em_epoch;
     A.dbg_levels = getenv("BVC_DBG_LEVELS") ? atoi(getenv("BVC_DBG_LEVELS")) : 2 * kLevels;
@@ -859,6 +878,9 @@ hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n
     else hipLaunchKernelGGL(region_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, A);
     int64_t wide_grid = cap > 0 ? cap : (int64_t)2 * st.n_cu;
     if (wide_grid > regions) wide_grid = regions;
+    int64_t tiny_grid = cap > 0 ? cap : (int64_t)5 * st.n_cu;
+    if (tiny_grid > regions) tiny_grid = regions;
+    hipLaunchKernelGGL(region_tiny_kernel, dim3((unsigned)tiny_grid), dim3(64 * kRegionWaves), 0, stream, A);
     hipLaunchKernelGGL(region_wide_kernel, dim3((unsigned)wide_grid), dim3(64 * kRegionWaves), 0, stream, A);
     *taken_out = taken;
     return hipGetLastError();

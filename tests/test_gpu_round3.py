@@ -52,6 +52,8 @@ def test_item_engine_agrees_with_the_wave_engine_and_the_oracle(ctx):
             sites.append(random_site(rng, nind, af=af, qlo=0, qhi=30))                    # qualities 0 and 1: wave engine
         elif kind == 7:
             sites.append(_site_with_quals(rng, max(nind, 2000), list(range(5, 37)), af=af))  # exactly 32 values: item engine
+        elif kind in (3, 4) and s >= 96:
+            sites.append(_site_with_quals(rng, nind, [2, 12, 23, 37], af=af))               # binned: with its neighbours a tiny region
         else:
             sites.append(random_site(rng, nind, af=af, second_af=af / 3 if s % 16 == 3 else 0.0))
     B, Q, R = pad_rows(sites)
@@ -77,12 +79,13 @@ def test_item_engine_agrees_with_the_wave_engine_and_the_oracle(ctx):
     assert ties <= 4
 
 
-@pytest.mark.parametrize("n_values", [32, 33, 41, 48, 49])
+@pytest.mark.parametrize("n_values", [1, 4, 8, 9, 32, 33, 41, 48, 49])
 def test_class_capacity_boundaries_of_the_item_engine(ctx, n_values):
-    """32 quality values on an allele fill the two lanes x 16 classes of the narrow region kernel; 33..48 (Illumina's
-    unbinned 41) send the site's whole REGION to the wide one (two lanes x 24); 49 send the site to the one-wavefront-per-site
-    kernels.  Whichever path: the record is the oracle's.  The tile mixes sites of the tested width with narrow ones, so
-    that regions of both kinds occur in one call."""
+    """A region of six sites belongs to one of three launches by the most quality values any of its sites has on an allele:
+    <= 8 the tiny one (binned qualities; one lane per allele), <= 32 the narrow one (two lanes x 16 classes), 33..48
+    (Illumina's unbinned 41) the wide one (two lanes x 24); a site with 49 or more goes to the one-wavefront-per-site
+    kernels.  Whichever path: the record is the oracle's.  The tile mixes sites of the tested width with sites of 20
+    values, so that regions of different kinds occur in one call."""
     rng = np.random.default_rng(n_values)
     sites = []
     for i, af in enumerate((0.0, 0.01, 0.2, 0.0, 0.05, 0.5, 0.0, 0.1, 0.0, 0.3, 0.0, 0.02, 0.0, 0.0)):
