@@ -397,6 +397,7 @@ int bvc_create(bvc_ctx **out, int device)
     ctx->ls.group_pipe = env_int("BVC_GROUP_PIPE", 0, 1, 1);
     ctx->ls.em_streams = env_int("BVC_EM_STREAMS", 0, 3, 0);
     ctx->ls.em_engine = env_int("BVC_EM_ENGINE", 0, 1, 0);
+    ctx->ls.dbg_levels = env_int("BVC_DBG_LEVELS", 0, 6, 0);
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return BVC_ERR_DEVICE; }
     // likelihood table from the host's exp(), as the CPU path computes it (src/BaseType.cpp:13,15)
     QualLut lut;

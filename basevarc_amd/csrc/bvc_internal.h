@@ -21,6 +21,7 @@ struct LaunchState {
                                // 1 = one wavefront per site for every site (em_kernel.hip): A/B runs.  The two agree to
                                // rounding (1e-15 on AF), not bit for bit: a call's records never depend on the call's
                                // size or neighbours with either, but they depend on this choice
+    int dbg_levels = 0;            // BVC_DBG_LEVELS (timing only, records wrong): cut region_kernel short after a phase; 0 = run all
     mutable uint32_t em_epoch = 0; // stage-2 launches of this context so far (em_items.hip: the narrow launch tells the wide one)
     uint64_t attr_done = 0;    // kernels whose dynamic-LDS attribute has been raised on this context's device
 };

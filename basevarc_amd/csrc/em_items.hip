@@ -36,7 +36,6 @@
 // min_af <= 0, duplicate candidates) stay with em_kernel.hip's one-wavefront-per-site kernels, flagged per site.
 // FP64 throughout; no MFMA (nothing here is a dense contraction).
 #include <algorithm>
-#include <cstdlib>
 
 #include "bvc_device.h"
 #include "bvc_internal.h"
@@ -873,7 +872,7 @@ hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n
     A.kind_epoch = reinterpret_cast<uint32_t *>(taken + (((size_t)n_sites + 255) & ~(size_t)255));
     A.epoch = ++st.em_epoch;                                     // never 0; a stale word can only cost the wide launch a scan
     if (A.epoch == 0) A.epoch = ++st.em_epoch;
-    A.dbg_levels = getenv("BVC_DBG_LEVELS") ? atoi(getenv("BVC_DBG_LEVELS")) : 2 * kLevels;
+    A.dbg_levels = st.dbg_levels > 0 ? st.dbg_levels : 2 * kLevels;
     if (grid < regions) hipLaunchKernelGGL(region_walk_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, A);
     else hipLaunchKernelGGL(region_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, A);
     int64_t wide_grid = cap > 0 ? cap : (int64_t)2 * st.n_cu;
