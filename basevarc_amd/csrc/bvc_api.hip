@@ -398,6 +398,7 @@ int bvc_create(bvc_ctx **out, int device)
     ctx->ls.em_streams = env_int("BVC_EM_STREAMS", 0, 3, 0);
     ctx->ls.em_engine = env_int("BVC_EM_ENGINE", 0, 1, 0);
     ctx->ls.dbg_levels = env_int("BVC_DBG_LEVELS", 0, 6, 0);
+    ctx->ls.em_tiny_regions = env_int("BVC_EM_TINY_REGIONS", 0, 1, 0);
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return BVC_ERR_DEVICE; }
     // likelihood table from the host's exp(), as the CPU path computes it (src/BaseType.cpp:13,15)
     QualLut lut;
@@ -998,6 +999,7 @@ int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value)
     if (std::strcmp(key, "hist_split") == 0 && value >= 0 && value <= 64) { ctx->ls.hist_split = value; return BVC_OK; }
     if (std::strcmp(key, "group_pipe") == 0 && (value == 0 || value == 1)) { ctx->ls.group_pipe = value; return BVC_OK; }
     if (std::strcmp(key, "em_engine") == 0 && value >= 0 && value <= 1) { ctx->ls.em_engine = value; return BVC_OK; }
+    if (std::strcmp(key, "em_tiny_regions") == 0 && value >= 0 && value <= 1) { ctx->ls.em_tiny_regions = value; return BVC_OK; }
     if (std::strcmp(key, "em_streams") == 0 && value >= 0 && value <= 3) {
         int rcj = join_side(ctx);
         if (rcj != BVC_OK) return rcj;

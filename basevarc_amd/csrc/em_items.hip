@@ -731,10 +731,14 @@ struct RegionArgs {
     uint32_t *kind_epoch;        // [0] / [1]: set to `epoch` by the narrow launch when some region is the tiny / the wide launch's
     uint32_t epoch;
     int dbg_levels;
+    int tiny_regions;            // LaunchState::em_tiny_regions
 };
 
-// A region belongs to ONE of three launches by the most class places any of its sites needs on an allele: <= 8 tiny,
-// <= 32 narrow, <= 48 wide.  Each runs the classes phase of the regions it looks at and goes on only with its own; the
+// A region belongs to ONE launch by the most class places any of its sites needs on an allele: <= 32 narrow, <= 48 wide
+// (and, with LaunchState::em_tiny_regions, <= 8 tiny).  The narrow and the wide kernel place class c of an allele in the
+// same lane and slot and add in the same order (the wide one's extra slots are empty for a narrow site and add exact
+// zeros; rcp_all<24> is rcp_all<16> on the first sixteen), so a site's record does not depend on which of the two its
+// region went to, i.e. not on its neighbours.  The tiny kernel (one lane per allele) adds in another order: opt-in.  Each runs the classes phase of the regions it looks at and goes on only with its own; the
 // narrow launch comes first, and the other two return at once when it has met no region of theirs in this call.
 template <bool WALK, int CPB>
 __device__ __forceinline__ void region_body(Region<CPB> &R, const RegionArgs &A)
@@ -765,7 +769,7 @@ __device__ __forceinline__ void region_body(Region<CPB> &R, const RegionArgs &A)
     // whose region this is (uniform over the workgroup): tiny when every taken site has at most kTiny class places per
     // allele, wide when some site has more than kNarrow, narrow otherwise
     const int need = R.need;
-    const int kind = need <= kTiny ? kTiny : (need <= kNarrow ? kNarrow : kWide);
+    const int kind = (A.tiny_regions && need <= kTiny) ? kTiny : (need <= kNarrow ? kNarrow : kWide);
     if (CPB == kNarrow && kind != kNarrow && threadIdx.x == 0) A.kind_epoch[kind == kWide ? 1 : 0] = A.epoch;
     if (kind == CPB) {
     // records of the sites that ended in the classes phase (no observation, no candidate)
@@ -873,13 +877,16 @@ hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n
     A.epoch = ++st.em_epoch;                                     // never 0; a stale word can only cost the wide launch a scan
     if (A.epoch == 0) A.epoch = ++st.em_epoch;
     A.dbg_levels = st.dbg_levels > 0 ? st.dbg_levels : 2 * kLevels;
+    A.tiny_regions = st.em_tiny_regions;
     if (grid < regions) hipLaunchKernelGGL(region_walk_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, A);
     else hipLaunchKernelGGL(region_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, A);
     int64_t wide_grid = cap > 0 ? cap : (int64_t)2 * st.n_cu;
     if (wide_grid > regions) wide_grid = regions;
-    int64_t tiny_grid = cap > 0 ? cap : (int64_t)5 * st.n_cu;
-    if (tiny_grid > regions) tiny_grid = regions;
-    hipLaunchKernelGGL(region_tiny_kernel, dim3((unsigned)tiny_grid), dim3(64 * kRegionWaves), 0, stream, A);
+    if (st.em_tiny_regions) {
+        int64_t tiny_grid = cap > 0 ? cap : (int64_t)5 * st.n_cu;
+        if (tiny_grid > regions) tiny_grid = regions;
+        hipLaunchKernelGGL(region_tiny_kernel, dim3((unsigned)tiny_grid), dim3(64 * kRegionWaves), 0, stream, A);
+    }
     hipLaunchKernelGGL(region_wide_kernel, dim3((unsigned)wide_grid), dim3(64 * kRegionWaves), 0, stream, A);
     *taken_out = taken;
     return hipGetLastError();

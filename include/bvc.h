@@ -243,7 +243,11 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
  *                      orders: calls, depths, pass counts and every integer field agree (except where two subsets tie
  *                      to rounding), AF / chi / var_qual agree to ~1e-15 relative, not bit for
  *                      bit.  With either engine a site's record never depends on the call's size or on its neighbours.
- *                      Environment: BVC_EM_ENGINE. */
+ *                      Environment: BVC_EM_ENGINE.
+ *   "em_tiny_regions"  0 (default) / 1: with 1, regions of six sites that all have at most 8 quality values per allele
+ *                      (binned qualities) take a kernel with one lane per allele (stage 2 1.36 x faster on such data).  That
+ *                      kernel adds in a different order, so a site's AF / chi could differ in the last bits with the
+ *                      binning of its five region neighbours: off by default.  Environment: BVC_EM_TINY_REGIONS. */
 int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value);
 
 /* ---- measurement aid ------------------------------------------------------------------------------- */

@@ -79,13 +79,35 @@ def test_item_engine_agrees_with_the_wave_engine_and_the_oracle(ctx):
     assert ties <= 4
 
 
+def test_a_sites_record_does_not_depend_on_its_region_neighbours(ctx):
+    """Stage 2 takes six consecutive sites of a call as a region, and a region with a site of 33..48 quality values goes to
+    the wide kernel whole.  The narrow and the wide kernel must give a narrow site the same record, bit for bit: the same
+    twelve sites as one call, with a 41-value site spliced in at different places (which moves the region boundaries and
+    sends different neighbours to the wide kernel), and one by one."""
+    rng = np.random.default_rng(5)
+    narrow = [random_site(rng, int(n), af=af, qlo=5, qhi=36) for n, af in zip([3000, 40, 700, 9000, 12, 2500, 300, 5000, 80, 1500, 20000, 600],
+                                                                              [0.0, 0.3, 0.02, 0.0, 0.5, 0.1, 0.0, 0.004, 0.0, 0.2, 0.0, 0.05])]
+    wide = _site_with_quals(rng, 6000, list(range(2, 43)), af=0.05)
+    m = 0.001
+    B, Q, R = pad_rows(narrow)
+    alone = ctx.lrt_dense(B, Q, R, m)
+    one_by_one = [ctx.lrt_dense(*pad_rows([s]), m)[0] for s in narrow]
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(alone, one_by_one))
+    for at in (0, 1, 5, 6, 7, 12):
+        mixed = narrow[:at] + [wide] + narrow[at:]
+        got = ctx.lrt_dense(*pad_rows(mixed), m)
+        rest = [got[i] for i in range(len(mixed)) if i != at]
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(alone, rest)), at
+        assert_site_matches(got[at], orc.basetype_lrt(wide[0], wide[1], wide[2], m), where=f"wide site at {at}", path_strict=False)
+
+
 @pytest.mark.parametrize("n_values", [1, 4, 8, 9, 32, 33, 41, 48, 49])
 def test_class_capacity_boundaries_of_the_item_engine(ctx, n_values):
-    """A region of six sites belongs to one of three launches by the most quality values any of its sites has on an allele:
-    <= 8 the tiny one (binned qualities; one lane per allele), <= 32 the narrow one (two lanes x 16 classes), 33..48
-    (Illumina's unbinned 41) the wide one (two lanes x 24); a site with 49 or more goes to the one-wavefront-per-site
-    kernels.  Whichever path: the record is the oracle's.  The tile mixes sites of the tested width with sites of 20
-    values, so that regions of different kinds occur in one call."""
+    """A region of six sites belongs to a launch by the most quality values any of its sites has on an allele: <= 32 the
+    narrow one (two lanes x 16 classes), 33..48 (Illumina's unbinned 41) the wide one (two lanes x 24), and -- with the
+    opt-in knob "em_tiny_regions" -- <= 8 the tiny one (binned qualities; one lane per allele); a site with 49 or more goes
+    to the one-wavefront-per-site kernels.  Whichever path: the record is the oracle's.  The tile mixes sites of the tested
+    width with sites of 20 values, so that regions of different kinds occur in one call; both settings of the knob."""
     rng = np.random.default_rng(n_values)
     sites = []
     for i, af in enumerate((0.0, 0.01, 0.2, 0.0, 0.05, 0.5, 0.0, 0.1, 0.0, 0.3, 0.0, 0.02, 0.0, 0.0)):
@@ -94,12 +116,16 @@ def test_class_capacity_boundaries_of_the_item_engine(ctx, n_values):
     n_values_of = [n_values if i % 5 != 4 and i < 8 else 20 for i in range(len(sites))]
     B, Q, R = pad_rows(sites)
     m = caller_min_af(6000)
-    got = ctx.lrt_dense(B, Q, R, m)
-    for s, (b, q, r) in enumerate(sites):
-        assert len(np.unique(q[b == r])) == n_values_of[s]
-        exp = orc.basetype_lrt(b, q, r, m)
-        assert_site_matches(got[s], exp, where=f"{n_values} values, site {s}", path_strict=False)
-        assert_path_difference_is_a_tie(got[s], exp, where=f"{n_values} values, site {s}")
+    from basevarc_amd import Context
+    for tiny in (0, 1):
+        with Context(0) as c:
+            c.set_tuning("em_tiny_regions", tiny)
+            got = c.lrt_dense(B, Q, R, m)
+        for s, (b, q, r) in enumerate(sites):
+            assert len(np.unique(q[b == r])) == n_values_of[s]
+            exp = orc.basetype_lrt(b, q, r, m)
+            assert_site_matches(got[s], exp, where=f"{n_values} values, site {s}, tiny {tiny}", path_strict=False)
+            assert_path_difference_is_a_tie(got[s], exp, where=f"{n_values} values, site {s}")
 
 
 def test_ragged_sites_at_one_byte_per_observation(ctx):
