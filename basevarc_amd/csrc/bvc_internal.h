@@ -17,6 +17,8 @@ struct LaunchState {
     int64_t host_chunk_bytes = (int64_t)1 << 29;   // BVC_PTR_HOST calls: bytes per array and staging chunk
     int em_streams = 0;        // overlap mode: side streams stage 2 alternates between: 0 = by call shape, 1..3
     int group_pipe = 1;        // any-order group histogram: issue the next chunk's loads before counting the current one
+    int group_log2c = -1;      // any-order group histograms: -1 = as many LDS copies per histogram as fit 64 KiB; 0..5 = at most
+                               // 2^n copies (A/B runs: fewer copies = smaller workgroups' LDS = more resident wavefronts)
     int em_engine = 0;         // stage 2: 0 = item engine (em_items.hip; em_kernel.hip takes the sites it leaves),
                                // 1 = one wavefront per site for every site (em_kernel.hip): A/B runs.  The two agree to
                                // rounding (1e-15 on AF), not bit for bit: a call's records never depend on the call's

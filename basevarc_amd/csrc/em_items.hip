@@ -1,5 +1,5 @@
 // em_items.hip -- stage 2 of the basetype path on gfx950, "item engine": the EM fits of a call are the work items,
-// several of them share a wavefront, and a workgroup takes a REGION of 8 sites through the whole likelihood-ratio
+// several of them share a wavefront, and a workgroup takes a REGION of 6 sites through the whole likelihood-ratio
 // test in one launch: classes -> fits of the first level -> decisions -> fits of the next level -> ... with workgroup
 // barriers between the phases and every intermediate (class tables, fit descriptors and results, site state) in LDS.
 //

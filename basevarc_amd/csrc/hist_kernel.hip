@@ -1172,6 +1172,7 @@ hipError_t launch_hist_dense(LaunchState &st, hipStream_t stream, int64_t n_site
                            n_sites, n_samples, row_stride, bases, quals, n_hist, group_scratch, counts);
         int log2c = 0;
         while (log2c < 5 && (size_t)n_hist * BVC_NCLASS * (2u << log2c) <= (size_t)kLdsWords) ++log2c;
+        if (st.group_log2c >= 0 && st.group_log2c < log2c) log2c = st.group_log2c;
         const size_t glds = ((size_t)n_hist * BVC_NCLASS << log2c) * sizeof(uint32_t);
         // 33 histograms (32 groups + "no group") of one copy each are 66 KiB: the attribute is raised to that once
         constexpr size_t kGroupLdsMax = (size_t)(BVC_MAX_GROUPS + 1) * BVC_NCLASS * sizeof(uint32_t);
@@ -1257,6 +1258,7 @@ hipError_t launch_hist_packed_groups(LaunchState &st, hipStream_t stream, int64_
                        row_stride, packed, n_hist, group_scratch, counts);
     int log2c = 0;
     while (log2c < 5 && (size_t)n_hist * kPackedSlots * (2u << log2c) <= (size_t)kLdsWords) ++log2c;
+    if (st.group_log2c >= 0 && st.group_log2c < log2c) log2c = st.group_log2c;
     const size_t glds = ((size_t)n_hist * kPackedSlots << log2c) * sizeof(uint32_t);
     using GK = void (*)(int64_t, int64_t, int64_t, const uint8_t *, const uint8_t *, int, uint32_t *, const int64_t *);
     static const GK gk[2][6] = {

@@ -80,7 +80,7 @@ int32_t bvchost_site_size(const bvchost_site *s) { return (int32_t)s->col.aiv.si
 // fields: 0 base, 1 mapq, 2 qual, 3 rpr, 4 strand, 5 is_indel, 6 sample index
 int32_t bvchost_site_field(const bvchost_site *s, int32_t k, int field)
 {
-    const AlleleInfo &a = s->col.aiv[(size_t)k];
+    const Entry &a = s->col.aiv[(size_t)k];
     switch (field) {
     case 0: return a.base; case 1: return a.mapq; case 2: return a.qual; case 3: return a.rpr;
     case 4: return a.strand; case 5: return a.is_indel; default: return s->col.sample[(size_t)k];

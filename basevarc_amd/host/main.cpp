@@ -399,7 +399,7 @@ struct TileRunner {
                 T.packed.assign((size_t)(ns * stride), (uint8_t)0xFF);
                 for (int64_t s = 0; s < ns && fits; ++s)
                     for (size_t k = 0; k < sites[s].aiv.size(); ++k) {
-                        const AlleleInfo &a = sites[s].aiv[k];
+                        const Entry &a = sites[s].aiv[k];
                         if (a.is_indel == 0) {
                             if (a.base > 3u) continue;             // not A/C/G/T: no observation, as in the two-byte tile
                             if (a.qual > 62u) { fits = false; break; }
@@ -418,7 +418,7 @@ struct TileRunner {
                 T.quals.assign((size_t)(ns * stride), (int8_t)0);
                 for (int64_t s = 0; s < ns; ++s)
                     for (size_t k = 0; k < sites[s].aiv.size(); ++k) {
-                        const AlleleInfo &a = sites[s].aiv[k];
+                        const Entry &a = sites[s].aiv[k];
                         if (a.is_indel == 0) {
                             const int64_t col = groups->column_of[(size_t)sites[s].sample[k]];
                             T.bases[(size_t)(s * stride + col)] = (int8_t)a.base;

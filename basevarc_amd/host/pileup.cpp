@@ -78,16 +78,11 @@ int parse_pileup_line(const char *line, size_t len, int32_t j0, SiteColumn &site
             ai.qual = (uint8_t)field[2];
             ai.rpr = (uint8_t)field[3];
             ai.strand = (uint8_t)(field[4] & 1);
-            if (ai.base != 4) {                                 // skip N base, :427
-                site.aiv.push_back(ai);
-                site.aiv.back().indel.clear();
-                site.sample.push_back(j);
-            }
+            if (ai.base != 4) site.add(ai, j);                  // skip N base, :427
         } else if (c != '.') {
             ai.is_indel = 1;
             ai.indel.assign(tok, p - tok);
-            site.aiv.push_back(ai);
-            site.sample.push_back(j);
+            site.add(ai, j);
         }
         ++j;
     }
@@ -125,6 +120,8 @@ bool parse_pileup_bin(const unsigned char *p, size_t len, int32_t j0, SiteColumn
 {
     const unsigned char *end = p + len;
     AlleleInfo &ai = g_carry;
+    site.aiv.reserve(site.aiv.size() + len / 9);                 // an entry takes at least nine bytes of payload
+    site.sample.reserve(site.sample.size() + len / 9);
     while (p < end) {
         if (end - p < 9) return false;
         const int32_t j = j0 + (int32_t)get_u32(p);
@@ -135,19 +132,14 @@ bool parse_pileup_bin(const unsigned char *p, size_t len, int32_t j0, SiteColumn
             if ((size_t)(end - p) < 11 + n) return false;
             ai.is_indel = 1;
             ai.indel.assign(reinterpret_cast<const char *>(p + 11), n);
-            site.aiv.push_back(ai);
-            site.sample.push_back(j);
+            site.add(ai, j);
             p += 11 + n;
         } else {                                                 // base token, through the same bit-field widths
             ai.is_indel = 0;
             ai.base = (uint8_t)(p[4] & 7);
             ai.mapq = p[5]; ai.qual = p[6]; ai.rpr = p[7];
             ai.strand = (uint8_t)(flags & 1);
-            if (ai.base != 4) {                                  // skip N base, :427
-                site.aiv.push_back(ai);
-                site.aiv.back().indel.clear();
-                site.sample.push_back(j);
-            }
+            if (ai.base != 4) site.add(ai, j);                   // skip N base, :427
             p += 9;
         }
     }
@@ -211,17 +203,13 @@ std::string vcf_header(const Groups &g, const std::string &reference, const std:
 std::string cvg_line(const std::string &chr, int32_t pos, int8_t ref_base, const SiteColumn &site,
                      const bvc_group_result *grp, int n_groups)
 {
-    // ONE pass over the position's entries: depth per base (non-indel entries), and forward / reverse counts per base
-    // value of EVERY entry -- indel entries take part in the strand tallies with the fields they carry (src/BaseVarC.cpp:
-    // 575-590 reads a.base and a.strand of all of aiv) -- from which the ref and alt columns are picked afterwards.
-    int cnt[4] = {0, 0, 0, 0};
-    int fwd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // depth per base (non-indel entries) and forward / reverse counts per base value of EVERY entry -- indel entries
+    // take part in the strand tallies with the fields they carry (src/BaseVarC.cpp:575-590 reads a.base and a.strand
+    // of all of aiv) -- were taken as the entries were appended (SiteColumn::add); the ref and alt columns are picked
+    // from them here.
+    const int32_t *cnt = site.cnt, *fwd = site.fwd, *rev = site.rev;
     std::map<std::string, int> indel_m;    // the reference iterates a hash map here (:570-573): order by key instead
-    for (auto const &a : site.aiv) {
-        if (a.is_indel == 0) { if (a.base < 4) cnt[a.base] += 1; }
-        else indel_m[a.indel] += 1;
-        (a.strand == 1 ? fwd : rev)[a.base & 7u] += a.base < 8u ? 1 : 0;
-    }
+    for (auto const &t : site.indels) indel_m[t] += 1;
     std::string indels = ".";
     if (!indel_m.empty()) {
         indels.clear();
@@ -230,7 +218,7 @@ std::string cvg_line(const std::string &chr, int32_t pos, int8_t ref_base, const
     }
     // sortidx: indices by descending count; std::sort on four elements is an insertion sort, ties keep order
     int didx[4] = {0, 1, 2, 3};
-    std::stable_sort(didx, didx + 4, [&cnt](int a, int b) { return cnt[a] > cnt[b]; });
+    std::stable_sort(didx, didx + 4, [cnt](int a, int b) { return cnt[a] > cnt[b]; });
     int alt_base = (didx[0] != ref_base) ? didx[0] : didx[1];
     // an entry counts as ref when its base equals ref_base, else as alt when it equals alt_base (alt_base != ref_base
     // unless ref_base is outside 0..3, where no entry matches it)
@@ -303,7 +291,7 @@ std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int32_t 
     size_t k = 0;
     for (int32_t i = 0; i < n_samples; ++i) {
         if (k >= site.sample.size() || site.sample[k] != i) { samgt += "./.\t"; continue; }
-        const AlleleInfo &a = site.aiv[k++];
+        const Entry &a = site.aiv[k++];
         if (!has_gt[a.base]) { alt_gt[a.base] = "./."; has_gt[a.base] = true; }
         const std::string &gt = (a.base == ref_base) ? std::string("0/.") : alt_gt[a.base];
         // BASE2CHAR has four entries in the reference (src/BaseType.h:24); an indel entry carrying an N base

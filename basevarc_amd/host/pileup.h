@@ -30,13 +30,40 @@ struct AlleleInfo {                 // src/BamProcess.h:30-39
     std::string indel;
 };
 
+// What the position loop keeps of one entry: eight bytes.  (The indel text of an entry, which only the CVG line's
+// "Indels" column reads, is kept once per indel entry in SiteColumn::indels -- an AlleleInfo per entry would be 40 bytes
+// of which 32 are an empty string for all but a few entries per thousand, and the loops over a position's entries
+// are memory-bound at 1e5 samples.)
+struct Entry {
+    uint8_t base, mapq, qual, rpr, strand, is_indel;
+    uint16_t pad;
+};
+
 // One position: the entries of the samples that have data, in sample order (aiv), and which sample each
-// entry belongs to (the inverse of the reference's `idx` map, src/BaseVarC.cpp:428-429).
+// entry belongs to (the inverse of the reference's `idx` map, src/BaseVarC.cpp:428-429).  The tallies of the CVG line
+// (src/BaseVarC.cpp:560-590: depth per base over the non-indel entries, forward / reverse counts per base value over
+// ALL entries) are taken as the entries are appended, while each is in registers: cvg_line does not walk them again.
 struct SiteColumn {
     int32_t pos = 0;
-    std::vector<AlleleInfo> aiv;
+    std::vector<Entry> aiv;
     std::vector<int32_t> sample;
-    void clear() { aiv.clear(); sample.clear(); }
+    std::vector<std::string> indels;   // indel text of the entries with is_indel = 1, in entry order
+    int32_t cnt[4] = {0, 0, 0, 0};
+    int32_t fwd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void clear()
+    {
+        aiv.clear(); sample.clear(); indels.clear();
+        for (int i = 0; i < 4; ++i) cnt[i] = 0;
+        for (int i = 0; i < 8; ++i) { fwd[i] = 0; rev[i] = 0; }
+    }
+    void add(const AlleleInfo &a, int32_t j)
+    {
+        aiv.push_back(Entry{a.base, a.mapq, a.qual, a.rpr, a.strand, a.is_indel, 0});
+        sample.push_back(j);
+        if (a.is_indel) indels.push_back(a.indel);
+        else if (a.base < 4) cnt[a.base] += 1;
+        if (a.base < 8u) (a.strand == 1 ? fwd : rev)[a.base] += 1;
+    }
 };
 
 // Population groups: name-sorted (std::map order in the reference, src/BaseVarC.cpp:98, 358-362).
