@@ -311,6 +311,37 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_bytes_kernel(
     }
 }
 
+// Sum and clear the 1 << LOG2C copies of counter `slot` (layout [slot][copy]).  With four copies or more the lane reads
+// and clears 16 bytes at a time, and the order in which it visits its quads is rotated by the slot so that the 16 lanes
+// of a ds_read_b128 lane group (consecutive slots) touch 64 distinct banks: quad id = (slot * QUADS + j) mod 16 takes only
+// 16 / QUADS values over 16 consecutive slots, and slots that share one differ in slot / (16 / QUADS) mod QUADS.  (The plain
+// loop -- one dword at a time at a stride of 1 << LOG2C dwords across lanes -- is a 16-way conflict at 16 copies: a
+// quarter of the 1024-thread kernel's time.)
+template <int LOG2C>
+__device__ __forceinline__ uint32_t fold_copies(uint32_t *hist, int slot)
+{
+    constexpr int C = 1 << LOG2C;
+    uint32_t sum = 0;
+    if (C >= 4) {
+        constexpr int QUADS = C / 4;
+        const int rot = QUADS > 1 ? slot / (16 / QUADS) : 0;
+#pragma unroll
+        for (int j = 0; j < QUADS; ++j) {
+            u32x4 *p = reinterpret_cast<u32x4 *>(&hist[slot * C + 4 * ((j + rot) & (QUADS - 1))]);
+            const u32x4 x = *p;
+            sum += x.x + x.y + x.z + x.w;
+            *p = u32x4{0u, 0u, 0u, 0u};
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < C; ++v) {
+            sum += hist[slot * C + v];
+            hist[slot * C + v] = 0;
+        }
+    }
+    return sum;
+}
+
 // Four covered samples of one lane in group mode: counter byte address =
 //   hist << (11 + L) | base << (9 + L) | qual << (2 + L) | copy << 2      (L = log2 of the copies)
 template <int LOG2C>
@@ -397,13 +428,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
             add_checked((uint8_t)brow[i], (uint8_t)qrow[i], hist_of_sample[i]);
         __syncthreads();
         for (int key = tid; key < n_hist * BVC_NCLASS; key += kHistThreads) {
-            uint32_t s = 0;
-#pragma unroll
-            for (int v = 0; v < (1 << LOG2C); ++v) {
-                s += hist[(key << LOG2C) + v];
-                hist[(key << LOG2C) + v] = 0;
-            }
-            grp_counts[site * n_hist * BVC_NCLASS + key] = s;
+            grp_counts[site * n_hist * BVC_NCLASS + key] = fold_copies<LOG2C>(hist, key);
         }
         __syncthreads();
     }
@@ -981,8 +1006,8 @@ __device__ __forceinline__ uint32_t shl_half(uint32_t w, uint32_t shift)
 // (label << 8 | packed byte) << (2 + LOG2C) | copy << 2.  The 16-bit (label, byte) pairs of two samples are put
 // together by one v_perm_b32, each sample then takes one SDWA shift and one add: 2.5 VALU instructions per sample, two
 // load streams instead of three, no "covered?" test (0xFF counts into slot 255 of its histogram and is dropped).
-template <int LOG2C, bool ALIGNED>
-__global__ __launch_bounds__(kHistThreads) void hist_packed_groups_kernel(
+template <int LOG2C, bool ALIGNED, int THREADS = kHistThreads>
+__global__ __launch_bounds__(THREADS) void hist_packed_groups_kernel(
     int64_t n_sites, int64_t n_samples, int64_t row_stride, const uint8_t *__restrict__ packed,
     const uint8_t *__restrict__ hist_of_sample, int n_groups, uint32_t *__restrict__ grp_counts,
     const int64_t *__restrict__ bounds)
@@ -995,7 +1020,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_packed_groups_kernel(
     const int words = (n_hist * kPackedSlots) << LOG2C;
     const uint32_t lane_off = (uint32_t)tid & ((1u << LOG2C) - 1u);
     const uint32_t lane_base = lds_address(hist) + (lane_off << 2);
-    for (int i = tid * 4; i < words; i += kHistThreads * 4)
+    for (int i = tid * 4; i < words; i += THREADS * 4)
         *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
     constexpr uint32_t SH = 2 + LOG2C;
@@ -1013,19 +1038,19 @@ __global__ __launch_bounds__(kHistThreads) void hist_packed_groups_kernel(
         const uint8_t *row = packed + site * row_stride;
         if (ALIGNED) {
             const u32x4 *rv = reinterpret_cast<const u32x4 *>(row);
-            constexpr int64_t kBlockChunks = 2 * (int64_t)kHistThreads;
+            constexpr int64_t kBlockChunks = 2 * (int64_t)THREADS;
             for (int64_t cb = 0; cb < n16; cb += kBlockChunks) {
                 u32x4 p[2], g[2];
                 if (cb + kBlockChunks <= n16) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const int64_t c = cb + tid + (int64_t)u * kHistThreads;
+                        const int64_t c = cb + tid + (int64_t)u * THREADS;
                         p[u] = __builtin_nontemporal_load(&rv[c]); g[u] = gv[c];
                     }
                 } else {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const int64_t c = cb + tid + (int64_t)u * kHistThreads;
+                        const int64_t c = cb + tid + (int64_t)u * THREADS;
                         p[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // past the end: slot 255 ...
                         g[u] = u32x4{0u, 0u, 0u, 0u};                                       // ... of histogram 0
                         if (c < n16) { p[u] = __builtin_nontemporal_load(&rv[c]); g[u] = gv[c]; }
@@ -1038,19 +1063,15 @@ __global__ __launch_bounds__(kHistThreads) void hist_packed_groups_kernel(
                 }
             }
         }
-        for (int64_t i = (n16 << 4) + tid; i < n_samples; i += kHistThreads)
+        for (int64_t i = (n16 << 4) + tid; i < n_samples; i += THREADS)
             lds_add_one(((((uint32_t)hist_of_sample[i] << 8) | row[i]) << SH) + lane_base);
         __syncthreads();
-        for (int key = tid; key < n_hist * BVC_NCLASS; key += kHistThreads) {
+        for (int key = tid; key < n_hist * BVC_NCLASS; key += THREADS) {
             const int h = key >> 9, cls = key & 511, q = cls & 127;
             uint32_t sum = 0;
             if (q < 64) {
                 const int slot = (h << 8) | ((cls >> 7) << 6) | q;
-#pragma unroll
-                for (int v = 0; v < (1 << LOG2C); ++v) {
-                    sum += hist[(slot << LOG2C) + v];
-                    hist[(slot << LOG2C) + v] = 0;
-                }
+                sum = fold_copies<LOG2C>(hist, slot);
                 if (q == 63) sum = 0;
             }
             grp_counts[site * n_hist * BVC_NCLASS + key] = sum;
@@ -1133,7 +1154,9 @@ enum KernelSlot : uint32_t {
     kSlotPacked0 = 24, kSlotPacked1 = 25, kSlotPackedRanges0 = 26, kSlotPackedRanges1 = 27,
     kSlotPackedGroups = 32,    // + 6 * aligned + log2c (0..5)
     kSlotCsrPacked0 = 44, kSlotCsrPacked1 = 45,
+    kSlotPackedGroupsBig = 46,
 };
+constexpr size_t kBigLdsBytes = 144 * 1024;      // a workgroup may take the CU's whole LDS (160 KiB); stage 2 keeps 16 KiB beside it
 
 static hipError_t raise_lds(LaunchState &st, uint32_t slot, const void *kernel, size_t bytes)
 {
@@ -1266,6 +1289,21 @@ hipError_t launch_hist_packed_groups(LaunchState &st, hipStream_t stream, int64_
          hist_packed_groups_kernel<3, false>, hist_packed_groups_kernel<4, false>, hist_packed_groups_kernel<5, false>},
         {hist_packed_groups_kernel<0, true>, hist_packed_groups_kernel<1, true>, hist_packed_groups_kernel<2, true>,
          hist_packed_groups_kernel<3, true>, hist_packed_groups_kernel<4, true>, hist_packed_groups_kernel<5, true>}};
+    // One workgroup of 1024 threads with 16 copies per histogram (bank = copy + 16 * (slot & 1): exactly two lanes of a
+    // 32-lane group on a bank) when that fits the CU's LDS and the 64 KiB form would have fewer copies: 4 <= k <= 8 groups.
+    // Alone it is 3 % slower than three 512-thread workgroups with 8 copies (0.78 against 0.76 ms at k = 5, N = 1e6, 4000
+    // sites), underneath stage 2 -- the way the calls run -- 5 % faster (0.90 against 0.95) and stage 2 itself a fifth
+    // (profiles/r03_group_anyorder_experiments.txt).  The same form of the two-byte kernel (8 copies, 96 KiB) LOSES 15 %
+    // underneath stage 2 and is not kept.
+    if (st.group_big_lds && aligned && log2c < 4 && ((size_t)n_hist * kPackedSlots << 4) * sizeof(uint32_t) <= kBigLdsBytes) {
+        auto bk = hist_packed_groups_kernel<4, true, 1024>;
+        const size_t blds = ((size_t)n_hist * kPackedSlots << 4) * sizeof(uint32_t);
+        e = raise_lds(st, kSlotPackedGroupsBig, reinterpret_cast<const void *>(bk), kBigLdsBytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bk, dim3((unsigned)(n_sites < 4096 ? n_sites : 4096)), dim3(1024), blds, stream, n_sites,
+                           n_samples, row_stride, packed, hist_of_sample, n_groups, counts, group_scratch);
+        return hipGetLastError();
+    }
     const GK k = gk[aligned ? 1 : 0][log2c];
     e = raise_lds(st, kSlotPackedGroups + (aligned ? 6 : 0) + log2c, reinterpret_cast<const void *>(k), (size_t)kLdsWords * sizeof(uint32_t));
     if (e != hipSuccess) return e;
