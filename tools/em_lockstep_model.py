@@ -1,5 +1,5 @@
 """Model of the item engine's lockstep loss on synthetic sites (CPU only; uses the numpy restatement for per-fit pass counts).
-A region = 6 consecutive sites; per level the fits go to four lists (3-4 units: 8 per wavefront, 1-2 units: 16 per wavefront;
+A region = 6 consecutive sites; per level the fits go to four lists (3-4 units and 1-2 units, 8 fits per wavefront either way;
 "slow" = the subset leaves out the deepest candidate) and a wavefront runs as many passes as its longest fit.
 Prints the wave-passes of (a) site order, (b) sites ordered within the region by a proxy, (c) by the true pass count.
 usage: python tools/em_lockstep_model.py [n_samples] [n_sites]"""
@@ -99,7 +99,7 @@ def cost(order_fn, region=6, by_level=None):
                         work += p * (4 if nu >= 3 else 2)
                         if by_level is not None: by_level[level][0] += p * (4 if nu >= 3 else 2)
             for l, items in lists.items():
-                per = 8 if l < 2 else 16
+                per = 8                                     # 8 items per wavefront in both shapes (2 lanes x 4 units, 4 lanes x 2 units)
                 for i in range(0, len(items), per):
                     tot += max(items[i:i + per]) * 32           # a wavefront pass costs the same whatever it holds: 32 rows of lanes
                     if by_level is not None: by_level[level][1] += max(items[i:i + per]) * 32; by_level[level][2 + l] += max(items[i:i + per]) * 32
