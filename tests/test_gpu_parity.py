@@ -1260,6 +1260,17 @@ def test_packed_group_mode_gives_the_records_of_the_two_byte_group_mode(ctx, k):
             ctx.synchronize()
             assert torch.equal(got, want), (k, n, layout)
             assert torch.equal(ggot, gwant), (k, n, layout)
+            if layout == "any" and n != 6000:                    # the any-order kernel's other shapes: 512-thread workgroups,
+                from basevarc_amd import Context                 # fewer LDS copies per histogram (the conflict-free fold's other branch)
+                for knob, val in (("group_big_lds", 0), ("group_copies_log2", 1), ("group_copies_log2", 0)):
+                    with Context(0) as other:
+                        other.set_tuning("group_big_lds", 0)
+                        other.set_tuning(knob, val)
+                        o1, o2 = other.lrt_dense_groups_packed_device(p, r, m, gt, k)
+                        t1, t2 = other.lrt_dense_groups_device(b, q, r, m, gt, k)
+                        other.synchronize()
+                        assert torch.equal(o1, want) and torch.equal(o2, gwant), (k, n, knob, val)
+                        assert torch.equal(t1, want) and torch.equal(t2, gwant), (k, n, knob, val)
             if n <= 6016:
                 hres, hg = ctx.lrt_dense_groups_packed(p.cpu().numpy(), r.cpu().numpy(), m, g, k)
                 assert hres.tobytes() == results_from_tensor(want).tobytes()
