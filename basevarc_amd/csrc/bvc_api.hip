@@ -52,6 +52,7 @@ struct bvc_ctx {
     size_t stage_cap[2] = {0, 0};
     hipStream_t copy = nullptr;
     hipEvent_t ev_upload[2] = {nullptr, nullptr};
+    hipEvent_t ev_set_free[2] = {nullptr, nullptr};   // ragged host calls: the kernels that read staging set k have finished
     LaunchState ls;                    // launch policy + one-time kernel setup of this context
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;   // free events
@@ -427,6 +428,7 @@ int bvc_create(bvc_ctx **out, int device)
         ok = hipEventCreateWithFlags(&ctx->ev_hist_done[b], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&ctx->ev_em_done[b], hipEventDisableTiming) == hipSuccess;
     for (int b = 0; b < 2 && ok; ++b) ok = hipEventCreateWithFlags(&ctx->ev_upload[b], hipEventDisableTiming) == hipSuccess;
+    for (int b = 0; b < 2 && ok; ++b) ok = hipEventCreateWithFlags(&ctx->ev_set_free[b], hipEventDisableTiming) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); bvc_destroy(ctx); return BVC_ERR_DEVICE; }
     *out = ctx;
     return BVC_OK;
@@ -453,6 +455,7 @@ void bvc_destroy(bvc_ctx *ctx)
         if (ctx->d_emg[b]) (void)hipFree(ctx->d_emg[b]);
     for (int b = 0; b < 2; ++b) {
         if (ctx->ev_upload[b]) (void)hipEventDestroy(ctx->ev_upload[b]);
+        if (ctx->ev_set_free[b]) (void)hipEventDestroy(ctx->ev_set_free[b]);
         if (ctx->d_stage[b]) (void)hipFree(ctx->d_stage[b]);
     }
     for (auto &t : ctx->ev_pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.c); (void)hipEventDestroy(t.d); }
@@ -741,6 +744,108 @@ int bvc_lrt_hist(bvc_ctx *ctx, int64_t n_sites, const uint32_t *counts, const in
     return BVC_OK;
 }
 
+// Ragged host-pointer calls (bvc_lrt_csr, bvc_lrt_csr_comb, bvc_lrt_csr_packed).  quals == nullptr: packed observations.
+// The per-site arrays (offsets, ref_base, candidate lists) go up once and the records come down once; the observations go
+// through two staging sets in chunks of sites, the upload of chunk i + 1 (copy stream) under the kernels of chunk i, the
+// sets handed back and forth by events -- the host blocks only in its uploads (pageable memory) and at the end.  A chunk's
+// observations keep their element offsets: they are staged `lead` = offsets[s0] mod 256 bytes into the set and the kernels
+// get the staging address minus offsets[s0] as their array base (never dereferenced outside the chunk), so every site
+// sees the alignment it has in a one-piece call.  (Per-chunk uploads of the small arrays, a per-chunk download and a
+// per-chunk synchronize cost 0.12 ms a chunk -- more than the kernels they were to hide; without them a chunk costs 0.06.)
+static int run_csr_host(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets, const int8_t *bases, const int8_t *quals,
+                        const int8_t *ref_base, double min_af, const int8_t *base_comb, const uint8_t *n_comb,
+                        bvc_site_result *results)
+{
+    const int64_t total = offsets[n_sites];
+    // bytes per chunk and array: host_chunk_kib (512 MiB by default).  Smaller chunks do not pay: a pageable upload of 400 MB
+    // takes 7.07 ms (56.6 GB/s), the whole call 7.54 ms in one piece and 7.50 / 7.53 / 7.70 ms in 3 / 6 / 12 chunks -- what
+    // the hidden kernels give, the extra uploads take (profiles/r03_host_pointer_ragged_chunks.txt).
+    const int64_t target = ctx->ls.host_chunk_bytes;
+    const int64_t mean = total / n_sites > 0 ? total / n_sites : 1;
+    int64_t chunk = target / mean;
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_sites) chunk = n_sites;
+    int64_t widest = 0;
+    for (int64_t s0 = 0; s0 < n_sites; s0 += chunk) {
+        const int64_t s1 = s0 + chunk < n_sites ? s0 + chunk : n_sites;
+        if (offsets[s1] - offsets[s0] > widest) widest = offsets[s1] - offsets[s0];
+    }
+    const int arrays = quals ? 2 : 1;
+    const size_t arr_al = ((size_t)widest + 256 + 255) & ~(size_t)255;       // + the lead
+    const size_t off_al = ((size_t)(n_sites + 1) * 8 + 255) & ~(size_t)255;
+    const size_t site_al = ((size_t)n_sites + 255) & ~(size_t)255;
+    const size_t comb_al = ((size_t)n_sites * 4 + 255) & ~(size_t)255;
+    const size_t res_al = ((size_t)n_sites * sizeof(bvc_site_result) + 255) & ~(size_t)255;
+    const size_t head = off_al + 2 * site_al + comb_al + res_al;             // set 0 carries the per-site arrays in front
+    const int n_sets = n_sites > chunk ? 2 : 1;
+    int rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage[0]), &ctx->stage_cap[0], head + (size_t)arrays * arr_al + 256);
+    if (rc == BVC_OK && n_sets > 1) rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage[1]), &ctx->stage_cap[1], (size_t)arrays * arr_al + 256);
+    if (rc != BVC_OK) return rc;
+    int64_t *d_o = reinterpret_cast<int64_t *>(ctx->d_stage[0]);
+    int8_t *d_r = reinterpret_cast<int8_t *>(ctx->d_stage[0] + off_al);
+    uint8_t *d_nc = reinterpret_cast<uint8_t *>(d_r + site_al);
+    int8_t *d_cb = reinterpret_cast<int8_t *>(d_nc + site_al);
+    bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(d_cb + comb_al);
+    auto d_b = [&](int set) { return reinterpret_cast<int8_t *>(ctx->d_stage[set]) + (set == 0 ? head : 0); };
+    // an early exit must not leave an upload or a kernel running on the staging sets: the next call may free or refill them
+    auto drained = [&](int code) {
+        if (code != BVC_OK) {
+            (void)hipStreamSynchronize(ctx->copy);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipGetLastError();
+        }
+        return code;
+    };
+#define BVC_HIP_D(call)                                                                   \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) return drained(fail(ctx, BVC_ERR_DEVICE, #call, e__));     \
+    } while (0)
+    BVC_HIP_D(hipMemcpyAsync(d_o, offsets, (size_t)(n_sites + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    BVC_HIP_D(hipMemcpyAsync(d_r, ref_base, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
+    if (base_comb) {
+        BVC_HIP_D(hipMemcpyAsync(d_nc, n_comb, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP_D(hipMemcpyAsync(d_cb, base_comb, (size_t)n_sites * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    auto upload = [&](int set, int64_t s0, int64_t ns, bool reuse) -> int {
+        const int64_t o0 = offsets[s0];
+        const size_t bytes = (size_t)(offsets[s0 + ns] - o0), lead = (size_t)(o0 & 255);
+        if (reuse) BVC_HIP_D(hipStreamWaitEvent(ctx->copy, ctx->ev_set_free[set], 0));   // the kernels of chunk i - 2 are done with it
+        if (bytes) BVC_HIP_D(hipMemcpyAsync(d_b(set) + lead, bases + o0, bytes, hipMemcpyHostToDevice, ctx->copy));
+        if (bytes && quals) BVC_HIP_D(hipMemcpyAsync(d_b(set) + arr_al + lead, quals + o0, bytes, hipMemcpyHostToDevice, ctx->copy));
+        BVC_HIP_D(hipEventRecord(ctx->ev_upload[set], ctx->copy));
+        return BVC_OK;
+    };
+    int set = 0;
+    rc = upload(0, 0, n_sites < chunk ? n_sites : chunk, false);
+    if (rc != BVC_OK) return rc;
+    int64_t i = 0;
+    for (int64_t s0 = 0; s0 < n_sites; s0 += chunk, set ^= 1, ++i) {
+        const int64_t ns = n_sites - s0 < chunk ? n_sites - s0 : chunk;
+        const int64_t o0 = offsets[s0];
+        const uintptr_t shift = (uintptr_t)(o0 - (o0 & 255));                // array base = staging + lead - o0
+        const int8_t *pb = reinterpret_cast<const int8_t *>(reinterpret_cast<uintptr_t>(d_b(set)) - shift);
+        const int8_t *pq = quals ? reinterpret_cast<const int8_t *>(reinterpret_cast<uintptr_t>(d_b(set) + arr_al) - shift) : nullptr;
+        BVC_HIP_D(hipStreamWaitEvent(ctx->stream, ctx->ev_upload[set], 0));
+        rc = run_csr_device(ctx, ns, d_o + s0, pb, pq, d_r + s0, min_af, base_comb ? d_cb + s0 * 4 : nullptr,
+                            base_comb ? d_nc + s0 : nullptr, d_res + s0);
+        if (rc != BVC_OK) return drained(rc);
+        // the histogram kernels are the only readers of the set and they run on the context's stream
+        BVC_HIP_D(hipEventRecord(ctx->ev_set_free[set], ctx->stream));
+        const int64_t s1 = s0 + chunk;
+        if (s1 < n_sites) {
+            rc = upload(set ^ 1, s1, n_sites - s1 < chunk ? n_sites - s1 : chunk, i >= 1);
+            if (rc != BVC_OK) return drained(rc);
+        }
+    }
+    rc = join_side(ctx);
+    if (rc != BVC_OK) return drained(rc);
+    BVC_HIP_D(hipMemcpyAsync(results, d_res, (size_t)n_sites * sizeof(bvc_site_result), hipMemcpyDeviceToHost, ctx->stream));
+    BVC_HIP_D(hipStreamSynchronize(ctx->stream));
+#undef BVC_HIP_D
+    return BVC_OK;
+}
+
 int bvc_lrt_csr_comb(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
                      const int8_t *bases, const int8_t *quals, const int8_t *ref_base,
                      double min_af, const int8_t *base_comb, const uint8_t *n_comb,
@@ -760,37 +865,7 @@ int bvc_lrt_csr_comb(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
         if (offsets[s + 1] < offsets[s]) return fail(ctx, BVC_ERR_ARG, "offsets must start at 0 and be non-decreasing");
     if (total > 0 && (!bases || !quals)) return fail(ctx, BVC_ERR_ARG, "null data pointer");
     if (base_comb && (rc = check_comb_host(ctx, n_sites, base_comb, n_comb)) != BVC_OK) return rc;
-    const size_t ta = ((size_t)total + 255) & ~(size_t)255;
-    const size_t oa = ((size_t)(n_sites + 1) * 8 + 255) & ~(size_t)255;
-    const size_t sa = ((size_t)n_sites + 255) & ~(size_t)255;
-    const size_t ca = ((size_t)n_sites * 4 + 255) & ~(size_t)255;
-    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage[0]), &ctx->stage_cap[0],
-                oa + 2 * ta + 2 * sa + ca + (size_t)n_sites * sizeof(bvc_site_result) + 256);
-    if (rc != BVC_OK) return rc;
-    int64_t *d_o = reinterpret_cast<int64_t *>(ctx->d_stage[0]);
-    int8_t *d_b = reinterpret_cast<int8_t *>(ctx->d_stage[0] + oa);
-    int8_t *d_q = d_b + ta;
-    int8_t *d_r = d_q + ta;
-    uint8_t *d_nc = reinterpret_cast<uint8_t *>(d_r + sa);
-    int8_t *d_cb = reinterpret_cast<int8_t *>(d_nc + sa);
-    bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(d_cb + ca);
-    BVC_HIP(ctx, hipMemcpyAsync(d_o, offsets, (size_t)(n_sites + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (total > 0) {
-        BVC_HIP(ctx, hipMemcpyAsync(d_b, bases, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
-        BVC_HIP(ctx, hipMemcpyAsync(d_q, quals, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
-    }
-    BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
-    if (base_comb) {
-        BVC_HIP(ctx, hipMemcpyAsync(d_nc, n_comb, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
-        BVC_HIP(ctx, hipMemcpyAsync(d_cb, base_comb, (size_t)n_sites * 4, hipMemcpyHostToDevice, ctx->stream));
-    }
-    rc = run_csr_device(ctx, n_sites, d_o, d_b, d_q, d_r, min_af, base_comb ? d_cb : nullptr, base_comb ? d_nc : nullptr, d_res);
-    if (rc == BVC_OK) rc = join_side(ctx);
-    if (rc != BVC_OK) return rc;
-    BVC_HIP(ctx, hipMemcpyAsync(results, d_res, (size_t)n_sites * sizeof(bvc_site_result), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return BVC_OK;
+    return run_csr_host(ctx, n_sites, offsets, bases, quals, ref_base, min_af, base_comb, n_comb, results);
 }
 
 int bvc_lrt_csr_packed(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets, const uint8_t *packed,
@@ -809,27 +884,8 @@ int bvc_lrt_csr_packed(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets, co
     for (int64_t s = 0; s < n_sites; ++s)
         if (offsets[s + 1] < offsets[s]) return fail(ctx, BVC_ERR_ARG, "offsets must start at 0 and be non-decreasing");
     if (total > 0 && !packed) return fail(ctx, BVC_ERR_ARG, "null data pointer");
-    // one staging set: offsets | observations | ref | records (half the bytes of bvc_lrt_csr over the host link)
-    const size_t ta = ((size_t)total + 255) & ~(size_t)255;
-    const size_t oa = ((size_t)(n_sites + 1) * 8 + 255) & ~(size_t)255;
-    const size_t sa = ((size_t)n_sites + 255) & ~(size_t)255;
-    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage[0]), &ctx->stage_cap[0],
-                oa + ta + sa + (size_t)n_sites * sizeof(bvc_site_result) + 256);
-    if (rc != BVC_OK) return rc;
-    int64_t *d_o = reinterpret_cast<int64_t *>(ctx->d_stage[0]);
-    int8_t *d_p = reinterpret_cast<int8_t *>(ctx->d_stage[0] + oa);
-    int8_t *d_r = d_p + ta;
-    bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(d_r + sa);
-    BVC_HIP(ctx, hipMemcpyAsync(d_o, offsets, (size_t)(n_sites + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (total > 0) BVC_HIP(ctx, hipMemcpyAsync(d_p, packed, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
-    BVC_HIP(ctx, hipMemcpyAsync(d_r, ref_base, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
-    rc = run_csr_device(ctx, n_sites, d_o, d_p, nullptr, d_r, min_af, nullptr, nullptr, d_res);
-    if (rc == BVC_OK) rc = join_side(ctx);
-    if (rc != BVC_OK) return rc;
-    BVC_HIP(ctx, hipMemcpyAsync(results, d_res, (size_t)n_sites * sizeof(bvc_site_result), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return BVC_OK;
+    // half the bytes of bvc_lrt_csr over the host link
+    return run_csr_host(ctx, n_sites, offsets, obs, nullptr, ref_base, min_af, nullptr, nullptr, results);
 }
 
 int bvc_lrt_csr(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,

@@ -168,6 +168,44 @@ def test_ragged_sites_at_one_byte_per_observation(ctx):
     assert all(o.cpu().numpy().tobytes() == want.tobytes() for o in outs)
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_ragged_host_pointer_calls_go_through_in_chunks(overlap):
+    """Ragged calls with host pointers stage their sites through two device buffers in chunks, the upload of chunk i + 1
+    under the kernels of chunk i; a chunk keeps its element offsets (the kernels get the staging address minus the first
+    offset).  With the chunk size turned down ("host_chunk_kib") 400 sites of 0..9000 observations go through in dozens of
+    chunks, chunk boundaries at every alignment: the records must be those of the device-pointer call on the whole tile,
+    byte for byte -- two-byte, one-byte, and with per-site candidate lists."""
+    import torch
+    from basevarc_amd import Context
+    rng = np.random.default_rng(2024)
+    lens = rng.integers(0, 9000, 400)
+    lens[[0, 17, 399]] = 0
+    lens[5] = 70001
+    sites = [random_site(rng, int(n), af=[0.0, 0.02, 0.3][i % 3], qlo=2, qhi=40) for i, n in enumerate(lens)]
+    offs = np.zeros(len(sites) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(lens)
+    bases = np.concatenate([s[0] for s in sites]).astype(np.int8)
+    quals = np.concatenate([s[1] for s in sites]).astype(np.int8)
+    ref = np.array([s[2] for s in sites], dtype=np.int8)
+    packed = _pack_numpy(bases, quals)
+    comb = np.tile(np.array([0, 1, 2, 3], dtype=np.int8), (len(sites), 1))
+    comb[::3] = [2, 0, 3, 1]
+    n_comb = (1 + np.arange(len(sites)) % 4).astype(np.uint8)
+    m = 0.001
+    with Context(0) as one:
+        dev = lambda a: torch.from_numpy(a).cuda()
+        want = one.lrt_csr_device(dev(offs), dev(bases), dev(quals), dev(ref), m).cpu().numpy().tobytes()
+        want_comb = one.lrt_csr(offs, bases, quals, ref, m, comb, n_comb).tobytes()     # one chunk (default chunk size)
+    with Context(0) as c:
+        c.set_overlap(overlap)
+        for kib in (16, 100, 4096):
+            c.set_tuning("host_chunk_kib", kib)
+            assert c.lrt_csr(offs, bases, quals, ref, m).tobytes() == want, kib
+            assert c.lrt_csr_packed(offs, packed, ref, m).tobytes() == want, kib
+            assert c.lrt_csr(offs, bases, quals, ref, m, comb, n_comb).tobytes() == want_comb, kib
+        c.join(); c.synchronize()
+
+
 def test_base_comb_entries_outside_acgt_are_ignored_with_device_pointers(ctx):
     """include/bvc.h, base_comb contract: with host pointers an entry outside 0..3 is BVC_ERR_ARG; with device pointers
     the kernels apply the reference's rule -- such a candidate has depth 0 (src/BaseType.cpp:79) and falls to the min_af
