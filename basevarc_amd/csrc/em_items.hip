@@ -1,5 +1,5 @@
 // em_items.hip -- stage 2 of the basetype path on gfx950, "item engine": the EM fits of a call are the work items,
-// several of them share a wavefront, and a workgroup takes a REGION of 6 sites through the whole likelihood-ratio
+// several of them share a wavefront, and a workgroup takes a REGION of 8 sites through the whole likelihood-ratio
 // test in one launch: classes -> fits of the first level -> decisions -> fits of the next level -> ... with workgroup
 // barriers between the phases and every intermediate (class tables, fit descriptors and results, site state) in LDS.
 //
@@ -102,7 +102,14 @@ struct ItemSite {
 // ("slow" = the subset leaves out the deepest candidate: such fits run to the iteration cap)
 constexpr int kLists = 4;
 constexpr int kLevels = 3;
-constexpr int kRegionSites = 6;           // sites of a workgroup: 6 x (full model + 4 subsets) = 24 + 6 items in 3 + 1 wavefronts
+#ifndef BVC_REGION_SITES
+#define BVC_REGION_SITES 8
+#endif
+// sites of a workgroup.  8 x (full model + 4 subsets) = 32 + 8 fits: four full wavefronts and a full "slow" one, and the
+// two-allele level after it 16 + 8.  (6 sites -- 24 + 6 fits, one slot per wavefront -- leave the slow wavefronts a quarter
+// empty: the same time alone, 10 % slower underneath a histogram pass; 12 are too few regions per launch: 0.31 against
+// 0.23 ms per 4000 sites alone.  profiles/r03_region_sites.txt)
+constexpr int kRegionSites = BVC_REGION_SITES;
 constexpr int kRegionWaves = 4;
 // places of the region's item arrays per list: a site has at most 4 / 1 / 2 / 1 items in lists 0..3 at any level
 constexpr int kListAt[kLists + 1] = {0, 4 * kRegionSites, 5 * kRegionSites, 7 * kRegionSites, 8 * kRegionSites};

@@ -80,7 +80,7 @@ def test_item_engine_agrees_with_the_wave_engine_and_the_oracle(ctx):
 
 
 def test_a_sites_record_does_not_depend_on_its_region_neighbours(ctx):
-    """Stage 2 takes six consecutive sites of a call as a region, and a region with a site of 33..48 quality values goes to
+    """Stage 2 takes eight consecutive sites of a call as a region, and a region with a site of 33..48 quality values goes to
     the wide kernel whole.  The narrow and the wide kernel must give a narrow site the same record, bit for bit: the same
     twelve sites as one call, with a 41-value site spliced in at different places (which moves the region boundaries and
     sends different neighbours to the wide kernel), and one by one."""
@@ -93,7 +93,7 @@ def test_a_sites_record_does_not_depend_on_its_region_neighbours(ctx):
     alone = ctx.lrt_dense(B, Q, R, m)
     one_by_one = [ctx.lrt_dense(*pad_rows([s]), m)[0] for s in narrow]
     assert all(a.tobytes() == b.tobytes() for a, b in zip(alone, one_by_one))
-    for at in (0, 1, 5, 6, 7, 12):
+    for at in (0, 1, 5, 6, 7, 8, 9, 12):
         mixed = narrow[:at] + [wide] + narrow[at:]
         got = ctx.lrt_dense(*pad_rows(mixed), m)
         rest = [got[i] for i in range(len(mixed)) if i != at]
