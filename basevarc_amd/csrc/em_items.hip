@@ -189,6 +189,7 @@ struct Region {
     int want[kRegionSites][kLists];
     int count[kLists];
     int need;                                            // most class places a taken site of the region needs on an allele
+    int next_slot;                                       // wavefront-slots of the running level handed out so far
     alignas(8) uint8_t tab[kRegionSites][site_table_bytes<CPB>()];
 };
 
@@ -794,18 +795,24 @@ __device__ __forceinline__ void region_body(Region<CPB> &R, const RegionArgs &A)
             int tot = 0;
             for (int w = 0; w < kRegionSites; ++w) tot += R.want[w][threadIdx.x];
             R.count[threadIdx.x] = tot;
+            if (threadIdx.x == 0) R.next_slot = 0;
         }
         __syncthreads();
         const int c0 = R.count[0], c1 = R.count[1], c2 = R.count[2], c3 = R.count[3];
         if (c0 + c1 + c2 + c3 == 0) break;                       // (uniform over the workgroup)
         constexpr int kPerWave4 = 16 >> log2g4<CPB>(), kPerWave2 = 2 * (16 >> log2g2<CPB>());
-        const int w0 = (c0 + kPerWave4 - 1) / kPerWave4, w1 = w0 + (c1 + kPerWave4 - 1) / kPerWave4;
-        const int w2 = w1 + (c2 + kPerWave2 - 1) / kPerWave2, w3 = w2 + (c3 + kPerWave2 - 1) / kPerWave2;
-        // (the wavefront that takes slot 0 rotates with the region: a level with fewer slots than wavefronts would
-        // otherwise load the same SIMDs in every workgroup of the CU)
-        for (int slot = (wave + (int)region) % kRegionWaves; slot < w3; slot += kRegionWaves) {
-            const int l = slot < w0 ? 0 : (slot < w1 ? 1 : (slot < w2 ? 2 : 3));
-            const int in_list = slot - (l == 0 ? 0 : (l == 1 ? w0 : (l == 2 ? w1 : w2)));
+        // wavefront-slots of the level, the slow lists first: a region of eight full sites has five slots at its first
+        // level, and the wavefront that gets a second one should not be the one that runs the 101 passes of the slow fits.
+        // A wavefront takes the next slot when it is done with its last (LDS counter).
+        const int w1 = (c1 + kPerWave4 - 1) / kPerWave4, w3 = w1 + (c3 + kPerWave2 - 1) / kPerWave2;
+        const int w0 = w3 + (c0 + kPerWave4 - 1) / kPerWave4, w2 = w0 + (c2 + kPerWave2 - 1) / kPerWave2;
+        for (;;) {
+            int slot = 0;
+            if (lane == 0) slot = atomicAdd(&R.next_slot, 1);
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            if (slot >= w2) break;
+            const int l = slot < w1 ? 1 : (slot < w3 ? 3 : (slot < w0 ? 0 : 2));
+            const int in_list = slot - (l == 1 ? 0 : (l == 3 ? w1 : (l == 0 ? w3 : w0)));
             const int base = l == 0 ? kListAt[0] : (l == 1 ? kListAt[1] : (l == 2 ? kListAt[2] : kListAt[3]));
             const int cnt = l == 0 ? c0 : (l == 1 ? c1 : (l == 2 ? c2 : c3));
             if (l < 2) fit_body<4, log2g4<CPB>(), CPB>(base + in_list * kPerWave4, base + cnt, R.items, R.outs, &R.tab[0][0], A.lut->e);
