@@ -37,15 +37,18 @@ N_SIMD = 1024                # 256 CUs x 4 SIMDs
 ENGINE_CLOCK_HZ = 2.4e9      # MI355X peak engine clock
 VALU_CYCLES_PER_WAVE_INST = 4     # wave64 FP64 / 32-bit VALU instruction (tools/micro/valu_rate.hip)
 # Issue slots (4 cycles each; v_rcp_f64 and the lane swaps count for what they cost, 4 and 2) the item engine needs per
-# E+M pass of ONE fit when every lane group of its wavefronts works: fit_kernel's pass is 150 slots for 8 four-allele
-# items or 16 two-allele items (ISA of em_items.hip, fit_body<4,1> / <2,1>); a site's passes are about 64 % four-allele
-# (full model + 3-subsets) and 36 % two-allele (the nested levels) on the synthetic workload: 0.64 * 18.75 + 0.36 * 9.4.
+# E+M pass of ONE fit when every lane group of its wavefronts works: a pass of eight four-allele fits (two lanes x 16
+# classes per allele) is 150 slots = 18.75 per fit, a pass of eight two-allele fits (four lanes x 8 classes) half that; a
+# site's passes are about 64 % four-allele (full model + 3-subsets) and 36 % two-allele (the nested levels) on the
+# synthetic workload: 0.64 * 18.75 + 0.36 * 9.4.  Cross-check by counters: at N = 1e6, where every fit runs to the cap and
+# a region's wavefronts are full, the kernel executes 19.6 VALU instructions per site-pass all told and spends 80 % of
+# its time in the fit phases (profiles/r03_stage2_pmc.txt, r03_region_kernel_phases.txt): 15.7.
 # (Round 2's one-wavefront-per-site kernel: 63 instructions per pass, 82 slots all told.)
 EM_ISSUE_SLOTS_PER_PASS = 15.4
 # What it EXECUTES per site-pass (SQ_INSTS_VALU of region_kernel / (sites x passes), profiles/r03_stage2_pmc.txt): a
 # wavefront runs until its slowest fit stops and a region's wavefronts meet at a barrier per level, so the shorter the
 # fits (small N) the more passes run on fits that have already stopped.
-EM_VALU_EXECUTED_PER_PASS = {10_000: 32.3, 100_000: 26.5, 1_000_000: 22.0}
+EM_VALU_EXECUTED_PER_PASS = {10_000: 28.9, 100_000: 23.6, 1_000_000: 19.6}
 
 
 def parse():
