@@ -43,6 +43,14 @@
 namespace bvc {
 namespace {
 
+// -DBVC_CHECK_LDS: every LDS index the region kernels derive from LDS contents is checked and a violation traps (diagnostic
+// builds only: tools/check_lds.sh)
+#ifdef BVC_CHECK_LDS
+#define BVC_LDS_CHECK(cond) do { if (!(cond)) __builtin_trap(); } while (0)
+#else
+#define BVC_LDS_CHECK(cond) do { } while (0)
+#endif
+
 constexpr double kLrtThreshold = 24.0;    // LRT_THRESHOLD, src/BaseType.h:9
 constexpr int kEmIters = 100;             // src/BaseType.cpp:46
 constexpr double kEmEpsilon = 0.001;      // src/BaseType.cpp:45
@@ -239,6 +247,7 @@ __device__ __forceinline__ void site_emit(RegionT &R, int ls, int lane)
         fi.e_excl = (double)(total_i - depth_sum);
         fi.inv_n = inv_n;
         fi.ll_excl = ll_excl;
+        BVC_LDS_CHECK(idx >= kListAt[l] && idx < kListAt[l + 1]);
         if (lane == 0) { R.items[idx] = fi; S.item[c] = idx; }
     }
 }
@@ -509,7 +518,9 @@ __device__ __forceinline__ void fit_body(int item0, int item_end, const FitItem 
     bool active = false;
     if (valid) {
         const FitItem *fi = items + item;
+        BVC_LDS_CHECK(item >= 0 && item < kListAt[kLists] && (unsigned)fi->site < (unsigned)kRegionSites);
         const int base = fi->base[unit];
+        BVC_LDS_CHECK(base == 0xFF || base < 4);
         e_excl = fi->e_excl;
         fb_scale = fi->inv_n;
         if (base != 0xFF) {
@@ -630,6 +641,7 @@ __device__ __forceinline__ void site_decide(RegionT &R, int ls, int lane, int64_
 
     auto fit_loglik = [&](int idx, uint32_t pm, double (&ex)[4], int &passes) -> double {
         (void)pm;
+        BVC_LDS_CHECK(idx >= 0 && idx < kListAt[kLists]);
         const FitOut &o = R.outs[idx];
 #pragma unroll
         for (int u = 0; u < 4; ++u) ex[u] = o.ex[u];
@@ -815,6 +827,7 @@ __device__ __forceinline__ void region_body(Region<CPB> &R, const RegionArgs &A)
             const int in_list = slot - (l == 1 ? 0 : (l == 3 ? w1 : (l == 0 ? w3 : w0)));
             const int base = l == 0 ? kListAt[0] : (l == 1 ? kListAt[1] : (l == 2 ? kListAt[2] : kListAt[3]));
             const int cnt = l == 0 ? c0 : (l == 1 ? c1 : (l == 2 ? c2 : c3));
+            BVC_LDS_CHECK(in_list >= 0 && cnt >= 0 && base + cnt <= (l == 0 ? kListAt[1] : (l == 1 ? kListAt[2] : (l == 2 ? kListAt[3] : kListAt[4]))));
             if (l < 2) fit_body<4, log2g4<CPB>(), CPB>(base + in_list * kPerWave4, base + cnt, R.items, R.outs, &R.tab[0][0], A.lut->e);
             else fit_body<2, log2g2<CPB>(), CPB>(base + in_list * kPerWave2, base + cnt, R.items, R.outs, &R.tab[0][0], A.lut->e);
         }
