@@ -928,7 +928,7 @@ static int lrt_groups_impl(bvc_ctx *ctx, bool packed, int64_t n_sites, int64_t n
         if (rc2 != BVC_OK) return rc2;
         rc2 = ensure(ctx, reinterpret_cast<void **>(gp), gcap, gbytes);
         if (rc2 != BVC_OK) return rc2;
-        const size_t lbytes = (size_t)n_samples + 256;                 // the call's labels clamped to 0..n_groups
+        const size_t lbytes = group_labels_bytes(n_samples, ns);       // the call's labels clamped to 0..n_groups + a flag per site
         if (lbytes > ctx->grp_labels_cap) { int rj = join_side(ctx); if (rj != BVC_OK) return rj; }
         rc2 = ensure(ctx, reinterpret_cast<void **>(&ctx->d_grp_labels), &ctx->grp_labels_cap, lbytes);
         if (rc2 != BVC_OK) return rc2;

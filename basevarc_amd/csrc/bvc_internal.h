@@ -19,8 +19,8 @@ struct LaunchState {
     int group_pipe = 1;        // any-order group histogram: issue the next chunk's loads before counting the current one
     int group_log2c = -1;      // any-order group histograms: -1 = as many LDS copies per histogram as fit 64 KiB; 0..5 = at most
                                // 2^n copies (A/B runs: fewer copies = smaller workgroups' LDS = more resident wavefronts)
-    int group_big_lds = 1;     // any-order group histograms on packed tiles: 1 = one 1024-thread workgroup per CU with 16 copies per
-                               // histogram (96 KiB of LDS at k = 5) when that fits 144 KiB, 0 = 512-thread workgroups of up to 64 KiB
+    int group_big_lds = 1;     // any-order group histograms, 4..8 groups: 1 = one 1024-thread workgroup per CU with 256 slots x 16 copies
+                               // per histogram (96 KiB of LDS at k = 5; two-byte rows packed in registers), 0 = 512-thread workgroups of <= 64 KiB
     int em_engine = 0;         // stage 2: 0 = item engine (em_items.hip; em_kernel.hip takes the sites it leaves),
                                // 1 = one wavefront per site for every site (em_kernel.hip): A/B runs.  The two agree to
                                // rounding (1e-15 on AF), not bit for bit: a call's records never depend on the call's
@@ -49,8 +49,12 @@ hipError_t launch_hist_dense(LaunchState &st, hipStream_t stream, int64_t n_site
                              int n_groups, uint32_t *counts, int split, int64_t *group_scratch = nullptr,
                              uint8_t *hist_of_sample = nullptr);
 constexpr int kGroupScratchWords = BVC_MAX_GROUPS + 4;
-// Group mode needs group_scratch (kGroupScratchWords int64 of device memory) and hist_of_sample (n_samples bytes,
-// 16-byte aligned): calls whose samples are ordered by group take the column-range kernel (decided on the device),
+// The label buffer of a group call (hist_of_sample): the labels clamped to 0..n_groups, then one flag per site ("redo with
+// the general kernel", hist_dense_groups_slots_kernel).
+inline size_t group_redo_offset(int64_t n_samples) { return ((size_t)n_samples + 255) & ~(size_t)255; }
+inline size_t group_labels_bytes(int64_t n_samples, int64_t n_sites) { return group_redo_offset(n_samples) + (size_t)n_sites + 256; }
+// Group mode needs group_scratch (kGroupScratchWords int64 of device memory) and hist_of_sample (group_labels_bytes(),
+// 256-byte aligned): calls whose samples are ordered by group take the column-range kernel (decided on the device),
 // the others index their histograms with the clamped labels written to hist_of_sample.
 // Number of sample-range splits per site launch_hist_dense should use for this shape (1 = none).
 int choose_hist_split(const LaunchState &st, int64_t n_sites, int64_t n_samples);

@@ -366,7 +366,7 @@ template <int LOG2C, bool PIPE>
 __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
     int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *__restrict__ bases,
     const int8_t *__restrict__ quals, const uint8_t *__restrict__ hist_of_sample, int n_groups,
-    uint32_t *__restrict__ grp_counts, const int64_t *__restrict__ bounds)
+    uint32_t *__restrict__ grp_counts, const int64_t *__restrict__ bounds, const uint8_t *__restrict__ only)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     if (bounds && bounds[0] == 0) return;        // samples are ordered by group: hist_dense_ranges_kernel has the call
@@ -404,6 +404,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
     const int64_t n16 = n_samples >> 4;
     const u32x4 *gv = reinterpret_cast<const u32x4 *>(hist_of_sample);
     for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
+        if (only && !only[site]) continue;       // hist_dense_groups_slots_kernel has done this site
         const int8_t *brow = bases + site * row_stride;
         const int8_t *qrow = quals + site * row_stride;
         const u32x4 *bv = reinterpret_cast<const u32x4 *>(brow);
@@ -1080,6 +1081,106 @@ __global__ __launch_bounds__(THREADS) void hist_packed_groups_kernel(
     }
 }
 
+// Labels in any order on TWO-BYTE rows, 4..8 groups: the rows are packed in registers -- a 16-sample chunk whose bases
+// are all 0..3 and whose qualities are all below 63 becomes (b << 6) | q per word, one instruction per four samples -- and
+// counted the way hist_packed_groups_kernel<4, true, 1024> counts packed rows: 256 slots x 16 copies per histogram, one
+// 1024-thread workgroup per CU, every bank exactly two deep (the general two-byte kernel above: 512 classes x 4 copies,
+// three to four deep).  Any other chunk goes sample by sample; a site with a covered sample of quality 63..127 -- no
+// place in 256 slots -- is flagged in `redo`, and hist_dense_groups_kernel runs after this kernel on the flagged sites only.
+__global__ __launch_bounds__(1024) void hist_dense_groups_slots_kernel(
+    int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *__restrict__ bases,
+    const int8_t *__restrict__ quals, const uint8_t *__restrict__ hist_of_sample, int n_groups,
+    uint32_t *__restrict__ grp_counts, const int64_t *__restrict__ bounds, uint8_t *__restrict__ redo)
+{
+    constexpr int LOG2C = 4, THREADS = 1024;
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [hist][slot 256][copy 16], then one word: the site's flag
+    if (bounds[0] == 0) return;                                   // ordered by group: hist_dense_ranges_kernel has the call
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    const int n_hist = n_groups + 1;
+    const int words = (n_hist * kPackedSlots) << LOG2C;
+    volatile uint32_t *s_redo = &hist[words];
+    const uint32_t lane_off = (uint32_t)tid & ((1u << LOG2C) - 1u);
+    const uint32_t lane_base = lds_address(hist) + (lane_off << 2);
+    for (int i = tid * 4; i < words; i += THREADS * 4)
+        *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
+    if (tid == 0) *s_redo = 0u;
+    __syncthreads();
+    constexpr uint32_t SH = 2 + LOG2C;
+    auto count_word = [&](uint32_t pw, uint32_t gw) {
+        const uint32_t lo = __builtin_amdgcn_perm(gw, pw, 0x05010400u);   // [g1 p1 g0 p0]
+        const uint32_t hi = __builtin_amdgcn_perm(gw, pw, 0x07030602u);   // [g3 p3 g2 p2]
+        lds_add_one(shl_half<0>(lo, SH) + lane_base);
+        lds_add_one(shl_half<1>(lo, SH) + lane_base);
+        lds_add_one(shl_half<0>(hi, SH) + lane_base);
+        lds_add_one(shl_half<1>(hi, SH) + lane_base);
+    };
+    bool flagged = false;                                         // this lane met a covered sample of quality 63..127
+    auto count_sample = [&](uint32_t b, uint32_t q, uint32_t h) {  // the two-byte rule, one sample
+        if (b < 4u && q < 63u) lds_add_one((((h << 8) | (b << 6) | q) << SH) + lane_base);
+        else if (b < 4u && q < 128u) flagged = true;
+    };
+    const int64_t n16 = n_samples >> 4;
+    const u32x4 *gv = reinterpret_cast<const u32x4 *>(hist_of_sample);
+    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
+        const int8_t *brow = bases + site * row_stride;
+        const int8_t *qrow = quals + site * row_stride;
+        const u32x4 *bv = reinterpret_cast<const u32x4 *>(brow);
+        const u32x4 *qv = reinterpret_cast<const u32x4 *>(qrow);
+        constexpr int64_t kBlockChunks = 2 * (int64_t)THREADS;
+        for (int64_t cb = 0; cb < n16; cb += kBlockChunks) {
+            u32x4 b[2], q[2], g[2];
+            bool in[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t c = cb + tid + (int64_t)u * THREADS;
+                in[u] = cb + kBlockChunks <= n16 || c < n16;
+                b[u] = u32x4{0u, 0u, 0u, 0u}; q[u] = b[u]; g[u] = b[u];
+                if (in[u]) { b[u] = __builtin_nontemporal_load(&bv[c]); q[u] = __builtin_nontemporal_load(&qv[c]); g[u] = gv[c]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                // every base 0..3 and every quality below 63?  (q + 1 reaches bit 6 from 63 on; a carry out of a byte can
+                // only send a chunk the slow way needlessly)
+                const uint32_t qo = q[u].x | q[u].y | q[u].z | q[u].w;
+                const uint32_t q1 = (q[u].x + 0x01010101u) | (q[u].y + 0x01010101u) | (q[u].z + 0x01010101u) | (q[u].w + 0x01010101u);
+                const uint32_t bad = ((b[u].x | b[u].y | b[u].z | b[u].w) & 0xFCFCFCFCu) | ((qo | q1) & 0xC0C0C0C0u);
+                if (__ballot(in[u] && bad != 0) == 0) {
+                    if (in[u]) {
+                        count_word((b[u].x << 6) | q[u].x, g[u].x); count_word((b[u].y << 6) | q[u].y, g[u].y);
+                        count_word((b[u].z << 6) | q[u].z, g[u].z); count_word((b[u].w << 6) | q[u].w, g[u].w);
+                    }
+                } else if (in[u]) {
+                    const uint32_t bw[4] = {b[u].x, b[u].y, b[u].z, b[u].w}, qw[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                    const uint32_t gw[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            count_sample((bw[w] >> (8 * k)) & 0xFFu, (qw[w] >> (8 * k)) & 0xFFu, (gw[w] >> (8 * k)) & 0xFFu);
+                }
+            }
+        }
+        for (int64_t i = (n16 << 4) + tid; i < n_samples; i += THREADS)
+            count_sample((uint8_t)brow[i], (uint8_t)qrow[i], hist_of_sample[i]);
+        if (flagged) *s_redo = 1u;
+        flagged = false;
+        __syncthreads();
+        for (int key = tid; key < n_hist * BVC_NCLASS; key += THREADS) {
+            const int h = key >> 9, cls = key & 511, qq = cls & 127;
+            uint32_t sum = 0;
+            if (qq < 64) {
+                const int slot = (h << 8) | ((cls >> 7) << 6) | qq;
+                sum = fold_copies<LOG2C>(hist, slot);
+                if (qq == 63) sum = 0;                            // only chunks past a row's end count there
+            }
+            grp_counts[site * n_hist * BVC_NCLASS + key] = sum;
+        }
+        if (tid == 0) { redo[site] = (uint8_t)*s_redo; *s_redo = 0u; }
+        __syncthreads();
+    }
+}
+
 // (bases, quals) -> packed bytes.  bad += covered samples whose quality does not fit (63..127): written as "no
 // observation", so a caller that finds bad != 0 must not use the packed tile.
 __global__ void pack_dense_kernel(int64_t n_sites, int64_t n_samples, int64_t stride_in, const int8_t *__restrict__ bases,
@@ -1154,7 +1255,7 @@ enum KernelSlot : uint32_t {
     kSlotPacked0 = 24, kSlotPacked1 = 25, kSlotPackedRanges0 = 26, kSlotPackedRanges1 = 27,
     kSlotPackedGroups = 32,    // + 6 * aligned + log2c (0..5)
     kSlotCsrPacked0 = 44, kSlotCsrPacked1 = 45,
-    kSlotPackedGroupsBig = 46,
+    kSlotPackedGroupsBig = 46, kSlotGroupSlots = 47,
 };
 constexpr size_t kBigLdsBytes = 144 * 1024;      // a workgroup may take the CU's whole LDS (160 KiB); stage 2 keeps 16 KiB beside it
 
@@ -1202,7 +1303,7 @@ hipError_t launch_hist_dense(LaunchState &st, hipStream_t stream, int64_t n_site
         const int64_t ggrid = n_sites < 4096 ? n_sites : 4096;
         if (aligned) {                           // hist_of_sample is the context's own 256-byte aligned buffer
             using FastKernel = void (*)(int64_t, int64_t, int64_t, const int8_t *, const int8_t *, const uint8_t *, int,
-                                        uint32_t *, const int64_t *);
+                                        uint32_t *, const int64_t *, const uint8_t *);
             static const FastKernel fast[2][6] = {
                 {hist_dense_groups_kernel<0, false>, hist_dense_groups_kernel<1, false>, hist_dense_groups_kernel<2, false>,
                  hist_dense_groups_kernel<3, false>, hist_dense_groups_kernel<4, false>, hist_dense_groups_kernel<5, false>},
@@ -1212,8 +1313,20 @@ hipError_t launch_hist_dense(LaunchState &st, hipStream_t stream, int64_t n_site
             const FastKernel fk = fast[pipe][log2c];
             e = raise_lds(st, (pipe ? kSlotGroupPipe : kSlotGroup) + log2c, reinterpret_cast<const void *>(fk), kGroupLdsMax);
             if (e != hipSuccess) return e;
+            // 4..8 groups: packed in registers and counted in 256 slots x 16 copies first; the general kernel then takes the
+            // sites that kernel flags (a covered sample of quality 63 or more), all sites otherwise
+            const uint8_t *only = nullptr;
+            const size_t slds = ((size_t)n_hist * kPackedSlots << 4) * sizeof(uint32_t) + 16;
+            if (st.group_big_lds && log2c < 3 && slds <= kBigLdsBytes) {
+                e = raise_lds(st, kSlotGroupSlots, reinterpret_cast<const void *>(hist_dense_groups_slots_kernel), kBigLdsBytes);
+                if (e != hipSuccess) return e;
+                uint8_t *redo = hist_of_sample + group_redo_offset(n_samples);
+                hipLaunchKernelGGL(hist_dense_groups_slots_kernel, dim3((unsigned)ggrid), dim3(1024), slds, stream, n_sites, n_samples,
+                                   row_stride, bases, quals, hist_of_sample, n_groups, counts, group_scratch, redo);
+                only = redo;
+            }
             hipLaunchKernelGGL(fk, dim3((unsigned)ggrid), dim3(kHistThreads), glds, stream, n_sites, n_samples, row_stride,
-                               bases, quals, hist_of_sample, n_groups, counts, group_scratch);
+                               bases, quals, hist_of_sample, n_groups, counts, group_scratch, only);
         } else {
             e = raise_lds(st, kSlotGroupByte, reinterpret_cast<const void *>(hist_dense_groups_bytes_kernel), kGroupLdsMax);
             if (e != hipSuccess) return e;
