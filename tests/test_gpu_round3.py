@@ -206,6 +206,49 @@ def test_ragged_host_pointer_calls_go_through_in_chunks(overlap):
         c.join(); c.synchronize()
 
 
+def test_any_order_groups_on_two_byte_rows_with_qualities_the_slots_cannot_hold(ctx):
+    """With 4..8 groups and labels in any order, two-byte rows are packed in registers and counted in 256 slots per histogram
+    (hist_dense_groups_slots_kernel); a site with a covered sample of quality 63..127 has no place there, is flagged, and
+    is redone by the general kernel.  Sites of every kind side by side -- all qualities below 63, one sample at 63 / 64 / 127,
+    most samples at 63 and more, uncovered samples scattered, a row length off the 16-sample grid: the records (site and
+    group) must be those of the general kernel alone ("group_big_lds" = 0), byte for byte, and agree with the oracle."""
+    import torch
+    from basevarc_amd import Context
+    from basevarc_amd.lib import GROUP_DTYPE, results_from_tensor
+    rng = np.random.default_rng(636)
+    n, k = 40_000 + 7, 5
+    m = caller_min_af(n)
+    kinds = ["low", "one63", "one64", "one127", "mostly_high", "low", "holes", "high_holes", "low", "one100"]
+    sites = []
+    for i, kind in enumerate(kinds * 2):
+        b, q, r = random_site(rng, n, af=[0.0, 0.03, 0.3][i % 3], qlo=5, qhi=40)
+        if kind.startswith("one"):
+            q[rng.integers(0, n)] = int(kind[3:])
+        if kind in ("mostly_high", "high_holes"):
+            sel = rng.random(n) < 0.7
+            q[sel] = rng.integers(63, 128, int(sel.sum()))
+        if kind in ("holes", "high_holes"):
+            b[rng.random(n) < 0.2] = -1
+        sites.append((b, q, r))
+    B, Q, R = pad_rows(sites, width=n + 41)
+    labels = rng.integers(0, k + 2, n + 41).astype(np.uint8)      # k and k + 1: in no group
+    tb, tq, tr, tg = (torch.from_numpy(x).cuda() for x in (B, Q, R, labels))
+    got = ctx.lrt_dense_groups_device(tb[:, :n], tq[:, :n], tr, m, tg[:n], k)
+    ctx.synchronize()
+    with Context(0) as plain:
+        plain.set_tuning("group_big_lds", 0)
+        want = plain.lrt_dense_groups_device(tb[:, :n], tq[:, :n], tr, m, tg[:n], k)
+        plain.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(got, want))
+    res = results_from_tensor(got[0])
+    gres = got[1].cpu().numpy().view(GROUP_DTYPE).reshape(len(sites), k)
+    for s in (1, 3, 4, 7, 9, 14):
+        o, gd, ga, ran, pres = orc.dense_site_groups(B[s, :n], Q[s, :n], int(R[s]), m, labels[:n], k, use_hist=True)
+        assert_site_matches(res[s], o, where=f"site {s} ({(kinds * 2)[s]})", path_strict=False)
+        assert np.array_equal(gres[s]["depth"], gd) and np.array_equal(gres[s]["ran"], ran), s
+        np.testing.assert_allclose(gres[s]["af"], ga, rtol=0, atol=1e-6)
+
+
 def test_base_comb_entries_outside_acgt_are_ignored_with_device_pointers(ctx):
     """include/bvc.h, base_comb contract: with host pointers an entry outside 0..3 is BVC_ERR_ARG; with device pointers
     the kernels apply the reference's rule -- such a candidate has depth 0 (src/BaseType.cpp:79) and falls to the min_af
