@@ -99,7 +99,10 @@ def group_labels(np, n, k, layout):
 def hist_kernel_name(groups, layout):
     if groups <= 0:
         return "hist_dense_kernel"
-    return "hist_dense_ranges_kernel" if layout == "ordered" else "hist_dense_groups_kernel"
+    if layout == "ordered":
+        return "hist_dense_ranges_kernel"
+    # any order: 4..7 groups take the kernel that packs the rows in registers (256 slots x 16 copies per histogram)
+    return "hist_dense_groups_slots_kernel" if 4 <= groups <= 7 else "hist_dense_groups_kernel"
 
 
 def main():

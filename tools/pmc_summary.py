@@ -23,7 +23,7 @@ def short(name):
     m = re.search(r"(lrt_groups_kernel|lrt_kernel)<(\d+)", name)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
-    for k in ("region_walk_kernel", "region_kernel", "group_comb_kernel", "group_records_kernel", "hist_dense_slots_kernel", "group_slots_kernel", "hist_dense_groups_bytes_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel", "hist_wave_kernel", "hist_packed_groups_kernel", "hist_packed_ranges_kernel", "hist_packed_kernel", "pack_dense_kernel",
+    for k in ("region_walk_kernel", "region_kernel", "group_comb_kernel", "group_records_kernel", "hist_dense_slots_kernel", "group_slots_kernel", "hist_dense_groups_bytes_kernel", "hist_dense_groups_slots_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel", "hist_wave_kernel", "hist_packed_groups_kernel", "hist_packed_ranges_kernel", "hist_packed_kernel", "pack_dense_kernel",
               "hist_dense_kernel", "hist_csr_block_kernel", "group_bounds_kernel", "var_qual_kernel",
               "synth_dense_kernel", "sum_groups_kernel", "stream_read_kernel"):
         if k in name:
@@ -98,7 +98,7 @@ def main():
     doc.update({"hist_kernel_sha16": sha, "commit": commit, "summary": f"profiles/{tag}_pmc_summary.md",
                 "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of 16 B/lane streams), WRITE_SIZE KiB x 1024"})
     doc.setdefault("kernels", {})
-    for kname in ("hist_dense_kernel", "hist_dense_groups_kernel", "hist_dense_ranges_kernel", "hist_packed_kernel",
+    for kname in ("hist_dense_kernel", "hist_dense_groups_kernel", "hist_dense_groups_slots_kernel", "hist_dense_ranges_kernel", "hist_packed_kernel",
                   "hist_packed_groups_kernel", "hist_packed_ranges_kernel"):
         bps = 1 if "packed" in kname else 2          # bytes per (site, sample) of the kernel's input layout
         alg = float(bps) * n_samples * sites
@@ -106,7 +106,7 @@ def main():
         if "FETCH_SIZE" not in h or h["FETCH_SIZE"] < 1000:        # the kernel that returned at once has no traffic
             continue
         # gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide (16 B/lane) coalesced streaming read -- checked on a
-        # known byte count with tools/micro/read_bw.hip.  The doubling is applied ONLY to the six streaming histogram
+        # known byte count with tools/micro/read_bw.hip.  The doubling is applied ONLY to the seven streaming histogram
         # kernels listed above, whose input is read that way; the byte-wise kernels, group_bounds_kernel, the stage-2
         # kernels and everything else appear in the tables above with their raw counter values, uncorrected.
         fetch = h["FETCH_SIZE"] * 1024 * 2
