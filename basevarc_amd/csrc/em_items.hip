@@ -735,7 +735,7 @@ __device__ __forceinline__ void site_decide(RegionT &R, int ls, int lane, int64_
     }
 }
 
-// ---- region_kernel: one workgroup of five wavefronts per region of eight sites ---------------------------------------
+// ---- region_kernel: one workgroup of four wavefronts per region of eight sites ---------------------------------------
 struct RegionArgs {
     int64_t n_sites;
     int n_groups;
