@@ -144,6 +144,7 @@ bool BgzfWriter::close()
 BgzfReader::BgzfReader(const std::string &path)
     : fp_(std::fopen(path.c_str(), "rb")), bgzf_(false), block_addr_(0), next_addr_(0), pos_(0), eof_(false)
 {
+    file_at_ = UINT64_MAX; zs_ready_ = false;
     if (fp_) {
         unsigned char h[16];
         bgzf_ = std::fread(h, 1, 16, fp_) == 16 && h[0] == 0x1f && h[1] == 0x8b && (h[3] & 4) && h[12] == 'B' && h[13] == 'C';
@@ -151,32 +152,46 @@ BgzfReader::BgzfReader(const std::string &path)
     }
 }
 
-BgzfReader::~BgzfReader() { if (fp_) std::fclose(fp_); }
+BgzfReader::~BgzfReader()
+{
+    if (zs_ready_) inflateEnd(&zs_);
+    if (fp_) std::fclose(fp_);
+}
 
 bool BgzfReader::load_block()
 {
     while (!eof_) {
         block_addr_ = next_addr_;
         unsigned char h[18];
-        if (std::fseek(fp_, (long)block_addr_, SEEK_SET) != 0 || std::fread(h, 1, 18, fp_) != 18) { eof_ = true; break; }
+        // sequential reading leaves the file where the next block starts: seek only after BgzfReader::seek or at the start
+        if (file_at_ != block_addr_ && std::fseek(fp_, (long)block_addr_, SEEK_SET) != 0) { eof_ = true; break; }
+        file_at_ = UINT64_MAX;
+        if (std::fread(h, 1, 18, fp_) != 18) { eof_ = true; break; }
         if (h[0] != 0x1f || h[1] != 0x8b || h[12] != 'B' || h[13] != 'C') { eof_ = true; break; }
         const size_t bsize = ((size_t)h[16] | ((size_t)h[17] << 8)) + 1;
-        std::vector<unsigned char> comp(bsize - 18);
-        if (std::fread(comp.data(), 1, comp.size(), fp_) != comp.size()) { eof_ = true; break; }
+        if (bsize < 18 + 8) { eof_ = true; break; }
+        comp_.resize(bsize - 18);
+        if (std::fread(comp_.data(), 1, comp_.size(), fp_) != comp_.size()) { eof_ = true; break; }
         next_addr_ = block_addr_ + bsize;
-        const size_t clen = comp.size() - 8;
+        file_at_ = next_addr_;
+        const size_t clen = comp_.size() - 8;
         uint32_t isize = 0;
-        for (int i = 0; i < 4; ++i) isize |= (uint32_t)comp[clen + 4 + i] << (8 * i);
-        block_.assign(isize, 0);
+        for (int i = 0; i < 4; ++i) isize |= (uint32_t)comp_[clen + 4 + i] << (8 * i);
+        block_.resize(isize);
         pos_ = 0;
         if (isize == 0) continue;               // empty block (the EOF marker): try the next one
-        z_stream zs;
-        std::memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, -15) != Z_OK) { eof_ = true; break; }
-        zs.next_in = comp.data(); zs.avail_in = (uInt)clen;
-        zs.next_out = block_.data(); zs.avail_out = isize;
-        const int rc = inflate(&zs, Z_FINISH);
-        inflateEnd(&zs);
+        // one inflate state for the reader's life (inflateInit2 allocates and clears about 40 KB: per block it cost a
+        // tenth of the inflate itself)
+        if (!zs_ready_) {
+            std::memset(&zs_, 0, sizeof zs_);
+            if (inflateInit2(&zs_, -15) != Z_OK) { eof_ = true; break; }
+            zs_ready_ = true;
+        } else if (inflateReset(&zs_) != Z_OK) {
+            eof_ = true; break;
+        }
+        zs_.next_in = comp_.data(); zs_.avail_in = (uInt)clen;
+        zs_.next_out = block_.data(); zs_.avail_out = isize;
+        const int rc = inflate(&zs_, Z_FINISH);
         if (rc != Z_STREAM_END) { eof_ = true; block_.clear(); break; }
         return true;
     }

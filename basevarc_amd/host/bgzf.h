@@ -14,6 +14,8 @@
 #include <thread>
 #include <vector>
 
+#include <zlib.h>
+
 namespace bvchost {
 
 class BgzfWriter {
@@ -50,6 +52,8 @@ class BgzfReader {
  public:
     explicit BgzfReader(const std::string &path);
     ~BgzfReader();
+    BgzfReader(const BgzfReader &) = delete;            // owns a FILE and an inflate state
+    BgzfReader &operator=(const BgzfReader &) = delete;
     bool ok() const { return fp_ != nullptr; }
     bool is_bgzf() const { return bgzf_; }
     // one line without its terminator; false at end of file
@@ -67,6 +71,10 @@ class BgzfReader {
     std::vector<unsigned char> block_;
     size_t pos_;
     bool eof_;
+    uint64_t file_at_;                          // file offset the FILE is known to stand at (UINT64_MAX: unknown)
+    std::vector<unsigned char> comp_;           // the compressed block, reused
+    z_stream zs_;                               // one inflate state for the reader's life
+    bool zs_ready_;
 };
 
 }  // namespace bvchost

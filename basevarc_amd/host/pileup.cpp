@@ -58,8 +58,50 @@ int parse_pileup_line(const char *line, size_t len, int32_t j0, SiteColumn &site
     const char *p = line, *end = line + len;
     int32_t j = j0;
     AlleleInfo &ai = g_carry;
+    // As in parse_pileup_bin: room for every entry the line can hold is made once (a token takes at least two bytes), the
+    // entries are written in place and the tallies of the base tokens are kept in locals.
+    const size_t n0 = site.aiv.size();
+    site.aiv.resize(n0 + len / 2 + 1);
+    site.sample.resize(n0 + len / 2 + 1);
+    Entry *e = site.aiv.data() + n0;
+    int32_t *sj = site.sample.data() + n0;
+    int32_t tally[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [strand][base] over the base tokens
+    // up to three decimal digits (what the writer prints for an 8-bit field); false = not a digit at *q
+    auto num3 = [](const char *&q, unsigned &v) -> bool {
+        unsigned d = (unsigned)(unsigned char)*q - '0';
+        if (d > 9u) return false;
+        v = d; ++q;
+        d = (unsigned)(unsigned char)*q - '0';
+        if (d <= 9u) {
+            v = v * 10u + d; ++q;
+            d = (unsigned)(unsigned char)*q - '0';
+            if (d <= 9u) { v = v * 10u + d; ++q; }
+        }
+        return true;
+    };
     while (p < end) {
         if (*p == '.' && end - p >= 2 && p[1] == ' ') { p += 2; ++j; continue; }   // "no data": nine tokens in ten at 10 % coverage
+        if (end - p >= 20) {
+            // the common data token, "base,mapq,qual,rpr,strand " exactly as format_pileup_token writes it; anything else
+            // (a sign, a fourth digit, a missing field, a token at the very end of the line) goes the general way below
+            const char *q = p;
+            unsigned v0, v1, v2, v3, v4;
+            if (num3(q, v0) && *q == ',' && num3(++q, v1) && *q == ',' && num3(++q, v2) && *q == ',' && num3(++q, v3) &&
+                *q == ',' && num3(++q, v4) && *q == ' ') {
+                ai.is_indel = 0;
+                ai.base = (uint8_t)(v0 & 7u);                   // bit-field widths, src/BamProcess.h:32-37
+                ai.mapq = (uint8_t)v1; ai.qual = (uint8_t)v2; ai.rpr = (uint8_t)v3;
+                ai.strand = (uint8_t)(v4 & 1u);
+                if (ai.base != 4) {                             // skip N base, :427
+                    *e++ = Entry{ai.base, ai.mapq, ai.qual, ai.rpr, ai.strand, 0, 0};
+                    *sj++ = j;
+                    tally[ai.strand << 3 | ai.base] += 1;
+                }
+                p = q + 1;
+                ++j;
+                continue;
+            }
+        }
         while (p < end && *p == ' ') ++p;                       // strtok_r skips runs of delimiters
         if (p >= end || *p == '\n') break;
         const char *tok = p;
@@ -79,14 +121,26 @@ int parse_pileup_line(const char *line, size_t len, int32_t j0, SiteColumn &site
             ai.qual = (uint8_t)field[2];
             ai.rpr = (uint8_t)field[3];
             ai.strand = (uint8_t)(field[4] & 1);
-            if (ai.base != 4) site.add(ai, j);                  // skip N base, :427
+            if (ai.base != 4) {                                 // skip N base, :427
+                *e++ = Entry{ai.base, ai.mapq, ai.qual, ai.rpr, ai.strand, 0, 0};
+                *sj++ = j;
+                tally[ai.strand << 3 | ai.base] += 1;
+            }
         } else if (c != '.') {
             ai.is_indel = 1;
             ai.indel.assign(tok, p - tok);
-            site.add(ai, j);
+            site.indels.push_back(ai.indel);
+            *e++ = Entry{ai.base, ai.mapq, ai.qual, ai.rpr, ai.strand, 1, 0};
+            *sj++ = j;
+            if (ai.base < 8u) (ai.strand == 1 ? site.fwd : site.rev)[ai.base] += 1;   // an indel entry counts with the fields it inherits
         }
         ++j;
     }
+    const size_t n_used = (size_t)(e - site.aiv.data());
+    site.aiv.resize(n_used);
+    site.sample.resize(n_used);
+    for (int b = 0; b < 8; ++b) { site.rev[b] += tally[b]; site.fwd[b] += tally[8 + b]; }
+    for (int b = 0; b < 4; ++b) site.cnt[b] += tally[b] + tally[8 + b];
     return j - j0;
 }
 
