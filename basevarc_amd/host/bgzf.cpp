@@ -154,49 +154,123 @@ BgzfReader::BgzfReader(const std::string &path)
 
 BgzfReader::~BgzfReader()
 {
+    settle();
     if (zs_ready_) inflateEnd(&zs_);
     if (fp_) std::fclose(fp_);
 }
 
-bool BgzfReader::load_block()
+bool BgzfReader::fetch(uint64_t from, std::vector<unsigned char> &out, uint64_t &at, uint64_t &next)
 {
-    while (!eof_) {
-        block_addr_ = next_addr_;
+    for (;;) {
+        at = from;
         unsigned char h[18];
         // sequential reading leaves the file where the next block starts: seek only after BgzfReader::seek or at the start
-        if (file_at_ != block_addr_ && std::fseek(fp_, (long)block_addr_, SEEK_SET) != 0) { eof_ = true; break; }
+        if (file_at_ != at && std::fseek(fp_, (long)at, SEEK_SET) != 0) return false;
         file_at_ = UINT64_MAX;
-        if (std::fread(h, 1, 18, fp_) != 18) { eof_ = true; break; }
-        if (h[0] != 0x1f || h[1] != 0x8b || h[12] != 'B' || h[13] != 'C') { eof_ = true; break; }
+        if (std::fread(h, 1, 18, fp_) != 18) return false;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[12] != 'B' || h[13] != 'C') return false;
         const size_t bsize = ((size_t)h[16] | ((size_t)h[17] << 8)) + 1;
-        if (bsize < 18 + 8) { eof_ = true; break; }
+        if (bsize < 18 + 8) return false;
         comp_.resize(bsize - 18);
-        if (std::fread(comp_.data(), 1, comp_.size(), fp_) != comp_.size()) { eof_ = true; break; }
-        next_addr_ = block_addr_ + bsize;
-        file_at_ = next_addr_;
+        if (std::fread(comp_.data(), 1, comp_.size(), fp_) != comp_.size()) return false;
+        next = at + bsize;
+        file_at_ = next;
         const size_t clen = comp_.size() - 8;
         uint32_t isize = 0;
         for (int i = 0; i < 4; ++i) isize |= (uint32_t)comp_[clen + 4 + i] << (8 * i);
-        block_.resize(isize);
-        pos_ = 0;
-        if (isize == 0) continue;               // empty block (the EOF marker): try the next one
-        // one inflate state for the reader's life (inflateInit2 allocates and clears about 40 KB: per block it cost a
-        // tenth of the inflate itself)
+        if (isize == 0) { from = next; continue; }      // empty block (the EOF marker): try the next one
+        out.resize(isize);
+        // one inflate state for the reader's life (inflateInit2 allocates and clears about 40 KB)
         if (!zs_ready_) {
             std::memset(&zs_, 0, sizeof zs_);
-            if (inflateInit2(&zs_, -15) != Z_OK) { eof_ = true; break; }
+            if (inflateInit2(&zs_, -15) != Z_OK) return false;
             zs_ready_ = true;
         } else if (inflateReset(&zs_) != Z_OK) {
-            eof_ = true; break;
+            return false;
         }
         zs_.next_in = comp_.data(); zs_.avail_in = (uInt)clen;
-        zs_.next_out = block_.data(); zs_.avail_out = isize;
-        const int rc = inflate(&zs_, Z_FINISH);
-        if (rc != Z_STREAM_END) { eof_ = true; block_.clear(); break; }
-        return true;
+        zs_.next_out = out.data(); zs_.avail_out = isize;
+        return inflate(&zs_, Z_FINISH) == Z_STREAM_END;
     }
-    block_.clear(); pos_ = 0;
-    return false;
+}
+
+bool BgzfReader::load_block()
+{
+    bool got = false;
+    if (!eof_) {
+        if (pool_) {
+            {
+                std::unique_lock<std::mutex> lk(pool_->mu_);
+                if (ahead_state_ == kNone) { ahead_from_ = next_addr_; ahead_state_ = kQueued; pool_->q_.push_back(this); pool_->work_cv_.notify_one(); }
+                pool_->done_cv_.wait(lk, [this] { return ahead_state_ == kReady; });
+                ahead_state_ = kNone;
+            }
+            got = ahead_ok_;
+            if (got) {
+                block_.swap(ahead_block_);
+                block_addr_ = ahead_at_; next_addr_ = ahead_next_;
+                pool_->submit(this);                    // the block after this one, while this one is consumed
+            }
+        } else {
+            got = fetch(next_addr_, block_, block_addr_, next_addr_);
+        }
+    }
+    pos_ = 0;
+    if (!got) { eof_ = true; block_.clear(); }
+    return got;
+}
+
+void BgzfReader::settle()
+{
+    if (!pool_) return;
+    std::unique_lock<std::mutex> lk(pool_->mu_);
+    pool_->done_cv_.wait(lk, [this] { return ahead_state_ != kQueued; });
+    ahead_state_ = kNone;
+}
+
+void BgzfReader::attach(InflatePool *pool)
+{
+    settle();
+    pool_ = pool;
+    if (pool_ && fp_ && !eof_) pool_->submit(this);
+}
+
+InflatePool::InflatePool(int n_threads)
+{
+    for (int i = 0; i < (n_threads > 0 ? n_threads : 1); ++i) th_.emplace_back([this] { run(); });
+}
+
+InflatePool::~InflatePool()
+{
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+    work_cv_.notify_all();
+    for (auto &t : th_) t.join();
+}
+
+void InflatePool::submit(BgzfReader *r)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    if (r->ahead_state_ != BgzfReader::kNone) return;
+    r->ahead_from_ = r->next_addr_;
+    r->ahead_state_ = BgzfReader::kQueued;
+    q_.push_back(r);
+    work_cv_.notify_one();
+}
+
+void InflatePool::run()
+{
+    for (;;) {
+        BgzfReader *r;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            work_cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+            if (q_.empty()) return;                     // stop_, and nothing left to do
+            r = q_.front(); q_.pop_front();
+        }
+        r->ahead_ok_ = r->fetch(r->ahead_from_, r->ahead_block_, r->ahead_at_, r->ahead_next_);
+        { std::lock_guard<std::mutex> g(mu_); r->ahead_state_ = BgzfReader::kReady; }
+        done_cv_.notify_all();
+    }
 }
 
 size_t BgzfReader::read(void *dst, size_t n)
@@ -229,6 +303,7 @@ bool BgzfReader::getline(std::string &line)
 
 bool BgzfReader::seek(uint64_t voffset)
 {
+    settle();
     eof_ = false;
     next_addr_ = voffset >> 16;
     block_.clear(); pos_ = 0;

@@ -48,6 +48,29 @@ class BgzfWriter {
     bool closing_ = false;
 };
 
+class BgzfReader;
+
+// Read-ahead for BgzfReaders: a few threads that inflate, for every reader attached to the pool, the block after the one
+// being consumed.  The position loop of the host program reads one line (or record) of every temp batch per position --
+// a hundred readers per thread at 1e5 samples -- and inflating their blocks was 70 % of the loop with the text form.
+class InflatePool {
+ public:
+    explicit InflatePool(int n_threads);
+    ~InflatePool();
+    InflatePool(const InflatePool &) = delete;
+    InflatePool &operator=(const InflatePool &) = delete;
+ private:
+    friend class BgzfReader;
+    void submit(BgzfReader *r);                 // r's read-ahead runs on a worker
+    void wait(BgzfReader *r);                   // until it is done
+    void run();
+    std::mutex mu_;
+    std::condition_variable work_cv_, done_cv_;
+    std::deque<BgzfReader *> q_;
+    bool stop_ = false;
+    std::vector<std::thread> th_;
+};
+
 class BgzfReader {
  public:
     explicit BgzfReader(const std::string &path);
@@ -62,8 +85,15 @@ class BgzfReader {
     bool seek(uint64_t voffset);                // BGZF virtual offset: compressed block start << 16 | within-block
     uint64_t tell() const { return (block_addr_ << 16) | (uint64_t)pos_; }
     static bool has_eof_marker(const std::string &path);   // bgzf_check_EOF
+    // From now on the block after the current one is inflated by `pool` while this one is consumed.  The pool must
+    // outlive the reader.
+    void attach(InflatePool *pool);
  private:
+    friend class InflatePool;
     bool load_block();
+    // the first non-empty block at or after file offset `from`, inflated into `out`; false at the end of the file
+    bool fetch(uint64_t from, std::vector<unsigned char> &out, uint64_t &at, uint64_t &next);
+    void settle();                              // waits for a read-ahead in flight and drops its result
     FILE *fp_;
     bool bgzf_;
     uint64_t block_addr_;
@@ -75,6 +105,13 @@ class BgzfReader {
     std::vector<unsigned char> comp_;           // the compressed block, reused
     z_stream zs_;                               // one inflate state for the reader's life
     bool zs_ready_;
+    // read-ahead (fp_, comp_, zs_, file_at_ and the ahead_* fields belong to the worker while ahead_state_ is kQueued)
+    enum { kNone = 0, kQueued = 1, kReady = 2 };
+    InflatePool *pool_ = nullptr;
+    int ahead_state_ = kNone;                   // guarded by the pool's mutex
+    bool ahead_ok_ = false;
+    uint64_t ahead_from_ = 0, ahead_at_ = 0, ahead_next_ = 0;
+    std::vector<unsigned char> ahead_block_;
 };
 
 }  // namespace bvchost

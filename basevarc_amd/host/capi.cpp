@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -172,6 +173,46 @@ int bvchost_bgzf_write(const char *path, const char *data, int64_t n, int64_t pi
     if (!w.ok()) return 0;
     for (int64_t i = 0; i < n; i += piece) w.write(data + i, (size_t)(n - i < piece ? n - i : piece));
     return w.close() ? 1 : 0;
+}
+
+// Test hook: reads `n_files` BGZF files the way the position loop does -- round robin, one line (by_line) or `piece` bytes
+// of each per turn -- through readers attached to an InflatePool of `threads` threads (0: no pool), a seek back to the
+// start of file 0 after `seek_after` turns, and returns a 64-bit FNV-1a hash over everything read (order included).
+uint64_t bvchost_bgzf_read_hash(const char *const *paths, int32_t n_files, int32_t threads, int32_t by_line, int64_t piece,
+                                int64_t seek_after, int64_t *bytes_out)
+{
+    uint64_t h = 1469598103934665603ULL;
+    auto mix = [&h](const char *p, size_t n) { for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ULL; } };
+    int64_t total = 0;
+    {
+        std::unique_ptr<InflatePool> pool(threads > 0 ? new InflatePool(threads) : nullptr);
+        std::vector<std::unique_ptr<BgzfReader>> rd;
+        for (int32_t i = 0; i < n_files; ++i) {
+            rd.emplace_back(new BgzfReader(paths[i]));
+            if (!rd.back()->ok()) return 0;
+            if (pool) rd.back()->attach(pool.get());
+        }
+        std::vector<char> live((size_t)n_files, 1);
+        std::string line;
+        std::vector<char> buf((size_t)(piece > 0 ? piece : 1));
+        int n_live = n_files;
+        for (int64_t turn = 0; n_live > 0; ++turn) {
+            if (turn == seek_after && n_files > 0) { rd[0]->seek(0); if (!live[0]) { live[0] = 1; ++n_live; } }
+            for (int32_t i = 0; i < n_files; ++i) {
+                if (!live[(size_t)i]) continue;
+                if (by_line) {
+                    if (!rd[(size_t)i]->getline(line)) { live[(size_t)i] = 0; --n_live; continue; }
+                    mix(line.data(), line.size()); mix("\n", 1); total += (int64_t)line.size() + 1;
+                } else {
+                    const size_t got = rd[(size_t)i]->read(buf.data(), buf.size());
+                    if (got == 0) { live[(size_t)i] = 0; --n_live; continue; }
+                    mix(buf.data(), got); total += (int64_t)got;
+                }
+            }
+        }
+    }   // readers go before the pool
+    if (bytes_out) *bytes_out = total;
+    return h;
 }
 
 int64_t bvchost_write_synth_batches(const char *out_prefix, int32_t n_samples, int32_t n_pos, int32_t thread, int32_t batch,

@@ -21,6 +21,7 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <stdexcept>
@@ -521,8 +522,13 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
     // writers' own
     BgzfWriter fpv(opt::output + "." + std::to_string(ithread) + ".vcf.gz", 6, true);
     BgzfWriter fpc(opt::output + "." + std::to_string(ithread) + ".cvg.gz", 6, true);
+    // the blocks of the temp batches are inflated ahead of the position loop by threads of their own (the loop takes a
+    // line of every batch per position; inflating was 70 % of it with the text form): BVC_HOST_INFLATE_THREADS, 0 = none
+    const int n_inflate = getenv("BVC_HOST_INFLATE_THREADS") ? atoi(getenv("BVC_HOST_INFLATE_THREADS")) : 2;
+    std::unique_ptr<InflatePool> inflate_pool(n_inflate > 0 ? new InflatePool(n_inflate) : nullptr);
     std::vector<BatchInput *> fpiv;
     for (auto const &f : ftmp_v) fpiv.push_back(new BatchInput(f));
+    if (inflate_pool) for (auto fp : fpiv) fp->rd.attach(inflate_pool.get());
     // (BVC_HOST_PROFILE: on a GPU box the first ~0.5 s of every worker thread go to process-wide stalls while the HIP
     // runtime, started by bvc_device_count in main, finishes coming up -- whatever the thread does first pays them.)
     const double t_opened = StageClock::now();

@@ -529,3 +529,32 @@ def test_bgzf_writer_with_its_own_deflate_thread_writes_the_same_stream(H, tmp_p
     ref = str(tmp_path / "fg.gz")
     assert H.bvchost_bgzf_write(ref.encode(), data, len(data), 99999, 6, 0) == 1
     assert open(ref, "rb").read() == files[0]
+
+
+def test_bgzf_readers_with_read_ahead_give_the_same_bytes(H, tmp_path):
+    """The position loop's temp-batch readers have their next block inflated ahead by a small thread pool (InflatePool).
+    Several files read round robin -- by line and in odd-sized pieces, with a seek back to the start in the middle -- must
+    give exactly the bytes of the readers without read-ahead, in the same order, for 1, 2 and 5 pool threads."""
+    rng = np.random.default_rng(9)
+    H.bvchost_bgzf_write.restype = C.c_int
+    H.bvchost_bgzf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int, C.c_int]
+    H.bvchost_bgzf_read_hash.restype = C.c_uint64
+    H.bvchost_bgzf_read_hash.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                         C.POINTER(C.c_int64)]
+    paths, total = [], 0
+    for i, n_lines in enumerate((30000, 0, 1, 700, 9000, 25000, 3)):
+        lines = [" ".join(("." if rng.random() < 0.9 else "0,40,%d,7,1" % rng.integers(10, 41)) for _ in range(int(rng.integers(1, 60))))
+                 for _ in range(n_lines)]
+        data = ("".join(l + "\n" for l in lines)).encode()
+        f = str(tmp_path / f"b{i}.gz")
+        assert H.bvchost_bgzf_write(f.encode(), data, len(data), 65537, [6, 0][i % 2], 0) == 1
+        paths.append(f.encode()); total += len(data)
+    arr = (C.c_char_p * len(paths))(*paths)
+    for by_line, piece in ((1, 0), (0, 777), (0, 200001)):
+        want_bytes = C.c_int64(0)
+        want = H.bvchost_bgzf_read_hash(arr, len(paths), 0, by_line, piece, 5, C.byref(want_bytes))
+        assert want_bytes.value > total                    # file 0.. read once, the start of file 0 twice (the seek)
+        for threads in (1, 2, 5):
+            got_bytes = C.c_int64(0)
+            assert H.bvchost_bgzf_read_hash(arr, len(paths), threads, by_line, piece, 5, C.byref(got_bytes)) == want
+            assert got_bytes.value == want_bytes.value
