@@ -1151,13 +1151,24 @@ __global__ __launch_bounds__(1024) void hist_dense_groups_slots_kernel(
                         count_word((b[u].z << 6) | q[u].z, g[u].z); count_word((b[u].w << 6) | q[u].w, g[u].w);
                     }
                 } else if (in[u]) {
+                    // some sample of the wavefront is not a covered one of quality below 63 (tiles with coverage below 1: nearly
+                    // every chunk): the bytes are sorted out four at a time -- a sample that is not covered becomes 0xFF
+                    // (slot 255, dropped by the fold), a covered one of quality 63 and more flags the site -- and counted
+                    // like the others.  (Sample by sample this path was VALU-bound: 2.26 ms per 4000 sites at 70 %
+                    // coverage against 1.37 at full coverage.)
                     const uint32_t bw[4] = {b[u].x, b[u].y, b[u].z, b[u].w}, qw[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
                     const uint32_t gw[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
 #pragma unroll
-                    for (int w = 0; w < 4; ++w)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            count_sample((bw[w] >> (8 * k)) & 0xFFu, (qw[w] >> (8 * k)) & 0xFFu, (gw[w] >> (8 * k)) & 0xFFu);
+                    for (int w = 0; w < 4; ++w) {
+                        // 0x80 in every byte of x that is not zero
+                        auto nonzero = [](uint32_t x) { return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; };
+                        const uint32_t b_out = nonzero(bw[w] & 0xFCFCFCFCu);                       // not a base: no observation
+                        // quality 63 and more: q + 1 reaches bit 6 (a carry out of a byte of 0xFF can only flag the next one)
+                        const uint32_t q_out = nonzero(((qw[w] + 0x01010101u) | qw[w]) & 0xC0C0C0C0u);
+                        flagged |= (q_out & ~b_out) != 0u;
+                        const uint32_t drop = ((b_out | q_out) >> 7) * 0xFFu;                      // 0xFF in the bytes to drop
+                        count_word((((bw[w] & 0x03030303u) << 6) | qw[w]) | drop, gw[w]);
+                    }
                 }
             }
         }
