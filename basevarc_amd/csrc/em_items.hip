@@ -551,16 +551,38 @@ __device__ __forceinline__ void fit_body(int item0, int item_end, const FitItem 
         // stop-rule bracket of THIS pass: A = sum_b |f_b - f_b(previous pass)| D_b(previous pass), lane partial
         double ta = fabs(fb - fprev) * dprev;
         const double g = fma(-4.0, fb, 1.0);
-        double m[kSlots], y[kSlots];
-#pragma unroll
-        for (int k = 0; k < kSlots; ++k) m[k] = fma(g, e[k], fb);      // class marginal f + (1 - 4 f) e
-        rcp_all<kSlots>(m, y);
         double ysum0 = 0.0, ysum1 = 0.0, acc_e0 = 0.0, acc_e1 = 0.0;
+#ifdef BVC_RCP_CHUNK
+        constexpr int CH = kSlots > BVC_RCP_CHUNK ? BVC_RCP_CHUNK : kSlots;
+#else
+        constexpr int CH = kSlots;
+#endif
 #pragma unroll
-        for (int k = 0; k < kSlots; k += 2) {
-            const double r0 = n[k] * y[k], r1 = n[k + 1] * y[k + 1];
-            ysum0 += r0; ysum1 += r1;
-            acc_e0 = fma(r0, e[k], acc_e0); acc_e1 = fma(r1, e[k + 1], acc_e1);
+        for (int c0 = 0; c0 < kSlots; c0 += CH) {
+            constexpr int kLast = kSlots % CH == 0 ? CH : kSlots % CH;
+            if (c0 + CH <= kSlots) {
+                double m[CH], y[CH];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) m[k] = fma(g, e[c0 + k], fb);      // class marginal f + (1 - 4 f) e
+                rcp_all<CH>(m, y);
+#pragma unroll
+                for (int k = 0; k < CH; k += 2) {
+                    const double r0 = n[c0 + k] * y[k], r1 = n[c0 + k + 1] * y[k + 1];
+                    ysum0 += r0; ysum1 += r1;
+                    acc_e0 = fma(r0, e[c0 + k], acc_e0); acc_e1 = fma(r1, e[c0 + k + 1], acc_e1);
+                }
+            } else {
+                double m[kLast], y[kLast];
+#pragma unroll
+                for (int k = 0; k < kLast; ++k) m[k] = fma(g, e[c0 + k], fb);
+                rcp_all<kLast>(m, y);
+#pragma unroll
+                for (int k = 0; k < kLast; k += 2) {
+                    const double r0 = n[c0 + k] * y[k], r1 = n[c0 + k + 1] * y[k + 1];
+                    ysum0 += r0; ysum1 += r1;
+                    acc_e0 = fma(r0, e[c0 + k], acc_e0); acc_e1 = fma(r1, e[c0 + k + 1], acc_e1);
+                }
+            }
         }
         const double acc_e = acc_e0 + acc_e1;
         const double acc_d = fma(-4.0, acc_e, ysum0 + ysum1);   // sum n d / m with d = 1 - 4 e
@@ -843,7 +865,12 @@ __device__ __forceinline__ void region_body(Region<CPB> &R, const RegionArgs &A)
 }
 
 // One region per workgroup: three workgroups (12 wavefronts) per CU.
-__global__ __launch_bounds__(64 * kRegionWaves) __attribute__((amdgpu_waves_per_eu(3, 3))) void region_kernel(RegionArgs A)
+#ifdef BVC_RCP_CHUNK
+#define BVC_REGION_WAVES_PER_EU 4
+#else
+#define BVC_REGION_WAVES_PER_EU 3
+#endif
+__global__ __launch_bounds__(64 * kRegionWaves) __attribute__((amdgpu_waves_per_eu(BVC_REGION_WAVES_PER_EU, BVC_REGION_WAVES_PER_EU))) void region_kernel(RegionArgs A)
 {
     __shared__ Region<kNarrow> R;
     region_body<false, kNarrow>(R, A);
