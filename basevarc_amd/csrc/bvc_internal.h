@@ -19,8 +19,9 @@ struct LaunchState {
     int group_pipe = 1;        // any-order group histogram: issue the next chunk's loads before counting the current one
     int group_log2c = -1;      // any-order group histograms: -1 = as many LDS copies per histogram as fit 64 KiB; 0..5 = at most
                                // 2^n copies (A/B runs: fewer copies = smaller workgroups' LDS = more resident wavefronts)
-    int group_big_lds = 1;     // any-order group histograms, 4..8 groups: 1 = one 1024-thread workgroup per CU with 256 slots x 16 copies
-                               // per histogram (96 KiB of LDS at k = 5; two-byte rows packed in registers), 0 = 512-thread workgroups of <= 64 KiB
+    int group_big_lds = 1;     // any-order group histograms, 4 groups and more: 1 = one 1024-thread workgroup per CU with 256 slots x
+                               // 16 / 8 / 4 copies per histogram (up to 9 / 18 / 36 histograms in 144 KiB of LDS; two-byte rows packed in
+                               // registers), 0 = 512-thread workgroups of <= 64 KiB
     int em_engine = 0;         // stage 2: 0 = item engine (em_items.hip; em_kernel.hip takes the sites it leaves),
                                // 1 = one wavefront per site for every site (em_kernel.hip): A/B runs.  The two agree to
                                // rounding (1e-15 on AF), not bit for bit: a call's records never depend on the call's

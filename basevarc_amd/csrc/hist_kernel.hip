@@ -1087,12 +1087,13 @@ __global__ __launch_bounds__(THREADS) void hist_packed_groups_kernel(
 // 1024-thread workgroup per CU, every bank exactly two deep (the general two-byte kernel above: 512 classes x 4 copies,
 // three to four deep).  Any other chunk goes sample by sample; a site with a covered sample of quality 63..127 -- no
 // place in 256 slots -- is flagged in `redo`, and hist_dense_groups_kernel runs after this kernel on the flagged sites only.
+template <int LOG2C>
 __global__ __launch_bounds__(1024) void hist_dense_groups_slots_kernel(
     int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *__restrict__ bases,
     const int8_t *__restrict__ quals, const uint8_t *__restrict__ hist_of_sample, int n_groups,
     uint32_t *__restrict__ grp_counts, const int64_t *__restrict__ bounds, uint8_t *__restrict__ redo)
 {
-    constexpr int LOG2C = 4, THREADS = 1024;
+    constexpr int THREADS = 1024;
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [hist][slot 256][copy 16], then one word: the site's flag
     if (bounds[0] == 0) return;                                   // ordered by group: hist_dense_ranges_kernel has the call
     __builtin_amdgcn_s_setprio(3);
@@ -1266,7 +1267,8 @@ enum KernelSlot : uint32_t {
     kSlotPacked0 = 24, kSlotPacked1 = 25, kSlotPackedRanges0 = 26, kSlotPackedRanges1 = 27,
     kSlotPackedGroups = 32,    // + 6 * aligned + log2c (0..5)
     kSlotCsrPacked0 = 44, kSlotCsrPacked1 = 45,
-    kSlotPackedGroupsBig = 46, kSlotGroupSlots = 47,
+    kSlotPackedGroupsBig = 46,  // + (4 - log2 copies): 46..48
+    kSlotGroupSlots = 49,       // + (4 - log2 copies): 49..51
 };
 constexpr size_t kBigLdsBytes = 144 * 1024;      // a workgroup may take the CU's whole LDS (160 KiB); stage 2 keeps 16 KiB beside it
 
@@ -1327,12 +1329,18 @@ hipError_t launch_hist_dense(LaunchState &st, hipStream_t stream, int64_t n_site
             // 4..8 groups: packed in registers and counted in 256 slots x 16 copies first; the general kernel then takes the
             // sites that kernel flags (a covered sample of quality 63 or more), all sites otherwise
             const uint8_t *only = nullptr;
-            const size_t slds = ((size_t)n_hist * kPackedSlots << 4) * sizeof(uint32_t) + 16;
+            // 256 slots x 16 / 8 / 4 copies per histogram in one workgroup's LDS: up to 9 / 18 / 36 histograms
+            int sl = 4;
+            while (sl > 2 && ((size_t)n_hist * kPackedSlots << sl) * sizeof(uint32_t) + 16 > kBigLdsBytes) --sl;
+            const size_t slds = ((size_t)n_hist * kPackedSlots << sl) * sizeof(uint32_t) + 16;
             if (st.group_big_lds && log2c < 3 && slds <= kBigLdsBytes) {
-                e = raise_lds(st, kSlotGroupSlots, reinterpret_cast<const void *>(hist_dense_groups_slots_kernel), kBigLdsBytes);
+                using SK = void (*)(int64_t, int64_t, int64_t, const int8_t *, const int8_t *, const uint8_t *, int, uint32_t *,
+                                    const int64_t *, uint8_t *);
+                const SK sk = sl == 4 ? hist_dense_groups_slots_kernel<4> : (sl == 3 ? hist_dense_groups_slots_kernel<3> : hist_dense_groups_slots_kernel<2>);
+                e = raise_lds(st, kSlotGroupSlots + (4 - sl), reinterpret_cast<const void *>(sk), kBigLdsBytes);
                 if (e != hipSuccess) return e;
                 uint8_t *redo = hist_of_sample + group_redo_offset(n_samples);
-                hipLaunchKernelGGL(hist_dense_groups_slots_kernel, dim3((unsigned)ggrid), dim3(1024), slds, stream, n_sites, n_samples,
+                hipLaunchKernelGGL(sk, dim3((unsigned)ggrid), dim3(1024), slds, stream, n_sites, n_samples,
                                    row_stride, bases, quals, hist_of_sample, n_groups, counts, group_scratch, redo);
                 only = redo;
             }
@@ -1419,10 +1427,12 @@ hipError_t launch_hist_packed_groups(LaunchState &st, hipStream_t stream, int64_
     // sites), underneath stage 2 -- the way the calls run -- 5 % faster (0.90 against 0.95) and stage 2 itself a fifth
     // (profiles/r03_group_anyorder_experiments.txt).  The same form of the two-byte kernel (8 copies, 96 KiB) LOSES 15 %
     // underneath stage 2 and is not kept.
-    if (st.group_big_lds && aligned && log2c < 4 && ((size_t)n_hist * kPackedSlots << 4) * sizeof(uint32_t) <= kBigLdsBytes) {
-        auto bk = hist_packed_groups_kernel<4, true, 1024>;
-        const size_t blds = ((size_t)n_hist * kPackedSlots << 4) * sizeof(uint32_t);
-        e = raise_lds(st, kSlotPackedGroupsBig, reinterpret_cast<const void *>(bk), kBigLdsBytes);
+    int bl = 4;                                                  // 16 / 8 / 4 copies in one workgroup's LDS: up to 9 / 18 / 36 histograms
+    while (bl > 2 && ((size_t)n_hist * kPackedSlots << bl) * sizeof(uint32_t) > kBigLdsBytes) --bl;
+    if (st.group_big_lds && aligned && log2c < bl && ((size_t)n_hist * kPackedSlots << bl) * sizeof(uint32_t) <= kBigLdsBytes) {
+        const GK bk = bl == 4 ? hist_packed_groups_kernel<4, true, 1024> : (bl == 3 ? hist_packed_groups_kernel<3, true, 1024> : hist_packed_groups_kernel<2, true, 1024>);
+        const size_t blds = ((size_t)n_hist * kPackedSlots << bl) * sizeof(uint32_t);
+        e = raise_lds(st, kSlotPackedGroupsBig + (4 - bl), reinterpret_cast<const void *>(bk), kBigLdsBytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(bk, dim3((unsigned)(n_sites < 4096 ? n_sites : 4096)), dim3(1024), blds, stream, n_sites,
                            n_samples, row_stride, packed, hist_of_sample, n_groups, counts, group_scratch);

@@ -101,8 +101,8 @@ def hist_kernel_name(groups, layout):
         return "hist_dense_kernel"
     if layout == "ordered":
         return "hist_dense_ranges_kernel"
-    # any order: 4..7 groups take the kernel that packs the rows in registers (256 slots x 16 copies per histogram)
-    return "hist_dense_groups_slots_kernel" if 4 <= groups <= 7 else "hist_dense_groups_kernel"
+    # any order: from 4 groups on the kernel that packs the rows in registers (256 slots x 16 / 8 / 4 copies per histogram)
+    return "hist_dense_groups_slots_kernel" if groups >= 4 else "hist_dense_groups_kernel"
 
 
 def main():

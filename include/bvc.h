@@ -232,8 +232,8 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
  *                      current one, 0 loads two chunks then counts both
  *   "group_copies_log2"  any-order group histograms: -1 (default) = as many LDS copies of each histogram as fit 64 KiB,
  *                      0..5 = at most 2^n copies (smaller workgroups, more of them resident; A/B runs)
- *   "group_big_lds"    any-order group histograms, 4..8 groups: 1 (default) = one 1024-thread workgroup per CU with 256
- *                      slots x 16 copies per histogram in up to 144 KiB of LDS (two-byte rows are packed in registers for
+ *   "group_big_lds"    any-order group histograms, 4 groups and more: 1 (default) = one 1024-thread workgroup per CU with 256
+ *                      slots x 16 / 8 / 4 copies per histogram in up to 144 KiB of LDS (two-byte rows are packed in registers for
  *                      it; sites with a covered quality of 63 or more are redone by the general kernel), 0 = 512-thread
  *                      workgroups of 64 KiB
  *   "host_chunk_kib"   BVC_PTR_HOST calls stage the tile through device memory in chunks of sites of at most this
