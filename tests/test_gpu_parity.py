@@ -1233,7 +1233,7 @@ def test_group_counts_up_to_the_maximum(ctx, k):
                 np.testing.assert_allclose(gres[s]["af"], ga, rtol=0, atol=AF_ATOL)
 
 
-@pytest.mark.parametrize("k", [1, 5, 7, 32])
+@pytest.mark.parametrize("k", [1, 5, 7, 12, 32])          # 2 / 6 / 8 / 13 / 33 histograms: every copy count of the any-order kernels
 def test_packed_group_mode_gives_the_records_of_the_two_byte_group_mode(ctx, k):
     """bvc_lrt_dense_groups_packed == bvc_lrt_dense_groups on the same observations, byte for byte (site records and
     group records): labels in any order and ordered by group, with and without samples in no group, rows of 6016
