@@ -97,6 +97,17 @@ int ensure(bvc_ctx *ctx, void **buf, size_t *cap, size_t need)
         want = need;
     }
     *cap = want;
+    // Fresh device memory holds whatever its last owner left.  No kernel of the library is meant to read scratch it has not
+    // written, and so that a slip there can never read another call's (or another process's) leftovers the new buffer is
+    // cleared before anything can touch it -- to 0xFF bytes in the -DBVC_POISON build, which makes such a slip loud.
+    // (Allocation happens once per buffer and size: the synchronize is not on the steady-state path.)
+#ifdef BVC_POISON
+    constexpr int kFill = 0xFF;
+#else
+    constexpr int kFill = 0;
+#endif
+    BVC_HIP(ctx, hipMemsetAsync(*buf, kFill, want, ctx->stream));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BVC_OK;
 }
 
@@ -306,8 +317,13 @@ int run_chunks(bvc_ctx *ctx, int64_t n_sites, int64_t chunk, Upload upload, Comp
     // an early exit must not leave an upload or a kernel running on the staging sets: the next call may free or refill them
     auto drained = [&](int code) {
         if (code != BVC_OK) {
+            // stage 2 of the chunks already launched may still run on the side streams and it reads / writes the staging sets
             (void)hipStreamSynchronize(ctx->copy);
             (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(ctx->side);
+            (void)hipStreamSynchronize(ctx->side_b);
+            (void)hipStreamSynchronize(ctx->side_c);
+            for (bool &p : ctx->em_pending) p = false;
             (void)hipGetLastError();
         }
         return code;
@@ -400,7 +416,11 @@ int bvc_create(bvc_ctx **out, int device)
     ctx->ls.group_big_lds = env_int("BVC_GROUP_BIG_LDS", 0, 1, 1);
     ctx->ls.em_streams = env_int("BVC_EM_STREAMS", 0, 3, 0);
     ctx->ls.em_engine = env_int("BVC_EM_ENGINE", 0, 1, 0);
+#ifdef BVC_DIAG_KNOBS
+    // timing experiments only (tools/em_stage2.py phase breakdown): cuts region_kernel short, so the records are WRONG.  Not
+    // compiled into the product: a stray environment variable must never be able to do that.
     ctx->ls.dbg_levels = env_int("BVC_DBG_LEVELS", 0, 6, 0);
+#endif
     ctx->ls.em_tiny_regions = env_int("BVC_EM_TINY_REGIONS", 0, 1, 0);
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return BVC_ERR_DEVICE; }
     // likelihood table from the host's exp(), as the CPU path computes it (src/BaseType.cpp:13,15)
@@ -790,8 +810,13 @@ static int run_csr_host(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets, c
     // an early exit must not leave an upload or a kernel running on the staging sets: the next call may free or refill them
     auto drained = [&](int code) {
         if (code != BVC_OK) {
+            // stage 2 of the chunks already launched may still run on the side streams and it reads / writes the staging sets
             (void)hipStreamSynchronize(ctx->copy);
             (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(ctx->side);
+            (void)hipStreamSynchronize(ctx->side_b);
+            (void)hipStreamSynchronize(ctx->side_c);
+            for (bool &p : ctx->em_pending) p = false;
             (void)hipGetLastError();
         }
         return code;
@@ -1046,6 +1071,22 @@ int bvc_lrt_dense_groups_packed(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples
     return lrt_groups_impl(ctx, true, n_sites, n_samples, row_stride, reinterpret_cast<const int8_t *>(packed), nullptr, ref_base,
                            min_af, group_of_sample, n_groups, results, grp_results, flags);
 }
+
+#ifdef BVC_CHECK_LDS
+// Diagnostic builds only (bvc_device.h): the violations the checked kernels recorded, 8 words per translation unit
+// (histogram kernels, wave engine, item engine): [0] count, [1..5] the first one's check id, value, limit, blockIdx.x,
+// threadIdx.x.  Synchronises the device.  reset != 0 clears the records.
+int bvc_debug_report(bvc_ctx *ctx, uint32_t *out24, int reset)
+{
+    if (!out24) return BVC_ERR_ARG;
+    if (ctx) BVC_HIP(ctx, hipSetDevice(ctx->device));            // null: the calling thread's current device
+    BVC_HIP(ctx, hipDeviceSynchronize());
+    BVC_HIP(ctx, debug_read_hist(out24, reset != 0));
+    BVC_HIP(ctx, debug_read_wave_engine(out24 + 8, reset != 0));
+    BVC_HIP(ctx, debug_read_items(out24 + 16, reset != 0));
+    return BVC_OK;
+}
+#endif
 
 int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value)
 {

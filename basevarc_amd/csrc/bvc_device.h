@@ -7,6 +7,65 @@ namespace bvc {
 
 constexpr int kWave = 64;          // CDNA wavefront
 
+// ---- diagnostic builds (never the product) ---------------------------------------------------------------------------
+// -DBVC_CHECK_LDS  every LDS address or index that is derived from DATA (input bytes, LDS contents) is checked against the
+//                  workgroup's LDS allocation / the array it indexes.  A violation is RECORDED -- (check id, value, limit,
+//                  blockIdx.x, threadIdx.x) in a per-translation-unit device buffer the host reads with bvc_debug_report() --
+//                  and the access is skipped or made harmless, so the run goes on and leaves evidence instead of a dead queue.
+// -DBVC_POISON     every kernel first fills its whole LDS allocation with 0xFF bytes, and every device scratch buffer the
+//                  context allocates is filled with 0xFF instead of zeros: a read-before-write of LDS or scratch then reads
+//                  the same loud pattern in every run instead of whatever the previous kernel or process left there.
+// tools/poison_run.sh builds with both and runs the GPU parity suite and the bench legs once.
+#if defined(BVC_CHECK_LDS) || defined(BVC_POISON)
+// bytes of LDS of the running workgroup: static part + the dynamic part of the launch (code object v5 hidden argument)
+__device__ __forceinline__ uint32_t lds_bytes_of_workgroup()
+{
+    return __builtin_amdgcn_groupstaticsize() + ((const uint32_t *)__builtin_amdgcn_implicitarg_ptr())[30];
+}
+#endif
+
+#ifdef BVC_CHECK_LDS
+// [0] violations so far, [1..5] the first one: check id, value, limit, blockIdx.x, threadIdx.x
+static __device__ uint32_t g_lds_violation[8];
+__device__ __forceinline__ bool lds_check_fail(uint32_t id, uint32_t value, uint32_t limit)
+{
+    if (atomicAdd(&g_lds_violation[0], 1u) == 0u) {
+        g_lds_violation[1] = id; g_lds_violation[2] = value; g_lds_violation[3] = limit;
+        g_lds_violation[4] = blockIdx.x; g_lds_violation[5] = threadIdx.x;
+    }
+    return false;
+}
+// true when value < limit; records the violation otherwise
+#define BVC_LDS_OK(id, value, limit) ((uint32_t)(value) < (uint32_t)(limit) ? true : bvc::lds_check_fail((id), (uint32_t)(value), (uint32_t)(limit)))
+#define BVC_DEFINE_DEBUG_READER(fn)                                                                              \
+    hipError_t fn(uint32_t *out8, bool reset)                                                                     \
+    {                                                                                                             \
+        hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lds_violation), 8 * sizeof(uint32_t));             \
+        if (e == hipSuccess && reset) {                                                                           \
+            const uint32_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                                    \
+            e = hipMemcpyToSymbol(HIP_SYMBOL(g_lds_violation), zero, sizeof zero);                                \
+        }                                                                                                         \
+        return e;                                                                                                 \
+    }
+#else
+#define BVC_LDS_OK(id, value, limit) (true)
+#endif
+
+#ifdef BVC_POISON
+// First statement of every kernel: the whole allocation to 0xFF, then a barrier (the kernel's own initialisation follows).
+__device__ __forceinline__ void poison_lds()
+{
+    typedef __attribute__((address_space(3))) uint32_t lds_word;
+    const uint32_t words = lds_bytes_of_workgroup() >> 2;
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x)
+        __hip_atomic_store((lds_word *)(uintptr_t)(i << 2), 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+}
+#define BVC_POISON_LDS() bvc::poison_lds()
+#else
+#define BVC_POISON_LDS() do { } while (0)
+#endif
+
 // ---- cross-lane movement -------------------------------------------------------------------------
 // DPP controls (ISA: quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141)
 constexpr int kDppXor1 = 0xB1;     // quad_perm [1,0,3,2]

@@ -114,4 +114,11 @@ hipError_t launch_synth_dense(hipStream_t stream, uint64_t seed, int64_t site0, 
                               int64_t n_samples, int64_t row_stride, uint32_t cov_thr16,
                               int8_t *bases, int8_t *quals, int8_t *ref_base);
 
+#ifdef BVC_CHECK_LDS
+// diagnostic builds: each translation unit's violation record (bvc_device.h)
+hipError_t debug_read_hist(uint32_t *out8, bool reset);
+hipError_t debug_read_wave_engine(uint32_t *out8, bool reset);
+hipError_t debug_read_items(uint32_t *out8, bool reset);
+#endif
+
 }  // namespace bvc

@@ -43,13 +43,8 @@
 namespace bvc {
 namespace {
 
-// -DBVC_CHECK_LDS: every LDS index the region kernels derive from LDS contents is checked and a violation traps (diagnostic
-// builds only: tools/check_lds.sh)
-#ifdef BVC_CHECK_LDS
-#define BVC_LDS_CHECK(cond) do { if (!(cond)) __builtin_trap(); } while (0)
-#else
-#define BVC_LDS_CHECK(cond) do { } while (0)
-#endif
+// -DBVC_CHECK_LDS (bvc_device.h): every LDS index the region kernels derive from LDS contents goes through BVC_LDS_OK, which
+// records a violation for the host (bvc_debug_report) and lets the code take a harmless path.  Check ids 11..16.
 
 constexpr double kLrtThreshold = 24.0;    // LRT_THRESHOLD, src/BaseType.h:9
 constexpr int kEmIters = 100;             // src/BaseType.cpp:46
@@ -247,8 +242,7 @@ __device__ __forceinline__ void site_emit(RegionT &R, int ls, int lane)
         fi.e_excl = (double)(total_i - depth_sum);
         fi.inv_n = inv_n;
         fi.ll_excl = ll_excl;
-        BVC_LDS_CHECK(idx >= kListAt[l] && idx < kListAt[l + 1]);
-        if (lane == 0) { R.items[idx] = fi; S.item[c] = idx; }
+        if (lane == 0 && BVC_LDS_OK(11, idx - kListAt[l], kListAt[l + 1] - kListAt[l])) { R.items[idx] = fi; S.item[c] = idx; }
     }
 }
 
@@ -511,19 +505,17 @@ __device__ __forceinline__ void fit_body(int item0, int item_end, const FitItem 
     const int row = lane >> 4, sub = lane & (G - 1), grp = (lane & 15) >> LOG2G;
     const int unit = ROWS == 4 ? row : (row & 1);
     const int item = item0 + (ROWS == 4 ? grp : (row >> 1) * kGroupsPerRow + grp);
-    const bool valid = item < item_end;
+    const bool valid = item < item_end && BVC_LDS_OK(12, item, kListAt[kLists]);
 
     double n[kSlots], e[kSlots];
     double fb = 0.0, e_excl = 0.0, fb_scale = 0.0;
     bool active = false;
     if (valid) {
         const FitItem *fi = items + item;
-        BVC_LDS_CHECK(item >= 0 && item < kListAt[kLists] && (unsigned)fi->site < (unsigned)kRegionSites);
         const int base = fi->base[unit];
-        BVC_LDS_CHECK(base == 0xFF || base < 4);
         e_excl = fi->e_excl;
         fb_scale = fi->inv_n;
-        if (base != 0xFF) {
+        if (base != 0xFF && BVC_LDS_OK(13, fi->site, kRegionSites) && BVC_LDS_OK(14, base, 4)) {
             active = true;
             fb = fi->f0[unit];
             const uint8_t *tab = cls + fi->site * site_table_bytes<CPB>();
@@ -663,7 +655,7 @@ __device__ __forceinline__ void site_decide(RegionT &R, int ls, int lane, int64_
 
     auto fit_loglik = [&](int idx, uint32_t pm, double (&ex)[4], int &passes) -> double {
         (void)pm;
-        BVC_LDS_CHECK(idx >= 0 && idx < kListAt[kLists]);
+        if (!BVC_LDS_OK(15, idx, kListAt[kLists])) idx = 0;
         const FitOut &o = R.outs[idx];
 #pragma unroll
         for (int u = 0; u < 4; ++u) ex[u] = o.ex[u];
@@ -849,7 +841,7 @@ __device__ __forceinline__ void region_body(Region<CPB> &R, const RegionArgs &A)
             const int in_list = slot - (l == 1 ? 0 : (l == 3 ? w1 : (l == 0 ? w3 : w0)));
             const int base = l == 0 ? kListAt[0] : (l == 1 ? kListAt[1] : (l == 2 ? kListAt[2] : kListAt[3]));
             const int cnt = l == 0 ? c0 : (l == 1 ? c1 : (l == 2 ? c2 : c3));
-            BVC_LDS_CHECK(in_list >= 0 && cnt >= 0 && base + cnt <= (l == 0 ? kListAt[1] : (l == 1 ? kListAt[2] : (l == 2 ? kListAt[3] : kListAt[4]))));
+            if (!BVC_LDS_OK(16, cnt, (l == 0 ? kListAt[1] : (l == 1 ? kListAt[2] : (l == 2 ? kListAt[3] : kListAt[4]))) - base + 1)) break;
             if (l < 2) fit_body<4, log2g4<CPB>(), CPB>(base + in_list * kPerWave4, base + cnt, R.items, R.outs, &R.tab[0][0], A.lut->e);
             else fit_body<2, log2g2<CPB>(), CPB>(base + in_list * kPerWave2, base + cnt, R.items, R.outs, &R.tab[0][0], A.lut->e);
         }
@@ -870,8 +862,15 @@ __device__ __forceinline__ void region_body(Region<CPB> &R, const RegionArgs &A)
 #else
 #define BVC_REGION_WAVES_PER_EU 3
 #endif
-__global__ __launch_bounds__(64 * kRegionWaves) __attribute__((amdgpu_waves_per_eu(BVC_REGION_WAVES_PER_EU, BVC_REGION_WAVES_PER_EU))) void region_kernel(RegionArgs A)
+// (diagnostic builds carry extra code: no occupancy target there, so that they do not spill where the product does not)
+#if defined(BVC_CHECK_LDS) || defined(BVC_POISON)
+#define BVC_OCCUPANCY(n)
+#else
+#define BVC_OCCUPANCY(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
+__global__ __launch_bounds__(64 * kRegionWaves) BVC_OCCUPANCY(BVC_REGION_WAVES_PER_EU) void region_kernel(RegionArgs A)
 {
+    BVC_POISON_LDS();
     __shared__ Region<kNarrow> R;
     region_body<false, kNarrow>(R, A);
 }
@@ -879,6 +878,7 @@ __global__ __launch_bounds__(64 * kRegionWaves) __attribute__((amdgpu_waves_per_
 // A bounded grid whose workgroups walk the regions (underneath a streaming histogram pass: one workgroup per CU).
 __global__ __launch_bounds__(64 * kRegionWaves) void region_walk_kernel(RegionArgs A)
 {
+    BVC_POISON_LDS();
     __shared__ Region<kNarrow> R;
     region_body<true, kNarrow>(R, A);
 }
@@ -887,19 +887,25 @@ __global__ __launch_bounds__(64 * kRegionWaves) void region_walk_kernel(RegionAr
 // 16 four-allele fits per wavefront; the grid walks the regions.
 __global__ __launch_bounds__(64 * kRegionWaves) void region_tiny_kernel(RegionArgs A)
 {
+    BVC_POISON_LDS();
     __shared__ Region<kTiny> R;
     region_body<true, kTiny>(R, A);
 }
 
 // The same for the regions with a site of 33..48 quality values on an allele (24 classes per lane: two wavefronts per
 // SIMD); the grid walks the regions.
-__global__ __launch_bounds__(64 * kRegionWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void region_wide_kernel(RegionArgs A)
+__global__ __launch_bounds__(64 * kRegionWaves) BVC_OCCUPANCY(2) void region_wide_kernel(RegionArgs A)
 {
+    BVC_POISON_LDS();
     __shared__ Region<kWide> R;
     region_body<true, kWide>(R, A);
 }
 
 }  // namespace
+
+#ifdef BVC_CHECK_LDS
+BVC_DEFINE_DEBUG_READER(debug_read_items)
+#endif
 
 size_t em_items_scratch_bytes(int64_t n_sites)
 {

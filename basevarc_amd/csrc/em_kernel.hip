@@ -267,8 +267,10 @@ __device__ bool lrt_site(const uint32_t *__restrict__ hist, int ref, double min_
         const uint32_t rowbits = (uint32_t)(nzmask >> (16 * row)) & 0xFFFFu;
         if (c != 0) {
             const int pos = cnt_row + __popc(rowbits & ((1u << t) - 1u));
-            s_n[row * 128 + pos] = c;
-            s_q[row * 128 + pos] = (uint8_t)q;
+            if (BVC_LDS_OK(21, pos, 128)) {
+                s_n[row * 128 + pos] = c;
+                s_q[row * 128 + pos] = (uint8_t)q;
+            }
         }
         cnt_row += __popc(rowbits);
         depth_lane += (int)c;
@@ -455,6 +457,7 @@ __global__ __launch_bounds__(64 * WPB) void lrt_kernel(int64_t n_sites, const ui
                                                  const uint8_t *__restrict__ taken,
                                                  bvc_site_result *__restrict__ results)
 {
+    BVC_POISON_LDS();
     __shared__ uint32_t s_n_all[WPB][512];
     __shared__ uint8_t s_q_all[WPB][512];
     // wave-uniform by construction: tell the compiler, so that the site state stays in scalar registers
@@ -495,6 +498,7 @@ __global__ __launch_bounds__(64 * WPB) void lrt_groups_kernel(int64_t n_sites, i
                                                         const uint8_t *__restrict__ taken,
                                                         bvc_group_result *__restrict__ grp_results)
 {
+    BVC_POISON_LDS();
     __shared__ uint32_t s_n_all[WPB][512];
     __shared__ uint8_t s_q_all[WPB][512];
     // wave-uniform by construction: tell the compiler, so that the site state stays in scalar registers
@@ -567,6 +571,7 @@ __global__ __launch_bounds__(64 * WPB) void lrt_groups_kernel(int64_t n_sites, i
 // var_qual = -10 log10(chisf(chi, 1)) for the records lrt_kernel left pending (src/BaseType.cpp:127-133).
 __global__ void var_qual_kernel(int64_t n_sites, bvc_site_result *__restrict__ results)
 {
+    BVC_POISON_LDS();
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_sites) return;
     if (!results[s].called || results[s].var_qual != kVarQualPending) return;
@@ -579,6 +584,7 @@ __global__ void var_qual_kernel(int64_t n_sites, bvc_site_result *__restrict__ r
 __global__ void sum_groups_kernel(int64_t total, int n_hist, const uint32_t *__restrict__ grp_counts,
                                   uint32_t *__restrict__ counts)
 {
+    BVC_POISON_LDS();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over n_sites * 512
     if (i >= total) return;
     const int64_t site = i / BVC_NCLASS;
@@ -594,6 +600,7 @@ __global__ void group_comb_kernel(int64_t n_pseudo, int n_groups, const int8_t *
                                   const bvc_site_result *__restrict__ overall, int8_t *__restrict__ comb,
                                   uint8_t *__restrict__ n_comb)
 {
+    BVC_POISON_LDS();
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pseudo) return;
     const int64_t site = p / n_groups;
@@ -615,6 +622,7 @@ __global__ void group_records_kernel(int64_t n_pseudo, int n_groups, const bvc_s
                                      const bvc_site_result *__restrict__ pseudo, const uint8_t *__restrict__ taken,
                                      bvc_group_result *__restrict__ grp_results)
 {
+    BVC_POISON_LDS();
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pseudo || !taken[p]) return;
     const int64_t site = p / n_groups;
@@ -636,6 +644,10 @@ __global__ void group_records_kernel(int64_t n_pseudo, int n_groups, const bvc_s
 }
 
 }  // namespace
+
+#ifdef BVC_CHECK_LDS
+BVC_DEFINE_DEBUG_READER(debug_read_wave_engine)
+#endif
 
 // Waves the EM kernels keep on the chip.  `shared` = the launch runs underneath a streaming histogram kernel
 // (overlap mode with long rows): 8 per CU = two 4-wave workgroups (swept 4..24 on MI355X at N = 1e6) leaves that

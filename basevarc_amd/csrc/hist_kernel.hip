@@ -56,7 +56,30 @@ __device__ __forceinline__ uint32_t lds_address(uint32_t *p) { return (uint32_t)
 
 __device__ __forceinline__ void lds_add_one(uint32_t lds_byte_address)
 {
+#ifdef BVC_CHECK_LDS
+    // the address was assembled from input bytes: inside this workgroup's allocation?
+    if (!BVC_LDS_OK(1, lds_byte_address, lds_bytes_of_workgroup() - 3u)) return;
+#endif
     __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)lds_byte_address, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// hist[idx] += 1 where idx was computed from a sample's bytes behind an explicit "covered?" test
+__device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t idx)
+{
+#ifdef BVC_CHECK_LDS
+    if (!BVC_LDS_OK(2, lds_address(hist) + (idx << 2), lds_bytes_of_workgroup() - 3u)) return;
+#endif
+    __hip_atomic_fetch_add(&hist[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ void lds_store(uint32_t lds_byte_address, uint32_t v)
+{
+    __hip_atomic_store((lds_u32 *)(uintptr_t)lds_byte_address, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ uint32_t lds_load(uint32_t lds_byte_address)
+{
+    return __hip_atomic_load((lds_u32 *)(uintptr_t)lds_byte_address, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // Workgroup barrier that orders LDS traffic only: the wave's LDS operations have completed (lgkmcnt) but its global
@@ -129,8 +152,7 @@ __device__ __forceinline__ void count_word_checked(uint32_t *__restrict__ hist, 
         const uint32_t b = (bw >> (8 * i)) & 0xFFu;
         const uint32_t q = (qw >> (8 * i)) & 0xFFu;
         if (b < 4u && q < 128u)                                   // covered sample
-            __hip_atomic_fetch_add(&hist[((b << 7) | q) * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            hist_add(hist, ((b << 7) | q) * kCopies + lane_off);
     }
 }
 
@@ -180,6 +202,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_kernel(
     int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *__restrict__ bases,
     const int8_t *__restrict__ quals, uint32_t *__restrict__ counts, int split)
 {
+    BVC_POISON_LDS();
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [class][copy]
     const int tid = threadIdx.x;
     const uint32_t lane_off = (uint32_t)(tid & (kCopies - 1));
@@ -229,8 +252,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_kernel(
                 for (int64_t i = cb * 16 + tid; i < i1; i += kHistThreads) {
                     const uint32_t b = (uint8_t)brow[i], q = (uint8_t)qrow[i];
                     if (b < 4u && q < 128u)
-                        __hip_atomic_fetch_add(&hist[((b << 7) | q) * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                        hist_add(hist, ((b << 7) | q) * kCopies + lane_off);
                 }
             }
         }
@@ -238,8 +260,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_kernel(
             for (int64_t i = (n16 << 4) + tid; i < n_samples; i += kHistThreads) {
                 const uint32_t b = (uint8_t)brow[i], q = (uint8_t)qrow[i];
                 if (b < 4u && q < 128u)
-                    __hip_atomic_fetch_add(&hist[((b << 7) | q) * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    hist_add(hist, ((b << 7) | q) * kCopies + lane_off);
             }
         }
         __syncthreads();
@@ -280,6 +301,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_bytes_kernel(
     const int8_t *__restrict__ quals, const uint8_t *__restrict__ group_of_sample, int n_groups, int log2c,
     uint32_t *__restrict__ grp_counts, const int64_t *__restrict__ bounds)
 {
+    BVC_POISON_LDS();
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     if (bounds && bounds[0] == 0) return;        // samples are ordered by group: hist_dense_ranges_kernel has the call
     const int tid = threadIdx.x;
@@ -295,8 +317,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_bytes_kernel(
             const uint32_t b = (uint8_t)brow[i], q = (uint8_t)qrow[i], g = group_of_sample[i];
             const uint32_t h = g < (uint32_t)n_groups ? g : (uint32_t)n_groups;
             if (b < 4u && q < 128u)
-                __hip_atomic_fetch_add(&hist[((h << (9 + log2c)) | (b << (7 + log2c)) | (q << log2c)) + lane_off], 1u,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                hist_add(hist, ((h << (9 + log2c)) | (b << (7 + log2c)) | (q << log2c)) + lane_off);
         }
         __syncthreads();
         for (int key = tid; key < n_hist * BVC_NCLASS; key += kHistThreads) {
@@ -368,6 +389,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
     const int8_t *__restrict__ quals, const uint8_t *__restrict__ hist_of_sample, int n_groups,
     uint32_t *__restrict__ grp_counts, const int64_t *__restrict__ bounds, const uint8_t *__restrict__ only)
 {
+    BVC_POISON_LDS();
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     if (bounds && bounds[0] == 0) return;        // samples are ordered by group: hist_dense_ranges_kernel has the call
     __builtin_amdgcn_s_setprio(3);               // as in hist_dense_kernel: ahead of the EM kernels it shares the chip with
@@ -382,8 +404,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
 
     auto add_checked = [&](uint32_t b, uint32_t q, uint32_t h) {
         if (b < 4u && q < 128u)
-            __hip_atomic_fetch_add(&hist[((h << (9 + LOG2C)) | (b << (7 + LOG2C)) | (q << LOG2C)) + lane_off], 1u,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            hist_add(hist, ((h << (9 + LOG2C)) | (b << (7 + LOG2C)) | (q << LOG2C)) + lane_off);
     };
     // the common case (every sample of the wave covered) skips the per-sample test, as in count_chunk
     auto count16 = [&](const u32x4 b, const u32x4 q, const u32x4 g) {
@@ -444,6 +465,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_groups_kernel(
 __global__ void group_bounds_kernel(const uint8_t *__restrict__ group_of_sample, int64_t n_samples, int n_groups,
                                     int64_t *__restrict__ scratch, uint8_t *__restrict__ hist_of_sample)
 {
+    BVC_POISON_LDS();
     const int n_hist = n_groups + 1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += (int64_t)gridDim.x * blockDim.x) {
         const int h = min((int)group_of_sample[i], n_groups);
@@ -465,6 +487,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_ranges_kernel(
     int64_t n_sites, int64_t n_samples, int64_t row_stride, const int8_t *__restrict__ bases,
     const int8_t *__restrict__ quals, int n_hist, const int64_t *__restrict__ scratch, uint32_t *__restrict__ grp_counts)
 {
+    BVC_POISON_LDS();
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [class][copy]
     (void)n_samples;
     if (scratch[0] != 0) return;
@@ -500,8 +523,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_dense_ranges_kernel(
         for (int64_t i = i0 + tid; i < i1; i += kHistThreads) {
             const uint32_t b = (uint8_t)brow[i], q = (uint8_t)qrow[i];
             if (b < 4u && q < 128u)
-                __hip_atomic_fetch_add(&hist[((b << 7) | q) * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                hist_add(hist, ((b << 7) | q) * kCopies + lane_off);
         }
     };
     // A work item is one (site, histogram) = one column range of one row.  The loads of the NEXT item's first block are
@@ -630,7 +652,7 @@ __device__ __forceinline__ void wave_count_range(uint32_t *__restrict__ hist, co
     const uint32_t copy = (uint32_t)lane & (kWaveCopies - 1);
     auto one = [&](uint32_t b, uint32_t q) {
         if (b < 4u && q < 128u)
-            __hip_atomic_fetch_add(&hist[((b << 7) | q) * kWaveCopies + copy], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            hist_add(hist, ((b << 7) | q) * kWaveCopies + copy);
     };
     auto scalar = [&](int64_t i0, int64_t i1) {
         for (int64_t i = i0 + lane; i < i1; i += 64) {
@@ -665,6 +687,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_wave_kernel(
     int64_t n_sites, const int64_t *__restrict__ offsets, int64_t n_samples, int64_t row_stride,
     const int8_t *__restrict__ bases, const int8_t *__restrict__ quals, uint32_t *__restrict__ counts)
 {
+    BVC_POISON_LDS();
     __shared__ __attribute__((aligned(16))) uint32_t hist_all[kCsrWaves][BVC_NCLASS * kWaveCopies];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -698,6 +721,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_csr_block_kernel(
     int64_t n_sites, const int64_t *__restrict__ offsets, const int8_t *__restrict__ bases,
     const int8_t *__restrict__ quals, uint32_t *__restrict__ counts)
 {
+    BVC_POISON_LDS();
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [class][copy]
     const int tid = threadIdx.x;
     const uint32_t lane_off = (uint32_t)(tid & (kCopies - 1));
@@ -711,8 +735,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_csr_block_kernel(
             if (PACKED) { q = b & 63u; b = q == 63u ? 0xFFu : b >> 6; }
             else q = (uint8_t)quals[i];
             if (b < 4u && q < 128u)
-                __hip_atomic_fetch_add(&hist[((b << 7) | q) * kCopies + lane_off], 1u, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                hist_add(hist, ((b << 7) | q) * kCopies + lane_off);
         }
     };
     for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
@@ -827,6 +850,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_packed_kernel(
     int64_t n_sites, int64_t n_samples, int64_t row_stride, const uint8_t *__restrict__ packed,
     uint32_t *__restrict__ counts, int split)
 {
+    BVC_POISON_LDS();
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [slot][copy], the kernel's only LDS: address 0
     const int tid = threadIdx.x;
     const uint32_t lane_base = lds_address(hist) + ((uint32_t)(tid & (kPackedCopies - 1)) << 2);
@@ -903,6 +927,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_packed_ranges_kernel(
     int64_t n_sites, int64_t row_stride, const uint8_t *__restrict__ packed, int n_hist,
     const int64_t *__restrict__ scratch, uint32_t *__restrict__ grp_counts)
 {
+    BVC_POISON_LDS();
     // [slot][copy] at LDS address 0 (the one-instruction counter address needs that: no static LDS in this kernel),
     // followed by the table of non-empty ranges
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
@@ -1013,6 +1038,7 @@ __global__ __launch_bounds__(THREADS) void hist_packed_groups_kernel(
     const uint8_t *__restrict__ hist_of_sample, int n_groups, uint32_t *__restrict__ grp_counts,
     const int64_t *__restrict__ bounds)
 {
+    BVC_POISON_LDS();
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     if (bounds[0] == 0) return;                                   // ordered by group: hist_packed_ranges_kernel has the call
     __builtin_amdgcn_s_setprio(3);
@@ -1093,6 +1119,7 @@ __global__ __launch_bounds__(1024) void hist_dense_groups_slots_kernel(
     const int8_t *__restrict__ quals, const uint8_t *__restrict__ hist_of_sample, int n_groups,
     uint32_t *__restrict__ grp_counts, const int64_t *__restrict__ bounds, uint8_t *__restrict__ redo)
 {
+    BVC_POISON_LDS();
     constexpr int THREADS = 1024;
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [hist][slot 256][copy 16], then one word: the site's flag
     if (bounds[0] == 0) return;                                   // ordered by group: hist_dense_ranges_kernel has the call
@@ -1100,12 +1127,14 @@ __global__ __launch_bounds__(1024) void hist_dense_groups_slots_kernel(
     const int tid = threadIdx.x;
     const int n_hist = n_groups + 1;
     const int words = (n_hist * kPackedSlots) << LOG2C;
-    volatile uint32_t *s_redo = &hist[words];
+    // the site's flag: one LDS word behind the histograms, reached through an LDS-typed address (ds_write_b32 / ds_read_b32;
+    // a volatile generic pointer would make these FLAT accesses through the LDS aperture)
+    const uint32_t redo_at = lds_address(hist) + ((uint32_t)words << 2);
     const uint32_t lane_off = (uint32_t)tid & ((1u << LOG2C) - 1u);
     const uint32_t lane_base = lds_address(hist) + (lane_off << 2);
     for (int i = tid * 4; i < words; i += THREADS * 4)
         *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
-    if (tid == 0) *s_redo = 0u;
+    if (tid == 0) lds_store(redo_at, 0u);
     __syncthreads();
     constexpr uint32_t SH = 2 + LOG2C;
     auto count_word = [&](uint32_t pw, uint32_t gw) {
@@ -1175,7 +1204,7 @@ __global__ __launch_bounds__(1024) void hist_dense_groups_slots_kernel(
         }
         for (int64_t i = (n16 << 4) + tid; i < n_samples; i += THREADS)
             count_sample((uint8_t)brow[i], (uint8_t)qrow[i], hist_of_sample[i]);
-        if (flagged) *s_redo = 1u;
+        if (flagged) lds_store(redo_at, 1u);
         flagged = false;
         __syncthreads();
         for (int key = tid; key < n_hist * BVC_NCLASS; key += THREADS) {
@@ -1188,7 +1217,7 @@ __global__ __launch_bounds__(1024) void hist_dense_groups_slots_kernel(
             }
             grp_counts[site * n_hist * BVC_NCLASS + key] = sum;
         }
-        if (tid == 0) { redo[site] = (uint8_t)*s_redo; *s_redo = 0u; }
+        if (tid == 0) { redo[site] = (uint8_t)lds_load(redo_at); lds_store(redo_at, 0u); }
         __syncthreads();
     }
 }
@@ -1199,6 +1228,7 @@ __global__ void pack_dense_kernel(int64_t n_sites, int64_t n_samples, int64_t st
                                   const int8_t *__restrict__ quals, int64_t stride_out, uint8_t *__restrict__ packed,
                                   unsigned long long *__restrict__ bad)
 {
+    BVC_POISON_LDS();
     const int64_t total = n_sites * n_samples;
     unsigned long long mine = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1219,6 +1249,7 @@ __global__ void pack_dense_kernel(int64_t n_sites, int64_t n_samples, int64_t st
 // loads, reads 6.38 and was below the kernel it is meant to cap).
 __global__ __launch_bounds__(512) void stream_read_kernel(const u32x4 *__restrict__ src, int64_t n16, uint32_t *__restrict__ sink)
 {
+    BVC_POISON_LDS();
     uint32_t acc = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1232,6 +1263,10 @@ __global__ __launch_bounds__(512) void stream_read_kernel(const u32x4 *__restric
 }
 
 }  // namespace
+
+#ifdef BVC_CHECK_LDS
+BVC_DEFINE_DEBUG_READER(debug_read_hist)
+#endif
 
 hipError_t launch_stream_read(hipStream_t stream, const void *src, int64_t bytes, uint32_t *sink)
 {

@@ -2,6 +2,7 @@
 // Integer arithmetic only, so any site can be regenerated bit for bit on the CPU by the test oracle
 // without ever storing or moving the tile.  Not part of the reference: it exists because the
 // benchmark configs (1e5 sites x 1e6 samples = 200 GB) can only be produced where they are consumed.
+#include "bvc_device.h"
 #include "bvc_internal.h"
 
 namespace bvc {
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(256) void synth_dense_kernel(uint64_t seed, int64_t
                                                           int8_t *__restrict__ bases, int8_t *__restrict__ quals,
                                                           int8_t *__restrict__ ref_base, int aligned)
 {
+    BVC_POISON_LDS();
     const int64_t s = blockIdx.y;
     const SiteParams p = site_params(seed, site0 + s);
     if (blockIdx.x == 0 && threadIdx.x == 0) ref_base[s] = (int8_t)p.ref;

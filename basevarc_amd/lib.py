@@ -186,6 +186,17 @@ class Context:
         return dict(hist_ms=p.hist_ms, em_ms=p.em_ms, hist_launches=p.hist_launches,
                     em_launches=p.em_launches, sites=p.sites)
 
+    def debug_report(self, reset=False):
+        """Diagnostic builds of the library only (-DBVC_CHECK_LDS, csrc/bvc_device.h): the recorded LDS bound violations as
+        {translation unit: [count, check id, value, limit, blockIdx.x, threadIdx.x]}; None with the product library."""
+        if not hasattr(self._L, "bvc_debug_report"):
+            return None
+        out = (C.c_uint32 * 24)()
+        self._L.bvc_debug_report.restype = C.c_int
+        self._L.bvc_debug_report.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
+        self._check(self._L.bvc_debug_report(self._h, out, int(bool(reset))))
+        return {tu: [int(x) for x in out[8 * i:8 * i + 6]] for i, tu in enumerate(("hist_kernel", "em_kernel", "em_items"))}
+
     # ---- host-pointer calls (numpy in, numpy structured array out)
     def lrt_dense(self, bases, quals, ref_base, min_af):
         b = np.ascontiguousarray(bases, dtype=np.int8)

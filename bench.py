@@ -324,6 +324,9 @@ def main():
         if a.groups > 0:
             out["verify_all"]["groups_tile0"] = verify_groups_tile(ctx, tiles, grp_results, group_t, call, min_af, a, np)
     if rank == 0:
+        rep = ctx.debug_report()
+        if rep is not None:                 # -DBVC_CHECK_LDS build (tools/poison_run.sh): never a measurement
+            out["diagnostic_build"] = {"lds_violations": rep, "note": "libbvc built with -DBVC_CHECK_LDS: timings are not the product's"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -2,7 +2,7 @@
 # Standard per-round capture on the GPU box: the default bench line (overlap) and a serial one, rocprofv3 kernel
 # stats of both, and PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_*) in serial mode for the three histogram kernels of the
 # dense entry points: plain, any-order groups, groups ordered by column.  usage: bash tools/profile_round.sh r02
-# Output under gpurun_out/<tag>/; `python tools/pmc_summary.py <tag> gpurun_out/<tag>/dense,gpurun_out/<tag>/groups_interleaved,gpurun_out/<tag>/groups_ordered`
+# Output under gpurun_out/<tag>/<part>_<time>/; `python tools/pmc_summary.py <tag> gpurun_out/<tag>/dense,gpurun_out/<tag>/groups_interleaved,gpurun_out/<tag>/groups_ordered`
 # (+ gpurun_out/<tag>/packed) turns the passes into profiles/<tag>_pmc_summary.md and profiles/pmc_traffic.json.
 set -e
 # A gpurun call is limited to 20 minutes: `bash tools/profile_round.sh r03 trace`, `... r03 pmc1`, `... r03 pmc2`, `... r03 align`
@@ -10,7 +10,8 @@ set -e
 TAG=${1:-rXX}
 PART=${2:-all}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/$TAG
+# every attempt of a part gets a directory of its own: a failing log is never overwritten by a retry
+O=$R/gpurun_out/$TAG/${PART}_$(date +%m%d_%H%M%S)
 mkdir -p $O
 cd $R
 if [ $PART = all ] || [ $PART = trace ]; then
