@@ -438,9 +438,15 @@ int bvc_create(bvc_ctx **out, int device)
         delete ctx;
         return BVC_ERR_ALLOC;
     }
-    bool ok = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&ctx->side_b, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&ctx->side_c, hipStreamNonBlocking) == hipSuccess &&
+    // Stage 2 runs on side streams underneath the histogram pass of the next call (overlap mode).  They get the LOWEST dispatch
+    // priority: when wave slots free up, the histogram kernel of the next call -- which the next stage 2 is waiting for -- goes
+    // first, instead of queueing behind two stage-2 launches that fill the chip (BVC_SIDE_PRIORITY=0: plain streams, A/B runs).
+    int prio_least = 0, prio_greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_least = 0; }
+    const int side_prio = env_int("BVC_SIDE_PRIORITY", 0, 1, 1) ? prio_least : 0;
+    bool ok = hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, side_prio) == hipSuccess &&
+              hipStreamCreateWithPriority(&ctx->side_b, hipStreamNonBlocking, side_prio) == hipSuccess &&
+              hipStreamCreateWithPriority(&ctx->side_c, hipStreamNonBlocking, side_prio) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&ctx->d_grp_scratch), kGroupScratchWords * sizeof(int64_t)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&ctx->d_sink), 256) == hipSuccess;

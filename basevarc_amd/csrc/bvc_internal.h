@@ -31,7 +31,7 @@ struct LaunchState {
                                // different order, so a site's last bits would depend on whether its five region neighbours are binned too
     int dbg_levels = 0;            // BVC_DBG_LEVELS (timing only, records wrong): cut region_kernel short after a phase; 0 = run all
     mutable uint32_t em_epoch = 0; // stage-2 launches of this context so far (em_items.hip: the narrow launch tells the wide one)
-    uint64_t attr_done = 0;    // kernels whose dynamic-LDS attribute has been raised on this context's device
+    mutable uint64_t attr_done = 0;    // kernels whose dynamic-LDS attribute has been raised on this context's device
 };
 
 // Base-quality -> likelihood table, built on the HOST with the same libm exp() the CPU path uses

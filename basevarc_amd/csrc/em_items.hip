@@ -1,7 +1,11 @@
 // em_items.hip -- stage 2 of the basetype path on gfx950, "item engine": the EM fits of a call are the work items,
-// several of them share a wavefront, and a workgroup takes a REGION of 8 sites through the whole likelihood-ratio
-// test in one launch: classes -> fits of the first level -> decisions -> fits of the next level -> ... with workgroup
-// barriers between the phases and every intermediate (class tables, fit descriptors and results, site state) in LDS.
+// eight of them share a wavefront, and ONE WAVEFRONT takes a REGION of 8 sites through the whole likelihood-ratio
+// test: classes -> fits of the first level -> decisions -> fits of the next level -> ... with every intermediate
+// (class tables, fit descriptors and results, site state) in the wavefront's own 11 KB of LDS.  No workgroup barrier
+// anywhere (round 3 gave a region to a workgroup of four wavefronts that met at a barrier after every phase: with five
+// wavefront-slots at the first level and three at the second for four wavefronts, and one wavefront per site in the site
+// phases, about half of the resident wavefronts were waiting at any time); the wavefronts of a workgroup are independent
+// and share nothing but the launch.
 //
 // Follows (paths under /root/reference), with the per-sample sums regrouped by class as in em_kernel.hip:
 //   BaseType::SetAlleleFreq  src/BaseType.cpp:25-39     -> site_emit
@@ -78,11 +82,12 @@ static_assert(sizeof(FitItem) == 64, "FitItem layout");
 
 struct FitOut {
     double ex[4];           // expect_allele_prob of the last pass, per unit
-    double ll;              // log-likelihood at the frequencies the last pass ran on (UpdateF, src/BaseType.cpp:58-62)
+    double fl[4];           // the frequencies that pass ran on, per unit (kept here, not in registers, until the epilogue)
+    double ll;              // log-likelihood at those frequencies (UpdateF, src/BaseType.cpp:58-62)
     int32_t passes;
     int32_t pad;
 };
-static_assert(sizeof(FitOut) == 48, "FitOut layout");
+static_assert(sizeof(FitOut) == 80, "FitOut layout");
 
 // Per-site state between the phases.
 struct ItemSite {
@@ -106,16 +111,16 @@ struct ItemSite {
 constexpr int kLists = 4;
 constexpr int kLevels = 3;
 #ifndef BVC_REGION_SITES
-#define BVC_REGION_SITES 8
+#define BVC_REGION_SITES 4
 #endif
 // sites of a workgroup.  8 x (full model + 4 subsets) = 32 + 8 fits: four full wavefronts and a full "slow" one, and the
 // two-allele level after it 16 + 8.  (6 sites -- 24 + 6 fits, one slot per wavefront -- leave the slow wavefronts a quarter
 // empty: the same time alone, 10 % slower underneath a histogram pass; 12 are too few regions per launch: 0.31 against
 // 0.23 ms per 4000 sites alone.  profiles/r03_region_sites.txt)
 constexpr int kRegionSites = BVC_REGION_SITES;
-constexpr int kRegionWaves = 4;
-// places of the region's item arrays per list: a site has at most 4 / 1 / 2 / 1 items in lists 0..3 at any level
-constexpr int kListAt[kLists + 1] = {0, 4 * kRegionSites, 5 * kRegionSites, 7 * kRegionSites, 8 * kRegionSites};
+// places of the region's item arrays: a site has at most five fits pending at any level (the full model and its four
+// subsets); the lists of a level lie one behind the other, their first places (Region::base) set per level
+constexpr int kPlaces = 5 * kRegionSites;
 
 // k-subsets of positions 0..n-1 in lexicographic order (what combs_ yields), as 4-bit position masks packed
 // least-significant first; count returned through `cnt`.
@@ -143,9 +148,18 @@ __device__ __forceinline__ int pick4i(const int32_t (&v)[4], int j)
 
 // Histogram of pseudo-site p: plain calls have one histogram per site; group calls run one pseudo-site per
 // (site, group) on the per-group histograms [site][n_groups + 1][512].
+// (32-bit division: a call has fewer than 2^31 / 64 sites, bvc_api.hip check_common, and at most 32 groups)
 __device__ __forceinline__ int64_t hist_index(int64_t p, int n_groups)
 {
-    return n_groups > 0 ? (p / n_groups) * (n_groups + 1) + p % n_groups : p;
+    if (n_groups <= 0) return p;
+    const uint32_t site = (uint32_t)p / (uint32_t)n_groups;
+    return (int64_t)site * (n_groups + 1) + ((uint32_t)p - site * (uint32_t)n_groups);
+}
+
+// Site whose reference base pseudo-site p compares its alleles with.
+__device__ __forceinline__ int64_t ref_index(int64_t p, int n_groups)
+{
+    return n_groups > 0 ? (int64_t)((uint32_t)p / (uint32_t)n_groups) : p;
 }
 
 template <class T>
@@ -187,24 +201,29 @@ __device__ __forceinline__ void count_wanted(uint32_t sets, int n_emit, int p_de
 template <int CPB>
 struct Region {
     ItemSite site[kRegionSites];
-    FitItem items[kListAt[kLists]];
-    FitOut outs[kListAt[kLists]];
+    FitItem items[kPlaces];
+    FitOut outs[kPlaces];
     int want[kRegionSites][kLists];
-    int count[kLists];
     int need;                                            // most class places a taken site of the region needs on an allele
-    int next_slot;                                       // wavefront-slots of the running level handed out so far
+    int next_slot;                                       // wavefront-slots of the running level handed out so far (teams of 2 or 4)
+    uint32_t arrive;                                     // team barrier: arrivals so far (never reset)
     alignas(8) uint8_t tab[kRegionSites][site_table_bytes<CPB>()];
 };
 
+// Two narrow regions fit the 32 KiB of LDS that two 64 KiB histogram workgroups leave on a CU (launch_lrt_items), four of any
+// kind one workgroup's dynamic LDS.
+static_assert(2 * sizeof(Region<kNarrow>) <= 32 * 1024 && 2 * sizeof(Region<kWide>) <= 32 * 1024, "stage 2 beside two histogram workgroups");
+static_assert(4 * sizeof(Region<kWide>) <= 64 * 1024, "a workgroup's regions");
+
 // Emits the fits S.sets of site `ls` of the region (wave-uniform): places from the prefix of `want` over the sites.
 template <class RegionT>
-__device__ __forceinline__ void site_emit(RegionT &R, int ls, int lane)
+__device__ __forceinline__ void site_emit(RegionT &R, int ls, int lane, const int (&first)[kLists])
 {
     ItemSite &S = R.site[ls];
     const uint32_t sets = S.sets;
     const int n_emit = S.n_emit, p_deepest = S.p_deepest;
     if (S.state != 1 || n_emit <= 0) return;
-    int at0 = kListAt[0], at1 = kListAt[1], at2 = kListAt[2], at3 = kListAt[3];
+    int at0 = first[0], at1 = first[1], at2 = first[2], at3 = first[3];
     for (int w = 0; w < ls; ++w) { at0 += R.want[w][0]; at1 += R.want[w][1]; at2 += R.want[w][2]; at3 += R.want[w][3]; }
     const int total_i = S.depth[0] + S.depth[1] + S.depth[2] + S.depth[3];
     const double inv_n = 1.0 / (double)total_i;
@@ -242,7 +261,7 @@ __device__ __forceinline__ void site_emit(RegionT &R, int ls, int lane)
         fi.e_excl = (double)(total_i - depth_sum);
         fi.inv_n = inv_n;
         fi.ll_excl = ll_excl;
-        if (lane == 0 && BVC_LDS_OK(11, idx - kListAt[l], kListAt[l + 1] - kListAt[l])) { R.items[idx] = fi; S.item[c] = idx; }
+        if (lane == 0 && BVC_LDS_OK(11, idx, kPlaces)) { R.items[idx] = fi; S.item[c] = idx; }
     }
 }
 
@@ -284,26 +303,23 @@ __device__ __forceinline__ void store_record(bvc_site_result *dst, const ItemSit
     *dst = r;
 }
 
-// ---- site_classes: one wavefront per site ------------------------------------------------------------------------
+// ---- site_classes: the wavefront, one site at a time (its 512 class counts already in registers: cnt8) --------------
 // Compacts the non-empty classes of each allele (ascending quality) into the site's table: class c of allele b at
 // [b][c], its count and its quality (e = eps / 3 comes from the context's table; empty places: n = 0 and the index of
 // e = 1/4, whose marginal f + (1 - 4 f) e is 1/4 whatever f: weight 0 in every sum and harmless in the product of a
 // lane's marginals).  Then the head of BaseType::LRT (src/BaseType.cpp:75-88): candidates by min_af, and the first
 // level's fits: the full model and, because they depend on nothing but the candidate list, its (n-1)-subsets.
 template <int CPB>
-__device__ __forceinline__ void site_classes(Region<CPB> &R, int ls, int lane, int64_t site, int n_groups,
-                                             const uint32_t *__restrict__ counts, int64_t hist_stride,
-                                             const QualLut *__restrict__ lut,
-                                             const int8_t *__restrict__ ref_base, double min_af,
-                                             const int8_t *__restrict__ comb, const uint8_t *__restrict__ n_comb,
-                                             uint8_t *__restrict__ taken, bvc_site_result *__restrict__ results)
+__device__ __forceinline__ int site_classes(Region<CPB> &R, int ls, int lane, int64_t site, const uint32_t (&cnt8)[8],
+                                            const QualLut *__restrict__ lut, double min_af,
+                                            const int8_t *__restrict__ comb, const uint8_t *__restrict__ n_comb,
+                                            uint8_t *__restrict__ taken)
 {
     const int row = lane >> 4, t = lane & 15;
     ItemSite S{};
     uint32_t sets = 0;
     int n_emit = 0, p_deepest = 0;
     bool finished = false;
-    const uint32_t *hist = counts + hist_index(site, n_groups) * hist_stride;
     uint32_t *tab_n = reinterpret_cast<uint32_t *>(R.tab[ls]) + row * CPB;
     uint8_t *tab_q = R.tab[ls] + 16 * CPB + row * CPB;
     int cnt_row = 0, depth_lane = 0;
@@ -312,7 +328,7 @@ __device__ __forceinline__ void site_classes(Region<CPB> &R, int ls, int lane, i
 #pragma unroll
     for (int lvl = 0; lvl < 8; ++lvl) {
         const int q = t + 16 * lvl;
-        const uint32_t c = hist[row * 128 + q];
+        const uint32_t c = cnt8[lvl];
         const uint64_t nzmask = __ballot(c != 0);
         const uint32_t rowbits = (uint32_t)(nzmask >> (16 * row)) & 0xFFFFu;
         if (c != 0) {
@@ -377,7 +393,6 @@ __device__ __forceinline__ void site_classes(Region<CPB> &R, int ls, int lane, i
         }
     }
     const bool mine = !(too_wide || any_low || dup);
-    if (mine && lane == 0) atomicMax(&R.need, need);
     S.blist = blist; S.n = (int8_t)n; S.k = (int8_t)n; S.first = 1;
     S.state = mine ? 1 : 0;
     if (mine) {
@@ -398,13 +413,13 @@ __device__ __forceinline__ void site_classes(Region<CPB> &R, int ls, int lane, i
     S.sets = sets; S.n_emit = (int8_t)n_emit; S.p_deepest = (int8_t)p_deepest;
     int want[kLists];
     count_wanted(sets, n_emit, p_deepest, want);
-    (void)ref_base; (void)results;
     if (lane == 0) {
         if (finished) S.state = 3;                               // record pending: written by the kernel that owns the region
         R.site[ls] = S;
         R.want[ls][0] = want[0]; R.want[ls][1] = want[1]; R.want[ls][2] = want[2]; R.want[ls][3] = want[3];
         taken[site] = mine ? 1 : 0;
     }
+    return mine ? need : 0;                                      // most class places on an allele of a site the engine takes
 }
 
 // ---- the fits: 64 / (ROWS * G) items per wavefront -----------------------------------------------------------------
@@ -501,20 +516,26 @@ __device__ __forceinline__ void fit_body(int item0, int item_end, const FitItem 
 {
     constexpr int G = 1 << LOG2G, kSlots = CPB / G;
     constexpr int kGroupsPerRow = 16 / G;
-    const int lane = threadIdx.x & (kWave - 1);
+    // (opaque to the optimiser: what is derived from the lane id below is then recomputed in every slot -- a handful of
+    // integer instructions -- instead of being kept in registers across the levels of the region, which the narrow kernel's
+    // 168 VGPRs have no room for)
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & (kWave - 1);
     const int row = lane >> 4, sub = lane & (G - 1), grp = (lane & 15) >> LOG2G;
     const int unit = ROWS == 4 ? row : (row & 1);
     const int item = item0 + (ROWS == 4 ? grp : (row >> 1) * kGroupsPerRow + grp);
-    const bool valid = item < item_end && BVC_LDS_OK(12, item, kListAt[kLists]);
+    const bool valid = item < item_end && BVC_LDS_OK(12, item, kPlaces);
 
     double n[kSlots], e[kSlots];
-    double fb = 0.0, e_excl = 0.0, fb_scale = 0.0;
+    double fb = 0.0;
     bool active = false;
+    // the fit's two constants are read from its descriptor in every pass (two LDS loads that have the whole pass to arrive)
+    // instead of living in four registers: the narrow kernel sits at the 168 VGPRs of three wavefronts per SIMD
+    const FitItem *fi_c = items + (valid ? item : item0);
     if (valid) {
         const FitItem *fi = items + item;
         const int base = fi->base[unit];
-        e_excl = fi->e_excl;
-        fb_scale = fi->inv_n;
         if (base != 0xFF && BVC_LDS_OK(13, fi->site, kRegionSites) && BVC_LDS_OK(14, base, 4)) {
             active = true;
             fb = fi->f0[unit];
@@ -536,12 +557,13 @@ __device__ __forceinline__ void fit_body(int item0, int item_end, const FitItem 
     // EM (src/Algorithm.cpp:115-130): pass 0, then at most kEmIters passes each followed by the stop rule.  An item
     // that stops writes its fit at once and runs on (its lanes are not masked: the passes of a converged fit are
     // ordinary arithmetic, and nothing of it is read again).
-    double fprev = fb, dprev = 0.0, fl = fb;
+    double fprev = fb, dprev = 0.0;
     int it = 0;
     bool done = !valid;
     while (true) {
         // stop-rule bracket of THIS pass: A = sum_b |f_b - f_b(previous pass)| D_b(previous pass), lane partial
         double ta = fabs(fb - fprev) * dprev;
+        const double e_excl = fi_c->e_excl, fb_scale = fi_c->inv_n;
         const double g = fma(-4.0, fb, 1.0);
         double ysum0 = 0.0, ysum1 = 0.0, acc_e0 = 0.0, acc_e1 = 0.0;
 #ifdef BVC_RCP_CHUNK
@@ -603,10 +625,10 @@ __device__ __forceinline__ void fit_body(int item0, int item_end, const FitItem 
         }
         const bool stop = !done && (conv || it == kEmIters);
         if (__ballot(stop) != 0) {
-            if (stop) fl = fb;                                   // the frequency this last pass ran on
             if (stop && sub == 0) {
                 FitOut *o = outs + item;
                 o->ex[unit] = active ? ex : 0.0;
+                o->fl[unit] = fb;                                // the frequency this last pass ran on
                 if (ROWS == 2) o->ex[unit + 2] = 0.0;
                 if (unit == 0) { o->passes = it + 1; o->pad = 0; }
             }
@@ -621,10 +643,16 @@ __device__ __forceinline__ void fit_body(int item0, int item_end, const FitItem 
     // UpdateF's log-likelihood (src/BaseType.cpp:58-62) at the frequencies of each item's last pass: the lane's
     // classes here, the alleles outside the subset from the item's constant
     {
+        const double fl = outs[valid ? item : item0].fl[unit];   // (a place that holds no item: its sum is never stored)
         const double g = fma(-4.0, fl, 1.0);
         double ll = 0.0;
 #pragma unroll
-        for (int k = 0; k < kSlots; ++k) ll = fma(n[k], log_pos(fma(g, e[k], fl)), ll);
+        for (int k = 0; k < kSlots; ++k) {
+            ll = fma(n[k], log_pos(fma(g, e[k], fl)), ll);
+            // four logarithms side by side are enough to fill the pipeline; all sixteen at once cost registers the kernel
+            // does not have at three wavefronts per SIMD
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
         ll = item_sum<ROWS, LOG2G>(ll);
         if (valid && unit == 0 && sub == 0) outs[item].ll = ll + items[item].ll_excl;
     }
@@ -636,6 +664,15 @@ __device__ __forceinline__ void fit_body(int item0, int item_end, const FitItem 
 constexpr int kLog2G4 = 1, kLog2G2 = 2;
 template <int CPB> constexpr int log2g4() { return CPB == kTiny ? 0 : kLog2G4; }
 template <int CPB> constexpr int log2g2() { return CPB == kTiny ? 1 : kLog2G2; }
+// The SLOW lists (fits that leave out the deepest allele: one per site and level) take twice the lanes per allele, four
+// items per wavefront: a region's few slow fits then fill their wavefront-slot, which costs two thirds of a fast one per pass,
+// instead of leaving half of a full-price slot empty.  Fixed per list, whatever the region size: a fit's arithmetic (which
+// lane holds which class, the order of the sums) must never depend on how the caller cut its tiles.
+#ifndef BVC_SLOW_EXTRA_LOG2G
+#define BVC_SLOW_EXTRA_LOG2G 1
+#endif
+template <int CPB> constexpr int log2g4s() { return log2g4<CPB>() + BVC_SLOW_EXTRA_LOG2G; }
+template <int CPB> constexpr int log2g2s() { return log2g2<CPB>() + BVC_SLOW_EXTRA_LOG2G; }
 
 // ---- site_decide: one wavefront per site, one level of BaseType::LRT -------------------------------------------------
 // Reads the fits of the pending level, takes the reference's decision (src/BaseType.cpp:93-110) and either sets up
@@ -655,7 +692,7 @@ __device__ __forceinline__ void site_decide(RegionT &R, int ls, int lane, int64_
 
     auto fit_loglik = [&](int idx, uint32_t pm, double (&ex)[4], int &passes) -> double {
         (void)pm;
-        if (!BVC_LDS_OK(15, idx, kListAt[kLists])) idx = 0;
+        if (!BVC_LDS_OK(15, idx, kPlaces)) idx = 0;
         const FitOut &o = R.outs[idx];
 #pragma unroll
         for (int u = 0; u < 4; ++u) ex[u] = o.ex[u];
@@ -741,7 +778,7 @@ __device__ __forceinline__ void site_decide(RegionT &R, int ls, int lane, int64_
     count_wanted(sets, n_emit, p_deepest, want);
     if (lane == 0) {
         if (finished) {
-            store_record(results + site, S, (int)ref_base[n_groups > 0 ? site / n_groups : site], S.n, S.blist);
+            store_record(results + site, S, (int)ref_base[ref_index(site, n_groups)], S.n, S.blist);
             S.state = 2;
         }
         R.site[ls] = S;
@@ -749,7 +786,7 @@ __device__ __forceinline__ void site_decide(RegionT &R, int ls, int lane, int64_
     }
 }
 
-// ---- region_kernel: one workgroup of four wavefronts per region of eight sites ---------------------------------------
+// ---- region kernels: one WAVEFRONT per region of eight sites -------------------------------------------------------------
 struct RegionArgs {
     int64_t n_sites;
     int n_groups;
@@ -768,137 +805,216 @@ struct RegionArgs {
     int tiny_regions;            // LaunchState::em_tiny_regions
 };
 
+// Orders the wavefront's own LDS traffic around a point: everything a region keeps in LDS is private to its wavefront, the
+// other wavefronts of the workgroup work on other regions and are never waited for.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// The 512 class counts of a site as the lanes of site_classes hold them: lane (row, t) has qualities t, t + 16, ... of allele `row`.
+__device__ __forceinline__ void load_counts(uint32_t (&c)[8], const uint32_t *__restrict__ counts, int64_t hist_stride, int64_t site,
+                                            int n_groups, int lane)
+{
+    const uint32_t *hist = counts + hist_index(site, n_groups) * hist_stride + (lane >> 4) * 128 + (lane & 15);
+#pragma unroll
+    for (int lvl = 0; lvl < 8; ++lvl) c[lvl] = hist[16 * lvl];
+}
+
 // A region belongs to ONE launch by the most class places any of its sites needs on an allele: <= 32 narrow, <= 48 wide
 // (and, with LaunchState::em_tiny_regions, <= 8 tiny).  The narrow and the wide kernel place class c of an allele in the
 // same lane and slot and add in the same order (the wide one's extra slots are empty for a narrow site and add exact
 // zeros; rcp_all<24> is rcp_all<16> on the first sixteen), so a site's record does not depend on which of the two its
-// region went to, i.e. not on its neighbours.  The tiny kernel (one lane per allele) adds in another order: opt-in.  Each runs the classes phase of the regions it looks at and goes on only with its own; the
-// narrow launch comes first, and the other two return at once when it has met no region of theirs in this call.
-template <bool WALK, int CPB>
-__device__ __forceinline__ void region_body(Region<CPB> &R, const RegionArgs &A)
+// region went to, i.e. not on its neighbours.  The tiny kernel (one lane per allele) adds in another order: opt-in.  Each
+// runs the classes phase of the regions it looks at and goes on only with its own; the narrow launch comes first, and the
+// other two return at once when it has met no region of theirs in this call.
+//
+// The wavefront's slots of a level -- eight fits each -- run one after the other, the slow lists first (their fits run to the
+// iteration cap whatever the site, so they share wavefront-passes with their like); a slot lasts as long as its slowest fit.
+// TEAM wavefronts share a region (1, 2 or 4; a workgroup holds 4 / TEAM regions): they split the site phases by site and the
+// fit phases by wavefront-slot (an LDS counter hands the slots out, the slow lists first), and meet at a team barrier between
+// the phases.  The barrier is an arrival counter in the region's LDS, never reset (phase p is over when it reads p * TEAM):
+// only the region's own wavefronts wait for one another, the rest of the workgroup is never involved.
+template <int TEAM, class RegionT>
+__device__ __forceinline__ void team_sync(RegionT &R, uint32_t &phase, int lane)
+{
+    if (TEAM == 1) { wave_sync(); return; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    phase += TEAM;
+    if (lane == 0) {
+        __hip_atomic_fetch_add(&R.arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&R.arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - phase > 0x7FFFFFFFu) __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <bool WALK, int CPB, int TEAM>
+__device__ __forceinline__ void region_body(Region<CPB> *regions, const RegionArgs &A)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int teams = (int)(blockDim.x >> 6) / TEAM;             // regions a workgroup works on at a time
+    const int member = wave % TEAM;
     const int lane = threadIdx.x & (kWave - 1);
+    Region<CPB> &R = regions[wave / TEAM];
     const int64_t n_sites = A.n_sites;
     const int64_t n_regions = (n_sites + kRegionSites - 1) / kRegionSites;
     // the narrow launch comes first and stamps these words when it meets a region for one of the others
     if (CPB == kWide && A.kind_epoch[1] != A.epoch) return;
     if (CPB == kTiny && A.kind_epoch[0] != A.epoch) return;
-    // one region per workgroup when the launch has the chip to itself (the dispatcher balances them); underneath a
-    // streaming histogram pass the launcher bounds the grid and a workgroup walks several regions
-    for (int64_t region = blockIdx.x; region < n_regions; region += WALK ? (int64_t)gridDim.x : n_regions) {
-    const int64_t site0 = region * kRegionSites;
-    if (threadIdx.x == 0) R.need = 0;
-    __syncthreads();
-    for (int ls = wave; ls < kRegionSites; ls += kRegionWaves) {
-        if (site0 + ls < n_sites) {
-            site_classes<CPB>(R, ls, lane, site0 + ls, A.n_groups, A.counts, A.hist_stride, A.lut, A.ref_base, A.min_af, A.comb,
-                              A.n_comb, A.taken, A.results);
-        } else if (lane == 0) {
-            R.site[ls].state = 2; R.site[ls].n_emit = 0;
-            R.want[ls][0] = 0; R.want[ls][1] = 0; R.want[ls][2] = 0; R.want[ls][3] = 0;
-        }
+    uint32_t phase = 0;
+    if (TEAM > 1) {
+        if (member == 0 && lane == 0) R.arrive = 0u;
+        __syncthreads();                                         // the only workgroup barrier: once, before any team barrier
     }
-    __syncthreads();
-    // whose region this is (uniform over the workgroup): tiny when every taken site has at most kTiny class places per
-    // allele, wide when some site has more than kNarrow, narrow otherwise
-    const int need = R.need;
-    const int kind = (A.tiny_regions && need <= kTiny) ? kTiny : (need <= kNarrow ? kNarrow : kWide);
-    if (CPB == kNarrow && kind != kNarrow && threadIdx.x == 0) A.kind_epoch[kind == kWide ? 1 : 0] = A.epoch;
-    if (kind == CPB) {
-    // records of the sites that ended in the classes phase (no observation, no candidate)
-    for (int ls = wave; ls < kRegionSites; ls += kRegionWaves)
-        if (lane == 0 && R.site[ls].state == 3) {
-            const int64_t site = site0 + ls;
-            store_record(A.results + site, R.site[ls], (int)A.ref_base[A.n_groups > 0 ? site / A.n_groups : site], R.site[ls].n,
-                         R.site[ls].blist);
-            R.site[ls].state = 2;
+    // team t of workgroup b walks regions b * teams + t, + gridDim.x * teams, ...: one region per team when the launch has the
+    // chip to itself, several underneath a streaming histogram pass, where the launcher bounds the grid
+    // (WALK = false: the launcher gives every team exactly one region; without the loop nothing is kept live across regions,
+    // which is what lets the narrow kernel hold three wavefronts per SIMD)
+    for (int64_t region = (int64_t)blockIdx.x * teams + wave / TEAM; region < n_regions; region += WALK ? (int64_t)gridDim.x * teams : n_regions) {
+        const int64_t site0 = region * kRegionSites;
+        if (member == 0 && lane == 0) { R.need = 0; R.next_slot = 0; }
+        if (TEAM > 1) team_sync<TEAM>(R, phase, lane);
+        // ---- classes: a member's sites one after the other, the next site's counts in flight while the current one is compacted
+        int need = 0;
+        uint32_t cnext[8];
+        if (site0 + member < n_sites) load_counts(cnext, A.counts, A.hist_stride, site0 + member, A.n_groups, lane);
+#pragma unroll 1
+        for (int ls = member; ls < kRegionSites; ls += TEAM) {
+            uint32_t c8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c8[k] = cnext[k];
+            if (ls + TEAM < kRegionSites && site0 + ls + TEAM < n_sites) load_counts(cnext, A.counts, A.hist_stride, site0 + ls + TEAM, A.n_groups, lane);
+            if (site0 + ls < n_sites) {
+                need = max(need, site_classes<CPB>(R, ls, lane, site0 + ls, c8, A.lut, A.min_af, A.comb, A.n_comb, A.taken));
+            } else if (lane == 0) {
+                R.site[ls].state = 2; R.site[ls].n_emit = 0;
+                R.want[ls][0] = 0; R.want[ls][1] = 0; R.want[ls][2] = 0; R.want[ls][3] = 0;
+            }
         }
-    for (int level = 0; level < kLevels && level < (A.dbg_levels >> 1); ++level) {
-        // the fits of this level, side by side in site order in each list
-        for (int ls = wave; ls < kRegionSites; ls += kRegionWaves) site_emit(R, ls, lane);
-        if (threadIdx.x < kLists) {
-            int tot = 0;
-            for (int w = 0; w < kRegionSites; ++w) tot += R.want[w][threadIdx.x];
-            R.count[threadIdx.x] = tot;
-            if (threadIdx.x == 0) R.next_slot = 0;
+        if (TEAM > 1) {
+            if (lane == 0) atomicMax(&R.need, need);
+            team_sync<TEAM>(R, phase, lane);
+            need = R.need;
+        } else {
+            wave_sync();
         }
-        __syncthreads();
-        const int c0 = R.count[0], c1 = R.count[1], c2 = R.count[2], c3 = R.count[3];
-        if (c0 + c1 + c2 + c3 == 0) break;                       // (uniform over the workgroup)
-        constexpr int kPerWave4 = 16 >> log2g4<CPB>(), kPerWave2 = 2 * (16 >> log2g2<CPB>());
-        // wavefront-slots of the level, the slow lists first: a region of eight full sites has five slots at its first
-        // level, and the wavefront that gets a second one should not be the one that runs the 101 passes of the slow fits.
-        // A wavefront takes the next slot when it is done with its last (LDS counter).
-        const int w1 = (c1 + kPerWave4 - 1) / kPerWave4, w3 = w1 + (c3 + kPerWave2 - 1) / kPerWave2;
-        const int w0 = w3 + (c0 + kPerWave4 - 1) / kPerWave4, w2 = w0 + (c2 + kPerWave2 - 1) / kPerWave2;
-        for (;;) {
+        // whose region this is: tiny when every taken site has at most kTiny class places per allele, wide when some site
+        // has more than kNarrow, narrow otherwise
+        const int kind = (A.tiny_regions && need <= kTiny) ? kTiny : (need <= kNarrow ? kNarrow : kWide);
+        if (CPB == kNarrow && kind != kNarrow && member == 0 && lane == 0) A.kind_epoch[kind == kWide ? 1 : 0] = A.epoch;
+        if (kind != CPB) {                                       // (the whole team: `need` is the region's)
+            if (TEAM > 1) team_sync<TEAM>(R, phase, lane);       // nobody rewrites R.need before everybody has read it
+            continue;
+        }
+        // records of the sites that ended in the classes phase (no observation, no candidate)
+        if (member == 0 && lane < kRegionSites && R.site[lane].state == 3) {
+            const int64_t site = site0 + lane;
+            store_record(A.results + site, R.site[lane], (int)A.ref_base[ref_index(site, A.n_groups)], R.site[lane].n,
+                         R.site[lane].blist);
+            R.site[lane].state = 2;
+        }
+        team_sync<TEAM>(R, phase, lane);
+        for (int level = 0; level < kLevels && level < (A.dbg_levels >> 1); ++level) {
+            // the fits of this level: list after list, each in site order
+            int cnt[kLists] = {0, 0, 0, 0};
+#pragma unroll
+            for (int w = 0; w < kRegionSites; ++w) {
+#pragma unroll
+                for (int l = 0; l < kLists; ++l) cnt[l] += R.want[w][l];
+            }
+            if (cnt[0] + cnt[1] + cnt[2] + cnt[3] == 0) break;   // (the same LDS words for the whole team)
+            const int first[kLists] = {0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2]};
+            if (!BVC_LDS_OK(16, first[3] + cnt[3], kPlaces + 1)) break;
+#pragma unroll 1
+            for (int ls = member; ls < kRegionSites; ls += TEAM) site_emit(R, ls, lane, first);
+            team_sync<TEAM>(R, phase, lane);
+            constexpr int kPerWave4 = 16 >> log2g4<CPB>(), kPerWave2 = 2 * (16 >> log2g2<CPB>());
+            constexpr int kPerWave4s = 16 >> log2g4s<CPB>(), kPerWave2s = 2 * (16 >> log2g2s<CPB>());
+            const FitItem *items = R.items;
+            FitOut *outs = R.outs;
+            const uint8_t *tabs = &R.tab[0][0];
+            const double *lut_e = A.lut->e;
+            // slots of the level, the slow lists first (the wavefront that gets a second slot should not be the one that runs the
+            // 101 passes of the slow fits): w1 of list 1, then list 3, list 0, list 2
+            const int w1 = (cnt[1] + kPerWave4s - 1) / kPerWave4s, w3 = w1 + (cnt[3] + kPerWave2s - 1) / kPerWave2s;
+            const int w0 = w3 + (cnt[0] + kPerWave4 - 1) / kPerWave4, w2 = w0 + (cnt[2] + kPerWave2 - 1) / kPerWave2;
             int slot = 0;
-            if (lane == 0) slot = atomicAdd(&R.next_slot, 1);
-            slot = __builtin_amdgcn_readfirstlane(slot);
-            if (slot >= w2) break;
-            const int l = slot < w1 ? 1 : (slot < w3 ? 3 : (slot < w0 ? 0 : 2));
-            const int in_list = slot - (l == 1 ? 0 : (l == 3 ? w1 : (l == 0 ? w3 : w0)));
-            const int base = l == 0 ? kListAt[0] : (l == 1 ? kListAt[1] : (l == 2 ? kListAt[2] : kListAt[3]));
-            const int cnt = l == 0 ? c0 : (l == 1 ? c1 : (l == 2 ? c2 : c3));
-            if (!BVC_LDS_OK(16, cnt, (l == 0 ? kListAt[1] : (l == 1 ? kListAt[2] : (l == 2 ? kListAt[3] : kListAt[4]))) - base + 1)) break;
-            if (l < 2) fit_body<4, log2g4<CPB>(), CPB>(base + in_list * kPerWave4, base + cnt, R.items, R.outs, &R.tab[0][0], A.lut->e);
-            else fit_body<2, log2g2<CPB>(), CPB>(base + in_list * kPerWave2, base + cnt, R.items, R.outs, &R.tab[0][0], A.lut->e);
+#pragma unroll 1
+            for (;;) {
+                if (TEAM > 1) {
+                    if (lane == 0) slot = atomicAdd(&R.next_slot, 1);
+                    slot = __builtin_amdgcn_readfirstlane(slot);
+                }
+                if (slot >= w2) break;
+                const int l = slot < w1 ? 1 : (slot < w3 ? 3 : (slot < w0 ? 0 : 2));
+                const int in_list = slot - (l == 1 ? 0 : (l == 3 ? w1 : (l == 0 ? w3 : w0)));
+                const int base = l == 0 ? first[0] : (l == 1 ? first[1] : (l == 2 ? first[2] : first[3]));
+                const int end = base + (l == 0 ? cnt[0] : (l == 1 ? cnt[1] : (l == 2 ? cnt[2] : cnt[3])));
+                if (l == 0) fit_body<4, log2g4<CPB>(), CPB>(base + in_list * kPerWave4, end, items, outs, tabs, lut_e);
+                else if (l == 2) fit_body<2, log2g2<CPB>(), CPB>(base + in_list * kPerWave2, end, items, outs, tabs, lut_e);
+                else if (BVC_SLOW_EXTRA_LOG2G == 0 && l == 1) fit_body<4, log2g4<CPB>(), CPB>(base + in_list * kPerWave4, end, items, outs, tabs, lut_e);
+                else if (BVC_SLOW_EXTRA_LOG2G == 0) fit_body<2, log2g2<CPB>(), CPB>(base + in_list * kPerWave2, end, items, outs, tabs, lut_e);
+                else if (l == 1) fit_body<4, log2g4s<CPB>(), CPB>(base + in_list * kPerWave4s, end, items, outs, tabs, lut_e);
+                else fit_body<2, log2g2s<CPB>(), CPB>(base + in_list * kPerWave2s, end, items, outs, tabs, lut_e);
+                if (TEAM == 1) ++slot;
+            }
+            team_sync<TEAM>(R, phase, lane);
+            if (TEAM > 1 && member == 0 && lane == 0) R.next_slot = 0;      // nobody takes a slot again before the barrier behind the next emit
+            if (level + 1 == (A.dbg_levels >> 1) && (A.dbg_levels & 1)) break;
+#pragma unroll 1
+            for (int ls = member; ls < kRegionSites; ls += TEAM)
+                if (site0 + ls < n_sites) site_decide(R, ls, lane, site0 + ls, A.n_groups, A.ref_base, A.results);
+            team_sync<TEAM>(R, phase, lane);
         }
-        __syncthreads();
-        if (level + 1 == (A.dbg_levels >> 1) && (A.dbg_levels & 1)) break;
-        for (int ls = wave; ls < kRegionSites; ls += kRegionWaves)
-            if (site0 + ls < n_sites) site_decide(R, ls, lane, site0 + ls, A.n_groups, A.ref_base, A.results);
-        __syncthreads();
-    }
-    }
-    __syncthreads();                                             // the region's LDS is reused by the next one
+        team_sync<TEAM>(R, phase, lane);                         // the region's LDS is reused by the next one
     }
 }
 
-// One region per workgroup: three workgroups (12 wavefronts) per CU.
-#ifdef BVC_RCP_CHUNK
-#define BVC_REGION_WAVES_PER_EU 4
-#else
-#define BVC_REGION_WAVES_PER_EU 3
-#endif
 // (diagnostic builds carry extra code: no occupancy target there, so that they do not spill where the product does not)
 #if defined(BVC_CHECK_LDS) || defined(BVC_POISON)
 #define BVC_OCCUPANCY(n)
 #else
 #define BVC_OCCUPANCY(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
-__global__ __launch_bounds__(64 * kRegionWaves) BVC_OCCUPANCY(BVC_REGION_WAVES_PER_EU) void region_kernel(RegionArgs A)
+#ifdef BVC_RCP_CHUNK
+#define BVC_REGION_WAVES_PER_EU 4
+#else
+#define BVC_REGION_WAVES_PER_EU 3
+#endif
+constexpr int kMaxRegionWaves = 4;               // wavefronts of a workgroup (4 / team regions in dynamic LDS)
+#ifndef BVC_REGION_TEAM
+#define BVC_REGION_TEAM 1
+#endif
+constexpr int kTeam = BVC_REGION_TEAM;          // wavefronts that share a region
+
+// The launch has the chip to itself, one region per wavefront: three narrow wavefronts per SIMD (168 VGPRs), two wide ones.
+__global__ __launch_bounds__(64 * kMaxRegionWaves) BVC_OCCUPANCY(BVC_REGION_WAVES_PER_EU) void region_kernel(RegionArgs A)
 {
     BVC_POISON_LDS();
-    __shared__ Region<kNarrow> R;
-    region_body<false, kNarrow>(R, A);
+    extern __shared__ __attribute__((aligned(16))) unsigned char region_lds[];
+    region_body<false, kNarrow, kTeam>(reinterpret_cast<Region<kNarrow> *>(region_lds), A);
 }
 
-// A bounded grid whose workgroups walk the regions (underneath a streaming histogram pass: one workgroup per CU).
-__global__ __launch_bounds__(64 * kRegionWaves) void region_walk_kernel(RegionArgs A)
+__global__ __launch_bounds__(64 * kMaxRegionWaves) BVC_OCCUPANCY(2) void region_wide_kernel(RegionArgs A)
 {
     BVC_POISON_LDS();
-    __shared__ Region<kNarrow> R;
-    region_body<true, kNarrow>(R, A);
+    extern __shared__ __attribute__((aligned(16))) unsigned char region_lds[];
+    region_body<false, kWide, kTeam>(reinterpret_cast<Region<kWide> *>(region_lds), A);
 }
 
-// The same for the regions whose sites have at most 8 quality values per allele (binned qualities): one lane per allele,
-// 16 four-allele fits per wavefront; the grid walks the regions.
-__global__ __launch_bounds__(64 * kRegionWaves) void region_tiny_kernel(RegionArgs A)
+// Underneath a streaming histogram pass: a few wavefronts per CU walk the regions; no occupancy target (no register pressure).
+// CPB = 32 narrow, 48 wide (a site of 33..48 quality values on an allele: 24 classes per lane), 8 tiny (binned qualities: one
+// lane per allele, 16 four-allele fits per wavefront; opt-in).
+template <int CPB>
+__global__ __launch_bounds__(64 * kMaxRegionWaves) void region_walk_kernel(RegionArgs A)
 {
     BVC_POISON_LDS();
-    __shared__ Region<kTiny> R;
-    region_body<true, kTiny>(R, A);
-}
-
-// The same for the regions with a site of 33..48 quality values on an allele (24 classes per lane: two wavefronts per
-// SIMD); the grid walks the regions.
-__global__ __launch_bounds__(64 * kRegionWaves) BVC_OCCUPANCY(2) void region_wide_kernel(RegionArgs A)
-{
-    BVC_POISON_LDS();
-    __shared__ Region<kWide> R;
-    region_body<true, kWide>(R, A);
+    extern __shared__ __attribute__((aligned(16))) unsigned char region_lds[];
+    region_body<true, CPB, kTeam>(reinterpret_cast<Region<CPB> *>(region_lds), A);
 }
 
 }  // namespace
@@ -921,15 +1037,29 @@ hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n
 {
     uint8_t *taken = static_cast<uint8_t *>(scratch);
     const int64_t regions = (n_sites + kRegionSites - 1) / kRegionSites;
-    // underneath a streaming histogram pass (overlap mode, long rows): ONE workgroup (four wavefronts) per CU.  The
-    // fits are dense FP64 work; at two workgroups per CU they take the histogram kernel from 1.18 to 1.34 ms per call
-    // and the packed one from 0.63 to 0.77, at one they leave both at their stand-alone speed and still finish well
-    // inside the histogram pass (profiles/r03_stage2_cap_under_hist.txt)
-    // (the knob counts wavefronts per CU: 4 = one workgroup on every CU, 2 = one on every other CU, 8 = two per CU)
-    int64_t grid = regions;
-    const int waves_per_cu = st.em_waves_per_cu > 0 ? st.em_waves_per_cu : (shared ? kRegionWaves : 0);
-    const int64_t cap = waves_per_cu > 0 ? std::max<int64_t>(1, (int64_t)waves_per_cu * st.n_cu / kRegionWaves) : 0;
-    if (cap > 0 && grid > cap) grid = cap;
+    // Wavefronts per workgroup and workgroups.  A wavefront is a region's whole engine, so the shape of the launch is free:
+    //  * the chip to itself: as many wavefronts per workgroup (<= 4: one per SIMD) as leave every CU a workgroup -- a 4000-site
+    //    call is 500 regions = 250 workgroups of two -- one region per wavefront, the dispatcher balances;
+    //  * underneath a streaming histogram pass (overlap mode, long rows): ONE workgroup per CU that walks the regions.  The
+    //    histogram kernels keep two 64 KiB workgroups on a CU, which leaves 32 KiB of its LDS: two wavefronts (2 x 11 KB).
+    //    They finish well inside the histogram pass and leave it its stand-alone speed (profiles/r04_stage2_wave_regions.txt).
+    // em_waves_per_cu (bvc_set_tuning) overrides: resident stage-2 wavefronts per CU.
+    int per_cu = 0;
+    if (st.em_waves_per_cu > 0) per_cu = st.em_waves_per_cu;
+    else if (shared) per_cu = 4;
+    constexpr int kMaxTeams = kMaxRegionWaves / kTeam;           // regions a workgroup can work on at a time
+    int teams;
+    int64_t grid;
+    if (per_cu > 0) {
+        const int want_teams = std::max(1, per_cu / kTeam);
+        teams = std::min(want_teams, kMaxTeams);
+        grid = (int64_t)st.n_cu * ((want_teams + teams - 1) / teams);
+        if (grid * teams > regions) grid = (regions + teams - 1) / teams;
+    } else {
+        teams = (int)std::min<int64_t>(kMaxTeams, std::max<int64_t>(1, (regions + st.n_cu - 1) / st.n_cu));
+        grid = (regions + teams - 1) / teams;
+    }
+    const int waves = teams * kTeam;
     RegionArgs A;
     A.n_sites = n_sites; A.n_groups = n_groups; A.counts = counts; A.hist_stride = hist_stride; A.lut = lut;
     A.ref_base = ref_base; A.min_af = min_af; A.comb = comb; A.n_comb = n_comb; A.taken = taken; A.results = results;
@@ -938,16 +1068,27 @@ hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n
     if (A.epoch == 0) A.epoch = ++st.em_epoch;
     A.dbg_levels = st.dbg_levels > 0 ? st.dbg_levels : 2 * kLevels;
     A.tiny_regions = st.em_tiny_regions;
-    if (grid < regions) hipLaunchKernelGGL(region_walk_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, A);
-    else hipLaunchKernelGGL(region_kernel, dim3((unsigned)grid), dim3(64 * kRegionWaves), 0, stream, A);
-    int64_t wide_grid = cap > 0 ? cap : (int64_t)2 * st.n_cu;
-    if (wide_grid > regions) wide_grid = regions;
-    if (st.em_tiny_regions) {
-        int64_t tiny_grid = cap > 0 ? cap : (int64_t)5 * st.n_cu;
-        if (tiny_grid > regions) tiny_grid = regions;
-        hipLaunchKernelGGL(region_tiny_kernel, dim3((unsigned)tiny_grid), dim3(64 * kRegionWaves), 0, stream, A);
+    const dim3 block(64 * waves), g((unsigned)grid);
+    // the wide kernels' dynamic LDS (4 x 13.4 KB) is beyond the 48 KiB a launch may ask for without the attribute
+    constexpr uint32_t kSlotRegionWide = 60;
+    if (!(st.attr_done & ((uint64_t)1 << kSlotRegionWide))) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(region_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(kMaxRegionWaves * sizeof(Region<kWide>)));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(region_walk_kernel<kWide>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kMaxRegionWaves * sizeof(Region<kWide>)));
+        if (e != hipSuccess) return e;
+        st.attr_done |= (uint64_t)1 << kSlotRegionWide;
     }
-    hipLaunchKernelGGL(region_wide_kernel, dim3((unsigned)wide_grid), dim3(64 * kRegionWaves), 0, stream, A);
+    if (per_cu > 0) {
+        hipLaunchKernelGGL(region_walk_kernel<kNarrow>, g, block, teams * sizeof(Region<kNarrow>), stream, A);
+        if (st.em_tiny_regions) hipLaunchKernelGGL(region_walk_kernel<kTiny>, g, block, teams * sizeof(Region<kTiny>), stream, A);
+        hipLaunchKernelGGL(region_walk_kernel<kWide>, g, block, teams * sizeof(Region<kWide>), stream, A);
+    } else {                                                     // grid * waves >= regions: one region per wavefront
+        hipLaunchKernelGGL(region_kernel, g, block, teams * sizeof(Region<kNarrow>), stream, A);
+        if (st.em_tiny_regions) hipLaunchKernelGGL(region_walk_kernel<kTiny>, g, block, teams * sizeof(Region<kTiny>), stream, A);
+        hipLaunchKernelGGL(region_wide_kernel, g, block, teams * sizeof(Region<kWide>), stream, A);
+    }
     *taken_out = taken;
     return hipGetLastError();
 }
