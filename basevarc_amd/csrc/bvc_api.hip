@@ -22,26 +22,26 @@ struct bvc_ctx {
     // [sites][512] scratch between the two stages.  Overlap mode cycles through kRing buffers: with three, the
     // histogram pass of call i+1 waits only for the EM of call i-2 (long finished), never for the one running
     // beside it, so both streams run back to back.
-    static constexpr int kRing = 3;
-    uint32_t *d_cnt[kRing] = {nullptr, nullptr, nullptr};
-    size_t cnt_cap[kRing] = {0, 0, 0};
+    static constexpr int kRing = 4;
+    uint32_t *d_cnt[kRing] = {};
+    size_t cnt_cap[kRing] = {};
     // overlap mode: stage 2 of call i runs on `side` while stage 1 of call i+1 streams on `stream`
     bool overlap = false;
     hipStream_t side = nullptr;        // stage 2 of even calls
     hipStream_t side_b = nullptr, side_c = nullptr;   // further stage-2 streams (two_em_streams below)
     unsigned side_flip = 0;
     int flip = 0;
-    hipEvent_t ev_hist_done[kRing] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_em_done[kRing] = {nullptr, nullptr, nullptr};
-    bool em_pending[kRing] = {false, false, false};
-    uint32_t *d_grp[kRing] = {nullptr, nullptr, nullptr};   // [sites][groups + 1][512] in group mode
-    size_t grp_cap[kRing] = {0, 0, 0};
+    hipEvent_t ev_hist_done[kRing] = {};
+    hipEvent_t ev_em_done[kRing] = {};
+    bool em_pending[kRing] = {};
+    uint32_t *d_grp[kRing] = {};   // [sites][groups + 1][512] in group mode
+    size_t grp_cap[kRing] = {};
     // item-engine scratch of stage 2 (em_items.hip), one per ring buffer (the stage 2 of consecutive calls may run
     // side by side); the last one serves bvc_lrt_hist on the context's own stream
-    void *d_em[kRing + 1] = {nullptr, nullptr, nullptr, nullptr};
-    size_t em_cap[kRing + 1] = {0, 0, 0, 0};
-    void *d_emg[kRing] = {nullptr, nullptr, nullptr};      // the same for the (site, group) pseudo-sites of group calls
-    size_t emg_cap[kRing] = {0, 0, 0};
+    void *d_em[kRing + 1] = {};
+    size_t em_cap[kRing + 1] = {};
+    void *d_emg[kRing] = {};      // the same for the (site, group) pseudo-sites of group calls
+    size_t emg_cap[kRing] = {};
     uint32_t *d_sink = nullptr;        // 256 bytes: sink of the streaming-read measurement kernel; bvc_pack_dense's counter at byte 64
     uint8_t *d_grp_labels = nullptr;   // group mode: the call's group vector clamped to 0..n_groups (hist_kernel.hip)
     size_t grp_labels_cap = 0;

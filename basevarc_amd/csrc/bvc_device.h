@@ -66,6 +66,13 @@ __device__ __forceinline__ void poison_lds()
 #define BVC_POISON_LDS() do { } while (0)
 #endif
 
+// Occupancy targets are for the product: the diagnostic builds carry extra code and must not spill where the product does not.
+#if defined(BVC_CHECK_LDS) || defined(BVC_POISON)
+#define BVC_WAVES_PER_EU(lo, hi)
+#else
+#define BVC_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#endif
+
 // ---- cross-lane movement -------------------------------------------------------------------------
 // DPP controls (ISA: quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141)
 constexpr int kDppXor1 = 0xB1;     // quad_perm [1,0,3,2]

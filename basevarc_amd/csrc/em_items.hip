@@ -111,7 +111,7 @@ struct ItemSite {
 constexpr int kLists = 4;
 constexpr int kLevels = 3;
 #ifndef BVC_REGION_SITES
-#define BVC_REGION_SITES 4
+#define BVC_REGION_SITES 8
 #endif
 // sites of a workgroup.  8 x (full model + 4 subsets) = 32 + 8 fits: four full wavefronts and a full "slow" one, and the
 // two-allele level after it 16 + 8.  (6 sites -- 24 + 6 fits, one slot per wavefront -- leave the slow wavefronts a quarter
@@ -669,7 +669,7 @@ template <int CPB> constexpr int log2g2() { return CPB == kTiny ? 1 : kLog2G2; }
 // instead of leaving half of a full-price slot empty.  Fixed per list, whatever the region size: a fit's arithmetic (which
 // lane holds which class, the order of the sums) must never depend on how the caller cut its tiles.
 #ifndef BVC_SLOW_EXTRA_LOG2G
-#define BVC_SLOW_EXTRA_LOG2G 1
+#define BVC_SLOW_EXTRA_LOG2G 0
 #endif
 template <int CPB> constexpr int log2g4s() { return log2g4<CPB>() + BVC_SLOW_EXTRA_LOG2G; }
 template <int CPB> constexpr int log2g2s() { return log2g2<CPB>() + BVC_SLOW_EXTRA_LOG2G; }
@@ -683,7 +683,11 @@ __device__ __forceinline__ void site_decide(RegionT &R, int ls, int lane, int64_
 {
     ItemSite S = R.site[ls];
     if (S.state != 1) {
-        if (lane == 0) { R.want[ls][0] = 0; R.want[ls][1] = 0; R.want[ls][2] = 0; R.want[ls][3] = 0; R.site[ls].n_emit = 0; }
+        // (an opaque zero: the optimiser otherwise builds the 16 bytes of zeros once per kernel, keeps them in four registers
+        // across the fits of every level and, at the narrow kernel's 168 VGPRs, spills them to scratch)
+        int zero = 0;
+        asm volatile("" : "+v"(zero));
+        if (lane == 0) { R.want[ls][0] = zero; R.want[ls][1] = zero; R.want[ls][2] = zero; R.want[ls][3] = zero; R.site[ls].n_emit = 0; }
         return;
     }
     uint32_t sets = 0;
@@ -803,6 +807,7 @@ struct RegionArgs {
     uint32_t epoch;
     int dbg_levels;
     int tiny_regions;            // LaunchState::em_tiny_regions
+    int64_t region0;             // first region of this launch (a call may be a sequence of launches)
 };
 
 // Orders the wavefront's own LDS traffic around a point: everything a region keeps in LDS is private to its wavefront, the
@@ -870,11 +875,12 @@ __device__ __forceinline__ void region_body(Region<CPB> *regions, const RegionAr
         if (member == 0 && lane == 0) R.arrive = 0u;
         __syncthreads();                                         // the only workgroup barrier: once, before any team barrier
     }
-    // team t of workgroup b walks regions b * teams + t, + gridDim.x * teams, ...: one region per team when the launch has the
-    // chip to itself, several underneath a streaming histogram pass, where the launcher bounds the grid
-    // (WALK = false: the launcher gives every team exactly one region; without the loop nothing is kept live across regions,
-    // which is what lets the narrow kernel hold three wavefronts per SIMD)
-    for (int64_t region = (int64_t)blockIdx.x * teams + wave / TEAM; region < n_regions; region += WALK ? (int64_t)gridDim.x * teams : n_regions) {
+    // team t of workgroup b takes region region0 + b * teams + t.  WALK = false: exactly that one -- the launcher sizes the
+    // grid, or cuts the call into a sequence of launches when stage 2 may hold only a few wavefronts per CU -- and without a
+    // loop nothing is kept live across regions, which is what lets the narrow kernel hold three wavefronts per SIMD (168
+    // VGPRs; the walking form needs 257).  WALK = true (experiments only): + gridDim.x * teams, ... to the end.
+    int64_t region = A.region0 + (int64_t)blockIdx.x * teams + wave / TEAM;
+    for (bool first = true; region < n_regions && (WALK || first); first = false, region += (int64_t)gridDim.x * teams) {
         const int64_t site0 = region * kRegionSites;
         if (member == 0 && lane == 0) { R.need = 0; R.next_slot = 0; }
         if (TEAM > 1) team_sync<TEAM>(R, phase, lane);
@@ -975,11 +981,7 @@ __device__ __forceinline__ void region_body(Region<CPB> *regions, const RegionAr
 }
 
 // (diagnostic builds carry extra code: no occupancy target there, so that they do not spill where the product does not)
-#if defined(BVC_CHECK_LDS) || defined(BVC_POISON)
-#define BVC_OCCUPANCY(n)
-#else
-#define BVC_OCCUPANCY(n) __attribute__((amdgpu_waves_per_eu(n, n)))
-#endif
+#define BVC_OCCUPANCY(n) BVC_WAVES_PER_EU(n, n)
 #ifdef BVC_RCP_CHUNK
 #define BVC_REGION_WAVES_PER_EU 4
 #else
@@ -987,34 +989,19 @@ __device__ __forceinline__ void region_body(Region<CPB> *regions, const RegionAr
 #endif
 constexpr int kMaxRegionWaves = 4;               // wavefronts of a workgroup (4 / team regions in dynamic LDS)
 #ifndef BVC_REGION_TEAM
-#define BVC_REGION_TEAM 1
+#define BVC_REGION_TEAM 2
 #endif
 constexpr int kTeam = BVC_REGION_TEAM;          // wavefronts that share a region
 
-// The launch has the chip to itself, one region per wavefront: three narrow wavefronts per SIMD (168 VGPRs), two wide ones.
-__global__ __launch_bounds__(64 * kMaxRegionWaves) BVC_OCCUPANCY(BVC_REGION_WAVES_PER_EU) void region_kernel(RegionArgs A)
-{
-    BVC_POISON_LDS();
-    extern __shared__ __attribute__((aligned(16))) unsigned char region_lds[];
-    region_body<false, kNarrow, kTeam>(reinterpret_cast<Region<kNarrow> *>(region_lds), A);
-}
-
-__global__ __launch_bounds__(64 * kMaxRegionWaves) BVC_OCCUPANCY(2) void region_wide_kernel(RegionArgs A)
-{
-    BVC_POISON_LDS();
-    extern __shared__ __attribute__((aligned(16))) unsigned char region_lds[];
-    region_body<false, kWide, kTeam>(reinterpret_cast<Region<kWide> *>(region_lds), A);
-}
-
-// Underneath a streaming histogram pass: a few wavefronts per CU walk the regions; no occupancy target (no register pressure).
-// CPB = 32 narrow, 48 wide (a site of 33..48 quality values on an allele: 24 classes per lane), 8 tiny (binned qualities: one
-// lane per allele, 16 four-allele fits per wavefront; opt-in).
+// One region per team of the launch: three narrow (or tiny) wavefronts per SIMD (168 VGPRs), two wide ones (24 classes per lane).
+// CPB = 32 narrow, 48 wide (a site of 33..48 quality values on an allele), 8 tiny (binned qualities: one lane per allele, 16
+// four-allele fits per wavefront; opt-in).
 template <int CPB>
-__global__ __launch_bounds__(64 * kMaxRegionWaves) void region_walk_kernel(RegionArgs A)
+__global__ __launch_bounds__(64 * kMaxRegionWaves) BVC_OCCUPANCY(CPB == kWide ? 2 : BVC_REGION_WAVES_PER_EU) void region_kernel(RegionArgs A)
 {
     BVC_POISON_LDS();
     extern __shared__ __attribute__((aligned(16))) unsigned char region_lds[];
-    region_body<true, CPB, kTeam>(reinterpret_cast<Region<CPB> *>(region_lds), A);
+    region_body<false, CPB, kTeam>(reinterpret_cast<Region<CPB> *>(region_lds), A);
 }
 
 }  // namespace
@@ -1037,29 +1024,30 @@ hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n
 {
     uint8_t *taken = static_cast<uint8_t *>(scratch);
     const int64_t regions = (n_sites + kRegionSites - 1) / kRegionSites;
-    // Wavefronts per workgroup and workgroups.  A wavefront is a region's whole engine, so the shape of the launch is free:
-    //  * the chip to itself: as many wavefronts per workgroup (<= 4: one per SIMD) as leave every CU a workgroup -- a 4000-site
-    //    call is 500 regions = 250 workgroups of two -- one region per wavefront, the dispatcher balances;
-    //  * underneath a streaming histogram pass (overlap mode, long rows): ONE workgroup per CU that walks the regions.  The
-    //    histogram kernels keep two 64 KiB workgroups on a CU, which leaves 32 KiB of its LDS: two wavefronts (2 x 11 KB).
-    //    They finish well inside the histogram pass and leave it its stand-alone speed (profiles/r04_stage2_wave_regions.txt).
-    // em_waves_per_cu (bvc_set_tuning) overrides: resident stage-2 wavefronts per CU.
+    // A team of wavefronts is a region's whole engine, so the shape of the launch is free:
+    //  * the chip to itself: as many teams per workgroup (<= 4 wavefronts: one per SIMD) as leave every CU a workgroup, one
+    //    region per team, the dispatcher balances;
+    //  * underneath a streaming histogram pass (overlap mode, long rows): at most ONE workgroup (four wavefronts) per CU at a
+    //    time -- a call is cut into a sequence of launches of n_cu workgroups (a 4000-site call is one launch of 250).  The
+    //    histogram kernels keep two 64 KiB workgroups on a CU, which leaves 32 KiB of its LDS (4 x 5.5 KB here) and, beside four
+    //    packed-histogram wavefronts of 64 VGPRs per SIMD, room for one narrow wavefront of 168.
+    // em_waves_per_cu (bvc_set_tuning) overrides: stage-2 wavefronts per CU and launch.
     int per_cu = 0;
     if (st.em_waves_per_cu > 0) per_cu = st.em_waves_per_cu;
     else if (shared) per_cu = 4;
     constexpr int kMaxTeams = kMaxRegionWaves / kTeam;           // regions a workgroup can work on at a time
     int teams;
-    int64_t grid;
+    int64_t wgs, per_launch;
     if (per_cu > 0) {
         const int want_teams = std::max(1, per_cu / kTeam);
         teams = std::min(want_teams, kMaxTeams);
-        grid = (int64_t)st.n_cu * ((want_teams + teams - 1) / teams);
-        if (grid * teams > regions) grid = (regions + teams - 1) / teams;
+        wgs = (regions + teams - 1) / teams;
+        per_launch = (int64_t)st.n_cu * ((want_teams + teams - 1) / teams);
     } else {
         teams = (int)std::min<int64_t>(kMaxTeams, std::max<int64_t>(1, (regions + st.n_cu - 1) / st.n_cu));
-        grid = (regions + teams - 1) / teams;
+        wgs = (regions + teams - 1) / teams;
+        per_launch = wgs;
     }
-    const int waves = teams * kTeam;
     RegionArgs A;
     A.n_sites = n_sites; A.n_groups = n_groups; A.counts = counts; A.hist_stride = hist_stride; A.lut = lut;
     A.ref_base = ref_base; A.min_af = min_af; A.comb = comb; A.n_comb = n_comb; A.taken = taken; A.results = results;
@@ -1068,27 +1056,29 @@ hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n
     if (A.epoch == 0) A.epoch = ++st.em_epoch;
     A.dbg_levels = st.dbg_levels > 0 ? st.dbg_levels : 2 * kLevels;
     A.tiny_regions = st.em_tiny_regions;
-    const dim3 block(64 * waves), g((unsigned)grid);
-    // the wide kernels' dynamic LDS (4 x 13.4 KB) is beyond the 48 KiB a launch may ask for without the attribute
+    A.region0 = 0;
+    // the wide kernels' dynamic LDS (4 x 14 KB) is beyond the 48 KiB a launch may ask for without the attribute
     constexpr uint32_t kSlotRegionWide = 60;
     if (!(st.attr_done & ((uint64_t)1 << kSlotRegionWide))) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(region_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(kMaxRegionWaves * sizeof(Region<kWide>)));
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(region_walk_kernel<kWide>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(kMaxRegionWaves * sizeof(Region<kWide>)));
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(region_kernel<kWide>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)(kMaxTeams * sizeof(Region<kWide>)));
         if (e != hipSuccess) return e;
         st.attr_done |= (uint64_t)1 << kSlotRegionWide;
     }
-    if (per_cu > 0) {
-        hipLaunchKernelGGL(region_walk_kernel<kNarrow>, g, block, teams * sizeof(Region<kNarrow>), stream, A);
-        if (st.em_tiny_regions) hipLaunchKernelGGL(region_walk_kernel<kTiny>, g, block, teams * sizeof(Region<kTiny>), stream, A);
-        hipLaunchKernelGGL(region_walk_kernel<kWide>, g, block, teams * sizeof(Region<kWide>), stream, A);
-    } else {                                                     // grid * waves >= regions: one region per wavefront
-        hipLaunchKernelGGL(region_kernel, g, block, teams * sizeof(Region<kNarrow>), stream, A);
-        if (st.em_tiny_regions) hipLaunchKernelGGL(region_walk_kernel<kTiny>, g, block, teams * sizeof(Region<kTiny>), stream, A);
-        hipLaunchKernelGGL(region_wide_kernel, g, block, teams * sizeof(Region<kWide>), stream, A);
-    }
+    const dim3 block(64 * teams * kTeam);
+    auto sequence = [&](auto kernel, size_t lds_per_team) {
+        for (int64_t w0 = 0; w0 < wgs; w0 += per_launch) {
+            A.region0 = w0 * teams;
+            hipLaunchKernelGGL(kernel, dim3((unsigned)std::min(per_launch, wgs - w0)), block, teams * lds_per_team, stream, A);
+        }
+        A.region0 = 0;
+    };
+    sequence(region_kernel<kNarrow>, sizeof(Region<kNarrow>));
+    if (st.em_tiny_regions) sequence(region_kernel<kTiny>, sizeof(Region<kTiny>));
+    // (A probe instead of the wide grid -- 32 single-wavefront workgroups that walk the regions, full grids only while a host-visible
+    // hint says recent calls had wide regions -- was built and measured in round 4: no gain, its wavefronts need MORE than half a
+    // SIMD's registers (268 VGPRs against 254) and wait for room just like the grid it replaces.  profiles/r04_stage2_teams.txt)
+    sequence(region_kernel<kWide>, sizeof(Region<kWide>));
     *taken_out = taken;
     return hipGetLastError();
 }

@@ -716,8 +716,16 @@ __global__ __launch_bounds__(kHistThreads) void hist_wave_kernel(
     }
 }
 
+// A long ragged site is 1e4-1e5 observations: a handful of load blocks, so what a site costs is not its bytes but the
+// round trips to memory it waits for one after the other.  Round 3 had five or six of them per site (its two offsets, the
+// unaligned head sample by sample, every block's loads before that block's counting, the tail) and read at 0.49 of the HBM
+// peak; here the next site's offsets are loaded while the current site is counted, head and tail (at most 15 observations
+// each) are loaded with the first block and counted last, and the loads of block k + 1 are issued before block k is counted.
+// (At most 80 VGPRs: the kernel shares the chip with two stage-2 launches of the calls before it, whose wavefronts hold 168
+// VGPRs each; a 512-thread workgroup needs two wavefronts on every SIMD of a CU at once, and 2 x 80 fit beside two of those
+// where 2 x 100 would wait for one of them to retire.)
 template <bool ALIGNED, bool PACKED = false>
-__global__ __launch_bounds__(kHistThreads) void hist_csr_block_kernel(
+__global__ __launch_bounds__(kHistThreads) BVC_WAVES_PER_EU(6, 8) void hist_csr_block_kernel(
     int64_t n_sites, const int64_t *__restrict__ offsets, const int8_t *__restrict__ bases,
     const int8_t *__restrict__ quals, uint32_t *__restrict__ counts)
 {
@@ -729,83 +737,105 @@ __global__ __launch_bounds__(kHistThreads) void hist_csr_block_kernel(
     for (int i = tid * 4; i < kLdsWords; i += kHistThreads * 4)
         *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
+    // one observation given as the two-byte kernels see it (PACKED: the byte decoded first)
+    auto one = [&](uint32_t b, uint32_t q) {
+        if (PACKED) { q = b & 63u; b = q == 63u ? 0xFFu : b >> 6; }
+        if (b < 4u && q < 128u) hist_add(hist, ((b << 7) | q) * kCopies + lane_off);
+    };
     auto scalar = [&](int64_t i0, int64_t i1) {
-        for (int64_t i = i0 + tid; i < i1; i += kHistThreads) {
-            uint32_t b = (uint8_t)bases[i], q;
-            if (PACKED) { q = b & 63u; b = q == 63u ? 0xFFu : b >> 6; }
-            else q = (uint8_t)quals[i];
-            if (b < 4u && q < 128u)
-                hist_add(hist, ((b << 7) | q) * kCopies + lane_off);
+        for (int64_t i = i0 + tid; i < i1; i += kHistThreads) one((uint8_t)bases[i], PACKED ? 0u : (uint32_t)(uint8_t)quals[i]);
+    };
+    constexpr int64_t kBlockChunks = (int64_t)kUnroll * kHistThreads;
+    const u32x4 *bv = reinterpret_cast<const u32x4 *>(bases);
+    const u32x4 *qv = reinterpret_cast<const u32x4 *>(quals);
+    const u32x4 kSkip = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // "no observation" in either form
+    // chunks [cb, cb + kBlockChunks) of a site's whole chunks [0, nc) (32-bit indices relative to the site's first chunk):
+    // whole blocks load without a test
+    auto fetch = [&](const u32x4 *sb, const u32x4 *sq, uint32_t cb, uint32_t nc, u32x4 (&b)[kUnroll], u32x4 (&q)[kUnroll]) {
+        if (cb + (uint32_t)kBlockChunks <= nc) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                b[u] = __builtin_nontemporal_load(&sb[cb + (uint32_t)tid + (uint32_t)u * kHistThreads]);
+                if (!PACKED) q[u] = __builtin_nontemporal_load(&sq[cb + (uint32_t)tid + (uint32_t)u * kHistThreads]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const uint32_t c = cb + (uint32_t)tid + (uint32_t)u * kHistThreads;
+                b[u] = kSkip; q[u] = u32x4{0u, 0u, 0u, 0u};
+                if (c < nc) {
+                    b[u] = __builtin_nontemporal_load(&sb[c]);
+                    if (!PACKED) q[u] = __builtin_nontemporal_load(&sq[c]);
+                }
+            }
         }
     };
-    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
-        const int64_t s0 = offsets[site], s1 = offsets[site + 1];
-        if (s1 - s0 < kCsrLong) continue;                        // hist_wave_kernel's (workgroup-uniform)
-        if (PACKED) {
-            // one array: the chunks of a block loaded, unpacked into the two-byte kernels' base and qual words, counted
+    auto count = [&](uint32_t cb, uint32_t nc, const u32x4 (&b)[kUnroll], const u32x4 (&q)[kUnroll]) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const uint32_t wave_first = cb + (uint32_t)(tid & ~63) + (uint32_t)u * kHistThreads;  // wave-uniform
+            if (wave_first >= nc) continue;                        // lanes past the end carry "no observation" and are skipped one by one
+            if (PACKED) {
+                u32x4 ub, uq;
+                unpack_chunk(b[u], ub, uq);
+                count_chunk(hist, ub, uq, lane_off);
+            } else {
+                count_chunk(hist, b[u], q[u], lane_off);
+            }
+        }
+    };
+
+    int64_t site = blockIdx.x;
+    int64_t s0 = 0, s1 = 0;
+    if (site < n_sites) { s0 = offsets[site]; s1 = offsets[site + 1]; }
+    while (site < n_sites) {
+        const int64_t next = site + gridDim.x;
+        int64_t n0 = 0, n1 = 0;
+        if (next < n_sites) { n0 = offsets[next]; n1 = offsets[next + 1]; }        // arrive while this site is counted
+        if (s1 - s0 >= kCsrLong) {                                   // shorter ones: hist_wave_kernel's (workgroup-uniform)
+            // [s0, s1) = unaligned head, whole 16-observation chunks [c0, c1) of the concatenated arrays, unaligned tail
             const int64_t c0 = (s0 + 15) >> 4, c1 = s1 >> 4;
             if (ALIGNED && c0 < c1) {
-                scalar(s0, c0 << 4);
-                const u32x4 *pv = reinterpret_cast<const u32x4 *>(bases);
-                for (int64_t cb = c0; cb < c1; cb += (int64_t)kUnroll * kHistThreads) {
-                    u32x4 v[kUnroll];
+                const u32x4 *sb = bv + c0, *sq = qv + c0;
+                const uint32_t nc = (uint32_t)(c1 - c0);
+                u32x4 b[kUnroll], q[kUnroll], nb[kUnroll], nq[kUnroll];
+                fetch(sb, sq, 0u, nc, b, q);
+                // head and tail: at most 15 observations each, one per lane of the first 16; their loads travel with the first block's
+                if (tid < 16) {
+                    const int64_t hi = s0 + tid, ti = (c1 << 4) + tid;
+                    uint32_t hb = 0xFFu, hq = 0u, tb = 0xFFu, tq = 0u;
+                    if (hi < (c0 << 4)) { hb = (uint8_t)bases[hi]; if (!PACKED) hq = (uint8_t)quals[hi]; }
+                    if (ti < s1) { tb = (uint8_t)bases[ti]; if (!PACKED) tq = (uint8_t)quals[ti]; }
+                    one(hb, hq); one(tb, tq);                    // (0xFF = "no observation" in either form)
+                }
+                for (uint32_t cb = 0; cb < nc; cb += (uint32_t)kBlockChunks) {
+                    const bool more = cb + (uint32_t)kBlockChunks < nc;
+                    if (more) fetch(sb, sq, cb + (uint32_t)kBlockChunks, nc, nb, nq);
+                    count(cb, nc, b, q);
+                    if (more) {
 #pragma unroll
-                    for (int u = 0; u < kUnroll; ++u) {
-                        const int64_t c = cb + tid + (int64_t)u * kHistThreads;
-                        v[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};     // "no observation"
-                        if (c < c1) v[u] = __builtin_nontemporal_load(&pv[c]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < kUnroll; ++u) {
-                        const int64_t wave_first = cb + (tid & ~63) + (int64_t)u * kHistThreads;   // wave-uniform
-                        u32x4 b, q;
-                        unpack_chunk(v[u], b, q);
-                        if (wave_first < c1) count_chunk(hist, b, q, lane_off);
+                        for (int u = 0; u < kUnroll; ++u) { b[u] = nb[u]; q[u] = nq[u]; }
                     }
                 }
-                scalar(c1 << 4, s1);
             } else {
                 scalar(s0, s1);
             }
-        } else {
-        // [s0, s1) = unaligned head, whole 16-sample chunks [c0, c1) of the concatenated arrays, unaligned tail
-        const int64_t c0 = (s0 + 15) >> 4, c1 = s1 >> 4;
-        if (ALIGNED && c0 < c1) {
-            scalar(s0, c0 << 4);
-            const u32x4 *bv = reinterpret_cast<const u32x4 *>(bases);
-            const u32x4 *qv = reinterpret_cast<const u32x4 *>(quals);
-            constexpr int64_t kBlockChunks = (int64_t)kUnroll * kHistThreads;
-            int64_t cb = c0;
-            for (; cb + kBlockChunks <= c1; cb += kBlockChunks) {
-                u32x4 b[kUnroll], q[kUnroll];
+            __syncthreads();
+            for (int key = tid; key < BVC_NCLASS; key += kHistThreads) {
+                uint32_t sum = 0;
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
-                    b[u] = __builtin_nontemporal_load(&bv[cb + tid + (int64_t)u * kHistThreads]);
-                    q[u] = __builtin_nontemporal_load(&qv[cb + tid + (int64_t)u * kHistThreads]);
+                for (int v = 0; v < kCopies; v += 4) {
+                    const int cc = (v + 4 * (key & 7)) & (kCopies - 1);      // rotated: the lanes of a ds_read_b128 group spread over banks
+                    u32x4 *p = reinterpret_cast<u32x4 *>(&hist[key * kCopies + cc]);
+                    const u32x4 x = *p;
+                    sum += x.x + x.y + x.z + x.w;
+                    *p = u32x4{0u, 0u, 0u, 0u};
                 }
-#pragma unroll
-                for (int u = 0; u < kUnroll; ++u) count_chunk(hist, b[u], q[u], lane_off);
+                counts[site * BVC_NCLASS + key] = sum;
             }
-            if (cb < c1) count_partial_block(hist, bv, qv, cb, c1, tid, lane_off);
-            scalar(c1 << 4, s1);
-        } else {
-            scalar(s0, s1);
+            __syncthreads();
         }
-        }
-        __syncthreads();
-        for (int key = tid; key < BVC_NCLASS; key += kHistThreads) {
-            uint32_t sum = 0;
-#pragma unroll
-            for (int v = 0; v < kCopies; v += 4) {
-                const int cc = (v + 4 * (key & 7)) & (kCopies - 1);      // rotated: the lanes of a ds_read_b128 group spread over banks
-                u32x4 *p = reinterpret_cast<u32x4 *>(&hist[key * kCopies + cc]);
-                const u32x4 x = *p;
-                sum += x.x + x.y + x.z + x.w;
-                *p = u32x4{0u, 0u, 0u, 0u};
-            }
-            counts[site * BVC_NCLASS + key] = sum;
-        }
-        __syncthreads();
+        site = next; s0 = n0; s1 = n1;
     }
 }
 

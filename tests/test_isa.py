@@ -30,7 +30,7 @@ def test_every_kernel_source_yields_kernels(kernels):
     assert all(k["instructions"] > 10 for k in kernels), [k["pretty"] for k in kernels if k["instructions"] <= 10]
     names = {k["pretty"].split("<")[0] for k in kernels}
     for must in ("hist_dense_kernel", "hist_packed_kernel", "hist_dense_groups_slots_kernel", "hist_packed_groups_kernel",
-                 "hist_csr_block_kernel", "hist_wave_kernel", "region_kernel", "region_walk_kernel", "region_wide_kernel",
+                 "hist_csr_block_kernel", "hist_wave_kernel", "region_kernel",
                  "lrt_kernel", "var_qual_kernel", "synth_dense_kernel"):
         assert must in names, must
 

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(classes_kernel|fit_kernel|decide_kernel|lrt_groups_kernel|lrt_kernel|var_qual_kernel|group_comb_kernel|group_records_kernel|hist_\w+kernel|synth_dense_kernel)", name)
+    m = re.search(r"(region_wide_probe_kernel|region_kernel<\d+>|classes_kernel|fit_kernel|decide_kernel|lrt_groups_kernel|lrt_kernel|var_qual_kernel|group_comb_kernel|group_records_kernel|hist_\w+kernel|synth_dense_kernel)", name)
     return m.group(1) if m else name[:40]
 
 
