@@ -213,6 +213,10 @@ __device__ __forceinline__ double log_pos(double x)
 }
 
 // ---- chi-square survival function, df = 1 --------------------------------------------------------
+// Attribution: kf_lgamma_dev / kf_gammaq_dev below restate, nearly statement for statement,
+// the numerical routines of htslib's kfunc.c (https://github.com/samtools/htslib, MIT/Expat licence, (c) Genome Research Ltd. and
+// Attractive Chaos), which the reference links through SeqLib (src/Algorithm.cpp:3-25; .gitmodules:1-3, submodule absent from the
+// reference tree).  The arithmetic has to be htslib's for the outputs to match the reference's; the constants are htslib's.
 // The reference's chisf(x, 1) = kf_gammaq(0.5, x/2) (src/Algorithm.cpp:3-7; htslib kfunc.c, absent from
 // the reference tree).  Same published algorithm as the reference links against: Lanczos-type
 // log-gamma, power series for P when z <= 1 or z < s, modified-Lentz continued fraction for Q otherwise;

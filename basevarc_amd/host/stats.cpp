@@ -8,6 +8,10 @@
 namespace bvchost {
 
 // ---- htslib kfunc.c restatements ---------------------------------------------------------------------
+// Attribution: kf_erfc, kf_lgamma / kf_gammaq and kt_fisher_exact (hypergeo_acc) below restate, nearly statement for statement,
+// the numerical routines of htslib's kfunc.c (https://github.com/samtools/htslib, MIT/Expat licence, (c) Genome Research Ltd. and
+// Attractive Chaos), which the reference links through SeqLib (src/Algorithm.cpp:3-25; .gitmodules:1-3, submodule absent from the
+// reference tree).  The arithmetic has to be htslib's for the outputs to match the reference's; the constants are htslib's.
 // erfc by W. J. Cody / Hart-style rational approximation as published in kfunc.c (kf_erfc): a degree-6 over
 // degree-7 rational in z = |x| sqrt(2) for z < 10/sqrt(2), a continued fraction beyond, 0/2 past z = 37.
 double kf_erfc(double x)

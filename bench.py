@@ -36,19 +36,22 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6
 N_SIMD = 1024                # 256 CUs x 4 SIMDs
 ENGINE_CLOCK_HZ = 2.4e9      # MI355X peak engine clock
 VALU_CYCLES_PER_WAVE_INST = 4     # wave64 FP64 / 32-bit VALU instruction (tools/micro/valu_rate.hip)
-# Issue slots (4 cycles each; v_rcp_f64 and the lane swaps count for what they cost, 4 and 2) the item engine needs per
-# E+M pass of ONE fit when every lane group of its wavefronts works: a pass of eight four-allele fits (two lanes x 16
-# classes per allele) is 150 slots = 18.75 per fit, a pass of eight two-allele fits (four lanes x 8 classes) half that; a
-# site's passes are about 64 % four-allele (full model + 3-subsets) and 36 % two-allele (the nested levels) on the
-# synthetic workload: 0.64 * 18.75 + 0.36 * 9.4.  Cross-check by counters: at N = 1e6, where every fit runs to the cap and
-# a region's wavefronts are full, the kernel executes 19.6 VALU instructions per site-pass all told and spends 80 % of
-# its time in the fit phases (profiles/r03_stage2_pmc.txt, r03_region_kernel_phases.txt): 15.7.
-# (Round 2's one-wavefront-per-site kernel: 63 instructions per pass, 82 slots all told.)
-EM_ISSUE_SLOTS_PER_PASS = 15.4
-# What it EXECUTES per site-pass (SQ_INSTS_VALU of region_kernel / (sites x passes), profiles/r03_stage2_pmc.txt): a
-# wavefront runs until its slowest fit stops and a region's wavefronts meet at a barrier per level, so the shorter the
-# fits (small N) the more passes run on fits that have already stopped.
-EM_VALU_EXECUTED_PER_PASS = {10_000: 28.9, 100_000: 23.6, 1_000_000: 19.6}
+# Stage 2's FP64-VALU roofline needs two per-pass figures that only a counter pass can give (SQ_INSTS_VALU of the region kernel
+# over sites x EM passes): what a pass NEEDS with every lane group busy and what the kernel EXECUTES at a given depth.  They live
+# in profiles/stage2_valu.json next to the hash of the kernel source they were measured on (tools/pmc_stage2.py --json), the way
+# pmc_traffic.json ties the HBM traffic to hist_kernel.hip: a later change of em_items.hip turns them "stale" in the bench line
+# instead of silently keeping numbers of another kernel.
+def stage2_valu():
+    p = os.path.join(ROOT, "profiles", "stage2_valu.json")
+    try:
+        d = json.load(open(p))
+    except Exception:
+        return None, "no profiles/stage2_valu.json"
+    from basevarc_amd.build import code_sha16
+    sha = code_sha16(os.path.join(ROOT, "basevarc_amd", "csrc", "em_items.hip"))
+    if d.get("em_items_sha16") != sha:
+        return None, f"stale: counters taken on em_items.hip {d.get('em_items_sha16')}, tree has {sha}"
+    return d, {"file": "profiles/stage2_valu.json", "em_items_sha16": sha, "summary": d.get("summary")}
 
 
 def parse():
@@ -212,10 +215,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # empirical read ceiling: one 8 GB tile through a plain 16 B/lane streaming kernel
-    empirical_gbs = ctx.stream_read_gbs(tiles[0][0].as_strided((tile_sizes[0], tiles[0][0].stride(0)), (tiles[0][0].stride(0), 1)))
     for _ in range(a.warmup):
         step()
+    barrier()
+    # empirical read ceiling: one tile (8 GB) through a plain 16 B/lane streaming kernel, AFTER the warm-up (clocks and memory
+    # up), seven separately timed passes of three sweeps each.  A ceiling is the best the part does on this shape: the maximum;
+    # the median rides along (round 3 took one measurement before the warm-up, which the driver's run put below the kernel it caps)
+    whole_tile = tiles[0][0].as_strided((tile_sizes[0], tiles[0][0].stride(0)), (tiles[0][0].stride(0), 1))
+    reads = sorted(ctx.stream_read_gbs(whole_tile, repeats=3) for _ in range(7))
+    empirical_gbs, empirical_median = reads[-1], reads[len(reads) // 2]
     barrier()
     log("timed region")
     ctx.set_profiling(a.profile_every <= 1)
@@ -287,7 +295,8 @@ def main():
             "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
             "avg_launch_ms": hist_ms, "launches_timed": int(prof["hist_launches"]), "algorithmic_bytes_per_launch": alg_bytes,
-            "empirical_stream_read_GBs": empirical_gbs, "frac_of_empirical": achieved / empirical_gbs if empirical_gbs else None,
+            "empirical_stream_read_GBs": empirical_gbs, "empirical_stream_read_median_GBs": empirical_median,
+            "frac_of_empirical": achieved / empirical_gbs if empirical_gbs else None,
             "traffic_note": "HBM bytes per launch from the COMMITTED rocprofv3 counter passes named in traffic_source (FETCH_SIZE and "
                             "WRITE_SIZE in separate --pmc runs, corrected as MI355X_MICROARCH.md prescribes), valid for the kernel source "
                             "hashed there; not re-measured in this run.  achieved / avg_launch_ms ARE measured in this run (HIP events)",
@@ -588,20 +597,22 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
 
 def em_roofline(rec, em_launch_ms, call_ms, depth=0):
     """FP64-VALU issue roofline of stage 2 where it is the bound: issue slots x 4 cycles against 1024 SIMDs x 2.4 GHz.
-    Numerator = E+M passes of a call (singleEM calls, as the reference counts them) x the slots a pass NEEDS in
-    fit_kernel with every lane group busy (EM_ISSUE_SLOTS_PER_PASS) -- so lockstep idling (a wavefront runs until its
-    slowest fit stops), the small kernels between the levels and launch tails all show up as lost fraction.  The
-    denominator is the wall time per call: the stage 2 of consecutive calls runs on two streams side by side."""
+    Numerator = E+M passes of a call (singleEM calls, as the reference counts them) x the slots a pass NEEDS in the region
+    kernel with every lane group busy -- so lockstep idling (a wavefront runs until its slowest fit stops), the site phases
+    between the levels and launch tails all show up as lost fraction.  The denominator is the wall time per call: the stage 2
+    of consecutive calls runs on two streams side by side.  Both per-pass figures come from profiles/stage2_valu.json and are
+    null ("stale") when that file was measured on another em_items.hip."""
     passes = float(rec["n_passes"].astype("int64").sum())
-    inst = passes * EM_ISSUE_SLOTS_PER_PASS
+    v, src = stage2_valu()
+    needed = v["needed_per_pass"] if v else None
+    executed = v["executed_per_pass"].get(str(depth)) if v else None
     peak = N_SIMD * ENGINE_CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST          # wave-instructions per second, whole chip
-    ach = inst / (call_ms * 1e-3) if call_ms > 0 else 0.0
-    executed = EM_VALU_EXECUTED_PER_PASS.get(depth)
-    return {"bound": "fp64_valu_issue", "kernel": "region_kernel (em_items.hip)", "achieved": ach / 1e9, "peak": peak / 1e9,
-            "unit": "G issue slots/s", "frac": ach / peak, "ms_per_call": call_ms,
+    ach = passes * needed / (call_ms * 1e-3) if needed and call_ms > 0 else None
+    return {"bound": "fp64_valu_issue", "kernel": "region_kernel (em_items.hip)", "achieved": ach / 1e9 if ach else None, "peak": peak / 1e9,
+            "unit": "G issue slots/s", "frac": ach / peak if ach else None, "ms_per_call": call_ms,
             "avg_launch_ms": em_launch_ms, "launches_overlap": True,
-            "em_passes_per_site": passes / max(1, len(rec)), "issue_slots_per_pass": EM_ISSUE_SLOTS_PER_PASS,
-            "valu_executed_per_pass": executed,
+            "em_passes_per_site": passes / max(1, len(rec)), "issue_slots_per_pass": needed,
+            "valu_executed_per_pass": executed, "valu_source": src,
             "frac_executed": (passes * executed / (call_ms * 1e-3) / peak) if executed and call_ms > 0 else None,
             "note": "no MFMA: the EM is a scalar recurrence per class, not a contraction; peak = 1024 SIMDs x 2.4 GHz / 4 cycles "
                     "(the chip holds about 2.17 GHz under this load)"}

@@ -14,6 +14,11 @@
  * The per-sample path keeps the reference's operation order (sums run j = 0..3 then i = 0..n-1,
  * a fresh zeroed 4*n scratch per E/M pass) so that it is also a fair CPU timing baseline.
  *
+ * Attribution: orc_kf_lgamma / orc_kf_gammaq (chisf) below restate, nearly statement for statement,
+ * the numerical routines of htslib's kfunc.c (https://github.com/samtools/htslib, MIT/Expat licence, (c) Genome Research Ltd. and
+ * Attractive Chaos), which the reference links through SeqLib (src/Algorithm.cpp:3-25; .gitmodules:1-3, submodule absent from the
+ * reference tree).  The arithmetic has to be htslib's for the outputs to match the reference's; the constants are htslib's.
+ *
  * ORC_MODE_COMPENSATED is NOT the reference's arithmetic: the same per-sample loops with the three
  * sums that run over all samples (M-step sums, delta, log-likelihood) accumulated in long double
  * (64-bit significand on x86-64), i.e. without the drift a double accumulator picks up over 1e6

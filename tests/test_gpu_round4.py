@@ -1,0 +1,161 @@
+"""GPU parity tests added in round 4 (run with -m gpu on an MI355X).
+
+* The any-order group histogram kernels that arrived late in round 3 -- hist_dense_groups_slots_kernel<4 | 3 | 2> (two-byte
+  rows packed in registers, 256 slots x 16 / 8 / 4 LDS copies per histogram) and hist_packed_groups_kernel<4 | 3 | 2, true,
+  1024> -- against the ORACLE's restatement of the caller's --group loop (src/BaseVarC.cpp:617-661), not against one another:
+  rows long enough for the kernels' full-block path (2 x 1024 chunks of 16 samples per block), labels in any order, samples in
+  no group, uncovered samples, and covered samples of quality 63 and more (the sites the slots kernel flags and the general
+  kernel redoes).
+* The rewritten hist_csr_block_kernel (loads of block k + 1 in flight while block k is counted; head and tail with the first
+  block): class counts of ragged sites of every length and alignment around its block size, bit-exact.
+* Stage 2's launch shapes (teams of wavefronts per region, sequences of launches underneath a histogram pass) never change a
+  record.
+"""
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests.sitegen import caller_min_af, random_site
+from tests.test_gpu_parity import AF_ATOL, assert_site_matches, pad_rows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from basevarc_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _long_group_tile(rng, k, ns, n, high_quals):
+    """ns sites x n samples at 90 % coverage, a third of the sites polymorphic; labels 0..k-1 in any order, about one sample
+    in k + 1 in no group (255); high_quals: a few covered samples of quality 63..93 in every other site."""
+    sites = []
+    for s in range(ns):
+        b, q, r = random_site(rng, n, af=(0.2 if s % 3 == 0 else 0.0), second_af=(0.05 if s % 6 == 0 else 0.0))
+        b = b.copy(); q = q.copy()
+        b[rng.random(n) >= 0.9] = -1                                  # uncovered
+        if high_quals and s % 2 == 1:
+            at = rng.choice(n, size=7, replace=False)
+            q[at] = rng.integers(63, 94, size=7).astype(np.int8)
+            b[at] = np.where(b[at] < 0, r, b[at])                     # ... and covered
+        sites.append((b, q, r))
+    B, Q, R = pad_rows(sites)
+    g = rng.integers(0, k + 1, size=n).astype(np.uint8)
+    g[g == k] = 255
+    return B, Q, R, g
+
+
+def _check_groups_against_the_oracle(res, gres, B, Q, R, m, g, k, where):
+    for s in range(B.shape[0]):
+        o, gd, ga, ran, pres = orc.dense_site_groups(B[s], Q[s], int(R[s]), m, g, k, use_hist=True)
+        assert_site_matches(res[s], o, where=f"{where} site {s}", path_strict=False)
+        assert np.array_equal(gres[s]["depth"], gd), (where, s)
+        assert np.array_equal(gres[s]["ran"], ran), (where, s)
+        assert np.array_equal(gres[s]["present"], pres), (where, s)
+        np.testing.assert_allclose(gres[s]["af"], ga, rtol=0, atol=AF_ATOL)
+
+
+@pytest.mark.parametrize("k", [5, 12, 26, 32])        # 6 / 13 / 27 / 33 histograms: 16, 8, 4 and 4 LDS copies of 256 slots
+def test_any_order_group_kernels_on_long_rows_against_the_oracle(ctx, k):
+    """Two-byte rows: hist_dense_groups_slots_kernel<4> (k = 5), <3> (k = 12), <2> (k = 26, 32) on rows of 70,016 samples =
+    two full blocks of 2 x 1024 chunks and a partial one; with qualities of 63 and more in every other site (flagged by the
+    slots kernel, redone by hist_dense_groups_kernel).  Every site record and every group record against the oracle's group
+    loop."""
+    rng = np.random.default_rng(4000 + k)
+    ns, n = 6, 70016
+    m = caller_min_af(n)
+    for high in (False, True):
+        B, Q, R, g = _long_group_tile(rng, k, ns, n, high)
+        res, gres = ctx.lrt_dense_groups(B, Q, R, m, g, k)
+        _check_groups_against_the_oracle(res, gres, B, Q, R, m, g, k, f"two-byte k={k} high={high}")
+        # the 512-thread general kernel alone on the same tile: the same records, byte for byte
+        from basevarc_amd import Context
+        with Context(0) as other:
+            other.set_tuning("group_big_lds", 0)
+            r2, g2 = other.lrt_dense_groups(B, Q, R, m, g, k)
+        assert r2.tobytes() == res.tobytes() and g2.tobytes() == gres.tobytes(), (k, high)
+
+
+@pytest.mark.parametrize("k", [5, 12, 26, 32])
+def test_packed_any_order_group_kernels_on_long_rows_against_the_oracle(ctx, k):
+    """Packed rows (one byte per sample): hist_packed_groups_kernel<4 | 3 | 2, true, 1024> on the same kind of tile (no
+    quality beyond 62: such tiles stay on the two-byte entry points), against the oracle's group loop."""
+    rng = np.random.default_rng(4100 + k)
+    ns, n = 6, 70016
+    m = caller_min_af(n)
+    B, Q, R, g = _long_group_tile(rng, k, ns, n, False)
+    P = np.where((B >= 0) & (B < 4), (B.astype(np.uint8) << 6) | Q.astype(np.uint8), 0xFF).astype(np.uint8)
+    res, gres = ctx.lrt_dense_groups_packed(P, R, m, g, k)
+    _check_groups_against_the_oracle(res, gres, B, Q, R, m, g, k, f"packed k={k}")
+
+
+def test_ragged_block_kernel_around_its_block_size(ctx):
+    """hist_csr_block_kernel takes the sites of 4096 observations and more in blocks of 2 x 512 chunks of 16: lengths just
+    below, at and above one, two and three blocks, every start alignment 0..15 (unaligned head and tail of up to 15
+    observations), uncovered observations inside, two-byte and one-byte forms, device pointers: records of the oracle, and the
+    one-byte records equal to the two-byte ones byte for byte."""
+    import torch
+    from basevarc_amd.lib import results_from_tensor
+    rng = np.random.default_rng(4200)
+    block = 2 * 512 * 16
+    lengths = [4096, 4097, block - 17, block, block + 1, 2 * block - 1, 2 * block + 16, 3 * block + 5, 40000, 123, 0, 15, 4095]
+    sites = []
+    for i, n in enumerate(lengths):
+        b, q, r = random_site(rng, n, af=0.1 if i % 2 else 0.0)
+        b = b.copy()
+        if n:
+            b[rng.random(n) >= 0.95] = -1
+        sites.append((b, q, r))
+    refs = np.array([r for _, _, r in sites], dtype=np.int8)
+    lens = np.array([len(b) for b, _, _ in sites], dtype=np.int64)
+    m = 0.001
+    for lead in range(16):
+        # `lead` observations that belong to no site in front: every site then starts at alignment (lead + lengths before it) mod 16
+        allb = np.concatenate([np.full(lead, 2, np.int8)] + [b for b, _, _ in sites])
+        allq = np.concatenate([np.full(lead, 30, np.int8)] + [q for _, q, _ in sites])
+        offs = lead + np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        tb, tq = torch.from_numpy(allb).cuda(), torch.from_numpy(allq).cuda()
+        to, tr = torch.from_numpy(offs).cuda(), torch.from_numpy(refs).cuda()
+        rec = results_from_tensor(ctx.lrt_csr_device(to, tb, tq, tr, m))
+        ctx.synchronize()
+        for s in range(len(sites)):
+            bs, qs = allb[offs[s]:offs[s + 1]], allq[offs[s]:offs[s + 1]]
+            exp = orc.hist_lrt(orc.dense_hist(bs, qs), int(refs[s]), m)
+            assert_site_matches(rec[s], exp, where=f"lead {lead} site {s} len {len(bs)}", path_strict=False)
+        pk = np.where(allb >= 0, (allb.astype(np.uint8) << 6) | allq.astype(np.uint8), 0xFF).astype(np.uint8)
+        rec1 = results_from_tensor(ctx.lrt_csr_packed_device(to, torch.from_numpy(pk).cuda(), tr, m))
+        ctx.synchronize()
+        assert rec1.tobytes() == rec.tobytes(), lead
+
+
+def test_stage2_launch_shapes_never_change_a_record(ctx):
+    """Stage 2 gives a region of eight sites to a team of wavefronts; how many wavefronts a call may hold per CU
+    (em_waves_per_cu: the walk underneath a histogram pass is a SEQUENCE of launches) and whether it runs beside a histogram pass
+    (overlap mode) are launch policies: the records of a tile are the same bytes under every one of them, for plain calls, calls
+    with a site count that leaves the last region partly empty, and group calls (pseudo-sites)."""
+    import torch
+    from basevarc_amd import Context
+    ns, n, k = 1003, 20000, 5
+    m = caller_min_af(n)
+    b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    r = torch.empty(ns, dtype=torch.int8, device="cuda")
+    ctx.synth_dense_device(11, 777, b, q, r, cov_thr16=int(0.8 * 65536))
+    g = torch.from_numpy((np.arange(n) % k).astype(np.uint8)).cuda()
+    want = ctx.lrt_dense_device(b, q, r, m)
+    gw, ggw = ctx.lrt_dense_groups_device(b, q, r, m, g, k)
+    ctx.synchronize()
+    for per_cu in (1, 2, 3, 4, 8):
+        for overlap in (False, True):
+            with Context(0) as other:
+                other.set_tuning("em_waves_per_cu", per_cu)
+                other.set_overlap(overlap)
+                for rep in range(2):
+                    got = other.lrt_dense_device(b, q, r, m)
+                    g1, g2 = other.lrt_dense_groups_device(b, q, r, m, g, k)
+                other.join(); other.synchronize()
+                assert torch.equal(got, want), (per_cu, overlap)
+                assert torch.equal(g1, gw) and torch.equal(g2, ggw), (per_cu, overlap)

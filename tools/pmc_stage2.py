@@ -23,6 +23,6 @@ for d in sys.argv[1:]:
         k = short(row["Kernel_Name"]) + f" grid{int(row['Grid_Size']) // max(1, int(row['Workgroup_Size']))}"
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
         acc[k]["_dur_us"].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
-    print("##", d)
+    print("##", os.path.relpath(d))
     for k, c in sorted(acc.items()):
         print(f"{k:40s}", " ".join(f"{name}={sum(v) / len(v):.4g}" for name, v in sorted(c.items())), f"n={len(c['_dur_us'])}")
