@@ -47,7 +47,7 @@ def build(force=False, verbose=False):
 
 
 HOST = os.path.join(HERE, "host")
-HOST_SOURCES = ["stats.cpp", "pileup.cpp", "bgzf.cpp", "bam.cpp"]
+HOST_SOURCES = ["stats.cpp", "pileup.cpp", "bgzf.cpp", "inflate.cpp", "bam.cpp"]
 HOST_LIB = os.path.join(HERE, "libbvchost.so")
 HOST_EXE = os.path.join(HERE, "BaseVarC")
 

@@ -1,10 +1,19 @@
 #include "bgzf.h"
 
+#include <atomic>
+
+#include "inflate.h"
+
 #include <zlib.h>
 
 #include <cstring>
 
 namespace bvchost {
+
+// blocks the fast decoder declined and zlib inflated (expected: none; tests/test_host.py reads it)
+std::atomic<long> g_zlib_fallbacks(0);
+long bgzf_zlib_fallbacks() { return g_zlib_fallbacks.load(); }
+
 
 static const size_t kBlockIn = 0xff00;          // uncompressed bytes per block
 static const unsigned char kEofMarker[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0,
@@ -180,6 +189,9 @@ bool BgzfReader::fetch(uint64_t from, std::vector<unsigned char> &out, uint64_t 
         for (int i = 0; i < 4; ++i) isize |= (uint32_t)comp_[clen + 4 + i] << (8 * i);
         if (isize == 0) { from = next; continue; }      // empty block (the EOF marker): try the next one
         out.resize(isize);
+        // the block decoder of inflate.cpp (both buffers whole in memory, size known); zlib only if it declines the stream
+        if (fast_inflate(comp_.data(), clen, out.data(), isize) == (long)isize) return true;
+        g_zlib_fallbacks.fetch_add(1, std::memory_order_relaxed);
         // one inflate state for the reader's life (inflateInit2 allocates and clears about 40 KB)
         if (!zs_ready_) {
             std::memset(&zs_, 0, sizeof zs_);

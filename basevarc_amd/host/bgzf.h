@@ -53,6 +53,8 @@ class BgzfReader;
 // Read-ahead for BgzfReaders: a few threads that inflate, for every reader attached to the pool, the block after the one
 // being consumed.  The position loop of the host program reads one line (or record) of every temp batch per position --
 // a hundred readers per thread at 1e5 samples -- and inflating their blocks was 70 % of the loop with the text form.
+long bgzf_zlib_fallbacks();                       // blocks the fast decoder (inflate.cpp) declined so far: zlib took them
+
 class InflatePool {
  public:
     explicit InflatePool(int n_threads);

@@ -10,6 +10,7 @@
 
 #include "bam.h"
 #include "bgzf.h"
+#include "inflate.h"
 #include "pileup.h"
 #include "stats.h"
 
@@ -41,6 +42,10 @@ static size_t copy_out(const std::string &s, char *out, size_t cap)
 }
 
 void bvchost_reset_parser(void) { reset_parser_carry(); }
+
+// inflate.cpp against zlib (tests): bytes written or -1
+long bvchost_fast_inflate(const unsigned char *in, size_t n, unsigned char *out, size_t cap) { return fast_inflate(in, n, out, cap); }
+long bvchost_zlib_fallbacks(void) { return bgzf_zlib_fallbacks(); }
 
 // site handle API (tests): build a SiteColumn from batch lines, then ask for its pieces
 struct bvchost_site { SiteColumn col; };

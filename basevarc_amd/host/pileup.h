@@ -14,6 +14,9 @@
 #include <map>
 #include <algorithm>
 #include <string>
+#include <memory>
+#include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/bvc.h"
@@ -43,10 +46,22 @@ struct Entry {
 // entry belongs to (the inverse of the reference's `idx` map, src/BaseVarC.cpp:428-429).  The tallies of the CVG line
 // (src/BaseVarC.cpp:560-590: depth per base over the non-indel entries, forward / reverse counts per base value over
 // ALL entries) are taken as the entries are appended, while each is in registers: cvg_line does not walk them again.
+// std::allocator whose value-less construct() default-initialises: resize() of a vector of trivial elements then leaves the new
+// elements unwritten instead of zero-filling them.  The parsers size a position's arrays for the most entries its line could hold
+// and write the real ones in place; at N = 1e5 samples the zero fill alone was 1.2 MB of stores per position.
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <class U> void construct(U *p) { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&... a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+
 struct SiteColumn {
     int32_t pos = 0;
-    std::vector<Entry> aiv;
-    std::vector<int32_t> sample;
+    std::vector<Entry, NoInitAlloc<Entry>> aiv;
+    std::vector<int32_t, NoInitAlloc<int32_t>> sample;
     std::vector<std::string> indels;   // indel text of the entries with is_indel = 1, in entry order
     int32_t cnt[4] = {0, 0, 0, 0};
     int32_t fwd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rev[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -558,3 +558,66 @@ def test_bgzf_readers_with_read_ahead_give_the_same_bytes(H, tmp_path):
             got_bytes = C.c_int64(0)
             assert H.bvchost_bgzf_read_hash(arr, len(paths), threads, by_line, piece, 5, C.byref(got_bytes)) == want
             assert got_bytes.value == want_bytes.value
+
+
+def test_block_inflate_equals_zlib_and_declines_bad_streams(H, tmp_path):
+    """inflate.cpp (the decoder the BGZF readers use for whole blocks) against zlib: empty, tiny, random, periodic and
+    pileup-text inputs; stored, fixed-code, dynamic-code, Huffman-only and RLE streams; several blocks per stream.  With too
+    little room, truncated or corrupted input it must return -1 or a wrong byte count -- never the expected one, never touch
+    memory outside its buffers (the sanitizer build, tools/sanitize_cpu.sh, runs this test too).  And a file written by the
+    BGZF writer is read back without one block falling back to zlib."""
+    import zlib
+    H.bvchost_fast_inflate.restype = C.c_long
+    H.bvchost_fast_inflate.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    H.bvchost_zlib_fallbacks.restype = C.c_long
+
+    def inflate(comp, cap):
+        out = C.create_string_buffer(max(cap, 1) + 64)
+        guard = b"\xA5" * 64
+        out[cap:cap + 64] = guard
+        r = H.bvchost_fast_inflate(comp, len(comp), out, cap)
+        assert out.raw[cap:cap + 64] == guard, "wrote past its output buffer"
+        return r, out.raw[:max(r, 0)]
+
+    rng = np.random.default_rng(77)
+    toks = [("%d,%d,%d,%d,%d " % (rng.integers(4), rng.integers(20, 61), rng.integers(10, 41), rng.integers(1, 100), rng.integers(2)))
+            if rng.random() < 0.1 else ". " for _ in range(30000)]
+    inputs = [b"", b"a", b"ab" * 5, b". " * 32000, rng.bytes(70000), bytes(rng.choice(list(b"ACGT"), 65000).tolist()),
+              "".join(toks).encode()[:65280]]
+    for n in (1, 2, 3, 7, 8, 9, 15, 16, 17, 255, 256, 257, 258, 259, 1000, 65280):
+        inputs.append(rng.bytes(n))
+        for period in (1, 2, 3, 4, 5, 7, 8, 9):
+            inputs.append((rng.bytes(period) * (n // period + 1))[:n])
+    checked = 0
+    for data in inputs:
+        for level in (0, 1, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+                one = co.compress(data) + co.flush()
+                co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+                step = max(1, len(data) // 3)
+                many = b"".join(co.compress(data[i:i + step]) + co.flush(zlib.Z_FULL_FLUSH) for i in range(0, len(data), step)) + co.flush()
+                for comp in (one, many):
+                    r, out = inflate(comp, len(data))
+                    assert r == len(data) and out == data, (len(data), level, strategy)
+                    checked += 1
+                    if len(data) > 4:
+                        assert inflate(comp, len(data) - 1)[0] != len(data)                   # too little room
+                        assert inflate(comp[:len(comp) // 2], len(data))[0] != len(data) or comp[:len(comp) // 2] == comp
+                        bad = bytearray(comp); bad[len(bad) // 2] ^= 0x55
+                        r2, out2 = inflate(bytes(bad), len(data))                              # corrupted: whatever it says, no crash,
+                        assert r2 <= len(data)                                                 # ... and never more than the room it was given
+    assert checked > 2000
+    # through the readers: nothing falls back to zlib
+    H.bvchost_bgzf_write.restype = C.c_int
+    H.bvchost_bgzf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int, C.c_int]
+    H.bvchost_bgzf_read_hash.restype = C.c_uint64
+    H.bvchost_bgzf_read_hash.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                         C.POINTER(C.c_int64)]
+    data = "".join(toks).encode() * 4
+    f = str(tmp_path / "t.gz").encode()
+    assert H.bvchost_bgzf_write(f, data, len(data), 65537, 6, 0) == 1
+    before = H.bvchost_zlib_fallbacks()
+    nbytes = C.c_int64(0)
+    H.bvchost_bgzf_read_hash((C.c_char_p * 1)(f), 1, 2, 0, 4096, 0, C.byref(nbytes))
+    assert nbytes.value >= len(data) and H.bvchost_zlib_fallbacks() == before

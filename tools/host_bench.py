@@ -4,6 +4,8 @@ on synthetic temp-batch files in both forms (the reference's text and the additi
 
 usage: tools/host_bench.py [n_samples] [n_positions] [threads] [coverage] [batch]
 The files are written by the host library's own generator (bvchost_write_synth_batches) under a temp directory.
+BVC_HOST_BENCH_FORMATS=text,raw restricts the forms; BVC_HOST_BENCH_INFLATE=1,2,4 runs the compute phase once per value of
+BVC_HOST_INFLATE_THREADS on the same files (default: the program's own default only).
 """
 import ctypes as C
 import gzip
@@ -55,7 +57,9 @@ def main():
             f.write(">chrS\n" + "A" * length + "\n")
         open(fa + ".fai", "w").write(f"chrS\t{length}\t6\t{length}\t{length + 1}\n")
         open(os.path.join(d, "bam.list"), "w").write("".join(f"s{i}.bam\n" for i in range(n)))
-        for fmt in ("text", "bin", "raw"):
+        formats = os.environ.get("BVC_HOST_BENCH_FORMATS", "text,bin,raw").split(",")
+        inflates = os.environ.get("BVC_HOST_BENCH_INFLATE", "").split(",")
+        for fmt in formats:
             out = os.path.join(d, f"bench_{fmt}.out")
             for t in range(thread):
                 os.makedirs(f"{out}.tmp.thread.{t}", exist_ok=True)
@@ -65,26 +69,31 @@ def main():
             assert entries >= 0
             size = sum(os.path.getsize(os.path.join(dp, f)) for t in range(thread)
                        for dp, _, fs in os.walk(f"{out}.tmp.thread.{t}") for f in fs)
-            t0 = time.perf_counter()
-            r = subprocess.run([exe, "basetype", "--rerun", "-t", str(thread), "-b", str(batch), "-i", os.path.join(d, "bam.list"),
-                                "-s", f"chrS:{start}-{start + npos}", "-r", fa, "-o", out], capture_output=True, text=True,
-                               env=dict(os.environ, BVC_HOST_PROFILE="1"))
-            dt = time.perf_counter() - t0
-            assert r.returncode == 0, r.stderr[-2000:]
-            prof = [l for l in r.stderr.splitlines() if l.startswith("[profile]")]
-            n_cvg = gzip.decompress(open(out + ".cvg.gz", "rb").read()).count(b"\n") - 3
-            n_vcf = sum(1 for l in gzip.decompress(open(out + ".vcf.gz", "rb").read()).split(b"\n") if l and not l.startswith(b"#"))
-            import re
-            loops = [float(m.group(1)) for m in (re.search(r"position loop ([0-9.e+-]+) s", l) for l in prof) if m]
-            print(json.dumps({"tmp_format": fmt, "positions_per_s_in_the_position_loops": round(npos / max(loops), 1) if loops else None, "n_samples": n, "positions": npos, "threads": thread, "coverage": cov,
-                              "entries": entries, "batch_files_MB": round(size / 1e6, 1), "generate_s": round(gen_s, 2),
-                              "seconds": round(dt, 3), "positions_per_s": round(npos / dt, 1),
-                              "entries_per_s": round(entries / dt), "cvg_lines": n_cvg, "vcf_lines": n_vcf, "profile": prof}))
+            for ii, infl in enumerate(inflates):
+                env = dict(os.environ, BVC_HOST_PROFILE="1")
+                keep = ["--keep_tmp"] if ii + 1 < len(inflates) else []       # the batches serve every run of the sweep
+                if infl:
+                    env["BVC_HOST_INFLATE_THREADS"] = infl
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, "basetype", "--rerun", "-t", str(thread), "-b", str(batch), "-i", os.path.join(d, "bam.list"),
+                                    "-s", f"chrS:{start}-{start + npos}", "-r", fa, "-o", out] + keep, capture_output=True, text=True, env=env)
+                dt = time.perf_counter() - t0
+                assert r.returncode == 0, r.stderr[-2000:]
+                prof = [l for l in r.stderr.splitlines() if l.startswith("[profile]")]
+                n_cvg = gzip.decompress(open(out + ".cvg.gz", "rb").read()).count(b"\n") - 3
+                n_vcf = sum(1 for l in gzip.decompress(open(out + ".vcf.gz", "rb").read()).split(b"\n") if l and not l.startswith(b"#"))
+                import re
+                loops = [float(m.group(1)) for m in (re.search(r"position loop ([0-9.e+-]+) s", l) for l in prof) if m]
+                print(json.dumps({"tmp_format": fmt, "inflate_threads": infl or "default", "positions_per_s_in_the_position_loops": round(npos / max(loops), 1) if loops else None, "n_samples": n, "positions": npos, "threads": thread, "coverage": cov,
+                                  "entries": entries, "batch_files_MB": round(size / 1e6, 1), "generate_s": round(gen_s, 2),
+                                  "seconds": round(dt, 3), "positions_per_s": round(npos / dt, 1),
+                                  "entries_per_s": round(entries / dt), "cvg_lines": n_cvg, "vcf_lines": n_vcf,
+                                  "profile": prof if thread <= 4 else prof[-1:] + prof[:2]}), flush=True)
             for k in (".cvg.gz", ".vcf.gz"):
                 os.replace(out + k, os.path.join(d, f"{fmt}{k}"))
-        same = all(gzip.decompress(open(os.path.join(d, "text" + k), "rb").read()) ==
-                   gzip.decompress(open(os.path.join(d, f + k), "rb").read()) for k in (".cvg.gz", ".vcf.gz") for f in ("bin", "raw"))
-        print(json.dumps({"text_bin_and_raw_outputs_identical": same}))
+        same = all(gzip.decompress(open(os.path.join(d, formats[0] + k), "rb").read()) ==
+                   gzip.decompress(open(os.path.join(d, f + k), "rb").read()) for k in (".cvg.gz", ".vcf.gz") for f in formats[1:])
+        print(json.dumps({"outputs_of_all_forms_identical": same, "forms": formats}))
     finally:
         shutil.rmtree(d, ignore_errors=True)
 

@@ -9,13 +9,13 @@ rm -rf "$W" && mkdir -p "$W" && git clone -q "$SRC" "$W/repo" && cd "$W/repo"
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -O1 -g"
 gcc $SAN -std=c99 -fPIC -fopenmp -ffp-contract=off -shared -o oracle/liborc.so oracle/basetype_oracle.c -lm
 g++ $SAN -std=c++11 -fPIC -pthread -Iinclude -shared -o basevarc_amd/libbvchost.so \
-    basevarc_amd/host/stats.cpp basevarc_amd/host/pileup.cpp basevarc_amd/host/bgzf.cpp basevarc_amd/host/bam.cpp \
+    basevarc_amd/host/stats.cpp basevarc_amd/host/pileup.cpp basevarc_amd/host/bgzf.cpp basevarc_amd/host/inflate.cpp basevarc_amd/host/bam.cpp \
     basevarc_amd/host/capi.cpp -lz
 # the GPU library is not under test here: reuse the tree's; the host executable is instrumented too (its --load
 # phase -- BGZF, BAM records, index seek, pileup, temp-batch writer -- runs without a GPU)
 cp "$SRC/basevarc_amd/libbvc.so" basevarc_amd/
 g++ $SAN -std=c++11 -pthread -Iinclude -o basevarc_amd/BaseVarC basevarc_amd/host/stats.cpp basevarc_amd/host/pileup.cpp \
-    basevarc_amd/host/bgzf.cpp basevarc_amd/host/bam.cpp basevarc_amd/host/capi.cpp basevarc_amd/host/main.cpp \
+    basevarc_amd/host/bgzf.cpp basevarc_amd/host/inflate.cpp basevarc_amd/host/bam.cpp basevarc_amd/host/capi.cpp basevarc_amd/host/main.cpp \
     -L basevarc_amd -lbvc -lz -Wl,-rpath,'$ORIGIN'
 touch basevarc_amd/libbvc.so basevarc_amd/libbvchost.so basevarc_amd/BaseVarC oracle/liborc.so
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
