@@ -33,16 +33,33 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + DEPS)
 
 
+# Flags of single translation units.  em_items.hip: the narrow region kernel sits at the 168 VGPRs of three wavefronts per
+# SIMD, and the machine-level loop-invariant code motion of this compiler keeps hoisting lane-constant addresses, zero vectors
+# and the like out of the region's level loop, where they stay live across the fits and end in scratch (or in 30-70 SGPR
+# spills); without that pass the kernel has no spill of either kind (tools/isa_report.py, tests/test_isa.py).
+PER_SOURCE_FLAGS = {"em_items.hip": ["-mllvm", "-disable-machine-licm"]}
+
+
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Returns the path of the library."""
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wextra", "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
-    cmd[1:1] = os.environ.get("BVC_EXTRA_FLAGS", "").split()      # experiments: -DBVC_HIST_UNROLL=8 ...
+    extra = os.environ.get("BVC_EXTRA_FLAGS", "").split()         # experiments: -DBVC_HIST_UNROLL=8 ...
+    common = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra"] + extra
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+        common.append("-Rpass-analysis=kernel-resource-usage")
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for f in SOURCES:                                            # one compile per source, side by side
+        obj = os.path.join(objdir, f.replace(".hip", ".o"))
+        procs.append((obj, subprocess.Popen(common + PER_SOURCE_FLAGS.get(f, []) + ["-c", os.path.join(CSRC, f), "-o", obj])))
+    objs = []
+    for obj, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, "hipcc -c " + obj)
+        objs.append(obj)
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 
 

@@ -429,6 +429,7 @@ int bvc_create(bvc_ctx **out, int device)
         const double eps = std::exp(-0.23025850929940458 * q);   // MLN10TO10, src/BaseType.h:10
         lut.a[q] = 1.0 - eps;
         lut.e[q] = eps / 3.0;
+        lut.log_e[q] = std::log(lut.e[q]);
     }
     lut.e_empty = 0.25;
     if (hipMalloc(reinterpret_cast<void **>(&ctx->d_lut), sizeof(QualLut)) != hipSuccess ||

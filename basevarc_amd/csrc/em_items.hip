@@ -214,54 +214,61 @@ struct Region {
 // kind one workgroup's dynamic LDS.
 static_assert(2 * sizeof(Region<kNarrow>) <= 32 * 1024 && 2 * sizeof(Region<kWide>) <= 32 * 1024, "stage 2 beside two histogram workgroups");
 static_assert(4 * sizeof(Region<kWide>) <= 64 * 1024, "a workgroup's regions");
+static_assert(5 * kRegionSites <= kWave, "region_emit: one lane per fit of the region");
 
-// Emits the fits S.sets of site `ls` of the region (wave-uniform): places from the prefix of `want` over the sites.
+// Emits the fits of the pending level for the whole region at once: lane 5 * ls + c builds fit c of site ls (its subset's alleles,
+// SetAlleleFreq's starting frequencies -- four f64 divisions --, what the alleles outside the subset add to E and to the
+// log-likelihood) and writes it to its place: list after list, each in site order, a site's fits in the order of its subsets.
+// (Round 3 did this site by site with every lane computing the same fit: 20 divisions in a row per site.)
 template <class RegionT>
-__device__ __forceinline__ void site_emit(RegionT &R, int ls, int lane, const int (&first)[kLists])
+__device__ __forceinline__ void region_emit(RegionT &R, int lane, const int (&first)[kLists])
 {
+    // (opaque, as in fit_body: what depends on the lane id only is then recomputed at every level instead of being hoisted out
+    // of the level loop and kept -- spilled, at the narrow kernel's 168 VGPRs -- across the fits)
+    asm volatile("" : "+v"(lane));
+    const int ls = (lane * 52) >> 8, c = lane - 5 * ls;          // lane / 5, lane % 5 for lane < 64
+    if (ls >= kRegionSites) return;
     ItemSite &S = R.site[ls];
     const uint32_t sets = S.sets;
     const int n_emit = S.n_emit, p_deepest = S.p_deepest;
-    if (S.state != 1 || n_emit <= 0) return;
-    int at0 = first[0], at1 = first[1], at2 = first[2], at3 = first[3];
-    for (int w = 0; w < ls; ++w) { at0 += R.want[w][0]; at1 += R.want[w][1]; at2 += R.want[w][2]; at3 += R.want[w][3]; }
-    const int total_i = S.depth[0] + S.depth[1] + S.depth[2] + S.depth[3];
-    const double inv_n = 1.0 / (double)total_i;
+    if (S.state != 1 || c >= n_emit) return;
+    const uint32_t pm = (sets >> (4 * c)) & 0xFu;
+    const int l = list_of(pm, p_deepest);
+    // place: the list's first place + the fits of the sites before this one in that list + this site's earlier fits in it
+    int idx = sel4(first, l);
+    for (int w = 0; w < ls; ++w) idx += R.want[w][l];
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2)
+        if (c2 < c) idx += list_of((sets >> (4 * c2)) & 0xFu, p_deepest) == l;
+    const int depth[4] = {S.depth[0], S.depth[1], S.depth[2], S.depth[3]};
+    const int total_i = depth[0] + depth[1] + depth[2] + depth[3];
     const uint32_t blist = S.blist;
-    int depth[4] = {S.depth[0], S.depth[1], S.depth[2], S.depth[3]};
+    if (!BVC_LDS_OK(11, idx, kPlaces)) return;
+    FitItem &fi = R.items[idx];                                  // written field by field, straight to LDS
+    S.item[c] = idx;
+    fi.site = ls;
+    int depth_sum = 0, u = 0;
+    uint32_t bases = 0xFFFFFFFFu, in_set = 0;
 #pragma unroll
-    for (int c = 0; c < 5; ++c) {
-        if (c >= n_emit) break;
-        const uint32_t pm = (sets >> (4 * c)) & 0xFu;
-        const int l = list_of(pm, p_deepest);
-        const int idx = l == 0 ? at0 : (l == 1 ? at1 : (l == 2 ? at2 : at3));
-        at0 += l == 0; at1 += l == 1; at2 += l == 2; at3 += l == 3;
-        FitItem fi;
-        fi.site = ls;
-        int depth_sum = 0, u = 0;
-        uint32_t bases = 0xFFFFFFFFu, in_set = 0;
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            if ((pm >> p) & 1u) {
-                const int b = (blist >> (4 * p)) & 3u;
-                bases = (bases & ~(0xFFu << (8 * u))) | ((uint32_t)b << (8 * u));
-                in_set |= 1u << b;
-                depth_sum += pick4i(depth, b);
-                ++u;
-            }
-        double ll_excl = 0.0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) ll_excl += ((in_set >> b) & 1u) ? 0.0 : S.lle[b];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                            // SetAlleleFreq (:25-39)
-            const int b = (bases >> (8 * q)) & 0xFFu;
-            fi.base[q] = (uint8_t)b;
-            fi.f0[q] = q < u ? (double)pick4i(depth, b & 3) / (double)depth_sum : 0.0;
+    for (int p = 0; p < 4; ++p)
+        if ((pm >> p) & 1u) {
+            const int b = (blist >> (4 * p)) & 3u;
+            bases = (bases & ~(0xFFu << (8 * u))) | ((uint32_t)b << (8 * u));
+            in_set |= 1u << b;
+            depth_sum += pick4i(depth, b);
+            ++u;
         }
-        fi.e_excl = (double)(total_i - depth_sum);
-        fi.inv_n = inv_n;
-        fi.ll_excl = ll_excl;
-        if (lane == 0 && BVC_LDS_OK(11, idx, kPlaces)) { R.items[idx] = fi; S.item[c] = idx; }
+    double ll_excl = 0.0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) ll_excl += ((in_set >> b) & 1u) ? 0.0 : S.lle[b];
+    fi.ll_excl = ll_excl;
+    fi.e_excl = (double)(total_i - depth_sum);
+    fi.inv_n = 1.0 / (double)total_i;
+    *reinterpret_cast<uint32_t *>(fi.base) = bases;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                                // SetAlleleFreq (:25-39)
+        const int b = (bases >> (8 * q)) & 0xFFu;
+        fi.f0[q] = q < u ? (double)pick4i(depth, b & 3) / (double)depth_sum : 0.0;
     }
 }
 
@@ -337,7 +344,7 @@ __device__ __forceinline__ int site_classes(Region<CPB> &R, int ls, int lane, in
                 tab_n[pos] = c;
                 tab_q[pos] = (uint8_t)q;
             }
-            lle = fma((double)c, log_pos(lut->e[q]), lle);
+            lle = fma((double)c, lut->log_e[q], lle);
             low_q |= q < 2;
         }
         cnt_row += __popc(rowbits);
@@ -935,8 +942,7 @@ __device__ __forceinline__ void region_body(Region<CPB> *regions, const RegionAr
             if (cnt[0] + cnt[1] + cnt[2] + cnt[3] == 0) break;   // (the same LDS words for the whole team)
             const int first[kLists] = {0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2]};
             if (!BVC_LDS_OK(16, first[3] + cnt[3], kPlaces + 1)) break;
-#pragma unroll 1
-            for (int ls = member; ls < kRegionSites; ls += TEAM) site_emit(R, ls, lane, first);
+            if (member == 0) region_emit(R, lane, first);
             team_sync<TEAM>(R, phase, lane);
             constexpr int kPerWave4 = 16 >> log2g4<CPB>(), kPerWave2 = 2 * (16 >> log2g2<CPB>());
             constexpr int kPerWave4s = 16 >> log2g4s<CPB>(), kPerWave2s = 2 * (16 >> log2g2s<CPB>());
@@ -971,9 +977,12 @@ __device__ __forceinline__ void region_body(Region<CPB> *regions, const RegionAr
             team_sync<TEAM>(R, phase, lane);
             if (TEAM > 1 && member == 0 && lane == 0) R.next_slot = 0;      // nobody takes a slot again before the barrier behind the next emit
             if (level + 1 == (A.dbg_levels >> 1) && (A.dbg_levels & 1)) break;
-#pragma unroll 1
-            for (int ls = member; ls < kRegionSites; ls += TEAM)
-                if (site0 + ls < n_sites) site_decide(R, ls, lane, site0 + ls, A.n_groups, A.ref_base, A.results);
+            // the decisions of the level, one LANE per site (the reference's few dozen scalar steps per site -- read the fits, first
+            // minimum, threshold, next subsets or the record -- once for the region instead of once per site)
+            int my = lane;
+            asm volatile("" : "+v"(my));                          // (opaque: nothing of the site's addressing is hoisted out of the level loop)
+            if (member == 0 && my < kRegionSites && site0 + my < n_sites)
+                site_decide(R, my, 0, site0 + my, A.n_groups, A.ref_base, A.results);
             team_sync<TEAM>(R, phase, lane);
         }
         team_sync<TEAM>(R, phase, lane);                         // the region's LDS is reused by the next one

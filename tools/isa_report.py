@@ -24,8 +24,10 @@ def assembly(source, extra_flags=()):
     hipcc = "/opt/rocm/bin/hipcc"
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "out.s")
+        sys.path.insert(0, ROOT)
+        from basevarc_amd.build import PER_SOURCE_FLAGS          # the flags the library is built with
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", out,
-               os.path.join(CSRC, source)] + list(extra_flags)
+               os.path.join(CSRC, source)] + PER_SOURCE_FLAGS.get(source, []) + list(extra_flags)
         subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         return open(out).read()
 
