@@ -222,8 +222,10 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
 
 /* ---- tuning (per context; additive, no counterpart in the reference) -------------------------------- */
 /* Launch policy of THIS context; results never depend on it.  Keys:
- *   "em_waves_per_cu"  0 = default policy, 1..32 resident stage-2 wavefronts per CU (the region kernel runs in workgroups
- *                      of four: 4 = one workgroup on every CU, 2 = on every other CU, 8 = two per CU)
+ *   "em_waves_per_cu"  0 = default policy, 1..32 = stage-2 wavefronts per CU and launch: a call's stage 2 then runs as a
+ *                      SEQUENCE of launches of at most that many wavefronts per CU (a region of eight sites belongs to a team
+ *                      of two wavefronts; a workgroup holds up to two teams).  Default: unbounded when stage 2 has the chip to
+ *                      itself, 4 underneath a streaming histogram pass (overlap mode, rows of 200,000 samples and more)
  *   "em_wpb"           waves per EM workgroup: 4 (default) or 1
  *   "hist_split"       0 = by tile shape, 1..64 workgroups sharing a site in the dense histogram pass
  *   "em_streams"       overlap mode: stage 2 of consecutive calls on one side stream (1), on two alternating ones (2: the
@@ -250,10 +252,10 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
  *                      to rounding), AF / chi / var_qual agree to ~1e-15 relative, not bit for
  *                      bit.  With either engine a site's record never depends on the call's size or on its neighbours.
  *                      Environment: BVC_EM_ENGINE.
- *   "em_tiny_regions"  0 (default) / 1: with 1, regions of six sites that all have at most 8 quality values per allele
+ *   "em_tiny_regions"  0 (default) / 1: with 1, regions of eight sites that all have at most 8 quality values per allele
  *                      (binned qualities) take a kernel with one lane per allele (stage 2 1.36 x faster on such data).  That
  *                      kernel adds in a different order, so a site's AF / chi could differ in the last bits with the
- *                      binning of its five region neighbours: off by default.  Environment: BVC_EM_TINY_REGIONS. */
+ *                      binning of its seven region neighbours: off by default.  Environment: BVC_EM_TINY_REGIONS. */
 int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value);
 
 /* ---- measurement aid ------------------------------------------------------------------------------- */
