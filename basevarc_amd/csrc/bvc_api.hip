@@ -422,7 +422,6 @@ int bvc_create(bvc_ctx **out, int device)
     ctx->ls.dbg_levels = env_int("BVC_DBG_LEVELS", 0, 6, 0);
 #endif
     ctx->ls.em_tiny_regions = env_int("BVC_EM_TINY_REGIONS", 0, 1, 0);
-    ctx->ls.em_repack = env_int("BVC_EM_REPACK", 0, 1, 1);
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return BVC_ERR_DEVICE; }
     // likelihood table from the host's exp(), as the CPU path computes it (src/BaseType.cpp:13,15)
     QualLut lut;
@@ -1109,7 +1108,6 @@ int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value)
     if (std::strcmp(key, "group_big_lds") == 0 && (value == 0 || value == 1)) { ctx->ls.group_big_lds = value; return BVC_OK; }
     if (std::strcmp(key, "em_engine") == 0 && value >= 0 && value <= 1) { ctx->ls.em_engine = value; return BVC_OK; }
     if (std::strcmp(key, "em_tiny_regions") == 0 && value >= 0 && value <= 1) { ctx->ls.em_tiny_regions = value; return BVC_OK; }
-    if (std::strcmp(key, "em_repack") == 0 && value >= 0 && value <= 1) { ctx->ls.em_repack = value; return BVC_OK; }
     if (std::strcmp(key, "em_streams") == 0 && value >= 0 && value <= 3) {
         int rcj = join_side(ctx);
         if (rcj != BVC_OK) return rcj;

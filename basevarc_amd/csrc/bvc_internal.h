@@ -30,9 +30,6 @@ struct LaunchState {
                                // kernel (binned qualities: 0.23 -> 0.17 ms per 4000 sites).  Off by default: that kernel adds in a
                                // different order, so a site's last bits would depend on whether its five region neighbours are binned too
     int dbg_levels = 0;            // BVC_DBG_LEVELS (timing only, records wrong): cut region_kernel short after a phase; 0 = run all
-    int em_repack = 1;             // stage 2: the wavefront-slots of the fast lists are cut at 32 and 64 passes and re-packed from the fits that
-                                   // have not stopped (em_items.hip, fit_body); 0 = every slot runs to its slowest fit.  A launch policy: a fit's
-                                   // passes and lanes are the same either way, no bit of a record depends on it (A/B runs, tests)
     mutable uint32_t em_epoch = 0; // stage-2 launches of this context so far (em_items.hip: the narrow launch tells the wide one)
     mutable uint64_t attr_done = 0;    // kernels whose dynamic-LDS attribute has been raised on this context's device
 };

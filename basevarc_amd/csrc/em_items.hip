@@ -81,15 +81,13 @@ struct FitItem {
 static_assert(sizeof(FitItem) == 64, "FitItem layout");
 
 struct FitOut {
-    double ex[8];           // [0..3]: expect_allele_prob of the last pass, per unit.  While a fit is PARKED (left unfinished by a slot that
-                            // was cut, see fit_body): [unit * lanes + sub] = the lane's D of the previous pass
-    double fl[4];           // the frequencies the last pass ran on, per unit (kept here, not in registers, until ll_body); parked: f of
-                            // the previous pass
+    double ex[4];           // expect_allele_prob of the last pass, per unit
+    double fl[4];           // the frequencies that pass ran on, per unit (kept here, not in registers, until the epilogue)
     double ll;              // log-likelihood at those frequencies (UpdateF, src/BaseType.cpp:58-62)
     int32_t passes;
     int32_t pad;
 };
-static_assert(sizeof(FitOut) == 112, "FitOut layout");
+static_assert(sizeof(FitOut) == 80, "FitOut layout");
 
 // Per-site state between the phases.
 struct ItemSite {
@@ -112,14 +110,6 @@ struct ItemSite {
 // ("slow" = the subset leaves out the deepest candidate: such fits run to the iteration cap)
 constexpr int kLists = 4;
 constexpr int kLevels = 3;
-// pass counts at which the slots of the FAST lists are cut and re-packed from the fits that have not stopped (fit_body)
-#ifndef BVC_REPACK_CUT0
-#define BVC_REPACK_CUT0 32
-#endif
-#ifndef BVC_REPACK_CUT1
-#define BVC_REPACK_CUT1 64
-#endif
-constexpr int kCut0 = BVC_REPACK_CUT0, kCut1 = BVC_REPACK_CUT1;
 #ifndef BVC_REGION_SITES
 #define BVC_REGION_SITES 8
 #endif
@@ -215,9 +205,7 @@ struct Region {
     FitOut outs[kPlaces];
     int want[kRegionSites][kLists];
     int need;                                            // most class places a taken site of the region needs on an allele
-    int next_slot[4];                                    // wavefront-slots handed out so far in each phase of the running level (teams of 2 or 4)
-    int n_parked[2][2];                                  // fits parked by the cut slots: [fast list 0 / 2][round parity]
-    uint8_t parked[2][2][kPlaces];                       // ... their places
+    int next_slot;                                       // wavefront-slots of the running level handed out so far (teams of 2 or 4)
     uint32_t arrive;                                     // team barrier: arrivals so far (never reset)
     alignas(8) uint8_t tab[kRegionSites][site_table_bytes<CPB>()];
 };
@@ -529,77 +517,43 @@ __device__ __forceinline__ double item_sum(double x)
     return unit_sum<LOG2G>(x);
 }
 
-// Where the lanes of a wavefront-slot sit: unit (allele) = row or row & 1, `sub` = lane of the unit, `pos` = which of the slot's fits.
-template <int ROWS, int LOG2G>
-struct SlotLane {
-    static constexpr int G = 1 << LOG2G, kGroupsPerRow = 16 / G;
-    int unit, sub, pos;
-    __device__ __forceinline__ SlotLane()
-    {
-        // (opaque to the optimiser: what is derived from the lane id is then recomputed in every slot -- a handful of integer
-        // instructions -- instead of being kept in registers across the levels of the region)
-        int tid = (int)threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        const int lane = tid & (kWave - 1);
-        const int row = lane >> 4, grp = (lane & 15) >> LOG2G;
-        sub = lane & (G - 1);
-        unit = ROWS == 4 ? row : (row & 1);
-        pos = ROWS == 4 ? grp : (row >> 1) * kGroupsPerRow + grp;
-    }
-};
-
-// The classes of the lane: counts and e = eps / 3 of class places sub, sub + G, ... of allele `base` of the fit's site.
-template <int LOG2G, int CPB>
-__device__ __forceinline__ void load_classes(double (&n)[CPB >> LOG2G], double (&e)[CPB >> LOG2G], const uint8_t *cls, int site, int base,
-                                             int sub, const double *lut_e)
-{
-    constexpr int G = 1 << LOG2G, kSlots = CPB / G;
-    const uint8_t *tab = cls + site * site_table_bytes<CPB>();
-    const uint32_t *tab_n = reinterpret_cast<const uint32_t *>(tab) + base * CPB + sub;
-    const uint8_t *tab_q = tab + 16 * CPB + base * CPB + sub;
-#pragma unroll
-    for (int k = 0; k < kSlots; ++k) {
-        n[k] = (double)tab_n[k * G];
-        e[k] = lut_e[tab_q[k * G]];
-    }
-}
-
-// One wavefront-slot of fits: the slot's fits are places ids[first + pos] (ids == nullptr: first + pos), those before `end`.
-// Passes it0 .. : a slot that starts at it0 > 0 RESUMES parked fits; a slot with it_cut <= kEmIters is CUT when the pass counter
-// reaches it_cut: the fits that have not stopped by then are parked -- f -> FitItem::f0, f of the previous pass -> FitOut::fl, every
-// lane's D of the previous pass -> FitOut::ex -- and their places appended to park_ids.  Parking and resuming change no bit of
-// a fit (the pass sequence and the lanes' roles are the same wherever it sits); they exist because the fits that share a slot run
-// in lockstep to the slowest, and at N = 1e4 the fast fits take 14..101 passes: cut slots are re-packed from their stragglers.
 template <int ROWS, int LOG2G, int CPB>
-__device__ __forceinline__ void fit_body(const uint8_t *ids, int first, int end, FitItem *items, FitOut *outs, const uint8_t *cls,
-                                         const double *lut_e, int it0, int it_cut, uint8_t *park_ids, int *park_n)
+__device__ __forceinline__ void fit_body(int item0, int item_end, const FitItem *items, FitOut *outs, const uint8_t *cls,
+                                         const double *lut_e)
 {
     constexpr int G = 1 << LOG2G, kSlots = CPB / G;
-    const SlotLane<ROWS, LOG2G> L;
-    const int unit = L.unit, sub = L.sub;
-    const bool valid = first + L.pos < end;
-    int item = first + L.pos;
-    if (ids) item = valid ? (int)ids[first + L.pos] : 0;
-    const bool ok = valid && BVC_LDS_OK(12, item, kPlaces);
+    constexpr int kGroupsPerRow = 16 / G;
+    // (opaque to the optimiser: what is derived from the lane id below is then recomputed in every slot -- a handful of
+    // integer instructions -- instead of being kept in registers across the levels of the region, which the narrow kernel's
+    // 168 VGPRs have no room for)
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & (kWave - 1);
+    const int row = lane >> 4, sub = lane & (G - 1), grp = (lane & 15) >> LOG2G;
+    const int unit = ROWS == 4 ? row : (row & 1);
+    const int item = item0 + (ROWS == 4 ? grp : (row >> 1) * kGroupsPerRow + grp);
+    const bool valid = item < item_end && BVC_LDS_OK(12, item, kPlaces);
 
     double n[kSlots], e[kSlots];
-    double fb = 0.0, fprev = 0.0, dprev = 0.0;
+    double fb = 0.0;
     bool active = false;
     // the fit's two constants are read from its descriptor in every pass (two LDS loads that have the whole pass to arrive)
     // instead of living in four registers: the narrow kernel sits at the 168 VGPRs of three wavefronts per SIMD
-    FitItem *fi_c = items + (ok ? item : 0);
-    if (ok) {
+    const FitItem *fi_c = items + (valid ? item : item0);
+    if (valid) {
         const FitItem *fi = items + item;
         const int base = fi->base[unit];
         if (base != 0xFF && BVC_LDS_OK(13, fi->site, kRegionSites) && BVC_LDS_OK(14, base, 4)) {
             active = true;
             fb = fi->f0[unit];
-            fprev = fb;
-            load_classes<LOG2G, CPB>(n, e, cls, fi->site, base, sub, lut_e);
-        }
-        if (it0 > 0) {                                           // a parked fit: where the cut slot left it
-            fprev = outs[item].fl[unit];
-            dprev = outs[item].ex[unit * G + sub];
+            const uint8_t *tab = cls + fi->site * site_table_bytes<CPB>();
+            const uint32_t *tab_n = reinterpret_cast<const uint32_t *>(tab) + base * CPB + sub;
+            const uint8_t *tab_q = tab + 16 * CPB + base * CPB + sub;
+#pragma unroll
+            for (int k = 0; k < kSlots; ++k) {
+                n[k] = (double)tab_n[k * G];
+                e[k] = lut_e[tab_q[k * G]];
+            }
         }
     }
     if (!active) {
@@ -610,8 +564,9 @@ __device__ __forceinline__ void fit_body(const uint8_t *ids, int first, int end,
     // EM (src/Algorithm.cpp:115-130): pass 0, then at most kEmIters passes each followed by the stop rule.  An item
     // that stops writes its fit at once and runs on (its lanes are not masked: the passes of a converged fit are
     // ordinary arithmetic, and nothing of it is read again).
-    int it = it0;
-    bool done = !ok;
+    double fprev = fb, dprev = 0.0;
+    int it = 0;
+    bool done = !valid;
     while (true) {
         // stop-rule bracket of THIS pass: A = sum_b |f_b - f_b(previous pass)| D_b(previous pass), lane partial
         double ta = fabs(fb - fprev) * dprev;
@@ -691,60 +646,23 @@ __device__ __forceinline__ void fit_body(const uint8_t *ids, int first, int end,
         dprev = acc_d;
         fb = ex;
         ++it;
-        if (it == it_cut) {                                      // (uniform) the slot is cut: park what has not stopped
-            if (!done) {
-                outs[item].ex[unit * G + sub] = dprev;
-                if (sub == 0) {
-                    items[item].f0[unit] = fb;
-                    outs[item].fl[unit] = fprev;
-                    if (unit == 0) {
-                        const int k = atomicAdd(park_n, 1);
-                        if (BVC_LDS_OK(17, k, kPlaces)) park_ids[k] = (uint8_t)item;
-                    }
-                }
-            }
-            break;
-        }
     }
-}
-
-// UpdateF's log-likelihood (src/BaseType.cpp:58-62) of the fits first .. end - 1 at the frequencies of each fit's last pass: the lane's
-// classes here, the alleles outside the subset from the fit's constant.  A phase of its own behind the fits of a level (all
-// lists), so that a slot that was cut and re-packed pays for it once, with full lanes.
-template <int ROWS, int LOG2G, int CPB>
-__device__ __forceinline__ void ll_body(int first, int end, const FitItem *items, FitOut *outs, const uint8_t *cls, const double *lut_e)
-{
-    constexpr int G = 1 << LOG2G, kSlots = CPB / G;
-    const SlotLane<ROWS, LOG2G> L;
-    const int unit = L.unit, sub = L.sub, item = first + L.pos;
-    const bool valid = item < end && BVC_LDS_OK(18, item, kPlaces);
-    double n[kSlots], e[kSlots];
-    bool active = false;
-    double fl = 0.25;
-    if (valid) {
-        const FitItem *fi = items + item;
-        const int base = fi->base[unit];
-        if (base != 0xFF && BVC_LDS_OK(13, fi->site, kRegionSites) && BVC_LDS_OK(14, base, 4)) {
-            active = true;
-            fl = outs[item].fl[unit];
-            load_classes<LOG2G, CPB>(n, e, cls, fi->site, base, sub, lut_e);
-        }
-    }
-    if (!active) {
+    // UpdateF's log-likelihood (src/BaseType.cpp:58-62) at the frequencies of each item's last pass: the lane's
+    // classes here, the alleles outside the subset from the item's constant
+    {
+        const double fl = outs[valid ? item : item0].fl[unit];   // (a place that holds no item: its sum is never stored)
+        const double g = fma(-4.0, fl, 1.0);
+        double ll = 0.0;
 #pragma unroll
-        for (int k = 0; k < kSlots; ++k) { n[k] = 0.0; e[k] = 0.25; }
+        for (int k = 0; k < kSlots; ++k) {
+            ll = fma(n[k], log_pos(fma(g, e[k], fl)), ll);
+            // four logarithms side by side are enough to fill the pipeline; all sixteen at once cost registers the kernel
+            // does not have at three wavefronts per SIMD
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        ll = item_sum<ROWS, LOG2G>(ll);
+        if (valid && unit == 0 && sub == 0) outs[item].ll = ll + items[item].ll_excl;
     }
-    const double g = fma(-4.0, fl, 1.0);
-    double ll = 0.0;
-#pragma unroll
-    for (int k = 0; k < kSlots; ++k) {
-        ll = fma(n[k], log_pos(fma(g, e[k], fl)), ll);
-        // four logarithms side by side are enough to fill the pipeline; all sixteen at once cost registers the kernel
-        // does not have at three wavefronts per SIMD
-        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
-    ll = item_sum<ROWS, LOG2G>(ll);
-    if (valid && unit == 0 && sub == 0) outs[item].ll = ll + items[item].ll_excl;
 }
 
 // Lanes per allele of the two item shapes: two for four-row items (8 per wavefront), four for two-row items (8 per
@@ -897,7 +815,6 @@ struct RegionArgs {
     int dbg_levels;
     int tiny_regions;            // LaunchState::em_tiny_regions
     int64_t region0;             // first region of this launch (a call may be a sequence of launches)
-    int repack;                  // LaunchState::em_repack: cut and re-pack the slots of the fast lists (a launch policy: no bit of a record depends on it)
 };
 
 // Orders the wavefront's own LDS traffic around a point: everything a region keeps in LDS is private to its wavefront, the
@@ -972,7 +889,7 @@ __device__ __forceinline__ void region_body(Region<CPB> *regions, const RegionAr
     int64_t region = A.region0 + (int64_t)blockIdx.x * teams + wave / TEAM;
     for (bool first = true; region < n_regions && (WALK || first); first = false, region += (int64_t)gridDim.x * teams) {
         const int64_t site0 = region * kRegionSites;
-        if (member == 0 && lane == 0) R.need = 0;
+        if (member == 0 && lane == 0) { R.need = 0; R.next_slot = 0; }
         if (TEAM > 1) team_sync<TEAM>(R, phase, lane);
         // ---- classes: a member's sites one after the other, the next site's counts in flight while the current one is compacted
         int need = 0;
@@ -1025,72 +942,40 @@ __device__ __forceinline__ void region_body(Region<CPB> *regions, const RegionAr
             if (cnt[0] + cnt[1] + cnt[2] + cnt[3] == 0) break;   // (the same LDS words for the whole team)
             const int first[kLists] = {0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2]};
             if (!BVC_LDS_OK(16, first[3] + cnt[3], kPlaces + 1)) break;
-            if (member == 0) {
-                region_emit(R, lane, first);
-                if (lane < 4) R.next_slot[lane] = 0;              // the slot counters of the level's phases, the lists of parked fits
-                if (lane < 4) R.n_parked[lane >> 1][lane & 1] = 0;
-            }
+            if (member == 0) region_emit(R, lane, first);
             team_sync<TEAM>(R, phase, lane);
             constexpr int kPerWave4 = 16 >> log2g4<CPB>(), kPerWave2 = 2 * (16 >> log2g2<CPB>());
             constexpr int kPerWave4s = 16 >> log2g4s<CPB>(), kPerWave2s = 2 * (16 >> log2g2s<CPB>());
-            FitItem *items = R.items;
+            const FitItem *items = R.items;
             FitOut *outs = R.outs;
             const uint8_t *tabs = &R.tab[0][0];
             const double *lut_e = A.lut->e;
-            // The level's wavefront-slots, in PHASES with a team barrier behind each:
-            //   0  every fit's first passes: the slow lists whole (their fits run to the iteration cap whatever the site, so they
-            //      share wavefront-passes with their like, and they come first: the wavefront that gets a second slot should not
-            //      be the one that runs 101 passes), the fast lists up to pass kCut[0];
-            //   1, 2  the fast fits that had not stopped when their slot was cut, re-packed eight to a slot from the lists of
-            //      parked places: passes kCut[0] .. kCut[1], then to the end;
-            //   3  the log-likelihoods of all fits of the level (ll_body).
-            // The fits of a slot run in lockstep to the slowest; at N = 1e4 a fast fit takes 14 .. 101 passes, and cutting the
-            // slots keeps the quick fits from riding along with the stragglers (A.repack = 0: phases 1 and 2 are empty).
-            const int cut0 = A.repack ? kCut0 : kEmIters + 2, cut1 = A.repack ? kCut1 : kEmIters + 2;
+            // slots of the level, the slow lists first (the wavefront that gets a second slot should not be the one that runs the
+            // 101 passes of the slow fits): w1 of list 1, then list 3, list 0, list 2
             const int w1 = (cnt[1] + kPerWave4s - 1) / kPerWave4s, w3 = w1 + (cnt[3] + kPerWave2s - 1) / kPerWave2s;
             const int w0 = w3 + (cnt[0] + kPerWave4 - 1) / kPerWave4, w2 = w0 + (cnt[2] + kPerWave2 - 1) / kPerWave2;
+            int slot = 0;
 #pragma unroll 1
-            for (int ph = 0; ph < 4; ++ph) {
-                // slots of this phase: [0, s_a) of the four-row shape, [s_a, s_b) of the two-row shape (phases 1, 2); w1..w2 (0, 3)
-                const int par = (ph - 1) & 1;                    // phases 1 / 2 read the parked lists of parity 0 / 1
-                const int n4 = (ph == 1 || ph == 2) ? R.n_parked[0][par] : 0, n2 = (ph == 1 || ph == 2) ? R.n_parked[1][par] : 0;
-                const int s_a = (n4 + kPerWave4 - 1) / kPerWave4, s_b = s_a + (n2 + kPerWave2 - 1) / kPerWave2;
-                const int n_slots = (ph == 0 || ph == 3) ? w2 : s_b;
-                if ((ph == 1 || ph == 2) && n_slots == 0) continue;                  // (uniform over the team: the same LDS words)
-                int slot = 0;
-#pragma unroll 1
-                for (;;) {
-                    if (TEAM > 1) {
-                        if (lane == 0) slot = atomicAdd(&R.next_slot[ph], 1);
-                        slot = __builtin_amdgcn_readfirstlane(slot);
-                    }
-                    if (slot >= n_slots) break;
-                    if (ph == 0 || ph == 3) {
-                        const int l = slot < w1 ? 1 : (slot < w3 ? 3 : (slot < w0 ? 0 : 2));
-                        const int in_list = slot - (l == 1 ? 0 : (l == 3 ? w1 : (l == 0 ? w3 : w0)));
-                        const int base = l == 0 ? first[0] : (l == 1 ? first[1] : (l == 2 ? first[2] : first[3]));
-                        const int end = base + (l == 0 ? cnt[0] : (l == 1 ? cnt[1] : (l == 2 ? cnt[2] : cnt[3])));
-                        const int never = kEmIters + 2;
-                        if (ph == 0) {
-                            if (l == 0) fit_body<4, log2g4<CPB>(), CPB>(nullptr, base + in_list * kPerWave4, end, items, outs, tabs, lut_e, 0, cut0, R.parked[0][0], &R.n_parked[0][0]);
-                            else if (l == 2) fit_body<2, log2g2<CPB>(), CPB>(nullptr, base + in_list * kPerWave2, end, items, outs, tabs, lut_e, 0, cut0, R.parked[1][0], &R.n_parked[1][0]);
-                            else if (l == 1) fit_body<4, log2g4s<CPB>(), CPB>(nullptr, base + in_list * kPerWave4s, end, items, outs, tabs, lut_e, 0, never, nullptr, nullptr);
-                            else fit_body<2, log2g2s<CPB>(), CPB>(nullptr, base + in_list * kPerWave2s, end, items, outs, tabs, lut_e, 0, never, nullptr, nullptr);
-                        } else {
-                            if (l == 0) ll_body<4, log2g4<CPB>(), CPB>(base + in_list * kPerWave4, end, items, outs, tabs, lut_e);
-                            else if (l == 2) ll_body<2, log2g2<CPB>(), CPB>(base + in_list * kPerWave2, end, items, outs, tabs, lut_e);
-                            else if (l == 1) ll_body<4, log2g4s<CPB>(), CPB>(base + in_list * kPerWave4s, end, items, outs, tabs, lut_e);
-                            else ll_body<2, log2g2s<CPB>(), CPB>(base + in_list * kPerWave2s, end, items, outs, tabs, lut_e);
-                        }
-                    } else {
-                        const int it0 = ph == 1 ? cut0 : cut1, cut = ph == 1 ? cut1 : kEmIters + 2;
-                        if (slot < s_a) fit_body<4, log2g4<CPB>(), CPB>(R.parked[0][par], slot * kPerWave4, n4, items, outs, tabs, lut_e, it0, cut, R.parked[0][par ^ 1], &R.n_parked[0][par ^ 1]);
-                        else fit_body<2, log2g2<CPB>(), CPB>(R.parked[1][par], (slot - s_a) * kPerWave2, n2, items, outs, tabs, lut_e, it0, cut, R.parked[1][par ^ 1], &R.n_parked[1][par ^ 1]);
-                    }
-                    if (TEAM == 1) ++slot;
+            for (;;) {
+                if (TEAM > 1) {
+                    if (lane == 0) slot = atomicAdd(&R.next_slot, 1);
+                    slot = __builtin_amdgcn_readfirstlane(slot);
                 }
-                team_sync<TEAM>(R, phase, lane);
+                if (slot >= w2) break;
+                const int l = slot < w1 ? 1 : (slot < w3 ? 3 : (slot < w0 ? 0 : 2));
+                const int in_list = slot - (l == 1 ? 0 : (l == 3 ? w1 : (l == 0 ? w3 : w0)));
+                const int base = l == 0 ? first[0] : (l == 1 ? first[1] : (l == 2 ? first[2] : first[3]));
+                const int end = base + (l == 0 ? cnt[0] : (l == 1 ? cnt[1] : (l == 2 ? cnt[2] : cnt[3])));
+                if (l == 0) fit_body<4, log2g4<CPB>(), CPB>(base + in_list * kPerWave4, end, items, outs, tabs, lut_e);
+                else if (l == 2) fit_body<2, log2g2<CPB>(), CPB>(base + in_list * kPerWave2, end, items, outs, tabs, lut_e);
+                else if (BVC_SLOW_EXTRA_LOG2G == 0 && l == 1) fit_body<4, log2g4<CPB>(), CPB>(base + in_list * kPerWave4, end, items, outs, tabs, lut_e);
+                else if (BVC_SLOW_EXTRA_LOG2G == 0) fit_body<2, log2g2<CPB>(), CPB>(base + in_list * kPerWave2, end, items, outs, tabs, lut_e);
+                else if (l == 1) fit_body<4, log2g4s<CPB>(), CPB>(base + in_list * kPerWave4s, end, items, outs, tabs, lut_e);
+                else fit_body<2, log2g2s<CPB>(), CPB>(base + in_list * kPerWave2s, end, items, outs, tabs, lut_e);
+                if (TEAM == 1) ++slot;
             }
+            team_sync<TEAM>(R, phase, lane);
+            if (TEAM > 1 && member == 0 && lane == 0) R.next_slot = 0;      // nobody takes a slot again before the barrier behind the next emit
             if (level + 1 == (A.dbg_levels >> 1) && (A.dbg_levels & 1)) break;
             // the decisions of the level, one LANE per site (the reference's few dozen scalar steps per site -- read the fits, first
             // minimum, threshold, next subsets or the record -- once for the region instead of once per site)
@@ -1181,7 +1066,6 @@ hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n
     A.dbg_levels = st.dbg_levels > 0 ? st.dbg_levels : 2 * kLevels;
     A.tiny_regions = st.em_tiny_regions;
     A.region0 = 0;
-    A.repack = st.em_repack;
     // the wide kernels' dynamic LDS (4 x 14 KB) is beyond the 48 KiB a launch may ask for without the attribute
     constexpr uint32_t kSlotRegionWide = 60;
     if (!(st.attr_done & ((uint64_t)1 << kSlotRegionWide))) {

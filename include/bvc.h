@@ -238,14 +238,11 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
  *                      slots x 16 / 8 / 4 copies per histogram in up to 144 KiB of LDS (two-byte rows are packed in registers for
  *                      it; sites with a covered quality of 63 or more are redone by the general kernel), 0 = 512-thread
  *                      workgroups of 64 KiB
- *   "em_repack"        1 (default): stage 2 cuts the wavefront-slots of its fast fits at 32 and 64 EM passes and re-packs the fits
- *                      that have not stopped, eight to a slot; 0: every slot runs to its slowest fit.  A fit's passes and the lanes
- *                      that compute it are the same either way: the records are byte-identical (tests/test_gpu_round4.py)
  *   "host_chunk_kib"   BVC_PTR_HOST calls stage the tile through device memory in chunks of sites of at most this
  *                      many KiB per array (default 524288 = 512 MiB); the upload of chunk i+1 runs under the kernels
  *                      of chunk i
  * A new context starts from the environment variables BVC_EM_WAVES_PER_CU, BVC_EM_WPB, BVC_HIST_SPLIT,
- * BVC_GROUP_PIPE, BVC_GROUP_LOG2C, BVC_GROUP_BIG_LDS, BVC_EM_STREAMS, BVC_EM_REPACK when they are set.
+ * BVC_GROUP_PIPE, BVC_GROUP_LOG2C, BVC_GROUP_BIG_LDS, BVC_EM_STREAMS when they are set.
  *
  * One key is NOT a launch policy:
  *   "em_engine"        0 (default) = the item engine of stage 2 (fits as work items, csrc/em_items.hip), 1 = one

@@ -133,8 +133,7 @@ def test_ragged_block_kernel_around_its_block_size(ctx):
 
 def test_stage2_launch_shapes_never_change_a_record(ctx):
     """Stage 2 gives a region of eight sites to a team of wavefronts; how many wavefronts a call may hold per CU
-    (em_waves_per_cu: the walk underneath a histogram pass is a SEQUENCE of launches), whether the slots of the fast fits are
-    cut at 32 and 64 passes and re-packed from their stragglers (em_repack) and whether it runs beside a histogram pass
+    (em_waves_per_cu: the walk underneath a histogram pass is a SEQUENCE of launches) and whether it runs beside a histogram pass
     (overlap mode) are launch policies: the records of a tile are the same bytes under every one of them, for plain calls, calls
     with a site count that leaves the last region partly empty, and group calls (pseudo-sites)."""
     import torch
@@ -149,15 +148,14 @@ def test_stage2_launch_shapes_never_change_a_record(ctx):
     want = ctx.lrt_dense_device(b, q, r, m)
     gw, ggw = ctx.lrt_dense_groups_device(b, q, r, m, g, k)
     ctx.synchronize()
-    for per_cu, repack in ((1, 1), (2, 1), (3, 0), (4, 1), (8, 1), (0, 0)):
+    for per_cu in (1, 2, 3, 4, 8):
         for overlap in (False, True):
             with Context(0) as other:
                 other.set_tuning("em_waves_per_cu", per_cu)
-                other.set_tuning("em_repack", repack)            # cut and re-packed slots or not: the same bytes
                 other.set_overlap(overlap)
                 for rep in range(2):
                     got = other.lrt_dense_device(b, q, r, m)
                     g1, g2 = other.lrt_dense_groups_device(b, q, r, m, g, k)
                 other.join(); other.synchronize()
-                assert torch.equal(got, want), (per_cu, repack, overlap)
-                assert torch.equal(g1, gw) and torch.equal(g2, ggw), (per_cu, repack, overlap)
+                assert torch.equal(got, want), (per_cu, overlap)
+                assert torch.equal(g1, gw) and torch.equal(g2, ggw), (per_cu, overlap)
