@@ -37,7 +37,9 @@ def needs_build():
 # SIMD, and the machine-level loop-invariant code motion of this compiler keeps hoisting lane-constant addresses, zero vectors
 # and the like out of the region's level loop, where they stay live across the fits and end in scratch (or in 30-70 SGPR
 # spills); without that pass the kernel has no spill of either kind (tools/isa_report.py, tests/test_isa.py).
-PER_SOURCE_FLAGS = {"em_items.hip": ["-mllvm", "-disable-machine-licm"]}
+PER_SOURCE_FLAGS = {"em_items.hip": ["-mllvm", "-disable-machine-licm"],
+                    # the one-wavefront-per-site kernels: 46-64 SGPR spills (to VGPR lanes) with the pass, 15-38 without, fewer VGPRs
+                    "em_kernel.hip": ["-mllvm", "-disable-machine-licm"]}
 
 
 def build(force=False, verbose=False):
