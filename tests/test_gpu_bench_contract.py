@@ -56,6 +56,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert hp["ragged_one_byte"]["records_identical_to_device_pointer_call"] is True
     assert legs["config1_1e4x1e4"]["roofline"]["bound"] == "fp64_valu_issue"
     assert legs["csr_coverage10pct"]["roofline"]["bound"] == "fp64_valu_issue" and legs["csr_coverage10pct"]["hist_roofline"]["bound"] == "hbm"
+    # the ragged histogram pass is reported twice: underneath stage 2 and with the chip to itself (faster alone)
+    hr = legs["csr_coverage10pct"]["hist_roofline"]
+    assert 0 < hr["frac"] <= hr["alone"]["frac"] * 1.05 and hr["alone"]["launches_timed"] >= 8
 
 
 def test_bench_under_the_drivers_multi_gpu_launcher_two_ranks_sharing_the_card():
