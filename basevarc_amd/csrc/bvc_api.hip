@@ -419,9 +419,10 @@ int bvc_create(bvc_ctx **out, int device)
 #ifdef BVC_DIAG_KNOBS
     // timing experiments only (tools/em_stage2.py phase breakdown): cuts region_kernel short, so the records are WRONG.  Not
     // compiled into the product: a stray environment variable must never be able to do that.
-    ctx->ls.dbg_levels = env_int("BVC_DBG_LEVELS", 0, 6, 0);
+    ctx->ls.dbg_levels = env_int("BVC_DBG_LEVELS", 0, 12, 0);
 #endif
     ctx->ls.em_tiny_regions = env_int("BVC_EM_TINY_REGIONS", 0, 1, 0);
+    ctx->ls.em_prune = env_int("BVC_EM_PRUNE", 0, 1, 1);
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return BVC_ERR_DEVICE; }
     // likelihood table from the host's exp(), as the CPU path computes it (src/BaseType.cpp:13,15)
     QualLut lut;
@@ -1108,6 +1109,7 @@ int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value)
     if (std::strcmp(key, "group_big_lds") == 0 && (value == 0 || value == 1)) { ctx->ls.group_big_lds = value; return BVC_OK; }
     if (std::strcmp(key, "em_engine") == 0 && value >= 0 && value <= 1) { ctx->ls.em_engine = value; return BVC_OK; }
     if (std::strcmp(key, "em_tiny_regions") == 0 && value >= 0 && value <= 1) { ctx->ls.em_tiny_regions = value; return BVC_OK; }
+    if (std::strcmp(key, "em_prune") == 0 && value >= 0 && value <= 1) { ctx->ls.em_prune = value; return BVC_OK; }
     if (std::strcmp(key, "em_streams") == 0 && value >= 0 && value <= 3) {
         int rcj = join_side(ctx);
         if (rcj != BVC_OK) return rcj;

@@ -29,6 +29,8 @@ struct LaunchState {
     int em_tiny_regions = 0;       // 1: regions whose sites all have <= 8 quality values per allele take the one-lane-per-allele
                                // kernel (binned qualities: 0.23 -> 0.17 ms per 4000 sites).  Off by default: that kernel adds in a
                                // different order, so a site's last bits would depend on whether its five region neighbours are binned too
+    int em_prune = 1;              // item engine: 1 = a level does not run the subset without the deepest candidate when a bound on its
+                                   // log-likelihood shows that it cannot be the level's first minimum (em_items.hip, site_decide); 0 = it always runs
     int dbg_levels = 0;            // BVC_DBG_LEVELS (timing only, records wrong): cut region_kernel short after a phase; 0 = run all
     mutable uint32_t em_epoch = 0; // stage-2 launches of this context so far (em_items.hip: the narrow launch tells the wide one)
     mutable uint64_t attr_done = 0;    // kernels whose dynamic-LDS attribute has been raised on this context's device

@@ -94,33 +94,36 @@ struct ItemSite {
     double lr_alt, chi;
     double base_frq[4];
     double lle[4];          // per allele: sum over its classes of n log e
+    double best_chi, best_lr, best_bp[4];   // second round of a level: the first minimum among the subsets of the first round
     int32_t depth[4];
     int32_t passes, fits;
-    int32_t item[5];        // pending items: index into the region's item / result arrays
+    int32_t item[4];        // pending items: index into the region's item / result arrays
     uint32_t sets;          // fits to emit next: 4-bit position masks over blist, packed
-    int8_t n_emit, p_deepest;
     uint32_t blist;         // candidates in order, 4 bits each
+    int8_t n_emit, p_deepest;
     int8_t n;               // candidates
     int8_t k;               // subset size of the pending level
     uint8_t state;          // 0 = left to em_kernel.hip, 1 = running here, 2 = record written
     uint8_t first;          // the pending level is the first one: full model + its (n-1)-subsets
+    uint8_t later;          // position mask of the level's LAST-RESORT subset (the one without the deepest candidate), 0 = none
+    uint8_t round2;         // the pending fit is that subset: the level's other subsets have been run and decided among
+    int8_t best_i;          // lexicographic index of the first minimum so far (round2)
 };
 
-// list 0 / 1: items of 3-4 units (four rows per item), fast / slow; list 2 / 3: items of 1-2 units, fast / slow
-// ("slow" = the subset leaves out the deepest candidate: such fits run to the iteration cap)
-constexpr int kLists = 4;
-constexpr int kLevels = 3;
+// list 0: items of 3-4 units (four rows per item); list 1: items of 1-2 units (two rows per item)
+constexpr int kLists = 2;
+// Engine rounds per site: three levels of the reference (the full model with its (n-1)-subsets, the (n-2)- and the
+// (n-3)-subsets), each at most twice (the last-resort subset of a level, when the bound cannot rule it out: see site_decide)
+constexpr int kRounds = 6;
 #ifndef BVC_REGION_SITES
 #define BVC_REGION_SITES 8
 #endif
-// sites of a workgroup.  8 x (full model + 4 subsets) = 32 + 8 fits: four full wavefronts and a full "slow" one, and the
-// two-allele level after it 16 + 8.  (6 sites -- 24 + 6 fits, one slot per wavefront -- leave the slow wavefronts a quarter
-// empty: the same time alone, 10 % slower underneath a histogram pass; 12 are too few regions per launch: 0.31 against
-// 0.23 ms per 4000 sites alone.  profiles/r03_region_sites.txt)
+// sites of a region.  (Round 3, when every subset was run: 8 x (full model + 4 subsets) = 32 + 8 fits; 6 sites left the slow
+// wavefronts a quarter empty, 12 are too few regions per launch: profiles/r03_region_sites.txt.)
 constexpr int kRegionSites = BVC_REGION_SITES;
-// places of the region's item arrays: a site has at most five fits pending at any level (the full model and its four
-// subsets); the lists of a level lie one behind the other, their first places (Region::base) set per level
-constexpr int kPlaces = 5 * kRegionSites;
+// places of the region's item arrays: a site has at most FOUR fits pending in any round (the full model and the three
+// (n-1)-subsets that keep the deepest candidate); the lists of a round lie one behind the other
+constexpr int kPlaces = 4 * kRegionSites;
 
 // k-subsets of positions 0..n-1 in lexicographic order (what combs_ yields), as 4-bit position masks packed
 // least-significant first; count returned through `cnt`.
@@ -162,16 +165,14 @@ __device__ __forceinline__ int64_t ref_index(int64_t p, int n_groups)
     return n_groups > 0 ? (int64_t)((uint32_t)p / (uint32_t)n_groups) : p;
 }
 
-template <class T>
-__device__ __forceinline__ T sel4(const T (&v)[kLists], int l)
-{
-    return l == 0 ? v[0] : (l == 1 ? v[1] : (l == 2 ? v[2] : v[3]));
-}
+// List of a fit: four rows per item for 3-4 alleles, two for 1-2.
+__device__ __forceinline__ int list_of(uint32_t pm) { return __popc(pm) >= 3 ? 0 : 1; }
 
-// List of a fit: four rows per item for 3-4 alleles, two for 1-2; "slow" when it leaves out the deepest candidate.
-__device__ __forceinline__ int list_of(uint32_t pm, int p_deepest)
+// `masks` (4-bit masks packed least-significant first) without its c-th one.
+__device__ __forceinline__ uint32_t drop_nibble(uint32_t masks, int c)
 {
-    return (__popc(pm) >= 3 ? 0 : 2) + (((pm >> p_deepest) & 1u) ? 0 : 1);
+    const uint32_t low = masks & ((1u << (4 * c)) - 1u);
+    return low | ((masks >> (4 * c + 4)) << (4 * c));
 }
 
 // Position (in the candidate list) of the deepest candidate, first one on ties.
@@ -186,15 +187,27 @@ __device__ __forceinline__ int deepest_position(const int32_t (&depth)[4], uint3
     return best;
 }
 
-__device__ __forceinline__ void count_wanted(uint32_t sets, int n_emit, int p_deepest, int (&want)[kLists])
+__device__ __forceinline__ void count_wanted(uint32_t sets, int n_emit, int (&want)[kLists])
 {
-    want[0] = want[1] = want[2] = want[3] = 0;
+    want[0] = want[1] = 0;
 #pragma unroll
-    for (int c = 0; c < 5; ++c)
+    for (int c = 0; c < 4; ++c)
         if (c < n_emit) {
-            const int l = list_of((sets >> (4 * c)) & 0xFu, p_deepest);
-            want[0] += l == 0; want[1] += l == 1; want[2] += l == 2; want[3] += l == 3;
+            const int l = list_of((sets >> (4 * c)) & 0xFu);
+            want[0] += l == 0; want[1] += l == 1;
         }
+}
+
+// The (n-1)-subsets of n candidates that a level runs first, and the one it keeps for later (`later`): the subset without the
+// deepest candidate (position p_deepest) is, of the n subsets in lexicographic order, number n - 1 - p_deepest.
+__device__ __forceinline__ uint32_t level_subsets(int n, int p_deepest, int &n_first, uint32_t &later)
+{
+    int cnt = 0;
+    const uint32_t masks = subset_masks(n, n - 1, cnt);
+    const int c_last = n - 1 - p_deepest;
+    later = (masks >> (4 * c_last)) & 0xFu;
+    n_first = cnt - 1;
+    return drop_nibble(masks, c_last);
 }
 
 // What a region keeps in LDS.
@@ -214,9 +227,9 @@ struct Region {
 // kind one workgroup's dynamic LDS.
 static_assert(2 * sizeof(Region<kNarrow>) <= 32 * 1024 && 2 * sizeof(Region<kWide>) <= 32 * 1024, "stage 2 beside two histogram workgroups");
 static_assert(4 * sizeof(Region<kWide>) <= 64 * 1024, "a workgroup's regions");
-static_assert(5 * kRegionSites <= kWave, "region_emit: one lane per fit of the region");
+static_assert(4 * kRegionSites <= kWave, "region_emit: one lane per fit of the region");
 
-// Emits the fits of the pending level for the whole region at once: lane 5 * ls + c builds fit c of site ls (its subset's alleles,
+// Emits the fits of the pending round for the whole region at once: lane 4 * ls + c builds fit c of site ls (its subset's alleles,
 // SetAlleleFreq's starting frequencies -- four f64 divisions --, what the alleles outside the subset add to E and to the
 // log-likelihood) and writes it to its place: list after list, each in site order, a site's fits in the order of its subsets.
 // (Round 3 did this site by site with every lane computing the same fit: 20 divisions in a row per site.)
@@ -226,20 +239,20 @@ __device__ __forceinline__ void region_emit(RegionT &R, int lane, const int (&fi
     // (opaque, as in fit_body: what depends on the lane id only is then recomputed at every level instead of being hoisted out
     // of the level loop and kept -- spilled, at the narrow kernel's 168 VGPRs -- across the fits)
     asm volatile("" : "+v"(lane));
-    const int ls = (lane * 52) >> 8, c = lane - 5 * ls;          // lane / 5, lane % 5 for lane < 64
+    const int ls = lane >> 2, c = lane & 3;
     if (ls >= kRegionSites) return;
     ItemSite &S = R.site[ls];
     const uint32_t sets = S.sets;
-    const int n_emit = S.n_emit, p_deepest = S.p_deepest;
+    const int n_emit = S.n_emit;
     if (S.state != 1 || c >= n_emit) return;
     const uint32_t pm = (sets >> (4 * c)) & 0xFu;
-    const int l = list_of(pm, p_deepest);
+    const int l = list_of(pm);
     // place: the list's first place + the fits of the sites before this one in that list + this site's earlier fits in it
-    int idx = sel4(first, l);
+    int idx = l == 0 ? first[0] : first[1];
     for (int w = 0; w < ls; ++w) idx += R.want[w][l];
 #pragma unroll
-    for (int c2 = 0; c2 < 4; ++c2)
-        if (c2 < c) idx += list_of((sets >> (4 * c2)) & 0xFu, p_deepest) == l;
+    for (int c2 = 0; c2 < 3; ++c2)
+        if (c2 < c) idx += list_of((sets >> (4 * c2)) & 0xFu) == l;
     const int depth[4] = {S.depth[0], S.depth[1], S.depth[2], S.depth[3]};
     const int total_i = depth[0] + depth[1] + depth[2] + depth[3];
     const uint32_t blist = S.blist;
@@ -402,28 +415,29 @@ __device__ __forceinline__ int site_classes(Region<CPB> &R, int ls, int lane, in
     const bool mine = !(too_wide || any_low || dup);
     S.blist = blist; S.n = (int8_t)n; S.k = (int8_t)n; S.first = 1;
     S.state = mine ? 1 : 0;
+    uint32_t later = 0;
     if (mine) {
         if (n == 0) {
             finished = true;                                     // :75, :84
         } else {
-            int cnt = 0;
             sets = (1u << n) - 1u;                               // the full model (:88)
             n_emit = 1;
             if (n >= 2) {
-                const uint32_t masks = subset_masks(n, n - 1, cnt);
-                sets |= masks << 4;
-                n_emit += cnt;
+                // ... and, with it, the (n-1)-subsets that keep the deepest candidate; the one without it waits (site_decide)
+                int n_first = 0;
+                p_deepest = deepest_position(S.depth, blist, n);
+                sets |= level_subsets(n, p_deepest, n_first, later) << 4;
+                n_emit += n_first;
             }
-            p_deepest = deepest_position(S.depth, blist, n);
         }
     }
-    S.sets = sets; S.n_emit = (int8_t)n_emit; S.p_deepest = (int8_t)p_deepest;
+    S.sets = sets; S.n_emit = (int8_t)n_emit; S.p_deepest = (int8_t)p_deepest; S.later = (uint8_t)later;
     int want[kLists];
-    count_wanted(sets, n_emit, p_deepest, want);
+    count_wanted(sets, n_emit, want);
     if (lane == 0) {
         if (finished) S.state = 3;                               // record pending: written by the kernel that owns the region
         R.site[ls] = S;
-        R.want[ls][0] = want[0]; R.want[ls][1] = want[1]; R.want[ls][2] = want[2]; R.want[ls][3] = want[3];
+        R.want[ls][0] = want[0]; R.want[ls][1] = want[1];
         taken[site] = mine ? 1 : 0;
     }
     return mine ? need : 0;                                      // most class places on an allele of a site the engine takes
@@ -671,38 +685,43 @@ __device__ __forceinline__ void fit_body(int item0, int item_end, const FitItem 
 constexpr int kLog2G4 = 1, kLog2G2 = 2;
 template <int CPB> constexpr int log2g4() { return CPB == kTiny ? 0 : kLog2G4; }
 template <int CPB> constexpr int log2g2() { return CPB == kTiny ? 1 : kLog2G2; }
-// The SLOW lists (fits that leave out the deepest allele: one per site and level) take twice the lanes per allele, four
-// items per wavefront: a region's few slow fits then fill their wavefront-slot, which costs two thirds of a fast one per pass,
-// instead of leaving half of a full-price slot empty.  Fixed per list, whatever the region size: a fit's arithmetic (which
-// lane holds which class, the order of the sums) must never depend on how the caller cut its tiles.
-#ifndef BVC_SLOW_EXTRA_LOG2G
-#define BVC_SLOW_EXTRA_LOG2G 0
-#endif
-template <int CPB> constexpr int log2g4s() { return log2g4<CPB>() + BVC_SLOW_EXTRA_LOG2G; }
-template <int CPB> constexpr int log2g2s() { return log2g2<CPB>() + BVC_SLOW_EXTRA_LOG2G; }
+// ---- site_decide: one lane per site, one round of BaseType::LRT ---------------------------------------------------------
+// Reads the fits of the pending round, takes the reference's decision (src/BaseType.cpp:93-110) and either sets up the next
+// round's fits or writes the record.
+//
+// The subset a level may not have to run.  A level fits every (n-1)-subset of the current candidates and goes on with the
+// FIRST MINIMUM of chi_c = 2 (lr_alt - loglik_c) (std::min_element, :99); nothing else of the other subsets is ever read
+// (:100-105).  The subset without the deepest candidate explains that allele's observations as errors, fits worst by far and
+// -- its EM runs to the cap of 101 passes whatever the site -- costs a quarter to a half of all the passes of a site.  Every
+// class marginal is at most 1 (a mixture of likelihoods with weights that sum to 1), and an observation of an allele outside
+// the subset has marginal e exactly (f = 0), so
+//        loglik_c  <=  sum over the alleles b outside c of  sum_q n_bq log e_q  =: U_c        (ItemSite::lle, no EM needed)
+// and chi_c >= 2 (lr_alt - U_c).  The level first runs the subsets that keep the deepest candidate; when that bound is above
+// their minimum chi by more than kPruneSlack (rounding of the sums: far below it), the last subset cannot be the first
+// minimum and is NOT RUN -- the level's decision, and with it every field of the record that the reference defines, is what
+// it would have been.  Otherwise (sites of a few observations; never on the bench tiles) it is run in a second round of the
+// level and joins the minimum exactly as std::min_element would have met it.  n_fits / n_passes of the record count what was
+// run.  `prune` = 0 (em_prune, include/bvc.h): the second round always runs.
+constexpr double kPruneSlackAbs = 1.0, kPruneSlackRel = 1e-6;
 
-// ---- site_decide: one wavefront per site, one level of BaseType::LRT -------------------------------------------------
-// Reads the fits of the pending level, takes the reference's decision (src/BaseType.cpp:93-110) and either sets up
-// the next level's fits or writes the record.
 template <class RegionT>
-__device__ __forceinline__ void site_decide(RegionT &R, int ls, int lane, int64_t site, int n_groups,
+__device__ __forceinline__ void site_decide(RegionT &R, int ls, int lane, int64_t site, int n_groups, int prune,
                                             const int8_t *__restrict__ ref_base, bvc_site_result *__restrict__ results)
 {
     ItemSite S = R.site[ls];
     if (S.state != 1) {
-        // (an opaque zero: the optimiser otherwise builds the 16 bytes of zeros once per kernel, keeps them in four registers
+        // (an opaque zero: the optimiser otherwise builds the bytes of zeros once per kernel, keeps them in registers
         // across the fits of every level and, at the narrow kernel's 168 VGPRs, spills them to scratch)
         int zero = 0;
         asm volatile("" : "+v"(zero));
-        if (lane == 0) { R.want[ls][0] = zero; R.want[ls][1] = zero; R.want[ls][2] = zero; R.want[ls][3] = zero; R.site[ls].n_emit = 0; }
+        if (lane == 0) { R.want[ls][0] = zero; R.want[ls][1] = zero; R.site[ls].n_emit = 0; }
         return;
     }
     uint32_t sets = 0;
     int n_emit = 0, p_deepest = 0;
     bool finished = false;
 
-    auto fit_loglik = [&](int idx, uint32_t pm, double (&ex)[4], int &passes) -> double {
-        (void)pm;
+    auto fit_loglik = [&](int idx, double (&ex)[4], int &passes) -> double {
         if (!BVC_LDS_OK(15, idx, kPlaces)) idx = 0;
         const FitOut &o = R.outs[idx];
 #pragma unroll
@@ -730,7 +749,7 @@ __device__ __forceinline__ void site_decide(RegionT &R, int ls, int lane, int64_
     if (S.first) {                                               // the full model (:88-90)
         double ex[4];
         int passes = 0;
-        S.lr_alt = fit_loglik(S.item[0], (1u << S.n) - 1u, ex, passes);
+        S.lr_alt = fit_loglik(S.item[0], ex, passes);
         by_base((1u << S.n) - 1u, ex, S.base_frq);
         S.passes += passes; S.fits += 1;
         first_sub = 1;
@@ -738,62 +757,105 @@ __device__ __forceinline__ void site_decide(RegionT &R, int ls, int lane, int64_
         S.first = 0;
     }
     const int n = S.n, k = S.k;
+    bool again = false;                                          // the level needs its second round
     if (k < 1) {
         finished = true;                                         // n == 1: no nested level
     } else {
-        int cnt = 0;
-        const uint32_t masks = subset_masks(n, k, cnt);
-        int i_min = 0;
-        double best_chi = 0.0, best_lr = 0.0, best_bp[4] = {0, 0, 0, 0};
+        // lexicographic number of the subset kept for later (level_subsets); the others keep their order around it
+        const int c_last = n - 1 - S.p_deepest;
+        int i_min = S.best_i;
+        double best_chi = S.best_chi, best_lr = S.best_lr;
+        double best_bp[4] = {S.best_bp[0], S.best_bp[1], S.best_bp[2], S.best_bp[3]};
+        if (!S.round2) {
+            const uint32_t masks = S.sets >> (4 * first_sub);
+            const int cnt = S.n_emit - first_sub;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c >= cnt) break;
-            const uint32_t pm = (masks >> (4 * c)) & 0xFu;
-            const int idx = first_sub ? S.item[c + 1] : S.item[c];
+            for (int c = 0; c < 3; ++c) {
+                if (c >= cnt) break;
+                const uint32_t pm = (masks >> (4 * c)) & 0xFu;
+                double ex[4];
+                int passes = 0;
+                const double ll = fit_loglik(first_sub ? S.item[c + 1] : S.item[c], ex, passes);
+                S.passes += passes; S.fits += 1;
+                const double chi_c = 2.0 * (S.lr_alt - ll);
+                if (c == 0 || chi_c < best_chi) {                // std::min_element: first minimum, '<'
+                    best_chi = chi_c; best_lr = ll; i_min = (S.later && c >= c_last) ? c + 1 : c;
+                    by_base(pm, ex, best_bp);
+                }
+            }
+            if (S.later) {
+                double u_c = 0.0;                                // U_c: the alleles outside the subset, candidates or not
+                uint32_t in_set = 0;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if ((S.later >> p) & 1u) in_set |= 1u << ((S.blist >> (4 * p)) & 3u);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) u_c += ((in_set >> b) & 1u) ? 0.0 : S.lle[b];
+                const double bound = 2.0 * (S.lr_alt - u_c);
+                // (NaN or infinities on either side: not ruled out)
+                const bool ruled_out = prune && bound > best_chi + (kPruneSlackAbs + kPruneSlackRel * fabs(u_c)) && bound < __builtin_huge_val();
+                again = !ruled_out;
+            }
+        } else {
+            // second round: the subset kept for later has been run (S.item[0]); it meets the first minimum of the others
             double ex[4];
             int passes = 0;
-            const double ll = fit_loglik(idx, pm, ex, passes);
+            const double ll = fit_loglik(S.item[0], ex, passes);
             S.passes += passes; S.fits += 1;
             const double chi_c = 2.0 * (S.lr_alt - ll);
-            if (c == 0 || chi_c < best_chi) {                    // std::min_element: first minimum, '<'
-                best_chi = chi_c; best_lr = ll; i_min = c;
-                by_base(pm, ex, best_bp);
+            if (chi_c < best_chi || (chi_c == best_chi && c_last < i_min)) {
+                best_chi = chi_c; best_lr = ll; i_min = c_last;
+                by_base(S.later, ex, best_bp);
             }
         }
-        S.lr_alt = best_lr;                                      // overwritten before the threshold test (:100-101)
-        S.chi = best_chi;
-        if (best_chi < kLrtThreshold) {
-            const uint32_t pm = (masks >> (4 * i_min)) & 0xFu;
-            uint32_t nl = 0;
-            int nn = 0;
+        if (again) {
+            S.best_chi = best_chi; S.best_lr = best_lr; S.best_i = (int8_t)i_min;
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-                if ((pm >> p) & 1u) { nl |= ((S.blist >> (4 * p)) & 3u) << (4 * nn); ++nn; }
-            S.blist = nl;
-            S.n = (int8_t)k;
+            for (int j = 0; j < 4; ++j) S.best_bp[j] = best_bp[j];
+            S.round2 = 1;
+            sets = S.later; n_emit = 1; p_deepest = S.p_deepest;
+        } else {
+            S.round2 = 0;
+            S.lr_alt = best_lr;                                  // overwritten before the threshold test (:100-101)
+            S.chi = best_chi;
+            if (best_chi < kLrtThreshold) {
+                // the subset that won, by its lexicographic number
+                int cnt_all = 0;
+                const uint32_t pm = (subset_masks(n, k, cnt_all) >> (4 * i_min)) & 0xFu;
+                uint32_t nl = 0;
+                int nn = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) S.base_frq[j] = best_bp[j];
-            S.k = (int8_t)(k - 1);
-            if (k - 1 >= 1) {
-                sets = subset_masks(k, k - 1, n_emit);
-                p_deepest = deepest_position(S.depth, nl, k);
+                for (int p = 0; p < 4; ++p)
+                    if ((pm >> p) & 1u) { nl |= ((S.blist >> (4 * p)) & 3u) << (4 * nn); ++nn; }
+                S.blist = nl;
+                S.n = (int8_t)k;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) S.base_frq[j] = best_bp[j];
+                S.k = (int8_t)(k - 1);
+                S.later = 0;
+                if (k - 1 >= 1) {
+                    uint32_t later = 0;
+                    p_deepest = deepest_position(S.depth, nl, k);
+                    sets = level_subsets(k, p_deepest, n_emit, later);
+                    S.later = (uint8_t)later;
+                } else {
+                    finished = true;
+                }
             } else {
                 finished = true;
             }
-        } else {
-            finished = true;
         }
     }
     S.sets = sets; S.n_emit = (int8_t)n_emit; S.p_deepest = (int8_t)p_deepest;
     int want[kLists];
-    count_wanted(sets, n_emit, p_deepest, want);
+    count_wanted(sets, n_emit, want);
     if (lane == 0) {
         if (finished) {
             store_record(results + site, S, (int)ref_base[ref_index(site, n_groups)], S.n, S.blist);
             S.state = 2;
         }
         R.site[ls] = S;
-        R.want[ls][0] = want[0]; R.want[ls][1] = want[1]; R.want[ls][2] = want[2]; R.want[ls][3] = want[3];
+        R.want[ls][0] = want[0]; R.want[ls][1] = want[1];
     }
 }
 
@@ -814,6 +876,7 @@ struct RegionArgs {
     uint32_t epoch;
     int dbg_levels;
     int tiny_regions;            // LaunchState::em_tiny_regions
+    int prune;                   // LaunchState::em_prune (site_decide)
     int64_t region0;             // first region of this launch (a call may be a sequence of launches)
 };
 
@@ -905,7 +968,7 @@ __device__ __forceinline__ void region_body(Region<CPB> *regions, const RegionAr
                 need = max(need, site_classes<CPB>(R, ls, lane, site0 + ls, c8, A.lut, A.min_af, A.comb, A.n_comb, A.taken));
             } else if (lane == 0) {
                 R.site[ls].state = 2; R.site[ls].n_emit = 0;
-                R.want[ls][0] = 0; R.want[ls][1] = 0; R.want[ls][2] = 0; R.want[ls][3] = 0;
+                R.want[ls][0] = 0; R.want[ls][1] = 0;
             }
         }
         if (TEAM > 1) {
@@ -931,29 +994,26 @@ __device__ __forceinline__ void region_body(Region<CPB> *regions, const RegionAr
             R.site[lane].state = 2;
         }
         team_sync<TEAM>(R, phase, lane);
-        for (int level = 0; level < kLevels && level < (A.dbg_levels >> 1); ++level) {
-            // the fits of this level: list after list, each in site order
-            int cnt[kLists] = {0, 0, 0, 0};
+        for (int round = 0; round < kRounds && round < (A.dbg_levels >> 1); ++round) {
+            // the fits of this round: list after list, each in site order
+            int cnt[kLists] = {0, 0};
 #pragma unroll
             for (int w = 0; w < kRegionSites; ++w) {
 #pragma unroll
                 for (int l = 0; l < kLists; ++l) cnt[l] += R.want[w][l];
             }
-            if (cnt[0] + cnt[1] + cnt[2] + cnt[3] == 0) break;   // (the same LDS words for the whole team)
-            const int first[kLists] = {0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2]};
-            if (!BVC_LDS_OK(16, first[3] + cnt[3], kPlaces + 1)) break;
+            if (cnt[0] + cnt[1] == 0) break;                     // (the same LDS words for the whole team)
+            const int first[kLists] = {0, cnt[0]};
+            if (!BVC_LDS_OK(16, cnt[0] + cnt[1], kPlaces + 1)) break;
             if (member == 0) region_emit(R, lane, first);
             team_sync<TEAM>(R, phase, lane);
             constexpr int kPerWave4 = 16 >> log2g4<CPB>(), kPerWave2 = 2 * (16 >> log2g2<CPB>());
-            constexpr int kPerWave4s = 16 >> log2g4s<CPB>(), kPerWave2s = 2 * (16 >> log2g2s<CPB>());
             const FitItem *items = R.items;
             FitOut *outs = R.outs;
             const uint8_t *tabs = &R.tab[0][0];
             const double *lut_e = A.lut->e;
-            // slots of the level, the slow lists first (the wavefront that gets a second slot should not be the one that runs the
-            // 101 passes of the slow fits): w1 of list 1, then list 3, list 0, list 2
-            const int w1 = (cnt[1] + kPerWave4s - 1) / kPerWave4s, w3 = w1 + (cnt[3] + kPerWave2s - 1) / kPerWave2s;
-            const int w0 = w3 + (cnt[0] + kPerWave4 - 1) / kPerWave4, w2 = w0 + (cnt[2] + kPerWave2 - 1) / kPerWave2;
+            // wavefront-slots of the round: w0 of list 0 (eight four-row fits each), then list 1; an LDS counter hands them out
+            const int w0 = (cnt[0] + kPerWave4 - 1) / kPerWave4, w1 = w0 + (cnt[1] + kPerWave2 - 1) / kPerWave2;
             int slot = 0;
 #pragma unroll 1
             for (;;) {
@@ -961,28 +1021,20 @@ __device__ __forceinline__ void region_body(Region<CPB> *regions, const RegionAr
                     if (lane == 0) slot = atomicAdd(&R.next_slot, 1);
                     slot = __builtin_amdgcn_readfirstlane(slot);
                 }
-                if (slot >= w2) break;
-                const int l = slot < w1 ? 1 : (slot < w3 ? 3 : (slot < w0 ? 0 : 2));
-                const int in_list = slot - (l == 1 ? 0 : (l == 3 ? w1 : (l == 0 ? w3 : w0)));
-                const int base = l == 0 ? first[0] : (l == 1 ? first[1] : (l == 2 ? first[2] : first[3]));
-                const int end = base + (l == 0 ? cnt[0] : (l == 1 ? cnt[1] : (l == 2 ? cnt[2] : cnt[3])));
-                if (l == 0) fit_body<4, log2g4<CPB>(), CPB>(base + in_list * kPerWave4, end, items, outs, tabs, lut_e);
-                else if (l == 2) fit_body<2, log2g2<CPB>(), CPB>(base + in_list * kPerWave2, end, items, outs, tabs, lut_e);
-                else if (BVC_SLOW_EXTRA_LOG2G == 0 && l == 1) fit_body<4, log2g4<CPB>(), CPB>(base + in_list * kPerWave4, end, items, outs, tabs, lut_e);
-                else if (BVC_SLOW_EXTRA_LOG2G == 0) fit_body<2, log2g2<CPB>(), CPB>(base + in_list * kPerWave2, end, items, outs, tabs, lut_e);
-                else if (l == 1) fit_body<4, log2g4s<CPB>(), CPB>(base + in_list * kPerWave4s, end, items, outs, tabs, lut_e);
-                else fit_body<2, log2g2s<CPB>(), CPB>(base + in_list * kPerWave2s, end, items, outs, tabs, lut_e);
+                if (slot >= w1) break;
+                if (slot < w0) fit_body<4, log2g4<CPB>(), CPB>(slot * kPerWave4, cnt[0], items, outs, tabs, lut_e);
+                else fit_body<2, log2g2<CPB>(), CPB>(cnt[0] + (slot - w0) * kPerWave2, cnt[0] + cnt[1], items, outs, tabs, lut_e);
                 if (TEAM == 1) ++slot;
             }
             team_sync<TEAM>(R, phase, lane);
             if (TEAM > 1 && member == 0 && lane == 0) R.next_slot = 0;      // nobody takes a slot again before the barrier behind the next emit
-            if (level + 1 == (A.dbg_levels >> 1) && (A.dbg_levels & 1)) break;
-            // the decisions of the level, one LANE per site (the reference's few dozen scalar steps per site -- read the fits, first
+            if (round + 1 == (A.dbg_levels >> 1) && (A.dbg_levels & 1)) break;
+            // the decisions of the round, one LANE per site (the reference's few dozen scalar steps per site -- read the fits, first
             // minimum, threshold, next subsets or the record -- once for the region instead of once per site)
             int my = lane;
-            asm volatile("" : "+v"(my));                          // (opaque: nothing of the site's addressing is hoisted out of the level loop)
+            asm volatile("" : "+v"(my));                          // (opaque: nothing of the site's addressing is hoisted out of the round loop)
             if (member == 0 && my < kRegionSites && site0 + my < n_sites)
-                site_decide(R, my, 0, site0 + my, A.n_groups, A.ref_base, A.results);
+                site_decide(R, my, 0, site0 + my, A.n_groups, A.prune, A.ref_base, A.results);
             team_sync<TEAM>(R, phase, lane);
         }
         team_sync<TEAM>(R, phase, lane);                         // the region's LDS is reused by the next one
@@ -1063,8 +1115,9 @@ hipError_t launch_lrt_items(const LaunchState &st, hipStream_t stream, int64_t n
     A.kind_epoch = reinterpret_cast<uint32_t *>(taken + (((size_t)n_sites + 255) & ~(size_t)255));
     A.epoch = ++st.em_epoch;                                     // never 0; a stale word can only cost the wide launch a scan
     if (A.epoch == 0) A.epoch = ++st.em_epoch;
-    A.dbg_levels = st.dbg_levels > 0 ? st.dbg_levels : 2 * kLevels;
+    A.dbg_levels = st.dbg_levels > 0 ? st.dbg_levels : 2 * kRounds;
     A.tiny_regions = st.em_tiny_regions;
+    A.prune = st.em_prune;
     A.region0 = 0;
     // the wide kernels' dynamic LDS (4 x 14 KB) is beyond the 48 KiB a launch may ask for without the attribute
     constexpr uint32_t kSlotRegionWide = 60;

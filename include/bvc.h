@@ -59,7 +59,7 @@ typedef struct bvc_site_result {
     double  lr_alt;         /* lr_alt_t at exit -- diagnostic */
     double  base_frq[4];    /* fitted frequencies of the accepted model, indexed by base -- diagnostic */
     int32_t depth[4];       /* BaseType::depth[A,C,G,T] */
-    int32_t n_passes;       /* number of E+M passes run (singleEM calls) -- diagnostic */
+    int32_t n_passes;       /* number of E+M passes run (singleEM calls) -- diagnostic; see "em_prune" */
     int8_t  alt_base[3];    /* BaseType::alt_bases, in the reference's order */
     uint8_t n_alt;
     uint8_t called;         /* return value of LRT() */
@@ -67,7 +67,7 @@ typedef struct bvc_site_result {
     int8_t  kept[4];        /* bases of the accepted model (`bases` at exit) */
     uint8_t status;         /* 0 ok; 1 = the reference's behaviour is undefined for this input
                                (bp[0] / min_element on an empty vector, only reachable with min_af <= 0) */
-    uint8_t n_fits;         /* EM() calls -- diagnostic */
+    uint8_t n_fits;         /* EM() calls run -- diagnostic; see "em_prune" */
 } bvc_site_result;
 
 /* Per (site, group) record for the caller's --group loop (src/BaseVarC.cpp:617-661). 48 bytes. */
@@ -255,7 +255,14 @@ int bvc_synth_dense(bvc_ctx *ctx, uint64_t seed, int64_t site0, int64_t n_sites,
  *   "em_tiny_regions"  0 (default) / 1: with 1, regions of eight sites that all have at most 8 quality values per allele
  *                      (binned qualities) take a kernel with one lane per allele (stage 2 1.36 x faster on such data).  That
  *                      kernel adds in a different order, so a site's AF / chi could differ in the last bits with the
- *                      binning of its seven region neighbours: off by default.  Environment: BVC_EM_TINY_REGIONS. */
+ *                      binning of its seven region neighbours: off by default.  Environment: BVC_EM_TINY_REGIONS.
+ *   "em_prune"         1 (default) / 0.  A level of the likelihood-ratio test goes on with the FIRST MINIMUM of chi over its
+ *                      subsets and reads nothing else of the others (src/BaseType.cpp:97-105).  With 1 the item engine runs the
+ *                      subsets that keep the deepest allele first and does not run the one without it when an upper bound on
+ *                      that subset's log-likelihood (every class marginal <= 1; the left-out allele's observations have
+ *                      marginal e exactly) puts its chi above the minimum of the others: the decision, and every field of the
+ *                      record the reference defines, is unchanged, the diagnostics n_fits / n_passes count what was run.  0 =
+ *                      the subset is always run (n_fits / n_passes then equal the reference's counts).  Environment: BVC_EM_PRUNE. */
 int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value);
 
 /* ---- measurement aid ------------------------------------------------------------------------------- */

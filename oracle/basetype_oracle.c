@@ -107,6 +107,8 @@ typedef struct site_model {
     double depth_total;
     int32_t n_fits, n_passes;
     int compensated;      /* 0: the reference's double accumulators; 1: long double (see header) */
+    double lle[4];        /* NOT the reference's: per base b, sum over its observations of log(eps/3) -- what they add to the
+                             log-likelihood of a model without b (their marginal is eps/3 exactly); only for the pruned counts */
 } site_model;
 
 /* One E+M pass: src/Algorithm.cpp:69-93.  marginal[] and expect[] arrive zeroed. */
@@ -195,6 +197,7 @@ typedef struct fit_set {
     int n_fit;                  /* lr.size() == bp.size(): only the non-skipped ones */
     double lr[6];
     double bp[6][ORC_NTYPE];
+    int32_t passes[6];          /* singleEM calls of each fitted subset (diagnostic) */
 } fit_set;
 
 /* BaseType::UpdateF, src/BaseType.cpp:41-71 (SetAlleleFreq :25-39 inlined). */
@@ -219,7 +222,9 @@ static void update_f(site_model *sm, const int8_t *bases, int n, int k, fit_set 
                 freq[fs->comb[c][t]] = (double)sm->depth[fs->comb[c][t]] / depth_sum;
         for (j = 0; j < ORC_NTYPE; ++j) freq_sum += freq[j];
         if (freq_sum == 0) continue;                      /* src/BaseType.cpp:54 */
+        fs->passes[fs->n_fit] = -sm->n_passes;
         em_fit(sm, freq, marginal, expect, 100, 0.001);   /* src/BaseType.cpp:45-46,56 */
+        fs->passes[fs->n_fit] += sm->n_passes;
         for (i = 0; i < sm->n; ++i) {
             double lm = log(marginal[i]);
             if (sm->compensated) loglik_c += sm->w ? (long double)sm->w[i] * lm : (long double)lm;
@@ -244,9 +249,11 @@ static int lrt_on_model(site_model *sm, int8_t ref_base, double min_af,
     double lr_alt = 0.0, chi = 0.0;
     double *marginal;
     fit_set fs;
+    int32_t skipped_fits = 0, skipped_passes = 0;
 
     memset(out, 0, sizeof(*out));
     out->tie_gap = HUGE_VAL;
+    out->prune_edge = HUGE_VAL;
     for (j = 0; j < 4; ++j) out->depth[j] = sm->depth[j];
     out->depth_total = sm->depth_total;
     if (sm->depth_total == 0) return 0;                    /* :75 */
@@ -263,7 +270,7 @@ static int lrt_on_model(site_model *sm, int8_t ref_base, double min_af,
     if (fs.n_fit == 0) {   /* reference reads bp[0] of an empty vector (:89): undefined */
         out->status = 1;
         free(marginal);
-        out->n_fits = sm->n_fits; out->n_passes = sm->n_passes;
+        out->n_fits = out->n_fits_pruned = sm->n_fits; out->n_passes = out->n_passes_pruned = sm->n_passes;
         return 0;
     }
     for (j = 0; j < ORC_NTYPE; ++j) base_frq[j] = fs.bp[0][j];
@@ -279,6 +286,34 @@ static int lrt_on_model(site_model *sm, int8_t ref_base, double min_af,
             if (chi_c[c] < best) { best = chi_c[c]; i_min = c; }
         for (c = 0; c < fs.n_fit; ++c)                     /* diagnostic: how close the runner-up was */
             if (c != i_min && chi_c[c] - best < out->tie_gap) out->tie_gap = chi_c[c] - best;
+        /* Diagnostic, NOT the reference's: what a level need not have run (see orc_result.n_fits_pruned).  The k = n - 1
+         * subset without the deepest candidate (first one on ties) is number n - 1 - p in lexicographic order. */
+        if (fs.n_fit == fs.n_comb && fs.n_fit >= 2) {
+            int p_deep = 0, c_last, t, bsel;
+            double best_other = 0.0, u_c = 0.0, bound, slack;
+            int have = 0;
+            for (j = 1; j < n; ++j) if (sm->depth[bases[j]] > sm->depth[bases[p_deep]]) p_deep = j;
+            c_last = n - 1 - p_deep;
+            for (c = 0; c < fs.n_fit; ++c)
+                if (c != c_last && (!have || chi_c[c] < best_other)) { best_other = chi_c[c]; have = 1; }
+            for (bsel = 0; bsel < 4; ++bsel) {
+                int inside = 0;
+                for (t = 0; t < k; ++t) if (fs.comb[c_last][t] == bsel) inside = 1;
+                if (!inside) u_c += sm->lle[bsel];
+            }
+            bound = 2.0 * (lr_alt - u_c);
+            slack = 1.0 + 1e-6 * fabs(u_c);
+            if (bound > best_other + slack && bound < HUGE_VAL) {
+                skipped_fits += 1;
+                skipped_passes += fs.passes[c_last];
+            }
+            if (bound == bound && best_other == best_other) {
+                double edge = fabs(bound - (best_other + slack)) / (fabs(bound) > 1.0 ? fabs(bound) : 1.0);
+                if (edge < out->prune_edge) out->prune_edge = edge;
+            } else {
+                out->prune_edge = 0.0;
+            }
+        }
         lr_alt = fs.lr[i_min];
         chi = chi_c[i_min];
         if (chi < ORC_LRT_THRESHOLD) {
@@ -299,6 +334,8 @@ static int lrt_on_model(site_model *sm, int8_t ref_base, double min_af,
     out->chi = chi;
     out->n_fits = sm->n_fits;
     out->n_passes = sm->n_passes;
+    out->n_fits_pruned = sm->n_fits - skipped_fits;
+    out->n_passes_pruned = sm->n_passes - skipped_passes;
     for (j = 0; j < n; ++j) {                              /* :111-116 */
         if (bases[j] != ref_base && out->n_alt < 4) {
             out->alt_base[out->n_alt] = bases[j];
@@ -351,6 +388,7 @@ int orc_basetype_lrt_mode(int32_t nind, const int8_t *bases, const int8_t *quals
             else L[(size_t)i * 4 + j] = exp(ORC_MLN10TO10 * quals[i]) / 3.0;
         }
         sm.depth[bases[i]] += 1;
+        sm.lle[bases[i]] += log(exp(ORC_MLN10TO10 * quals[i]) / 3.0);
     }
     for (j = 0; j < 4; ++j) sm.depth_total += sm.depth[j];
     sm.n = nind; sm.L = L; sm.w = NULL; sm.nsample = nind;
@@ -384,6 +422,7 @@ int orc_hist_lrt_mode(const uint32_t *counts512, int8_t ref_base, double min_af,
                 else L[n * 4 + j] = exp(ORC_MLN10TO10 * (int8_t)q) / 3.0;
             }
             w[n] = (double)c;
+            sm.lle[b] += (double)c * log(exp(ORC_MLN10TO10 * (int8_t)q) / 3.0);
             sm.depth[b] += (int32_t)c;
             total += c;
             n++;

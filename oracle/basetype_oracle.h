@@ -53,6 +53,15 @@ typedef struct orc_result {
     double  tie_gap;       /* diagnostic: smallest (runner-up chi - best chi) over the nested levels that had >= 2
                               fitted subsets (+inf when none had): which subset std::min_element picks is decided by
                               the last bits of the sums when this is at rounding level */
+    /* Diagnostics of what a level NEED NOT RUN (not the reference's behaviour: it runs everything).  A level only goes on
+     * with the first minimum of chi over its subsets (src/BaseType.cpp:99-105); the subset without the deepest candidate has
+     * loglik <= U = sum, over the alleles outside it, of their observations' log(eps/3) (every marginal <= 1), so when
+     * 2 (lr_alt - U) exceeds the minimum chi of the other subsets by more than 1 + 1e-6 |U| it cannot be that minimum.  The
+     * library's item engine skips such fits (include/bvc.h "em_prune"); its n_fits / n_passes then equal these: */
+    int32_t n_fits_pruned;
+    int32_t n_passes_pruned;
+    double  prune_edge;    /* smallest relative distance of such a test from its threshold (+inf: no test): a test this close
+                              to rounding level may fall either way on another evaluation order */
 } orc_result;
 
 /* htslib kfunc.c restatement (third-party, absent from /root/reference). */

@@ -20,6 +20,7 @@ class OrcResult(C.Structure):
         ("depth_total", C.c_double), ("depth", C.c_int32 * 4), ("n_kept", C.c_int32),
         ("kept", C.c_int8 * 4), ("base_frq", C.c_double * 4), ("lr_alt", C.c_double),
         ("n_fits", C.c_int32), ("n_passes", C.c_int32), ("status", C.c_int32), ("tie_gap", C.c_double),
+        ("n_fits_pruned", C.c_int32), ("n_passes_pruned", C.c_int32), ("prune_edge", C.c_double),
     ]
 
     def as_dict(self):
@@ -32,7 +33,8 @@ class OrcResult(C.Structure):
             kept=[int(self.kept[i]) for i in range(self.n_kept)],
             base_frq=[float(x) for x in self.base_frq], lr_alt=float(self.lr_alt),
             n_fits=int(self.n_fits), n_passes=int(self.n_passes), status=int(self.status),
-            tie_gap=float(self.tie_gap))
+            tie_gap=float(self.tie_gap), n_fits_pruned=int(self.n_fits_pruned),
+            n_passes_pruned=int(self.n_passes_pruned), prune_edge=float(self.prune_edge))
 
 
 def build(force=False):

@@ -10,13 +10,15 @@
   block): class counts of ragged sites of every length and alignment around its block size, bit-exact.
 * Stage 2's launch shapes (teams of wavefronts per region, sequences of launches underneath a histogram pass) never change a
   record.
+* The subset a level does not run (include/bvc.h "em_prune"): records with and without it are the same bytes in every field the
+  reference defines, the counts of what was run are the oracle's own.
 """
 import numpy as np
 import pytest
 
 from oracle import orc
 from tests.sitegen import caller_min_af, random_site
-from tests.test_gpu_parity import AF_ATOL, assert_site_matches, pad_rows
+from tests.test_gpu_parity import AF_ATOL, assert_site_matches, pad_rows, path_counts_match
 
 pytestmark = pytest.mark.gpu
 
@@ -159,3 +161,65 @@ def test_stage2_launch_shapes_never_change_a_record(ctx):
                 other.join(); other.synchronize()
                 assert torch.equal(got, want), (per_cu, overlap)
                 assert torch.equal(g1, gw) and torch.equal(g2, ggw), (per_cu, overlap)
+
+
+def _without_run_counts(rec):
+    """A record array with the two diagnostics that count what was RUN zeroed: everything else is what the reference defines."""
+    r = rec.copy()
+    r["n_fits"] = 0
+    r["n_passes"] = 0
+    return r.tobytes()
+
+
+def test_the_subset_a_level_does_not_run_never_changes_a_record(ctx):
+    """A level of the likelihood-ratio test goes on with the first minimum of chi over its subsets (src/BaseType.cpp:97-105).  By
+    default the item engine does not run the subset without the deepest allele when an upper bound on its log-likelihood rules
+    it out as that minimum (em_prune = 1), and runs it in a second round of the level when the bound cannot (shallow sites).
+    Sites of 1 .. 20,000 observations, monomorphic, bi- and tri-allelic, two alleles of equal depth: every field the reference
+    defines is the same BYTES with em_prune = 0 (everything run: the counts are then the reference's, strictly) and with
+    em_prune = 1 (the counts are then the oracle's pruned ones), both kinds of level outcome occur, and the sites of 3000 observations
+    and more run at most 70 % of the reference's passes between them."""
+    from basevarc_amd import Context
+    rng = np.random.default_rng(4400)
+    sites = []
+    for s in range(240):
+        nind = int(rng.choice([1, 2, 3, 4, 6, 9, 14, 25, 60, 400, 3000, 20000]))
+        af = float(rng.choice([0.0, 0.0, 0.01, 0.1, 0.5]))
+        b, q, r = random_site(rng, nind, af=af, second_af=(af / 2 if s % 5 == 0 else 0.0))
+        if s % 7 == 0 and nind >= 2:                              # two alleles of exactly equal depth, nothing else
+            b = np.array([0, 1] * (nind // 2), dtype=np.int8)
+            q = q[:len(b)]
+        sites.append((b, q, r))
+    B, Q, R = pad_rows(sites)
+    m = 0.001
+    with Context(0) as all_run:
+        all_run.set_tuning("em_prune", 0)
+        full = all_run.lrt_dense(B, Q, R, m)
+    pruned = ctx.lrt_dense(B, Q, R, m)
+    assert _without_run_counts(full) == _without_run_counts(pruned)
+    second_round = skipped = deep_run = deep_all = 0
+    for s, (b, q, r) in enumerate(sites):
+        o = orc.basetype_lrt(b, q, r, m)
+        assert_site_matches(full[s], o, where=f"all run, site {s}", path_strict=False)
+        if o["prune_edge"] < 1e-6 or o["tie_gap"] < 1e-9 * max(1.0, abs(o["lr_alt"])):
+            continue
+        assert (int(full[s]["n_fits"]), int(full[s]["n_passes"])) == (o["n_fits"], o["n_passes"]), s
+        assert (int(pruned[s]["n_fits"]), int(pruned[s]["n_passes"])) == (o["n_fits_pruned"], o["n_passes_pruned"]), (s, o)
+        skipped += o["n_fits"] - o["n_fits_pruned"]
+        second_round += (o["n_fits"] - o["n_fits_pruned"]) < _levels(o)      # some level had to run its last subset
+        if len(b) >= 3000:
+            deep_run += int(pruned[s]["n_passes"]); deep_all += int(full[s]["n_passes"])
+    assert skipped > 100 and second_round > 10, (skipped, second_round)
+    assert deep_run <= 0.7 * deep_all, (deep_run, deep_all)
+
+
+def _levels(o):
+    """Nested levels the oracle's site ran: n_fits = 1 + n + (n - 1) + ... over the levels it entered."""
+    fits, n, levels = o["n_fits"] - 1, None, 0
+    for n0 in (4, 3, 2):
+        f, lv, k = 0, 0, n0
+        while k >= 2 and f < fits:
+            f += k; lv += 1; k -= 1
+        if f == fits:
+            return lv
+    return 0
