@@ -431,6 +431,7 @@ int bvc_create(bvc_ctx **out, int device)
         lut.a[q] = 1.0 - eps;
         lut.e[q] = eps / 3.0;
         lut.log_e[q] = std::log(lut.e[q]);
+        lut.log_a[q] = std::log(lut.a[q]);                       // (-inf / NaN below quality 2: such sites never reach the item engine)
     }
     lut.e_empty = 0.25;
     if (hipMalloc(reinterpret_cast<void **>(&ctx->d_lut), sizeof(QualLut)) != hipSuccess ||

@@ -46,6 +46,7 @@ struct QualLut {
     double e_empty;            // e[128]: the "empty class place" of the item engine (em_items.hip), 1/4
     double log_e[128];         // log(e[q]) (libm, on the host): what a class of an allele outside the fitted subset adds to the
                                // log-likelihood per observation (em_items.hip, site_classes)
+    double log_a[128];         // log(a[q]): what a class of THE allele of a one-allele model adds per observation (its marginal is a)
 };
 
 // Stage 1: dense pileup rows -> per-site class counts.  counts must be zeroed by the caller when split > 1.

@@ -94,6 +94,7 @@ struct ItemSite {
     double lr_alt, chi;
     double base_frq[4];
     double lle[4];          // per allele: sum over its classes of n log e
+    double lla[4];          // per allele: sum over its classes of n log a (a = 1 - 3 e: the likelihood of the allele itself)
     double best_chi, best_lr, best_bp[4];   // second round of a level: the first minimum among the subsets of the first round
     int32_t depth[4];
     int32_t passes, fits;
@@ -112,9 +113,10 @@ struct ItemSite {
 
 // list 0: items of 3-4 units (four rows per item); list 1: items of 1-2 units (two rows per item)
 constexpr int kLists = 2;
-// Engine rounds per site: three levels of the reference (the full model with its (n-1)-subsets, the (n-2)- and the
-// (n-3)-subsets), each at most twice (the last-resort subset of a level, when the bound cannot rule it out: see site_decide)
-constexpr int kRounds = 6;
+// Engine rounds per site: the two levels of the reference that need EM (the full model with its (n-1)-subsets, and the
+// (n-2)-subsets when n = 4; one-allele models need none), each at most twice (the last-resort subset of a level, when the bound
+// cannot rule it out: see site_decide)
+constexpr int kRounds = 4;
 #ifndef BVC_REGION_SITES
 #define BVC_REGION_SITES 8
 #endif
@@ -147,6 +149,16 @@ __device__ __forceinline__ uint32_t subset_masks(int n, int k, int &cnt)
 __device__ __forceinline__ int pick4i(const int32_t (&v)[4], int j)
 {
     return j == 0 ? v[0] : (j == 1 ? v[1] : (j == 2 ? v[2] : v[3]));
+}
+
+// Log-likelihood of the model "allele b alone" (f_b = 1): every observation's marginal is its own likelihood of b, a for the
+// observations of b and e for the others -- no EM needed (site_decide).
+__device__ __forceinline__ double single_allele_loglik(const double (&lla)[4], const double (&lle)[4], int b)
+{
+    double ll = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ll += j == b ? lla[j] : lle[j];
+    return ll;
 }
 
 // Histogram of pseudo-site p: plain calls have one histogram per site; group calls run one pseudo-site per
@@ -225,8 +237,8 @@ struct Region {
 
 // Two narrow regions fit the 32 KiB of LDS that two 64 KiB histogram workgroups leave on a CU (launch_lrt_items), four of any
 // kind one workgroup's dynamic LDS.
-static_assert(2 * sizeof(Region<kNarrow>) <= 32 * 1024 && 2 * sizeof(Region<kWide>) <= 32 * 1024, "stage 2 beside two histogram workgroups");
-static_assert(4 * sizeof(Region<kWide>) <= 64 * 1024, "a workgroup's regions");
+static_assert(kRegionSites != 8 || (2 * sizeof(Region<kNarrow>) <= 32 * 1024 && 2 * sizeof(Region<kWide>) <= 32 * 1024), "stage 2 beside two histogram workgroups");
+static_assert(kRegionSites != 8 || 4 * sizeof(Region<kWide>) <= 64 * 1024, "a workgroup's regions");
 static_assert(4 * kRegionSites <= kWave, "region_emit: one lane per fit of the region");
 
 // Emits the fits of the pending round for the whole region at once: lane 4 * ls + c builds fit c of site ls (its subset's alleles,
@@ -343,7 +355,7 @@ __device__ __forceinline__ int site_classes(Region<CPB> &R, int ls, int lane, in
     uint32_t *tab_n = reinterpret_cast<uint32_t *>(R.tab[ls]) + row * CPB;
     uint8_t *tab_q = R.tab[ls] + 16 * CPB + row * CPB;
     int cnt_row = 0, depth_lane = 0;
-    double lle = 0.0;
+    double lle = 0.0, lla = 0.0;
     bool low_q = false;
 #pragma unroll
     for (int lvl = 0; lvl < 8; ++lvl) {
@@ -358,6 +370,7 @@ __device__ __forceinline__ int site_classes(Region<CPB> &R, int ls, int lane, in
                 tab_q[pos] = (uint8_t)q;
             }
             lle = fma((double)c, lut->log_e[q], lle);
+            lla = fma((double)c, lut->log_a[q], lla);
             low_q |= q < 2;
         }
         cnt_row += __popc(rowbits);
@@ -374,7 +387,9 @@ __device__ __forceinline__ int site_classes(Region<CPB> &R, int ls, int lane, in
     }
     const int depth_row = row_sum(depth_lane);
     lle = row_sum(lle);
+    lla = row_sum(lla);
     S.lle[0] = lane_value<0>(lle); S.lle[1] = lane_value<16>(lle); S.lle[2] = lane_value<32>(lle); S.lle[3] = lane_value<48>(lle);
+    S.lla[0] = lane_value<0>(lla); S.lla[1] = lane_value<16>(lla); S.lla[2] = lane_value<32>(lla); S.lla[3] = lane_value<48>(lla);
     S.depth[0] = __builtin_amdgcn_readlane(depth_row, 0);
     S.depth[1] = __builtin_amdgcn_readlane(depth_row, 16);
     S.depth[2] = __builtin_amdgcn_readlane(depth_row, 32);
@@ -419,11 +434,22 @@ __device__ __forceinline__ int site_classes(Region<CPB> &R, int ls, int lane, in
     if (mine) {
         if (n == 0) {
             finished = true;                                     // :75, :84
+        } else if (n == 1) {
+            // one candidate: the full model is "that allele alone" (:88-90) and there is no nested level.  Its EM needs no
+            // arithmetic: f = 1, every posterior is 1, expect = nind / nind = 1 exactly, delta = 0 after the second pass.
+            const int b0 = (int)(blist & 3u);
+            S.lr_alt = single_allele_loglik(S.lla, S.lle, b0);
+            S.base_frq[0] = b0 == 0 ? 1.0 : 0.0; S.base_frq[1] = b0 == 1 ? 1.0 : 0.0;
+            S.base_frq[2] = b0 == 2 ? 1.0 : 0.0; S.base_frq[3] = b0 == 3 ? 1.0 : 0.0;
+            S.passes = 2; S.fits = 1;
+            S.k = 0; S.first = 0;
+            finished = true;
         } else {
             sets = (1u << n) - 1u;                               // the full model (:88)
             n_emit = 1;
-            if (n >= 2) {
-                // ... and, with it, the (n-1)-subsets that keep the deepest candidate; the one without it waits (site_decide)
+            if (n >= 3) {
+                // ... and, with it, the (n-1)-subsets that keep the deepest candidate; the one without it waits (site_decide).
+                // (n = 2: the subsets are one-allele models, which site_decide evaluates without EM)
                 int n_first = 0;
                 p_deepest = deepest_position(S.depth, blist, n);
                 sets |= level_subsets(n, p_deepest, n_first, later) << 4;
@@ -760,7 +786,7 @@ __device__ __forceinline__ void site_decide(RegionT &R, int ls, int lane, int64_
     bool again = false;                                          // the level needs its second round
     if (k < 1) {
         finished = true;                                         // n == 1: no nested level
-    } else {
+    } else if (k >= 2) {
         // lexicographic number of the subset kept for later (level_subsets); the others keep their order around it
         const int c_last = n - 1 - S.p_deepest;
         int i_min = S.best_i;
@@ -833,18 +859,39 @@ __device__ __forceinline__ void site_decide(RegionT &R, int ls, int lane, int64_
                 for (int j = 0; j < 4; ++j) S.base_frq[j] = best_bp[j];
                 S.k = (int8_t)(k - 1);
                 S.later = 0;
-                if (k - 1 >= 1) {
+                if (k - 1 >= 2) {
                     uint32_t later = 0;
                     p_deepest = deepest_position(S.depth, nl, k);
                     sets = level_subsets(k, p_deepest, n_emit, later);
                     S.later = (uint8_t)later;
-                } else {
-                    finished = true;
-                }
+                }                                                // (k - 1 == 1: the one-allele level, below)
             } else {
                 finished = true;
             }
         }
+    }
+    if (!finished && !again && S.k == 1) {
+        // The last level (:93-110 with k = 1): the two one-allele models of the two candidates left.  Such a model needs no EM:
+        // f = 1, so every observation's marginal is its own likelihood of the allele (a for the allele's observations, e for the
+        // others: the sums over classes are the site's lla / lle), every posterior is 1 and expect = nind / nind = 1 exactly; the
+        // reference's EM stops after its second pass with delta = 0.  Both are "run" (two fits, four passes).
+        const int b0 = (int)(S.blist & 3u), b1 = (int)((S.blist >> 4) & 3u);
+        const double ll0 = single_allele_loglik(S.lla, S.lle, b0), ll1 = single_allele_loglik(S.lla, S.lle, b1);
+        const double chi0 = 2.0 * (S.lr_alt - ll0), chi1 = 2.0 * (S.lr_alt - ll1);
+        const bool second = chi1 < chi0;                         // std::min_element: first minimum, '<'
+        const double best_chi = second ? chi1 : chi0;
+        const int bb = second ? b1 : b0;
+        S.passes += 4; S.fits += 2;
+        S.lr_alt = second ? ll1 : ll0;
+        S.chi = best_chi;
+        if (best_chi < kLrtThreshold) {
+            S.blist = (uint32_t)bb;
+            S.n = 1;
+            S.base_frq[0] = bb == 0 ? 1.0 : 0.0; S.base_frq[1] = bb == 1 ? 1.0 : 0.0;
+            S.base_frq[2] = bb == 2 ? 1.0 : 0.0; S.base_frq[3] = bb == 3 ? 1.0 : 0.0;
+        }
+        S.k = 0;
+        finished = true;
     }
     S.sets = sets; S.n_emit = (int8_t)n_emit; S.p_deepest = (int8_t)p_deepest;
     int want[kLists];

@@ -599,7 +599,14 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
     dt, prof = timed_calls(ctx, fn1, n_calls)
     em_ms = prof["em_ms"] / max(1, prof["em_launches"])
     hist_ms = prof["hist_ms"] / max(1, prof["hist_launches"])
-    rec = results_from_tensor(res[0])
+    rec = results_from_tensor(res[0]).copy()
+    # (untimed) the same tile with every subset run: the passes the REFERENCE runs on it, and that nothing else of a record moves
+    ctx.join(); ctx.set_tuning("em_prune", 0)
+    b, q, r = t1[0]
+    rec_all = results_from_tensor(ctx.lrt_dense_device(b, q, r, m1)).copy()
+    ctx.join(); ctx.set_tuning("em_prune", 1)
+    ref_passes = float(rec_all["n_passes"].astype("int64").sum())
+    same = rec.copy(); same["n_passes"] = rec_all["n_passes"]; same["n_fits"] = rec_all["n_fits"]
     legs["config1_1e4x1e4"] = {
         "workload": f"BASELINE configs[1]: synthetic pileup {ns1} sites x {n1} samples, EM to convergence, "
                     f"{n_calls} calls of {ns1} sites",
@@ -607,14 +614,16 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
         "bound_by": "stage 2: region_kernel (FP64 VALU issue)",
         "roofline": em_roofline(rec, em_ms, dt / n_calls * 1e3, depth=n1),
         "hist_wave_kernel_ms_per_call_under_the_em": hist_ms,     # 0.05 ms alone (profiles/r02_kernel_stats_legs.csv)
+        "em_passes_per_site_of_the_reference": ref_passes / ns1,
+        "records_identical_with_every_subset_run_except_the_run_counts": bool(same.tobytes() == rec_all.tobytes()),
     }
     return legs
 
 
 def em_roofline(rec, em_launch_ms, call_ms, depth=0):
     """FP64-VALU issue roofline of stage 2 where it is the bound: issue slots x 4 cycles against 1024 SIMDs x 2.4 GHz.
-    Numerator = E+M passes of a call (singleEM calls, as the reference counts them) x the slots a pass NEEDS in the region
-    kernel with every lane group busy -- so lockstep idling (a wavefront runs until its slowest fit stops), the site phases
+    Numerator = E+M passes the call RAN (singleEM calls; record field n_passes -- the engine does not run the subsets a bound rules
+    out, include/bvc.h "em_prune") x the slots a pass NEEDS in the region kernel with every lane group busy -- so lockstep idling (a wavefront runs until its slowest fit stops), the site phases
     between the levels and launch tails all show up as lost fraction.  The denominator is the wall time per call: the stage 2
     of consecutive calls runs on two streams side by side.  Both per-pass figures come from profiles/stage2_valu.json and are
     null ("stale") when that file was measured on another em_items.hip."""
@@ -628,7 +637,9 @@ def em_roofline(rec, em_launch_ms, call_ms, depth=0):
             "unit": "G issue slots/s", "frac": ach / peak if ach else None, "ms_per_call": call_ms,
             "avg_launch_ms": em_launch_ms, "launches_overlap": True,
             "em_passes_per_site": passes / max(1, len(rec)), "issue_slots_per_pass": needed,
-            "valu_executed_per_pass": executed, "valu_source": src,
+            "valu_executed_per_pass": executed,
+            "valu_executed_per_reference_pass": (v.get("executed_per_reference_pass") or {}).get(str(depth)) if v else None,
+            "valu_source": src,
             "frac_executed": (passes * executed / (call_ms * 1e-3) / peak) if executed and call_ms > 0 else None,
             "note": "no MFMA: the EM is a scalar recurrence per class, not a contraction; peak = 1024 SIMDs x 2.4 GHz / 4 cycles "
                     "(the chip holds about 2.17 GHz under this load)"}

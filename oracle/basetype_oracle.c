@@ -288,7 +288,7 @@ static int lrt_on_model(site_model *sm, int8_t ref_base, double min_af,
             if (c != i_min && chi_c[c] - best < out->tie_gap) out->tie_gap = chi_c[c] - best;
         /* Diagnostic, NOT the reference's: what a level need not have run (see orc_result.n_fits_pruned).  The k = n - 1
          * subset without the deepest candidate (first one on ties) is number n - 1 - p in lexicographic order. */
-        if (fs.n_fit == fs.n_comb && fs.n_fit >= 2) {
+        if (fs.n_fit == fs.n_comb && fs.n_fit >= 2 && k >= 2) {   /* (one-allele levels need no EM at all: nothing to skip) */
             int p_deep = 0, c_last, t, bsel;
             double best_other = 0.0, u_c = 0.0, bound, slack;
             int have = 0;

@@ -56,7 +56,8 @@ typedef struct orc_result {
     /* Diagnostics of what a level NEED NOT RUN (not the reference's behaviour: it runs everything).  A level only goes on
      * with the first minimum of chi over its subsets (src/BaseType.cpp:99-105); the subset without the deepest candidate has
      * loglik <= U = sum, over the alleles outside it, of their observations' log(eps/3) (every marginal <= 1), so when
-     * 2 (lr_alt - U) exceeds the minimum chi of the other subsets by more than 1 + 1e-6 |U| it cannot be that minimum.  The
+     * 2 (lr_alt - U) exceeds the minimum chi of the other subsets by more than 1 + 1e-6 |U| it cannot be that minimum (levels
+     * of subsets of two alleles and more; the one-allele models of the last level cost nothing and always count).  The
      * library's item engine skips such fits (include/bvc.h "em_prune"); its n_fits / n_passes then equal these: */
     int32_t n_fits_pruned;
     int32_t n_passes_pruned;
