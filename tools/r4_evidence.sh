@@ -2,7 +2,7 @@
 # Round-4 evidence runs on the GPU box: every resident site against the CPU histogram path (plain and both group
 # layouts), seeds 1-3, five repeats of the default line.  Output: gpurun_out/r04_evidence/
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04_evidence; mkdir -p $O   # (one attempt per round; a second one goes to r04_evidence_<n>: never over a log)
+O=gpurun_out/${1:-r04_evidence}; mkdir -p $O   # (one attempt per tag: a second one goes to <tag>_<time>, never over a log)
 [ -f $O/seeds.jsonl ] && O=${O}_$(date +%H%M%S) && mkdir -p $O
 python bench.py --verify-all --no-legs --cpu-sites 32 > $O/verify_all_config3.json 2> $O/verify_all_config3.err
 python bench.py --groups 5 --verify-all --no-legs --cpu-sites 0 --steps 4 > $O/verify_groups_interleaved.json 2> $O/verify_groups_interleaved.err
