@@ -1,14 +1,13 @@
 // em_items.hip -- stage 2 of the basetype path on gfx950, "item engine": the EM fits of a call are the work items,
-// eight of them share a wavefront, and ONE WAVEFRONT takes a REGION of 8 sites through the whole likelihood-ratio
+// eight of them share a wavefront, and a TEAM of two wavefronts takes a REGION of 8 sites through the whole likelihood-ratio
 // test: classes -> fits of the first level -> decisions -> fits of the next level -> ... with every intermediate
-// (class tables, fit descriptors and results, site state) in the wavefront's own 11 KB of LDS.  No workgroup barrier
-// anywhere (round 3 gave a region to a workgroup of four wavefronts that met at a barrier after every phase: with five
-// wavefront-slots at the first level and three at the second for four wavefronts, and one wavefront per site in the site
-// phases, about half of the resident wavefronts were waiting at any time); the wavefronts of a workgroup are independent
-// and share nothing but the launch.
+// (class tables, fit descriptors and results, site state) in the region's own 11 KB of LDS.  The team meets at an arrival
+// counter in that LDS between the phases; no workgroup barrier after kernel entry (round 3 gave a region to a workgroup of
+// four wavefronts that met at s_barrier after every phase: about half of the resident wavefronts were waiting at any time);
+// the teams of a workgroup are independent and share nothing but the launch.
 //
 // Follows (paths under /root/reference), with the per-sample sums regrouped by class as in em_kernel.hip:
-//   BaseType::SetAlleleFreq  src/BaseType.cpp:25-39     -> site_emit
+//   BaseType::SetAlleleFreq  src/BaseType.cpp:25-39     -> region_emit
 //   BaseType::UpdateF        src/BaseType.cpp:41-71     -> one FitItem per subset: fit_body (EM), site_decide (log-likelihood)
 //   BaseType::LRT            src/BaseType.cpp:73-139    -> site_classes (:75-88), site_decide (one level of :93-110 per phase)
 //   combs_                   src/BaseType.cpp:237-255   -> subset_masks
@@ -32,10 +31,10 @@
 //   * the 16 reciprocals of a lane come from ONE v_rcp_f64 (16 issue cycles, four FMAs' worth): 1 / (m_0 ... m_15)
 //     refined once, times the other fifteen marginals by a product tree, 2.8 multiplications per class.
 // The items of a wavefront run in lockstep passes (each with its own pass counter), the wavefronts of a region meet
-// at a barrier after every level, and the hardware dispatches the regions dynamically.  Fits differ 7x in passes at
-// N = 1e4, so what shares a wavefront matters: the fits of one site converge alike except the subset that leaves out
-// the site's deepest allele (always slow), which is why a site's items are placed together and the "deepest allele
-// left out" items go to lists (wavefronts) of their own.
+// at a team barrier after every phase, and the hardware dispatches the regions dynamically.  Fits differ 7x in passes at
+// N = 1e4, so what shares a wavefront matters: the fits of one site converge alike, which is why a site's items are placed
+// together.  The one exception -- the subset that leaves out the site's deepest allele always creeps to the iteration cap --
+// is not run at all when a bound shows that it cannot be its level's minimum (site_decide), and one-allele models need no EM.
 // Sites the engine does not take (more than 32 quality values on one allele, a class of quality 0 or 1 -- d < 0 --,
 // min_af <= 0, duplicate candidates) stay with em_kernel.hip's one-wavefront-per-site kernels, flagged per site.
 // FP64 throughout; no MFMA (nothing here is a dense contraction).
@@ -953,10 +952,9 @@ __device__ __forceinline__ void load_counts(uint32_t (&c)[8], const uint32_t *__
 // runs the classes phase of the regions it looks at and goes on only with its own; the narrow launch comes first, and the
 // other two return at once when it has met no region of theirs in this call.
 //
-// The wavefront's slots of a level -- eight fits each -- run one after the other, the slow lists first (their fits run to the
-// iteration cap whatever the site, so they share wavefront-passes with their like); a slot lasts as long as its slowest fit.
+// The wavefront-slots of a round -- eight fits each -- run one after the other; a slot lasts as long as its slowest fit.
 // TEAM wavefronts share a region (1, 2 or 4; a workgroup holds 4 / TEAM regions): they split the site phases by site and the
-// fit phases by wavefront-slot (an LDS counter hands the slots out, the slow lists first), and meet at a team barrier between
+// fit phases by wavefront-slot (an LDS counter hands the slots out), and meet at a team barrier between
 // the phases.  The barrier is an arrival counter in the region's LDS, never reset (phase p is over when it reads p * TEAM):
 // only the region's own wavefronts wait for one another, the rest of the workgroup is never involved.
 template <int TEAM, class RegionT>
