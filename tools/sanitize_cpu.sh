@@ -20,4 +20,4 @@ g++ $SAN -std=c++11 -pthread -Iinclude -o basevarc_amd/BaseVarC basevarc_amd/hos
 touch basevarc_amd/libbvc.so basevarc_amd/libbvchost.so basevarc_amd/BaseVarC oracle/liborc.so
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
-    python -m pytest tests/test_oracle.py tests/test_host.py -x -q -m "not gpu"
+    python -m pytest tests/test_oracle.py tests/test_prune_bound.py tests/test_host.py -x -q -m "not gpu"
