@@ -56,6 +56,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert hp["bound"] == "pcie" and 0 < hp["ragged_one_byte"]["frac"] < 1 and 0 < hp["dense_one_byte"]["frac"] < 1
     assert hp["ragged_one_byte"]["records_identical_to_device_pointer_call"] is True
     assert legs["config1_1e4x1e4"]["roofline"]["bound"] == "fp64_valu_issue"
+    # the EM-bound legs are also timed with every subset of every level run (em_prune = 0): what the reference defines of a record
+    # is the same bytes, the engine runs fewer passes than the reference counts, and is not slower for it
+    for name in ("config1_1e4x1e4", "csr_coverage10pct"):
+        leg = legs[name]
+        assert leg["records_identical_with_every_subset_run_except_the_run_counts"] is True, name
+        assert leg["roofline"]["em_passes_per_site"] < leg["em_passes_per_site_of_the_reference"], name
+        assert leg["value"] > 0.95 * leg["value_with_every_subset_run"] > 0, name
     assert legs["csr_coverage10pct"]["roofline"]["bound"] == "fp64_valu_issue" and legs["csr_coverage10pct"]["hist_roofline"]["bound"] == "hbm"
     # the ragged histogram pass is reported twice: underneath stage 2 and with the chip to itself (faster alone)
     hr = legs["csr_coverage10pct"]["hist_roofline"]
