@@ -1,5 +1,6 @@
 // capi.cpp -- C entry points of the host-side pieces, for tests and for callers in other languages.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -46,6 +47,54 @@ void bvchost_reset_parser(void) { reset_parser_carry(); }
 // inflate.cpp against zlib (tests): bytes written or -1
 long bvchost_fast_inflate(const unsigned char *in, size_t n, unsigned char *out, size_t cap) { return fast_inflate(in, n, out, cap); }
 long bvchost_zlib_fallbacks(void) { return bgzf_zlib_fallbacks(); }
+
+// Micro-benchmarks of the two CPU costs of a text temp batch (tools/host_micro.py): seconds per pass over the input.
+// parse: every line of `text` through parse_pileup_line into one reused SiteColumn; inflate: every BGZF block of a file image
+// through fast_inflate (use_zlib = 0) -- *out_bytes gets the inflated size of one pass.
+double bvchost_bench_parse(const char *text, size_t len, int reps, int64_t *entries_out)
+{
+    SiteColumn col;
+    reset_parser_carry();
+    int64_t entries = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) {
+        const char *p = text, *end = text + len;
+        while (p < end) {
+            const char *nl = static_cast<const char *>(std::memchr(p, '\n', (size_t)(end - p)));
+            const size_t n = nl ? (size_t)(nl - p) : (size_t)(end - p);
+            col.clear();
+            parse_pileup_line(p, n, 0, col);
+            entries += (int64_t)col.aiv.size();
+            p += n + 1;
+        }
+    }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (entries_out) *entries_out = entries / (reps > 0 ? reps : 1);
+    return dt / (reps > 0 ? reps : 1);
+}
+double bvchost_bench_inflate(const unsigned char *file, size_t len, int reps, int64_t *out_bytes)
+{
+    std::vector<unsigned char> out(1 << 16);
+    int64_t total = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) {
+        size_t off = 0;
+        total = 0;
+        while (off + 28 <= len) {
+            const size_t bsize = ((size_t)file[off + 16] | ((size_t)file[off + 17] << 8)) + 1;
+            if (off + bsize > len) return -1.0;
+            const unsigned char *tail = file + off + bsize - 4;
+            const size_t isize = (size_t)tail[0] | ((size_t)tail[1] << 8) | ((size_t)tail[2] << 16) | ((size_t)tail[3] << 24);
+            if (isize > out.size()) return -1.0;
+            if (isize && fast_inflate(file + off + 18, bsize - 18 - 8, out.data(), isize) != (long)isize) return -2.0;
+            total += (int64_t)isize;
+            off += bsize;
+        }
+    }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (out_bytes) *out_bytes = total;
+    return dt / (reps > 0 ? reps : 1);
+}
 
 // site handle API (tests): build a SiteColumn from batch lines, then ask for its pieces
 struct bvchost_site { SiteColumn col; };

@@ -40,8 +40,8 @@ inline uint32_t reverse_bits(uint32_t code, int len)
     return r;
 }
 
-// Builds a two-level decoding table from code lengths (canonical Huffman, codes read LSB first).  `value(sym)` gives the
-// payload (upper bits) of a symbol's entry.  Returns false for an over-subscribed code; incomplete codes are allowed (their
+// Builds a two-level decoding table from code lengths (canonical Huffman, codes read LSB first).  `value(sym, bits)` gives a symbol's
+// entry for a code of `bits` bits (counted within its table level).  Returns false for an over-subscribed code; incomplete codes are allowed (their
 // unused patterns decode to kInvalid), as in streams with a single distance code.
 template <class Value>
 bool build_table(const uint8_t *lens, int n_syms, int table_bits, uint32_t *table, int table_cap, Value value)
@@ -89,37 +89,46 @@ bool build_table(const uint8_t *lens, int n_syms, int table_bits, uint32_t *tabl
         if (!l) continue;
         const uint32_t r = codes[s];
         if (l <= table_bits) {
-            const uint32_t e = value(s) | (uint32_t)l;
+            const uint32_t e = value(s, l);
             for (uint32_t i = r; i < (uint32_t)main_size; i += 1u << l) table[i] = e;
         } else {
             const uint32_t prefix = r & (uint32_t)(main_size - 1);
             const uint32_t head = table[prefix];
             const int sb = (int)((head >> 24) & 0xFu);
             const uint32_t off = (head >> 8) & 0xFFFFu;
-            const uint32_t e = value(s) | (uint32_t)(l - table_bits);
+            const uint32_t e = value(s, l - table_bits);
             for (uint32_t i = r >> table_bits; i < (1u << sb); i += 1u << (l - table_bits)) table[off + i] = e;
         }
     }
     return true;
 }
 
-// entry layouts (low 8 bits = bits to consume):
-//   literal      kLiteral | byte << 8
-//   length       base << 8 (bits 8..16) | extra << 20 (bits 20..23)          (neither kLiteral nor kEndOfBlock)
-//   end of block kEndOfBlock
-//   distance     base << 8 (bits 8..22) | extra << 24 (bits 24..27)
+// entry layouts (low 8 bits = bits to consume: the code, and for lengths / distances their extra bits with it):
+//   literal      kLiteral | byte << 8 | code bits
+//   length       base << 12 (bits 12..20) | code bits << 8 (bits 8..11) | code bits + extra bits
+//   end of block kEndOfBlock | code bits
+//   distance     base << 12 (bits 12..26) | code bits << 8 | code bits + extra bits
 //   sub-table    kSubTable | sub_bits << 24 | offset << 8 | first-level bits
-inline uint32_t lit_value(int s)
+// (second-level entries count their bits from behind the first-level bits, which the decoder drops first)
+// A length or distance is then  base + ((bits >> code bits) & ((1 << extra) - 1))  from ONE look at the bit buffer, and one shift
+// consumes the code and its extra bits together.
+inline uint32_t lit_value(int s, int code_bits)
 {
-    if (s < 256) return kLiteral | ((uint32_t)s << 8);
-    if (s == 256) return kEndOfBlock;
-    if (s > 285) return kInvalid;
-    return ((uint32_t)kLenBase[s - 257] << 8) | ((uint32_t)kLenExtra[s - 257] << 20);
+    if (s < 256) return kLiteral | ((uint32_t)s << 8) | (uint32_t)code_bits;
+    if (s == 256) return kEndOfBlock | (uint32_t)code_bits;
+    if (s > 285) return kInvalid | (uint32_t)code_bits;
+    return ((uint32_t)kLenBase[s - 257] << 12) | ((uint32_t)code_bits << 8) | (uint32_t)(code_bits + kLenExtra[s - 257]);
 }
-inline uint32_t dist_value(int s)
+inline uint32_t dist_value(int s, int code_bits)
 {
-    if (s > 29) return kInvalid;
-    return ((uint32_t)kDistBase[s] << 8) | ((uint32_t)kDistExtra[s] << 24);
+    if (s > 29) return kInvalid | (uint32_t)code_bits;
+    return ((uint32_t)kDistBase[s] << 12) | ((uint32_t)code_bits << 8) | (uint32_t)(code_bits + kDistExtra[s]);
+}
+inline uint32_t pre_value(int s, int code_bits) { return ((uint32_t)s << 8) | (uint32_t)code_bits; }
+inline uint32_t value_of(uint32_t e, uint64_t bits)               // length / distance entry: base + its extra bits
+{
+    const int code = (int)((e >> 8) & 0xFu), extra = (int)(e & 0xFFu) - code;
+    return ((e >> 12) & 0x7FFFu) + (uint32_t)((bits >> code) & ((1ull << extra) - 1ull));
 }
 
 struct Bits {
@@ -220,7 +229,7 @@ long fast_inflate(const unsigned char *in, size_t in_len, unsigned char *out, si
             static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
             uint8_t pl[19] = {0};
             for (int i = 0; i < hclen; ++i) { if (b.cnt < 3) b.refill(); pl[order[i]] = (uint8_t)b.take(3); }
-            if (!build_table(pl, 19, kPreBits, T.pre, 1 << kPreBits, [](int s) { return (uint32_t)s << 8; })) return -1;
+            if (!build_table(pl, 19, kPreBits, T.pre, 1 << kPreBits, pre_value)) return -1;
             uint8_t lens[kMaxLitSyms + kMaxDistSyms];
             int n = 0;
             while (n < hlit + hdist) {
@@ -245,6 +254,80 @@ long fast_inflate(const unsigned char *in, size_t in_len, unsigned char *out, si
             return -1;
         }
         // ---- symbols of the block
+        bool end_of_block = false;
+        // Fast loop: while at least 32 input bytes and 2 + 258 + 32 output bytes are left, an iteration -- up to two literals and a
+        // match -- cannot run out of either, so nothing inside tests a bound but the match's distance; the bit buffer is refilled
+        // without a branch (eight bytes loaded, as many whole bytes consumed as there is room for).
+        while (b.in_end - b.in >= 32 && o_end - o >= 2 + 258 + 32) {
+            uint64_t w;
+            std::memcpy(&w, b.in, 8);
+            b.buf |= w << b.cnt;
+            b.in += (63 - b.cnt) >> 3;
+            b.cnt |= 56;                                         // >= 56 bits: two literals (2 x 15) and a length (15 + 5) fit
+            uint32_t e = lit[b.buf & ((1u << kLitBits) - 1u)];
+            if (e & kLiteral) {
+                b.buf >>= (e & 0xFFu); b.cnt -= (int)(e & 0xFFu);
+                *o++ = (uint8_t)(e >> 8);
+                e = lit[b.buf & ((1u << kLitBits) - 1u)];
+                if (e & kLiteral) {
+                    b.buf >>= (e & 0xFFu); b.cnt -= (int)(e & 0xFFu);
+                    *o++ = (uint8_t)(e >> 8);
+                    e = lit[b.buf & ((1u << kLitBits) - 1u)];
+                    if (e & kLiteral) {                          // (a third one: 45 bits at most so far)
+                        b.buf >>= (e & 0xFFu); b.cnt -= (int)(e & 0xFFu);
+                        *o++ = (uint8_t)(e >> 8);                // (three literals leave room for no length code: next iteration)
+                        continue;
+                    }
+                }
+            }
+            if (e & (kSubTable | kEndOfBlock | kInvalid)) {
+                if (e & kSubTable) {
+                    b.buf >>= kLitBits; b.cnt -= kLitBits;
+                    e = lit[((e >> 8) & 0xFFFFu) + (uint32_t)(b.buf & ((1u << ((e >> 24) & 0xFu)) - 1u))];
+                    if (e & kLiteral) {
+                        b.buf >>= (e & 0xFFu); b.cnt -= (int)(e & 0xFFu);
+                        *o++ = (uint8_t)(e >> 8);
+                        continue;
+                    }
+                }
+                if (e & kInvalid) return -1;
+                if (e & kEndOfBlock) { b.buf >>= (e & 0xFFu); b.cnt -= (int)(e & 0xFFu); end_of_block = true; break; }
+            }
+            const uint32_t len = value_of(e, b.buf);
+            b.buf >>= (e & 0xFFu); b.cnt -= (int)(e & 0xFFu);
+            std::memcpy(&w, b.in, 8);                            // a distance: 15 + 13 bits
+            b.buf |= w << b.cnt;
+            b.in += (63 - b.cnt) >> 3;
+            b.cnt |= 56;
+            uint32_t d = dist[b.buf & ((1u << kDistBits) - 1u)];
+            if (d & (kSubTable | kInvalid)) {
+                if (d & kSubTable) {
+                    b.buf >>= kDistBits; b.cnt -= kDistBits;
+                    d = dist[((d >> 8) & 0xFFFFu) + (uint32_t)(b.buf & ((1u << ((d >> 24) & 0xFu)) - 1u))];
+                }
+                if (d & kInvalid) return -1;
+            }
+            const uint32_t distance = value_of(d, b.buf);
+            b.buf >>= (d & 0xFFu); b.cnt -= (int)(d & 0xFFu);
+            if (distance > (uint32_t)(o - out)) return -1;
+            // the copy may write up to 31 bytes past the match: there is room (the loop's condition)
+            const uint8_t *src = o - distance;
+            uint8_t *dst = o;
+            o += len;
+            if (distance >= 16) {
+                do { std::memcpy(dst, src, 16); src += 16; dst += 16; } while (dst < o);
+            } else if (distance >= 8) {
+                do { std::memcpy(dst, src, 8); src += 8; dst += 8; } while (dst < o);
+            } else {
+                uint64_t pat;
+                if (distance == 2) { uint16_t v; std::memcpy(&v, src, 2); pat = 0x0001000100010001ull * v; }
+                else if (distance == 1) pat = 0x0101010101010101ull * src[0];
+                else if (distance == 4) { uint32_t v; std::memcpy(&v, src, 4); pat = 0x0000000100000001ull * v; }
+                else { for (uint32_t i = 0; i < len; ++i) dst[i] = src[i]; continue; }
+                do { std::memcpy(dst, &pat, 8); dst += 8; } while (dst < o);
+            }
+        }
+        // the last symbols of the input / output (and of every block whose end the fast loop did not reach): every bound tested
         auto lit_entry = [&]() -> uint32_t {                     // (a second-level entry: the first-level bits are dropped here)
             uint32_t e = lit[b.peek(kLitBits)];
             if (e & kSubTable) {
@@ -253,7 +336,7 @@ long fast_inflate(const unsigned char *in, size_t in_len, unsigned char *out, si
             }
             return e;
         };
-        for (;;) {
+        while (!end_of_block) {
             b.refill();                                          // >= 56 bits: two literals (2 x 15) and a length (15 + 5) fit
             uint32_t e = lit_entry();
             if (e & kLiteral) {
@@ -269,9 +352,9 @@ long fast_inflate(const unsigned char *in, size_t in_len, unsigned char *out, si
                 }
             }
             if (e & kInvalid) return -1;
+            if (e & kEndOfBlock) { b.drop((int)(e & 0xFFu)); break; }
+            const uint32_t len = value_of(e, b.buf);
             b.drop((int)(e & 0xFFu));
-            if (e & kEndOfBlock) break;
-            const uint32_t len = ((e >> 8) & 0x1FFu) + b.take((int)((e >> 20) & 0xFu));
             if (b.cnt < 28) b.refill();                          // a distance: 15 + 13 bits
             uint32_t d = dist[b.peek(kDistBits)];
             if (d & kSubTable) {
@@ -279,8 +362,8 @@ long fast_inflate(const unsigned char *in, size_t in_len, unsigned char *out, si
                 d = dist[((d >> 8) & 0xFFFFu) + b.peek((int)((d >> 24) & 0xFu))];
             }
             if (d & kInvalid) return -1;
+            const uint32_t distance = value_of(d, b.buf);
             b.drop((int)(d & 0xFFu));
-            const uint32_t distance = ((d >> 8) & 0x7FFFu) + b.take((int)((d >> 24) & 0xFu));
             if (distance > (uint32_t)(o - out) || (size_t)(o_end - o) < len) return -1;
             copy_match(o, distance, len, o_end);
             o += len;
