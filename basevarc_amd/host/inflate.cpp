@@ -5,8 +5,11 @@
 // position is 200-300 KB of text in ~60 KB of deflate, and zlib's inflate (440 MB/s of output on this data) was two thirds of
 // the CPU time of the compute phase's host side -- on a box whose cgroup grants 16 CPUs that caps the feed whatever the
 // thread count.  This decoder keeps a 64-bit bit buffer refilled eight bytes at a time, decodes literal/length and distance
-// symbols through 11-bit / 8-bit first-level tables (second level for the longer codes), takes up to two literals per refill
-// and copies matches a word at a time (runs of ". " -- distance 2 -- by a repeated 8-byte pattern).
+// symbols through 11-bit / 8-bit first-level tables (second level for the longer codes) whose entries carry "code bits + extra
+// bits" so that a length or a distance is one look at the bit buffer and one shift, takes up to three literals per refill and
+// copies matches 16 bytes at a time (runs of ". " -- distance 2 -- by a repeated 8-byte pattern).  While 32 input bytes and a
+// longest match + 34 output bytes are left, the loop tests no bound but the match distance; the last symbols go through a loop
+// that tests them all.
 // Own code, written from RFC 1951; checked against zlib on random and adversarial streams (tests/test_host.py).
 #include "inflate.h"
 
