@@ -406,6 +406,11 @@ int bvc_create(bvc_ctx **out, int device)
     bvc_ctx *ctx = new (std::nothrow) bvc_ctx();
     if (!ctx) return BVC_ERR_ALLOC;
     ctx->device = device;
+#ifdef BVC_DIAG_KNOBS
+    // experiment (host program on a CPU quota): let host threads SLEEP in hipStreamSynchronize instead of polling.  Process-wide,
+    // which is why it is not a tuning of a context.
+    if (env_int("BVC_BLOCKING_SYNC", 0, 1, 0)) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+#endif
     ctx->ls.n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     // starting values of the tuning knobs (bvc_set_tuning changes them per context; results never depend on them)
     ctx->ls.em_waves_per_cu = env_int("BVC_EM_WAVES_PER_CU", 1, 32, 0);

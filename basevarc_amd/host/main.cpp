@@ -19,6 +19,7 @@
 #include <iostream>
 #include <chrono>
 #include <condition_variable>
+#include <sys/resource.h>
 #include <deque>
 #include <map>
 #include <memory>
@@ -741,9 +742,16 @@ static void run_basetype(int argc, char **argv)                          // src/
         std::cout << "merge subfiles done" << std::endl;
         if (!fov.close()) std::cerr << "warning: file cannot be closed" << std::endl;
         if (!foc.close()) std::cerr << "warning: file cannot be closed" << std::endl;
-        if (getenv("BVC_HOST_PROFILE"))
+        if (getenv("BVC_HOST_PROFILE")) {
+            // CPU time the whole process has consumed so far (all threads, the HIP runtime's included): on a box that grants a quota of
+            // CPUs this, not the thread count, is what the feed is bounded by
+            struct rusage ru;
+            getrusage(RUSAGE_SELF, &ru);
+            const double cpu = (double)ru.ru_utime.tv_sec + 1e-6 * (double)ru.ru_utime.tv_usec + (double)ru.ru_stime.tv_sec + 1e-6 * (double)ru.ru_stime.tv_usec;
             std::cerr << "[profile] main: compute phase (threads) " << t_joined - t_loaded << " s, merge of sub-files "
-                      << StageClock::now() - t_joined << " s" << std::endl;
+                      << StageClock::now() - t_joined << " s; process CPU time " << cpu << " s (user "
+                      << (double)ru.ru_utime.tv_sec + 1e-6 * (double)ru.ru_utime.tv_usec << ")" << std::endl;
+        }
     }
     for (int i = 0; i < thread; ++i) ::rmdir((opt::output + ".tmp.thread." + std::to_string(i)).c_str());
     time_t tim2 = time(0);
