@@ -50,3 +50,18 @@ for skew in (0, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 1 <<
     ctx.synth_dense_device(1, 0, b[:, :N], q[:, :N], r)
     ms = timed(b[:, :N], q[:, :N])
     print(f"skew {skew:>9d}: {ms:.4f} ms  {2.0 * S * N / ms / 1e9:.3f} TB/s", flush=True)
+del big, b, q
+torch.cuda.empty_cache()
+print("## one arena for six tile pairs (one hipMalloc), carved [b0 q0 b1 q1 ...]; then the same arena carved [b0..b5 q0..q5]")
+pairs = 6
+arena = torch.empty(2 * pairs * tile + (2 << 20), dtype=torch.int8, device=dev)
+base = (-arena.data_ptr()) % (2 << 20)                           # carve from a 2 MiB boundary
+print(f"arena at {arena.data_ptr():#x} (+{base})", flush=True)
+for layout in ("interleaved", "split"):
+    for t in range(pairs):
+        ob = base + (2 * t * tile if layout == "interleaved" else t * tile)
+        oq = base + ((2 * t + 1) * tile if layout == "interleaved" else (pairs + t) * tile)
+        b = arena[ob:ob + tile].view(S, stride); q = arena[oq:oq + tile].view(S, stride)
+        ctx.synth_dense_device(1, t * S, b[:, :N], q[:, :N], r)
+        ms = timed(b[:, :N], q[:, :N])
+        print(f"{layout} pair {t}: {ms:.4f} ms  {2.0 * S * N / ms / 1e9:.3f} TB/s", flush=True)
