@@ -223,3 +223,37 @@ def _levels(o):
         if f == fits:
             return lv
     return 0
+
+
+def test_skipped_subsets_on_every_entry_point(ctx):
+    """em_prune 1 against 0 on the other entry points: group calls (pseudo-sites with SetBase candidate lists: one, two and three
+    candidates), ragged sites and packed tiles -- site records and group records the same bytes apart from the two run counts."""
+    import torch
+    from basevarc_amd import Context
+    from basevarc_amd.lib import results_from_tensor
+    ns, n, k = 501, 30000, 5
+    m = caller_min_af(n)
+    b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    r = torch.empty(ns, dtype=torch.int8, device="cuda")
+    ctx.synth_dense_device(21, 4321, b, q, r, cov_thr16=int(0.7 * 65536))
+    g = torch.from_numpy((np.arange(n) % (k + 1)).astype(np.uint8)).cuda()
+    g[g == k] = 255
+    lens = torch.full((ns,), n, dtype=torch.int64)
+    offs = torch.zeros(ns + 1, dtype=torch.int64); offs[1:] = torch.cumsum(lens, 0)
+    out = {}
+    for prune in (1, 0):
+        with Context(0) as c:
+            c.set_tuning("em_prune", prune)
+            res, gres = c.lrt_dense_groups_device(b, q, r, m, g, k)
+            p, bad = c.pack_dense_device(b, q)
+            assert bad == 0
+            rp = c.lrt_dense_packed_device(p, r, m)
+            rc = c.lrt_csr_device(offs.cuda(), b.reshape(-1), q.reshape(-1), r, m)
+            c.synchronize()
+            out[prune] = (results_from_tensor(res).copy(), gres.cpu().numpy().tobytes(), results_from_tensor(rp).copy(),
+                          results_from_tensor(rc).copy())
+    assert out[1][1] == out[0][1]                                  # group records: no run counts in them
+    for i in (0, 2, 3):
+        assert _without_run_counts(out[1][i]) == _without_run_counts(out[0][i]), i
+        assert (out[1][i]["n_passes"] <= out[0][i]["n_passes"]).all() and out[1][i]["n_passes"].sum() < 0.8 * out[0][i]["n_passes"].sum(), i
