@@ -24,6 +24,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "none" and d["vs_baseline"] is None           # one GPU: nothing is scaled and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
+    # (outside the timed region) the same steps with every subset of every level run; at BASELINE size the two are equal (the histogram
+    # pass bounds the call), on this small workload stage 2 shows
+    assert 0 < d["value_with_every_subset_run"] <= 1.05 * d["value"]
     # a step is one pass over the whole resident workload (8000 sites here, in calls of 2000)
     assert d["config"]["sites_per_step"] == 8000 and d["config"]["sites_per_call"] == 2000
     assert d["value"] == pytest.approx(8000 / (d["ms_per_step"] / 1e3), rel=1e-3)
