@@ -26,13 +26,28 @@ def _hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+STAMP = LIB + ".flags"
+
+
+def _flag_stamp():
+    """What the library on disk must have been compiled with to count as the product: every flag that reaches hipcc, including the
+    experiment / diagnostic ones of BVC_EXTRA_FLAGS (-DBVC_POISON, -DBVC_CHECK_LDS ...).  Kept beside the library."""
+    extra = os.environ.get("BVC_EXTRA_FLAGS", "").split()
+    return repr((COMMON_FLAGS, extra, sorted(PER_SOURCE_FLAGS.items())))
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """True when the library is missing, older than a source, or was built with other flags than this process would use (so a
+    diagnostic build left behind by a failed or killed tools/poison_run.sh is never taken for the product)."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+        return True
+    if open(STAMP, encoding="utf-8").read() != _flag_stamp():
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + DEPS)
 
 
+COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra"]
 # Flags of single translation units.  em_items.hip: the narrow region kernel sits at the 168 VGPRs of three wavefronts per
 # SIMD, and the machine-level loop-invariant code motion of this compiler keeps hoisting lane-constant addresses, zero vectors
 # and the like out of the region's level loop, where they stay live across the fits and end in scratch (or in 30-70 SGPR
@@ -43,25 +58,45 @@ PER_SOURCE_FLAGS = {"em_items.hip": ["-mllvm", "-disable-machine-licm"],
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Returns the path of the library."""
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Returns the path of the library.
+
+    Objects and the linked library are made in a directory of this build's own and the library is moved into place in one
+    rename, so two builds at once (two ranks, two test processes) cannot mix their objects, and a build that fails or is killed
+    leaves the previous library untouched.  Every compiler started is waited for (or killed) before an error is raised."""
     if not force and not needs_build():
         return LIB
+    import tempfile
     extra = os.environ.get("BVC_EXTRA_FLAGS", "").split()         # experiments: -DBVC_HIST_UNROLL=8 ...
-    common = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra"] + extra
+    common = [_hipcc()] + COMMON_FLAGS + extra
     if verbose:
         common.append("-Rpass-analysis=kernel-resource-usage")
-    objdir = os.path.join(CSRC, "_obj")
-    os.makedirs(objdir, exist_ok=True)
-    procs = []
-    for f in SOURCES:                                            # one compile per source, side by side
-        obj = os.path.join(objdir, f.replace(".hip", ".o"))
-        procs.append((obj, subprocess.Popen(common + PER_SOURCE_FLAGS.get(f, []) + ["-c", os.path.join(CSRC, f), "-o", obj])))
-    objs = []
-    for obj, pr in procs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, "hipcc -c " + obj)
-        objs.append(obj)
-    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    os.makedirs(os.path.join(CSRC, "_obj"), exist_ok=True)
+    objdir = tempfile.mkdtemp(prefix="build.", dir=os.path.join(CSRC, "_obj"))
+    try:
+        procs = []
+        for f in SOURCES:                                            # one compile per source, side by side
+            obj = os.path.join(objdir, f.replace(".hip", ".o"))
+            procs.append((obj, subprocess.Popen(common + PER_SOURCE_FLAGS.get(f, []) + ["-c", os.path.join(CSRC, f), "-o", obj])))
+        failed = None
+        for obj, pr in procs:
+            if failed is not None:
+                pr.kill()
+            if pr.wait() != 0 and failed is None:
+                failed = (pr.returncode, obj)
+        if failed is not None:
+            raise subprocess.CalledProcessError(failed[0], "hipcc -c " + os.path.basename(failed[1]))
+        tmp_lib = os.path.join(objdir, "libbvc.so")
+        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib] + [o for o, _ in procs])
+        if os.path.exists(STAMP):
+            os.remove(STAMP)                                         # never a new library under an old stamp
+        os.replace(tmp_lib, LIB)
+        with open(STAMP + ".tmp", "w", encoding="utf-8") as f:
+            f.write(_flag_stamp())
+        os.replace(STAMP + ".tmp", STAMP)
+        for o, _ in procs:                                           # the objects of the library in place (tools/build_variants.sh links against them)
+            os.replace(o, os.path.join(CSRC, "_obj", os.path.basename(o)))
+    finally:
+        shutil.rmtree(objdir, ignore_errors=True)
     return LIB
 
 

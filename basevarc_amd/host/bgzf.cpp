@@ -6,13 +6,88 @@
 
 #include <zlib.h>
 
+#include <cstdlib>
 #include <cstring>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace bvchost {
 
 // blocks the fast decoder declined and zlib inflated (expected: none; tests/test_host.py reads it)
 std::atomic<long> g_zlib_fallbacks(0);
 long bgzf_zlib_fallbacks() { return g_zlib_fallbacks.load(); }
+// blocks whose inflated bytes did not hash to the CRC32 of their trailer (expected: none)
+std::atomic<long> g_crc_errors(0);
+long bgzf_crc_errors() { return g_crc_errors.load(); }
+
+// ---- CRC32 of a block (gzip trailer, RFC 1952) -----------------------------------------------------------------------
+// htslib verifies the CRC32 of every BGZF block it inflates, so the reference's bt_s does (bgzf_getline, src/BaseVarC.cpp:406);
+// so does this reader.  zlib's table-driven crc32 costs about as much as the block inflate of inflate.cpp itself, so on x86-64 with
+// PCLMULQDQ the bulk of a block goes through carry-less multiplication instead: four 128-bit lanes folded by x^512 mod P per 64
+// bytes, then by x^128, then a Barrett reduction (Gopal, Ozturk, Guilford, Wolrich, Feghali, Dixon, Karakoyunlu: "Fast CRC
+// computation for generic polynomials using PCLMULQDQ instruction", Intel 2009; constants for the reflected polynomial 0xEDB88320).
+// The bytes in front of and behind the multiple-of-16 middle go through zlib.  Checked against zlib in tests/test_host.py.
+#if defined(__x86_64__)
+__attribute__((target("pclmul,sse4.1")))
+static inline __m128i crc32_fold128(__m128i x, __m128i k3k4, __m128i next)      // x * x^128 mod P, plus the next 16 bytes
+{
+    const __m128i a = _mm_clmulepi64_si128(x, k3k4, 0x00);
+    return _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x, k3k4, 0x11), a), next);
+}
+
+__attribute__((target("pclmul,sse4.1")))
+static uint32_t crc32_fold(const unsigned char *buf, size_t len, uint32_t state)      // len >= 64 and a multiple of 16; raw state
+{
+    const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596, 0x0154442bd4);
+    const __m128i k3k4 = _mm_set_epi64x(0x00ccaa009e, 0x01751997d0);
+    const __m128i k5 = _mm_set_epi64x(0, 0x0163cd6124);
+    const __m128i poly = _mm_set_epi64x(0x01f7011641, 0x01db710641);
+    const __m128i *p = reinterpret_cast<const __m128i *>(buf);
+    __m128i x1 = _mm_loadu_si128(p), x2 = _mm_loadu_si128(p + 1), x3 = _mm_loadu_si128(p + 2), x4 = _mm_loadu_si128(p + 3);
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)state));
+    p += 4; len -= 64;
+    while (len >= 64) {
+        const __m128i a1 = _mm_clmulepi64_si128(x1, k1k2, 0x00), a2 = _mm_clmulepi64_si128(x2, k1k2, 0x00);
+        const __m128i a3 = _mm_clmulepi64_si128(x3, k1k2, 0x00), a4 = _mm_clmulepi64_si128(x4, k1k2, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, k1k2, 0x11); x2 = _mm_clmulepi64_si128(x2, k1k2, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, k1k2, 0x11); x4 = _mm_clmulepi64_si128(x4, k1k2, 0x11);
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, a1), _mm_loadu_si128(p));
+        x2 = _mm_xor_si128(_mm_xor_si128(x2, a2), _mm_loadu_si128(p + 1));
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, a3), _mm_loadu_si128(p + 2));
+        x4 = _mm_xor_si128(_mm_xor_si128(x4, a4), _mm_loadu_si128(p + 3));
+        p += 4; len -= 64;
+    }
+    x1 = crc32_fold128(x1, k3k4, x2); x1 = crc32_fold128(x1, k3k4, x3); x1 = crc32_fold128(x1, k3k4, x4);
+    while (len >= 16) { x1 = crc32_fold128(x1, k3k4, _mm_loadu_si128(p)); ++p; len -= 16; }
+    // 128 -> 64 bits
+    const __m128i mask32 = _mm_setr_epi32(~0, 0, ~0, 0);
+    __m128i t = _mm_clmulepi64_si128(x1, k3k4, 0x10);
+    x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), t);
+    t = _mm_srli_si128(x1, 4);
+    x1 = _mm_xor_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, mask32), k5, 0x00), t);
+    // Barrett reduction to 32 bits
+    t = _mm_clmulepi64_si128(_mm_and_si128(x1, mask32), poly, 0x10);
+    t = _mm_clmulepi64_si128(_mm_and_si128(t, mask32), poly, 0x00);
+    x1 = _mm_xor_si128(x1, t);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+#endif
+
+uint32_t bgzf_crc32(const unsigned char *buf, size_t len)
+{
+    uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+#if defined(__x86_64__)
+    static const bool have_clmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+    if (have_clmul && len >= 64) {
+        const size_t mid = len & ~(size_t)15;
+        crc = ~crc32_fold(buf, mid, ~crc);
+        buf += mid; len -= mid;
+    }
+#endif
+    return len ? (uint32_t)crc32(crc, buf, (uInt)len) : crc;
+}
 
 
 static const size_t kBlockIn = 0xff00;          // uncompressed bytes per block
@@ -189,8 +264,18 @@ bool BgzfReader::fetch(uint64_t from, std::vector<unsigned char> &out, uint64_t 
         for (int i = 0; i < 4; ++i) isize |= (uint32_t)comp_[clen + 4 + i] << (8 * i);
         if (isize == 0) { from = next; continue; }      // empty block (the EOF marker): try the next one
         out.resize(isize);
+        uint32_t want_crc = 0;
+        for (int i = 0; i < 4; ++i) want_crc |= (uint32_t)comp_[clen + i] << (8 * i);
+        // BVC_HOST_NO_CRC=1: the trailer's CRC32 is not compared (measurement aid; htslib always compares)
+        static const bool check_crc = getenv("BVC_HOST_NO_CRC") == nullptr;
+        auto crc_ok = [&]() {
+            if (!check_crc || bgzf_crc32(out.data(), isize) == want_crc) return true;
+            g_crc_errors.fetch_add(1, std::memory_order_relaxed);
+            std::fprintf(stderr, "ERROR: BGZF block at file offset %llu fails its CRC32\n", (unsigned long long)at);
+            return false;
+        };
         // the block decoder of inflate.cpp (both buffers whole in memory, size known); zlib only if it declines the stream
-        if (fast_inflate(comp_.data(), clen, out.data(), isize) == (long)isize) return true;
+        if (fast_inflate(comp_.data(), clen, out.data(), isize) == (long)isize) return crc_ok();
         g_zlib_fallbacks.fetch_add(1, std::memory_order_relaxed);
         // one inflate state for the reader's life (inflateInit2 allocates and clears about 40 KB)
         if (!zs_ready_) {
@@ -202,7 +287,7 @@ bool BgzfReader::fetch(uint64_t from, std::vector<unsigned char> &out, uint64_t 
         }
         zs_.next_in = comp_.data(); zs_.avail_in = (uInt)clen;
         zs_.next_out = out.data(); zs_.avail_out = isize;
-        return inflate(&zs_, Z_FINISH) == Z_STREAM_END;
+        return inflate(&zs_, Z_FINISH) == Z_STREAM_END && crc_ok();
     }
 }
 

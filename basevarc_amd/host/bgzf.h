@@ -54,6 +54,8 @@ class BgzfReader;
 // being consumed.  The position loop of the host program reads one line (or record) of every temp batch per position --
 // a hundred readers per thread at 1e5 samples -- and inflating their blocks was 70 % of the loop with the text form.
 long bgzf_zlib_fallbacks();                       // blocks the fast decoder (inflate.cpp) declined so far: zlib took them
+long bgzf_crc_errors();                           // blocks whose inflated bytes failed the CRC32 of their trailer so far
+uint32_t bgzf_crc32(const unsigned char *buf, size_t len);   // CRC32 (RFC 1952) of a buffer: PCLMULQDQ folding where the CPU has it
 
 class InflatePool {
  public:

@@ -47,6 +47,8 @@ void bvchost_reset_parser(void) { reset_parser_carry(); }
 // inflate.cpp against zlib (tests): bytes written or -1
 long bvchost_fast_inflate(const unsigned char *in, size_t n, unsigned char *out, size_t cap) { return fast_inflate(in, n, out, cap); }
 long bvchost_zlib_fallbacks(void) { return bgzf_zlib_fallbacks(); }
+long bvchost_crc_errors(void) { return bgzf_crc_errors(); }
+uint32_t bvchost_crc32(const unsigned char *buf, size_t len) { return bgzf_crc32(buf, len); }
 
 // Micro-benchmarks of the two CPU costs of a text temp batch (tools/host_micro.py): seconds per pass over the input.
 // parse: every line of `text` through parse_pileup_line into one reused SiteColumn; inflate: every BGZF block of a file image
@@ -81,8 +83,10 @@ double bvchost_bench_inflate(const unsigned char *file, size_t len, int reps, in
         size_t off = 0;
         total = 0;
         while (off + 28 <= len) {
+            // the BGZF header fetch() insists on: gzip magic, the 'BC' subfield, a block that holds its 18 + 8 frame bytes
+            if (file[off] != 0x1f || file[off + 1] != 0x8b || file[off + 12] != 'B' || file[off + 13] != 'C') return -1.0;
             const size_t bsize = ((size_t)file[off + 16] | ((size_t)file[off + 17] << 8)) + 1;
-            if (off + bsize > len) return -1.0;
+            if (bsize < 18 + 8 || off + bsize > len) return -1.0;
             const unsigned char *tail = file + off + bsize - 4;
             const size_t isize = (size_t)tail[0] | ((size_t)tail[1] << 8) | ((size_t)tail[2] << 16) | ((size_t)tail[3] << 24);
             if (isize > out.size()) return -1.0;

@@ -44,10 +44,12 @@ inline uint32_t reverse_bits(uint32_t code, int len)
 }
 
 // Builds a two-level decoding table from code lengths (canonical Huffman, codes read LSB first).  `value(sym, bits)` gives a symbol's
-// entry for a code of `bits` bits (counted within its table level).  Returns false for an over-subscribed code; incomplete codes are allowed (their
-// unused patterns decode to kInvalid), as in streams with a single distance code.
+// entry for a code of `bits` bits (counted within its table level).  Returns false for an over-subscribed code and -- zlib's rule
+// (inftrees.c: "incomplete set") -- for an incomplete one, except that a literal/length or distance code whose longest code has one
+// bit (a single distance code, say) or that has no code at all may be incomplete (`may_be_short`; the unused patterns decode to
+// kInvalid); the code-length code must be complete.  The decoder therefore declines exactly the code sets zlib rejects.
 template <class Value>
-bool build_table(const uint8_t *lens, int n_syms, int table_bits, uint32_t *table, int table_cap, Value value)
+bool build_table(const uint8_t *lens, int n_syms, int table_bits, uint32_t *table, int table_cap, bool may_be_short, Value value)
 {
     int count[16] = {0};
     for (int s = 0; s < n_syms; ++s) count[lens[s]]++;
@@ -61,6 +63,11 @@ bool build_table(const uint8_t *lens, int n_syms, int table_bits, uint32_t *tabl
         if (left < 0) return false;                              // over-subscribed
         code = (code + (uint32_t)count[l - 1]) << 1;
         next_code[l] = code;
+    }
+    if (left > 0) {                                                  // incomplete
+        int longest = 0;
+        for (int l = 1; l <= 15; ++l) if (count[l]) longest = l;
+        if (!may_be_short || longest > 1) return false;
     }
     const int main_size = 1 << table_bits;
     for (int i = 0; i < main_size; ++i) table[i] = kInvalid | 1u;
@@ -221,8 +228,8 @@ long fast_inflate(const unsigned char *in, size_t in_len, unsigned char *out, si
                 for (int s = 280; s < 288; ++s) l[s] = 8;
                 uint8_t d[kMaxDistSyms];
                 for (int s = 0; s < 32; ++s) d[s] = 5;
-                if (!build_table(l, 288, kLitBits, fixed_lit, (int)(sizeof fixed_lit / 4), lit_value) ||
-                    !build_table(d, 32, kDistBits, fixed_dist, (int)(sizeof fixed_dist / 4), dist_value)) return -1;
+                if (!build_table(l, 288, kLitBits, fixed_lit, (int)(sizeof fixed_lit / 4), true, lit_value) ||
+                    !build_table(d, 32, kDistBits, fixed_dist, (int)(sizeof fixed_dist / 4), true, dist_value)) return -1;
                 fixed_ready = true;
             }
             lit = fixed_lit; dist = fixed_dist;
@@ -232,7 +239,7 @@ long fast_inflate(const unsigned char *in, size_t in_len, unsigned char *out, si
             static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
             uint8_t pl[19] = {0};
             for (int i = 0; i < hclen; ++i) { if (b.cnt < 3) b.refill(); pl[order[i]] = (uint8_t)b.take(3); }
-            if (!build_table(pl, 19, kPreBits, T.pre, 1 << kPreBits, pre_value)) return -1;
+            if (!build_table(pl, 19, kPreBits, T.pre, 1 << kPreBits, false, pre_value)) return -1;
             uint8_t lens[kMaxLitSyms + kMaxDistSyms];
             int n = 0;
             while (n < hlit + hdist) {
@@ -250,8 +257,8 @@ long fast_inflate(const unsigned char *in, size_t in_len, unsigned char *out, si
                 while (rep--) lens[n++] = v;
             }
             if (b.overrun() || lens[256] == 0) return -1;
-            if (!build_table(lens, hlit, kLitBits, T.lit, (int)(sizeof T.lit / 4), lit_value) ||
-                !build_table(lens + hlit, hdist, kDistBits, T.dist, (int)(sizeof T.dist / 4), dist_value)) return -1;
+            if (!build_table(lens, hlit, kLitBits, T.lit, (int)(sizeof T.lit / 4), true, lit_value) ||
+                !build_table(lens + hlit, hdist, kDistBits, T.dist, (int)(sizeof T.dist / 4), true, dist_value)) return -1;
             lit = T.lit; dist = T.dist;
         } else {
             return -1;

@@ -109,6 +109,7 @@ typedef struct site_model {
     int compensated;      /* 0: the reference's double accumulators; 1: long double (see header) */
     double lle[4];        /* NOT the reference's: per base b, sum over its observations of log(eps/3) -- what they add to the
                              log-likelihood of a model without b (their marginal is eps/3 exactly); only for the pruned counts */
+    uint8_t seen_q[4][128]; /* input facts for orc_result.max_quals / min_qual (diagnostics, not results) */
 } site_model;
 
 /* One E+M pass: src/Algorithm.cpp:69-93.  marginal[] and expect[] arrive zeroed. */
@@ -256,11 +257,21 @@ static int lrt_on_model(site_model *sm, int8_t ref_base, double min_af,
     out->prune_edge = HUGE_VAL;
     for (j = 0; j < 4; ++j) out->depth[j] = sm->depth[j];
     out->depth_total = sm->depth_total;
+    out->min_qual = 127;
+    for (j = 0; j < 4; ++j) {                              /* input facts (diagnostics) */
+        int q, nq = 0;
+        for (q = 0; q < 128; ++q)
+            if (sm->seen_q[j][q]) { nq++; if (q < out->min_qual) out->min_qual = q; }
+        if (nq > out->max_quals) out->max_quals = nq;
+    }
     if (sm->depth_total == 0) return 0;                    /* :75 */
     if (!base_comb) { base_comb = default_comb; n_comb = 4; }
     for (c = 0; c < n_comb && n < 8; ++c) {
         int8_t b = base_comb[c];
-        if ((sm->depth[b] / sm->depth_total) >= min_af) bases[n++] = b;   /* :79 */
+        if ((sm->depth[b] / sm->depth_total) >= min_af) {  /* :79 */
+            for (j = 0; j < n; ++j) if (bases[j] == b) out->dup_candidate = 1;
+            bases[n++] = b;
+        }
     }
     if (n == 0) return 0;                                  /* :84 */
     if (n > 4) { out->status = 2; return 0; }              /* base_comb longer than 4: not a caller case */
@@ -389,6 +400,7 @@ int orc_basetype_lrt_mode(int32_t nind, const int8_t *bases, const int8_t *quals
         }
         sm.depth[bases[i]] += 1;
         sm.lle[bases[i]] += log(exp(ORC_MLN10TO10 * quals[i]) / 3.0);
+        if (quals[i] >= 0) sm.seen_q[bases[i]][quals[i]] = 1;
     }
     for (j = 0; j < 4; ++j) sm.depth_total += sm.depth[j];
     sm.n = nind; sm.L = L; sm.w = NULL; sm.nsample = nind;
@@ -422,6 +434,7 @@ int orc_hist_lrt_mode(const uint32_t *counts512, int8_t ref_base, double min_af,
                 else L[n * 4 + j] = exp(ORC_MLN10TO10 * (int8_t)q) / 3.0;
             }
             w[n] = (double)c;
+            sm.seen_q[b][q] = 1;
             sm.lle[b] += (double)c * log(exp(ORC_MLN10TO10 * (int8_t)q) / 3.0);
             sm.depth[b] += (int32_t)c;
             total += c;

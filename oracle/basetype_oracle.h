@@ -63,6 +63,11 @@ typedef struct orc_result {
     int32_t n_passes_pruned;
     double  prune_edge;    /* smallest relative distance of such a test from its threshold (+inf: no test): a test this close
                               to rounding level may fall either way on another evaluation order */
+    /* Facts about the INPUT (not results): which of the library's two stage-2 engines takes the site depends on them
+     * (include/bvc.h "em_engine"), and the tests use them to demand the right pair of run counts from each engine. */
+    int32_t max_quals;     /* most distinct base qualities among the observations of one base */
+    int32_t min_qual;      /* lowest base quality of an observation (127 when there is none) */
+    int32_t dup_candidate; /* 1 when a base passes the min_af filter twice (a SetBase list that repeats a base) */
 } orc_result;
 
 /* htslib kfunc.c restatement (third-party, absent from /root/reference). */

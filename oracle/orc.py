@@ -21,6 +21,7 @@ class OrcResult(C.Structure):
         ("kept", C.c_int8 * 4), ("base_frq", C.c_double * 4), ("lr_alt", C.c_double),
         ("n_fits", C.c_int32), ("n_passes", C.c_int32), ("status", C.c_int32), ("tie_gap", C.c_double),
         ("n_fits_pruned", C.c_int32), ("n_passes_pruned", C.c_int32), ("prune_edge", C.c_double),
+        ("max_quals", C.c_int32), ("min_qual", C.c_int32), ("dup_candidate", C.c_int32),
     ]
 
     def as_dict(self):
@@ -34,7 +35,8 @@ class OrcResult(C.Structure):
             base_frq=[float(x) for x in self.base_frq], lr_alt=float(self.lr_alt),
             n_fits=int(self.n_fits), n_passes=int(self.n_passes), status=int(self.status),
             tie_gap=float(self.tie_gap), n_fits_pruned=int(self.n_fits_pruned),
-            n_passes_pruned=int(self.n_passes_pruned), prune_edge=float(self.prune_edge))
+            n_passes_pruned=int(self.n_passes_pruned), prune_edge=float(self.prune_edge),
+            max_quals=int(self.max_quals), min_qual=int(self.min_qual), dup_candidate=int(self.dup_candidate))
 
 
 def build(force=False):

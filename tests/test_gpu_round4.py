@@ -201,6 +201,7 @@ def test_the_subset_a_level_does_not_run_never_changes_a_record(ctx):
     for s, (b, q, r) in enumerate(sites):
         o = orc.basetype_lrt(b, q, r, m)
         assert_site_matches(full[s], o, where=f"all run, site {s}", path_strict=False)
+        assert_path_difference_is_a_tie(full[s], o, where=f"all run, site {s}", counts="reference")
         if o["prune_edge"] < 1e-6 or o["tie_gap"] < 1e-9 * max(1.0, abs(o["lr_alt"])):
             continue
         assert (int(full[s]["n_fits"]), int(full[s]["n_passes"])) == (o["n_fits"], o["n_passes"]), s

@@ -11,7 +11,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-poison}_$(date +%m%d_%H%M%S)
 mkdir -p $O
 cd $R
-BVC_EXTRA_FLAGS="-DBVC_POISON -DBVC_CHECK_LDS" python -c "from basevarc_amd import build; build.build(force=True)" > $O/build.log 2>&1 || { echo "poison build failed" | tee $O/verdict; exit 1; }
+# exported for the whole run: build.needs_build() compares the flags a library was built with (libbvc.so.flags) with this variable,
+# so the tests' and the bench's own build() calls keep the diagnostic library instead of rebuilding the product
+export BVC_EXTRA_FLAGS="-DBVC_POISON -DBVC_CHECK_LDS"
+python -c "from basevarc_amd import build; build.build(force=True)" > $O/build.log 2>&1 || { echo "poison build failed" | tee $O/verdict; exit 1; }
 nm -D basevarc_amd/libbvc.so | grep -c bvc_debug_report > $O/has_debug_export
 rc=0
 timeout -k 10 900 python -m pytest tests -m gpu -q -x --deselect tests/test_gpu_host.py > $O/pytest_gpu.log 2>&1 || rc=$?
@@ -24,6 +27,7 @@ if [ $rc = 0 ]; then
   python -c "import json,sys; d=json.loads(open('$O/bench.json').read().strip().split('\n')[-1]); print('bench lds_violations:', d.get('diagnostic_build'))" >> $O/verdict 2>&1
 fi
 grep -il "aperture\|exception\|violation" $O/*.err $O/*.log 2>/dev/null | sed 's/^/mentions a fault: /' >> $O/verdict
+unset BVC_EXTRA_FLAGS
 python -c "from basevarc_amd import build; build.build(force=True)" > $O/rebuild.log 2>&1 && echo "product library rebuilt" >> $O/verdict
 cat $O/verdict
 exit $rc
