@@ -621,3 +621,86 @@ def test_block_inflate_equals_zlib_and_declines_bad_streams(H, tmp_path):
     nbytes = C.c_int64(0)
     H.bvchost_bgzf_read_hash((C.c_char_p * 1)(f), 1, 2, 0, 4096, 0, C.byref(nbytes))
     assert nbytes.value >= len(data) and H.bvchost_zlib_fallbacks() == before
+
+
+def test_bgzf_blocks_are_crc_checked_and_incomplete_code_sets_declined(H, tmp_path):
+    """htslib compares the CRC32 of every BGZF block it inflates (the reference reads its temp batches through bgzf_getline,
+    src/BaseVarC.cpp:406); so do the readers here.  (1) bgzf_crc32 -- PCLMULQDQ folding on x86-64 -- equals zlib's crc32 for every
+    length around its 16- and 64-byte steps; (2) a block whose payload still inflates to ISIZE bytes but whose trailer CRC is wrong
+    ends the read and is counted; (3) the block decoder declines the code sets zlib rejects as incomplete (a literal/length code
+    that leaves patterns unused and is longer than one bit), so that such a stream reaches zlib, which refuses it."""
+    import struct
+    import zlib
+    H.bvchost_crc32.restype = C.c_uint32
+    H.bvchost_crc32.argtypes = [C.c_char_p, C.c_size_t]
+    H.bvchost_crc_errors.restype = C.c_long
+    rng = np.random.default_rng(5)
+    for n in list(range(0, 200)) + [255, 256, 1000, 4095, 4096, 65279, 65280, 65536, 100001]:
+        d = rng.bytes(n)
+        assert H.bvchost_crc32(d, n) == (zlib.crc32(d) & 0xffffffff), n
+
+    def block(payload, crc=None):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(payload) + co.flush()
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp +
+                struct.pack("<II", zlib.crc32(payload) & 0xffffffff if crc is None else crc, len(payload)))
+    eof = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    H.bvchost_bgzf_read_hash.restype = C.c_uint64
+    H.bvchost_bgzf_read_hash.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                         C.POINTER(C.c_int64)]
+    a, b, c = (("line %d of block %s\n" % (i, t)) * 50 for i, t in enumerate("abc"))
+    good = str(tmp_path / "good.gz").encode()
+    open(good, "wb").write(block(a.encode()) + block(b.encode()) + block(c.encode()) + eof)
+    bad = str(tmp_path / "bad.gz").encode()
+    open(bad, "wb").write(block(a.encode()) + block(b.encode(), crc=(zlib.crc32(b.encode()) ^ 1) & 0xffffffff) + block(c.encode()) + eof)
+    for threads in (0, 2):
+        before = H.bvchost_crc_errors()
+        n_good, n_bad = C.c_int64(0), C.c_int64(0)
+        H.bvchost_bgzf_read_hash((C.c_char_p * 1)(good), 1, threads, 0, 4096, 0, C.byref(n_good))
+        assert n_good.value == len(a) + len(b) + len(c) and H.bvchost_crc_errors() == before
+        H.bvchost_bgzf_read_hash((C.c_char_p * 1)(bad), 1, threads, 0, 4096, 0, C.byref(n_bad))
+        assert n_bad.value == len(a) and H.bvchost_crc_errors() == before + 1      # the read ends at the damaged block
+
+    # (3) a dynamic block whose literal/length code is incomplete: lengths 2, 2, 2 for the symbols 'a', 'b' and 256 (Kraft sum 3/4);
+    # the same block with a fourth two-bit symbol ('c') is complete and must decode
+    class W:
+        def __init__(self): self.v = 0; self.n = 0; self.out = bytearray()
+        def put(self, val, bits):
+            self.v |= val << self.n; self.n += bits
+            while self.n >= 8: self.out.append(self.v & 0xff); self.v >>= 8; self.n -= 8
+        def done(self):
+            if self.n: self.out.append(self.v & 0xff)
+            return bytes(self.out)
+
+    def stream(complete):
+        w = W()
+        w.put(1, 1); w.put(2, 2)                            # last block, dynamic codes
+        w.put(0, 5); w.put(0, 5); w.put(15, 4)              # HLIT 257, HDIST 1, HCLEN 19
+        # code-length code (complete): symbol 0 -> '0', 2 -> '10', 18 -> '11' (codes are sent bit-reversed)
+        order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+        cl = {0: 1, 2: 2, 18: 2}
+        for s in order: w.put(cl.get(s, 0), 3)
+        sym0 = lambda: w.put(0, 1)
+        sym2 = lambda: w.put(0b01, 2)
+        def sym18(rep): w.put(0b11, 2); w.put(rep - 11, 7)
+        sym18(97)                                            # symbols 0..96: length 0
+        sym2(); sym2()                                       # 'a' (97), 'b' (98): length 2
+        if complete:
+            sym2(); sym18(138); sym18(18)                    # 'c' too; 100..255: length 0
+        else:
+            sym18(138); sym18(19)                            # 99..255: length 0
+        sym2()                                               # 256: length 2
+        sym0()                                               # the one distance code: length 0
+        if complete:                                         # canonical codes a = 00, b = 01, c = 10, 256 = 11
+            w.put(0b00, 2); w.put(0b10, 2); w.put(0b11, 2)   # a b end-of-block
+        else:                                                # a = 00, b = 01, 256 = 10; 11 is unused
+            w.put(0b00, 2); w.put(0b10, 2); w.put(0b01, 2)
+        return w.done()
+    H.bvchost_fast_inflate.restype = C.c_long
+    H.bvchost_fast_inflate.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    out = C.create_string_buffer(16)
+    assert zlib.decompressobj(-15).decompress(stream(True)) == b"ab"
+    assert H.bvchost_fast_inflate(stream(True), len(stream(True)), out, 2) == 2 and out.raw[:2] == b"ab"
+    with pytest.raises(zlib.error, match="invalid literal/lengths set"):
+        zlib.decompressobj(-15).decompress(stream(False))
+    assert H.bvchost_fast_inflate(stream(False), len(stream(False)), out, 2) == -1
