@@ -46,6 +46,20 @@ void bvchost_reset_parser(void) { reset_parser_carry(); }
 
 // inflate.cpp against zlib (tests): bytes written or -1
 long bvchost_fast_inflate(const unsigned char *in, size_t n, unsigned char *out, size_t cap) { return fast_inflate(in, n, out, cap); }
+// orchestration hooks (tests/test_host.py): the functions main.cpp itself calls
+void bvchost_thread_window(int64_t psize, int32_t thread, int32_t ithread, int64_t *lo, int64_t *hi)
+{
+    size_t l, h;
+    thread_window((size_t)psize, thread, ithread, l, h);
+    *lo = (int64_t)l; *hi = (int64_t)h;
+}
+int32_t bvchost_device_of_thread(int32_t ithread, int32_t devices_present, int32_t gpus_option) { return device_of_thread(ithread, devices_present, gpus_option); }
+int32_t bvchost_merge_subfiles(const char *out_prefix, const char *suffix, int32_t thread)
+{
+    BgzfWriter dst(std::string(out_prefix) + suffix);
+    if (!dst.ok() || !merge_subfiles(out_prefix, suffix, thread, dst)) return 0;
+    return dst.close() ? 1 : 0;
+}
 long bvchost_zlib_fallbacks(void) { return bgzf_zlib_fallbacks(); }
 long bvchost_crc_errors(void) { return bgzf_crc_errors(); }
 uint32_t bvchost_crc32(const unsigned char *buf, size_t len) { return bgzf_crc32(buf, len); }

@@ -140,15 +140,6 @@ static std::string tmp_name(int ithread, int ibatch)
     return opt::output + ".tmp.thread." + std::to_string(ithread) + "/batch." + std::to_string(ibatch);
 }
 
-// Per-thread window of positions (src/BaseVarC.cpp:399-403, 497, 523).  The reference's arithmetic can run a
-// non-last thread past the end when psize % thread is large; the range is clamped here.
-static void thread_window(size_t psize, int thread, int ithread, size_t &lo, size_t &hi)
-{
-    const size_t window = psize % thread + psize / thread;
-    lo = std::min(psize, (size_t)ithread * window);
-    hi = (ithread == thread - 1) ? psize : std::min(psize, (size_t)(ithread + 1) * window);
-}
-
 // ---- phase 1: BAM -> temp-batch pileup text (bt_r, src/BaseVarC.cpp:467-534) ------------------------------------
 static void bt_r(const std::vector<std::string> &bams, const std::vector<int32_t> &pv, const std::string &refseq,
                  const std::string &chr, int32_t rg_s, int32_t rg_e, int nb, int bc, int ib, int thread)
@@ -702,16 +693,15 @@ static void run_basetype(int argc, char **argv)                          // src/
     const double t_loaded = StageClock::now();
     std::cout << "basetype loading done -- " << ctime(&tim1);
     if (opt::load) std::exit(EXIT_SUCCESS);
-    int gpus = bvc_device_count();
+    const int gpus = bvc_device_count();
     if (gpus <= 0) throw std::runtime_error("ERROR: no gfx950 device (libbvc has no CPU fallback)");
-    if (opt::gpus > 0 && opt::gpus < gpus) gpus = opt::gpus;
     {
         std::vector<std::thread> workers;
         std::mutex mu;
         std::string werr;
         for (int i = 0; i < thread; ++i)
             workers.emplace_back([&, i]() {
-                try { bt_s(ftmp_vv[(size_t)i], pv, refseq, chr, rg_s, N, thread, i, i % gpus); }
+                try { bt_s(ftmp_vv[(size_t)i], pv, refseq, chr, rg_s, N, thread, i, device_of_thread(i, gpus, opt::gpus)); }
                 catch (const std::exception &e) { std::lock_guard<std::mutex> g(mu); if (werr.empty()) werr = e.what(); }
             });
         // Every worker is joined BEFORE anything can throw: unwinding past a joinable std::thread is std::terminate,
@@ -730,15 +720,8 @@ static void run_basetype(int argc, char **argv)                          // src/
         }
         // merge the per-thread sub-files in thread (= position) order (src/BaseVarC.cpp:268-296)
         BgzfWriter fov(opt::output + ".vcf.gz"), foc(opt::output + ".cvg.gz");
-        for (int i = 0; i < thread; ++i) {
-            const std::string subvcf = opt::output + "." + std::to_string(i) + ".vcf.gz";
-            const std::string subcvg = opt::output + "." + std::to_string(i) + ".cvg.gz";
-            // the reference re-reads and re-compresses the sub-files line by line (src/BaseVarC.cpp:279-290); BGZF
-            // files concatenate block for block, which yields the same uncompressed stream
-            if (!fov.append_file(subvcf) || !foc.append_file(subcvg)) throw std::runtime_error("ERROR: fail to write");
-            std::remove(subvcf.c_str());
-            std::remove(subcvg.c_str());
-        }
+        if (!merge_subfiles(opt::output, ".vcf.gz", thread, fov) || !merge_subfiles(opt::output, ".cvg.gz", thread, foc))
+            throw std::runtime_error("ERROR: fail to write");
         std::cout << "merge subfiles done" << std::endl;
         if (!fov.close()) std::cerr << "warning: file cannot be closed" << std::endl;
         if (!foc.close()) std::cerr << "warning: file cannot be closed" << std::endl;

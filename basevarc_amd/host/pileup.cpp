@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "bgzf.h"
 #include "stats.h"
 
 namespace bvchost {
@@ -437,6 +438,33 @@ std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int32_t 
     out.pop_back();
     out += "\tGT:AB:SO:BP\t" + samgt + "\n";
     return out;
+}
+
+// ---- orchestration ---------------------------------------------------------------------------------------
+void thread_window(size_t psize, int thread, int ithread, size_t &lo, size_t &hi)
+{
+    const size_t window = psize % (size_t)thread + psize / (size_t)thread;
+    lo = std::min(psize, (size_t)ithread * window);
+    hi = (ithread == thread - 1) ? psize : std::min(psize, (size_t)(ithread + 1) * window);
+}
+
+int device_of_thread(int ithread, int devices_present, int gpus_option)
+{
+    int g = devices_present;
+    if (gpus_option > 0 && gpus_option < g) g = gpus_option;
+    return g > 0 ? ithread % g : 0;
+}
+
+bool merge_subfiles(const std::string &out_prefix, const std::string &suffix, int thread, BgzfWriter &dst)
+{
+    for (int i = 0; i < thread; ++i) {
+        const std::string sub = out_prefix + "." + std::to_string(i) + suffix;
+        // the reference re-reads and re-compresses the sub-files line by line (src/BaseVarC.cpp:279-290); BGZF files
+        // concatenate block for block, which yields the same uncompressed stream
+        if (!dst.append_file(sub)) return false;
+        std::remove(sub.c_str());
+    }
+    return true;
 }
 
 }  // namespace bvchost

@@ -145,5 +145,18 @@ void group_af_info(const bvc_site_result &bt, const bvc_group_result *grp, const
 
 std::string fmt_fixed(double v, int prec);          // fmt's {:.Nf}
 
+// ---- orchestration (f3): who works on which positions, on which device, and how the pieces come together again ----------
+// Per-thread window of positions (src/BaseVarC.cpp:399-403, 497, 523): thread i takes [lo, hi) of the region's position list.
+// The reference's arithmetic (window = psize % T + psize / T) can run a non-last thread past the end when psize % T is
+// large; the range is clamped here.  The windows of threads 0..T-1 are disjoint, ascending and cover [0, psize).
+void thread_window(size_t psize, int thread, int ithread, size_t &lo, size_t &hi);
+// Device of a phase-2 thread (additive: the reference has one CPU path): thread i works on device i mod G, G = the devices present,
+// or --gpus when that is given and smaller.  Sites shard by position window, no device ever needs another's data.
+int device_of_thread(int ithread, int devices_present, int gpus_option);
+// Merge of the per-thread sub-files <out>.<i><suffix>, i = 0..T-1, into `dst` in thread order -- which is position order, since
+// the windows ascend with the thread index (src/BaseVarC.cpp:268-296) -- removing each after it is appended.
+class BgzfWriter;
+bool merge_subfiles(const std::string &out_prefix, const std::string &suffix, int thread, BgzfWriter &dst);
+
 }  // namespace bvchost
 #endif

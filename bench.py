@@ -359,6 +359,10 @@ def main():
         rep = ctx.debug_report()
         if rep is not None:                 # -DBVC_CHECK_LDS build (tools/poison_run.sh): never a measurement
             out["diagnostic_build"] = {"lds_violations": rep, "note": "libbvc built with -DBVC_CHECK_LDS: timings are not the product's"}
+        if "legs" in out:
+            # LAST key of the line, so that a reader who keeps only the tail of stdout still sees every leg: {leg: [value, frac of
+            # the leg's bounding roofline]} (sites/s; host_pointer_one_byte: the ragged one-byte call, frac of the PCIe peak)
+            out["legs_summary"] = legs_summary(out["legs"])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -652,6 +656,18 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
         "records_identical_with_every_subset_run_except_the_run_counts": bool(_same_but_run_counts(rec, rec_all)),
     }
     return legs
+
+
+def legs_summary(legs):
+    def sig(x):
+        return float(f"{x:.4g}")
+    out = {}
+    for name, leg in legs.items():
+        if name == "host_pointer_one_byte":
+            out[name] = [sig(leg["ragged_one_byte"]["sites_per_s"]), sig(leg["ragged_one_byte"]["frac"])]
+        else:
+            out[name] = [sig(leg["value"]), sig(leg["roofline"]["frac"])]
+    return out
 
 
 def em_roofline(rec, em_launch_ms, call_ms, depth=0):

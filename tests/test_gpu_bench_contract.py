@@ -46,6 +46,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert rf["frac_of_empirical"] <= 1.01 and rf["empirical_stream_read_median_GBs"] <= rf["empirical_stream_read_GBs"]
     assert "traffic_note" in rf
     assert len(d["per_rank"]) == 1 and d["per_rank"][0]["sites"] == 8000 and d["per_rank"][0]["calls_per_step"] == 4
+    # every leg's rate and roofline fraction once more as the LAST key of the line (a reader that keeps the tail of stdout sees them)
+    assert list(d.keys())[-1] == "legs_summary" and len(json.dumps(d["legs_summary"])) < 700
+    assert set(d["legs_summary"]) == set(d["legs"])
+    for name, (value, frac) in d["legs_summary"].items():
+        assert value > 0 and 0 < frac < 1, name
+        if name != "host_pointer_one_byte":
+            assert value == pytest.approx(d["legs"][name]["value"], rel=1e-3) and frac == pytest.approx(d["legs"][name]["roofline"]["frac"], rel=1e-3)
     # the other single-GPU configurations ride along as sub-records with their own roofline
     legs = d["legs"]
     for name in ("config1_1e4x1e4", "config4_groups5_interleaved", "config4_groups5_ordered", "csr_coverage10pct"):

@@ -704,3 +704,66 @@ def test_bgzf_blocks_are_crc_checked_and_incomplete_code_sets_declined(H, tmp_pa
     with pytest.raises(zlib.error, match="invalid literal/lengths set"):
         zlib.decompressobj(-15).decompress(stream(False))
     assert H.bvchost_fast_inflate(stream(False), len(stream(False)), out, 2) == -1
+
+
+@pytest.mark.parametrize("thread", [1, 3, 8, 16])
+def test_thread_windows_device_map_and_merge_order_give_position_ordered_output(H, tmp_path, thread):
+    """configs[3] on the host program's side (reference: per-thread windows src/BaseVarC.cpp:399-403, sub-file merge
+    :274-295), with the functions main.cpp itself calls: (1) the windows of T threads are disjoint, ascending, cover the position
+    list and agree with the load phase's rule for which temp file a position goes to; (2) thread i works on device i mod G for G in
+    {1, 2, 4, 8} devices present, `--gpus` only ever lowering G, every device taking floor or ceil of T / G threads; (3) sub-files
+    written per thread and merged in thread order hold the positions in ascending order, and the sub-files are gone afterwards.
+    No GPU is involved: which device a window is computed on cannot change its lines, because a site needs no other site's data."""
+    import gzip
+    H.bvchost_thread_window.restype = None
+    H.bvchost_thread_window.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    H.bvchost_device_of_thread.restype = C.c_int32
+    H.bvchost_device_of_thread.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    H.bvchost_merge_subfiles.restype = C.c_int32
+    H.bvchost_merge_subfiles.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
+    H.bvchost_bgzf_write.restype = C.c_int
+    H.bvchost_bgzf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int, C.c_int]
+
+    def windows(psize):
+        out = []
+        for i in range(thread):
+            lo, hi = C.c_int64(), C.c_int64()
+            H.bvchost_thread_window(psize, thread, i, C.byref(lo), C.byref(hi))
+            out.append((lo.value, hi.value))
+        return out
+    for psize in (0, 1, 5, 15, 16, 17, 31, 100, 1001, 78455):
+        w = windows(psize)
+        assert w[0][0] == 0 and w[-1][1] == psize and all(lo <= hi for lo, hi in w)
+        assert all(w[i][1] == w[i + 1][0] for i in range(thread - 1)), (psize, w)
+        window = psize % thread + psize // thread                      # the load phase's rule (bt_r, src/BaseVarC.cpp:497, 523)
+        for i in (0, psize // 3, psize // 2, psize - 1):
+            if 0 <= i < psize:
+                owner = min(i // window, thread - 1)
+                assert w[owner][0] <= i < w[owner][1], (psize, i, owner, w)
+    for present in (1, 2, 4, 8):
+        for opt in (0, 1, 2, 4, 8, 16):
+            g = present if opt <= 0 or opt >= present else opt
+            devs = [H.bvchost_device_of_thread(i, present, opt) for i in range(thread)]
+            assert devs == [i % g for i in range(thread)]
+            per = [devs.count(d) for d in range(g)]
+            assert max(per) - min(per) <= 1 or thread < g
+    # (3) T sub-files of a 78,455-position region (the test data's), merged
+    psize, start = 78455, 41197700
+    out = str(tmp_path / f"m{thread}")
+    for i, (lo, hi) in enumerate(windows(psize)):
+        for suffix in (".vcf.gz", ".cvg.gz"):
+            lines = "".join(f"chr17\t{start + p}\t{suffix}\n" for p in range(lo, hi) if suffix == ".cvg.gz" or p % 97 == 0)
+            if i == 0:
+                lines = "#header\n" + lines
+            data = lines.encode()
+            assert H.bvchost_bgzf_write(f"{out}.{i}{suffix}".encode(), data, len(data), 1 << 20, 6, 0) == 1
+    for suffix in (".vcf.gz", ".cvg.gz"):
+        assert H.bvchost_merge_subfiles(out.encode(), suffix.encode(), thread) == 1
+        raw = open(out + suffix, "rb").read()
+        assert raw[-28:-12] == raw[-28:][:16]                            # ends with the BGZF EOF block
+        text = gzip.decompress(raw).decode().splitlines()
+        assert text[0] == "#header"
+        pos = [int(l.split("\t")[1]) for l in text[1:]]
+        assert pos == sorted(pos) and len(set(pos)) == len(pos)
+        assert len(pos) == (psize if suffix == ".cvg.gz" else len(range(0, psize, 97)))
+        assert not any(os.path.exists(f"{out}.{i}{suffix}") for i in range(thread))
