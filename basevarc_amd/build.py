@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbvc.so")
-SOURCES = ["bvc_api.hip", "hist_kernel.hip", "em_kernel.hip", "em_items.hip", "synth_kernel.hip"]
+SOURCES = ["bvc_api.hip", "hist_kernel.hip", "em_kernel.hip", "em_items.hip", "synth_kernel.hip", "pileup_kernel.hip"]
 DEPS = ["bvc_device.h", "bvc_internal.h", "synth_tables.inc", os.path.join("..", "..", "include", "bvc.h")]
 
 
@@ -76,11 +76,16 @@ def build(force=False, verbose=False):
         procs = []
         for f in SOURCES:                                            # one compile per source, side by side
             obj = os.path.join(objdir, f.replace(".hip", ".o"))
-            procs.append((obj, subprocess.Popen(common + PER_SOURCE_FLAGS.get(f, []) + ["-c", os.path.join(CSRC, f), "-o", obj])))
+            # a session of its own: hipcc is a driver that starts compilers of its own, and a failed build ends them all
+            procs.append((obj, subprocess.Popen(common + PER_SOURCE_FLAGS.get(f, []) + ["-c", os.path.join(CSRC, f), "-o", obj],
+                                                start_new_session=True)))
         failed = None
         for obj, pr in procs:
-            if failed is not None:
-                pr.kill()
+            if failed is not None and pr.poll() is None:
+                try:
+                    os.killpg(pr.pid, 9)
+                except ProcessLookupError:
+                    pass
             if pr.wait() != 0 and failed is None:
                 failed = (pr.returncode, obj)
         if failed is not None:

@@ -53,6 +53,12 @@ struct bvc_ctx {
     hipStream_t copy = nullptr;
     hipEvent_t ev_upload[2] = {nullptr, nullptr};
     hipEvent_t ev_set_free[2] = {nullptr, nullptr};   // ragged host calls: the kernels that read staging set k have finished
+    // bvc_pileup_begin / bvc_pileup_finish: the tile's text, its line tables and counts, its parsed columns and records
+    char *d_pl_text = nullptr, *d_pl_meta = nullptr, *d_pl_out = nullptr;
+    size_t pl_text_cap = 0, pl_meta_cap = 0, pl_out_cap = 0;
+    PileupTile pl;                     // the tile between the two calls
+    bool pl_begun = false;
+    int64_t pl_entries = 0, pl_obs = 0, pl_indels = 0;
     LaunchState ls;                    // launch policy + one-time kernel setup of this context
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;   // free events
@@ -357,6 +363,72 @@ int run_chunks(bvc_ctx *ctx, int64_t n_sites, int64_t chunk, Upload upload, Comp
     return BVC_OK;
 }
 
+// Group calls: stage 1 (`stage1(grp_counts)`: one pass, n_groups + 1 histograms per site, [site][n_groups + 1][512]) on the
+// context's stream; stage 2 (sum, overall LRT, per-group LRT: src/BaseVarC.cpp:612-613, 617-661) on the same stream or, in
+// overlap mode, on a side stream.  Dense tiles and ragged columns differ only in their stage 1.
+template <class Stage1>
+int run_group_stages(bvc_ctx *ctx, int64_t ns, int n_groups, bool long_rows, Stage1 stage1, const int8_t *r, double min_af,
+                     bvc_site_result *res, bvc_group_result *gres)
+{
+    const int n_hist = n_groups + 1;
+    const int buf = ctx->overlap ? ctx->flip : 0;
+    if (ctx->overlap) ctx->flip = (ctx->flip + 1) % bvc_ctx::kRing;
+    uint32_t **cp = &ctx->d_cnt[buf];
+    size_t *ccap = &ctx->cnt_cap[buf];
+    uint32_t **gp = &ctx->d_grp[buf];
+    size_t *gcap = &ctx->grp_cap[buf];
+    const size_t cbytes = (size_t)ns * BVC_NCLASS * sizeof(uint32_t), gbytes = cbytes * (size_t)n_hist;
+    if (cbytes > *ccap || gbytes > *gcap) { int rj = join_side(ctx); if (rj != BVC_OK) return rj; }
+    int rc2 = ensure(ctx, reinterpret_cast<void **>(cp), ccap, cbytes);
+    if (rc2 != BVC_OK) return rc2;
+    rc2 = ensure(ctx, reinterpret_cast<void **>(gp), gcap, gbytes);
+    if (rc2 != BVC_OK) return rc2;
+    void *em_scratch = nullptr, *emg_scratch = nullptr;
+    rc2 = em_scratch_for(ctx, buf, ns, min_af, &em_scratch);
+    if (rc2 != BVC_OK) return rc2;
+    rc2 = em_scratch_for(ctx, buf, ns, min_af, &emg_scratch, n_groups);
+    if (rc2 != BVC_OK) return rc2;
+    if (ctx->overlap && ctx->em_pending[buf]) {
+        BVC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_em_done[buf], 0));
+        ctx->em_pending[buf] = false;
+    }
+    bvc_ctx::Triple t{nullptr, nullptr, nullptr, nullptr, ns};
+    const bool timed = ctx->profiling && take_timing_events(ctx, t);
+    auto bail = [&](int code) { give_back(ctx, t.a); give_back(ctx, t.b); give_back(ctx, t.c); give_back(ctx, t.d); return code; };
+#define BVC_HIP_T(call)                                                                     \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess) return bail(fail(ctx, BVC_ERR_DEVICE, #call, e__));          \
+    } while (0)
+    if (timed) BVC_HIP_T(hipEventRecord(t.a, ctx->stream));
+    BVC_HIP_T(stage1(*gp));
+    if (timed) BVC_HIP_T(hipEventRecord(t.b, ctx->stream));
+    hipStream_t s2 = ctx->stream;
+    if (ctx->overlap) {
+        s2 = em_stream(ctx, 2);
+        BVC_HIP_T(hipEventRecord(ctx->ev_hist_done[buf], ctx->stream));
+        BVC_HIP_T(hipStreamWaitEvent(s2, ctx->ev_hist_done[buf], 0));
+    }
+    if (timed) BVC_HIP_T(hipEventRecord(t.c, s2));
+    BVC_HIP_T(launch_sum_groups(s2, ns, n_hist, *gp, *cp));
+    const bool shared = ctx->overlap && long_rows;
+    const int per_launch = kGroupSharedWavesPerCu / em_stream_count(ctx, 2) > 2 ? kGroupSharedWavesPerCu / em_stream_count(ctx, 2) : 2;
+    BVC_HIP_T(launch_lrt(ctx->ls, s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared, per_launch, em_scratch));
+    BVC_HIP_T(launch_lrt_groups(ctx->ls, s2, ns, n_groups, *gp, r, min_af, ctx->d_lut, res, gres, shared, per_launch, emg_scratch));
+    if (timed) {
+        BVC_HIP_T(hipEventRecord(t.d, s2));
+        ctx->ev_pending.push_back(t);
+        t = bvc_ctx::Triple{nullptr, nullptr, nullptr, nullptr, 0};
+        if (ctx->ev_pending.size() > 256) reap_timing(ctx, false);
+    }
+    if (ctx->overlap) {
+        BVC_HIP_T(hipEventRecord(ctx->ev_em_done[buf], s2));
+        ctx->em_pending[buf] = true;
+    }
+#undef BVC_HIP_T
+    return BVC_OK;
+}
+
 int check_common(bvc_ctx *ctx, int64_t n_sites, const void *a, const void *b, const void *c, const void *d)
 {
     if (!ctx) return BVC_ERR_ARG;
@@ -498,6 +570,9 @@ void bvc_destroy(bvc_ctx *ctx)
     if (ctx->d_grp_scratch) (void)hipFree(ctx->d_grp_scratch);
     if (ctx->d_grp_labels) (void)hipFree(ctx->d_grp_labels);
     if (ctx->d_sink) (void)hipFree(ctx->d_sink);
+    if (ctx->d_pl_text) (void)hipFree(ctx->d_pl_text);
+    if (ctx->d_pl_meta) (void)hipFree(ctx->d_pl_meta);
+    if (ctx->d_pl_out) (void)hipFree(ctx->d_pl_out);
     delete ctx;
 }
 
@@ -934,6 +1009,240 @@ int bvc_lrt_csr(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets,
     return bvc_lrt_csr_comb(ctx, n_sites, offsets, bases, quals, ref_base, min_af, nullptr, nullptr, results, flags);
 }
 
+
+// ---- ragged group calls ----------------------------------------------------------------------------------------------------
+static int run_csr_groups_device(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets, const int8_t *bases, const int8_t *quals,
+                                 const int32_t *sample_of_obs, const int8_t *ref_base, double min_af, const uint8_t *group_of_sample,
+                                 int64_t n_samples, int32_t n_groups, bvc_site_result *results, bvc_group_result *grp_results)
+{
+    return run_group_stages(ctx, n_sites, n_groups, false,
+                            [&](uint32_t *gp) {
+                                return launch_hist_csr_groups(ctx->ls, ctx->stream, n_sites, offsets, bases, quals, sample_of_obs,
+                                                              group_of_sample, n_samples, n_groups, gp);
+                            },
+                            ref_base, min_af, results, grp_results);
+}
+
+static inline size_t al256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+int bvc_lrt_csr_groups(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets, const int8_t *bases, const int8_t *quals,
+                       const int32_t *sample_of_obs, const int8_t *ref_base, double min_af,
+                       const uint8_t *group_of_sample, int64_t n_samples, int32_t n_groups,
+                       bvc_site_result *results, bvc_group_result *grp_results, uint32_t flags)
+{
+    int rc = check_common(ctx, n_sites, offsets, ref_base, results, results);
+    if (rc != BVC_OK) return rc;
+    if (n_groups < 1 || n_groups > BVC_MAX_GROUPS) return fail(ctx, BVC_ERR_ARG, "n_groups must be 1..32");
+    if (n_samples < 0 || (n_samples > 0 && !group_of_sample) || !grp_results) return fail(ctx, BVC_ERR_ARG, "null group pointer");
+    if (n_sites == 0) return BVC_OK;
+    if (flags & BVC_PTR_DEVICE) {
+        if (!bases || !quals || !sample_of_obs) return fail(ctx, BVC_ERR_ARG, "null data pointer");
+        return run_csr_groups_device(ctx, n_sites, offsets, bases, quals, sample_of_obs, ref_base, min_af, group_of_sample, n_samples,
+                                     n_groups, results, grp_results);
+    }
+    const int64_t total = offsets[n_sites];
+    if (offsets[0] != 0 || total < 0) return fail(ctx, BVC_ERR_ARG, "offsets must start at 0 and be non-decreasing");
+    for (int64_t s = 0; s < n_sites; ++s)
+        if (offsets[s + 1] < offsets[s]) return fail(ctx, BVC_ERR_ARG, "offsets must start at 0 and be non-decreasing");
+    if (total > 0 && (!bases || !quals || !sample_of_obs)) return fail(ctx, BVC_ERR_ARG, "null data pointer");
+    // one piece through staging set 0: offsets | ref | labels | bases | quals | samples | records | group records
+    const size_t off_al = al256((size_t)(n_sites + 1) * 8), ref_al = al256((size_t)n_sites), g_al = al256((size_t)n_samples + 1);
+    const size_t arr_al = al256((size_t)total + 16), smp_al = al256((size_t)total * 4 + 16);
+    const size_t res_al = al256((size_t)n_sites * sizeof(bvc_site_result));
+    const size_t need = off_al + ref_al + g_al + 2 * arr_al + smp_al + res_al + (size_t)n_sites * n_groups * sizeof(bvc_group_result) + 256;
+    rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage[0]), &ctx->stage_cap[0], need);
+    if (rc != BVC_OK) return rc;
+    char *p = ctx->d_stage[0];
+    int64_t *d_o = reinterpret_cast<int64_t *>(p); p += off_al;
+    int8_t *d_r = reinterpret_cast<int8_t *>(p); p += ref_al;
+    uint8_t *d_g = reinterpret_cast<uint8_t *>(p); p += g_al;
+    int8_t *d_b = reinterpret_cast<int8_t *>(p); p += arr_al;
+    int8_t *d_q = reinterpret_cast<int8_t *>(p); p += arr_al;
+    int32_t *d_s = reinterpret_cast<int32_t *>(p); p += smp_al;
+    bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(p); p += res_al;
+    bvc_group_result *d_gres = reinterpret_cast<bvc_group_result *>(p);
+    auto drained = [&](int code) {
+        if (code != BVC_OK) {
+            (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->side); (void)hipStreamSynchronize(ctx->side_b);
+            (void)hipStreamSynchronize(ctx->side_c);
+            for (bool &pnd : ctx->em_pending) pnd = false;
+            (void)hipGetLastError();
+        }
+        return code;
+    };
+#define BVC_HIP_D(call)                                                                   \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) return drained(fail(ctx, BVC_ERR_DEVICE, #call, e__));     \
+    } while (0)
+    BVC_HIP_D(hipMemcpyAsync(d_o, offsets, (size_t)(n_sites + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    BVC_HIP_D(hipMemcpyAsync(d_r, ref_base, (size_t)n_sites, hipMemcpyHostToDevice, ctx->stream));
+    if (n_samples) BVC_HIP_D(hipMemcpyAsync(d_g, group_of_sample, (size_t)n_samples, hipMemcpyHostToDevice, ctx->stream));
+    if (total) {
+        BVC_HIP_D(hipMemcpyAsync(d_b, bases, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP_D(hipMemcpyAsync(d_q, quals, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP_D(hipMemcpyAsync(d_s, sample_of_obs, (size_t)total * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = run_csr_groups_device(ctx, n_sites, d_o, d_b, d_q, d_s, d_r, min_af, d_g, n_samples, n_groups, d_res, d_gres);
+    if (rc == BVC_OK) rc = join_side(ctx);
+    if (rc != BVC_OK) return drained(rc);
+    BVC_HIP_D(hipMemcpyAsync(results, d_res, (size_t)n_sites * sizeof(bvc_site_result), hipMemcpyDeviceToHost, ctx->stream));
+    BVC_HIP_D(hipMemcpyAsync(grp_results, d_gres, (size_t)n_sites * n_groups * sizeof(bvc_group_result), hipMemcpyDeviceToHost, ctx->stream));
+    BVC_HIP_D(hipStreamSynchronize(ctx->stream));
+#undef BVC_HIP_D
+    return BVC_OK;
+}
+
+// ---- temp-batch pileup text -> columns -> records (pileup_kernel.hip) -------------------------------------------------------
+int bvc_pileup_begin(bvc_ctx *ctx, const char *text, int64_t text_bytes, const uint32_t *line_start,
+                     const int32_t *sample0, const int32_t *n_in_batch, int32_t n_batches, int32_t n_positions,
+                     int64_t *n_entries, int64_t *n_indels)
+{
+    if (!ctx) return BVC_ERR_ARG;
+    ctx->pl_begun = false;
+    if (n_batches < 0 || n_positions < 0 || text_bytes < 0 || !n_entries || !n_indels) return fail(ctx, BVC_ERR_ARG, "bad argument");
+    if (text_bytes > (int64_t)0xFFFFFF00) return fail(ctx, BVC_ERR_ARG, "more than 4 GiB of text in one tile (use fewer positions)");
+    const int64_t n_lines = (int64_t)n_batches * n_positions;
+    if (n_lines > 0 && (!text || !line_start || !sample0 || !n_in_batch)) return fail(ctx, BVC_ERR_ARG, "null data pointer");
+    if (n_positions > (int32_t)(0x7FFFFFFF / 64)) return fail(ctx, BVC_ERR_ARG, "too many positions in one call (split the tile)");
+    BVC_HIP(ctx, hipSetDevice(ctx->device));
+    *n_entries = 0; *n_indels = 0;
+    // the line table is what the kernels index the text with: every line inside the text, the lines of a batch in order
+    for (int32_t b = 0; b < n_batches; ++b) {
+        const uint32_t *ls = line_start + (int64_t)b * (n_positions + 1);
+        if (n_in_batch[b] < 0) return fail(ctx, BVC_ERR_ARG, "negative batch size");
+        for (int32_t t = 0; t < n_positions; ++t)
+            if (ls[t + 1] <= ls[t]) return fail(ctx, BVC_ERR_ARG, "line_start: every line holds at least its newline, lines of a batch ascend");
+        if (n_positions > 0 && (int64_t)ls[n_positions] > text_bytes) return fail(ctx, BVC_ERR_ARG, "line_start points outside the text");
+    }
+    const size_t T = (size_t)n_positions, nb = (size_t)n_batches;
+    const size_t ls_al = al256(nb * (T + 1) * 4), b_al = al256(nb * 4), lw_al = al256((size_t)n_lines * 16), st_al = 256;
+    const size_t off_al = al256((T + 1) * 8), tal_al = al256(T * 32 * 4);
+    int rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_pl_text), &ctx->pl_text_cap, (size_t)text_bytes + 64);
+    if (rc == BVC_OK) rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_pl_meta), &ctx->pl_meta_cap, ls_al + 2 * b_al + lw_al + st_al + 2 * off_al + tal_al);
+    if (rc != BVC_OK) return rc;
+    char *p = ctx->d_pl_meta;
+    PileupTile &P = ctx->pl;
+    P = PileupTile{};
+    P.text = reinterpret_cast<const uint8_t *>(ctx->d_pl_text);
+    uint32_t *d_ls = reinterpret_cast<uint32_t *>(p); p += ls_al;
+    int32_t *d_s0 = reinterpret_cast<int32_t *>(p); p += b_al;
+    int32_t *d_nib = reinterpret_cast<int32_t *>(p); p += b_al;
+    P.line_start = d_ls; P.sample0 = d_s0; P.n_in_batch = d_nib;
+    P.line_words = reinterpret_cast<uint32_t *>(p); p += lw_al;
+    P.status = reinterpret_cast<uint32_t *>(p);
+    P.totals = reinterpret_cast<int64_t *>(p + 64); p += st_al;
+    P.entry_off = reinterpret_cast<int64_t *>(p); p += off_al;
+    P.obs_off = reinterpret_cast<int64_t *>(p); p += off_al;
+    P.tally = reinterpret_cast<int32_t *>(p);
+    P.n_batches = n_batches; P.n_pos = n_positions; P.n_lines = n_lines;
+    auto drained = [&](int code) { if (code != BVC_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); } return code; };
+#define BVC_HIP_D(call)                                                                   \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) return drained(fail(ctx, BVC_ERR_DEVICE, #call, e__));     \
+    } while (0)
+    BVC_HIP_D(hipMemsetAsync(P.status, 0, st_al + 2 * off_al + tal_al, ctx->stream));     // status, totals, offsets of an empty tile, tallies
+    if (n_lines > 0) {
+        BVC_HIP_D(hipMemcpyAsync(ctx->d_pl_text, text, (size_t)text_bytes, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP_D(hipMemcpyAsync(d_ls, line_start, nb * (T + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP_D(hipMemcpyAsync(d_s0, sample0, nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP_D(hipMemcpyAsync(d_nib, n_in_batch, nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP_D(launch_pileup_count(ctx->stream, P));
+    }
+    uint32_t st[4] = {0, 0, 0, 0};
+    int64_t tot[2] = {0, 0};
+    BVC_HIP_D(hipMemcpyAsync(st, P.status, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+    BVC_HIP_D(hipMemcpyAsync(tot, P.totals, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
+    BVC_HIP_D(hipStreamSynchronize(ctx->stream));
+#undef BVC_HIP_D
+    if (st[0] != 0) return BVC_PILEUP_IRREGULAR;
+    ctx->pl_entries = tot[0]; ctx->pl_obs = tot[1]; ctx->pl_indels = st[1];
+    ctx->pl_begun = true;
+    *n_entries = tot[0]; *n_indels = st[1];
+    return BVC_OK;
+}
+
+int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const uint8_t carry_in[5], uint8_t carry_out[5],
+                      const uint8_t *group_of_sample, int64_t n_samples, int32_t n_groups,
+                      int64_t *entry_off, int32_t *tally, bvc_pileup_entry *entries, int32_t *samples,
+                      bvc_pileup_indel *indels, bvc_site_result *results, bvc_group_result *grp_results)
+{
+    if (!ctx) return BVC_ERR_ARG;
+    if (!ctx->pl_begun) return fail(ctx, BVC_ERR_ARG, "bvc_pileup_finish without a bvc_pileup_begin that returned BVC_OK");
+    ctx->pl_begun = false;
+    PileupTile &P = ctx->pl;
+    const int64_t T = P.n_pos, n_e = ctx->pl_entries, n_o = ctx->pl_obs, n_i = ctx->pl_indels;
+    if (!carry_in || !carry_out || !entry_off) return fail(ctx, BVC_ERR_ARG, "null pointer");
+    if (T > 0 && (!ref_base || !tally || !results)) return fail(ctx, BVC_ERR_ARG, "null pointer");
+    if ((n_e > 0 && (!entries || !samples)) || (n_i > 0 && !indels)) return fail(ctx, BVC_ERR_ARG, "null pointer");
+    if (n_groups < 0 || n_groups > BVC_MAX_GROUPS) return fail(ctx, BVC_ERR_ARG, "n_groups must be 0..32");
+    if (n_groups > 0 && (!grp_results || n_samples < 0 || (n_samples > 0 && !group_of_sample))) return fail(ctx, BVC_ERR_ARG, "null group pointer");
+    BVC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t e_al = al256((size_t)n_e * sizeof(bvc_pileup_entry) + 16), s_al = al256((size_t)n_e * 4 + 16), o_al = al256((size_t)n_o + 16);
+    const size_t os_al = al256((size_t)n_o * 4 + 16), i_al = al256((size_t)n_i * sizeof(bvc_pileup_indel) + 16), r_al = al256((size_t)T + 16);
+    const size_t res_al = al256((size_t)T * sizeof(bvc_site_result)), g_al = al256((size_t)(n_groups ? n_samples : 0) + 16);
+    const size_t gres_al = al256((size_t)T * (size_t)n_groups * sizeof(bvc_group_result));
+    int rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_pl_out), &ctx->pl_out_cap, e_al + s_al + 2 * o_al + os_al + i_al + r_al + res_al + g_al + gres_al + 256);
+    if (rc != BVC_OK) return rc;
+    char *p = ctx->d_pl_out;
+    P.entries = reinterpret_cast<bvc_pileup_entry *>(p); p += e_al;
+    P.samples = reinterpret_cast<int32_t *>(p); p += s_al;
+    P.obs_base = reinterpret_cast<int8_t *>(p); p += o_al;
+    P.obs_qual = reinterpret_cast<int8_t *>(p); p += o_al;
+    P.obs_sample = reinterpret_cast<int32_t *>(p); p += os_al;
+    P.indels = reinterpret_cast<bvc_pileup_indel *>(p); p += i_al;
+    P.indel_cap = (uint32_t)n_i;
+    int8_t *d_ref = reinterpret_cast<int8_t *>(p); p += r_al;
+    bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(p); p += res_al;
+    uint8_t *d_g = reinterpret_cast<uint8_t *>(p); p += g_al;
+    bvc_group_result *d_gres = reinterpret_cast<bvc_group_result *>(p);
+    const uint32_t cin = (uint32_t)(carry_in[0] & 7u) | ((uint32_t)(carry_in[4] & 1u) << 3) | 0x80u | ((uint32_t)carry_in[1] << 8) |
+                         ((uint32_t)carry_in[2] << 16) | ((uint32_t)carry_in[3] << 24);
+    auto drained = [&](int code) {
+        if (code != BVC_OK) {
+            (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->side); (void)hipStreamSynchronize(ctx->side_b);
+            (void)hipStreamSynchronize(ctx->side_c);
+            for (bool &pnd : ctx->em_pending) pnd = false;
+            (void)hipGetLastError();
+        }
+        return code;
+    };
+#define BVC_HIP_D(call)                                                                   \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) return drained(fail(ctx, BVC_ERR_DEVICE, #call, e__));     \
+    } while (0)
+    uint32_t cout = cin;
+    if (T > 0) {
+        BVC_HIP_D(hipMemcpyAsync(d_ref, ref_base, (size_t)T, hipMemcpyHostToDevice, ctx->stream));
+        if (n_groups > 0 && n_samples > 0) BVC_HIP_D(hipMemcpyAsync(d_g, group_of_sample, (size_t)n_samples, hipMemcpyHostToDevice, ctx->stream));
+        if (P.n_lines > 0) BVC_HIP_D(launch_pileup_write(ctx->stream, P, cin));
+        if (n_groups > 0)
+            rc = run_csr_groups_device(ctx, T, P.obs_off, P.obs_base, P.obs_qual, P.obs_sample, d_ref, min_af, d_g, n_samples, n_groups, d_res, d_gres);
+        else
+            rc = run_csr_device(ctx, T, P.obs_off, P.obs_base, P.obs_qual, d_ref, min_af, nullptr, nullptr, d_res);
+        if (rc == BVC_OK) rc = join_side(ctx);
+        if (rc != BVC_OK) return drained(rc);
+        BVC_HIP_D(hipMemcpyAsync(results, d_res, (size_t)T * sizeof(bvc_site_result), hipMemcpyDeviceToHost, ctx->stream));
+        if (n_groups > 0)
+            BVC_HIP_D(hipMemcpyAsync(grp_results, d_gres, (size_t)T * (size_t)n_groups * sizeof(bvc_group_result), hipMemcpyDeviceToHost, ctx->stream));
+        BVC_HIP_D(hipMemcpyAsync(tally, P.tally, (size_t)T * 32 * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (n_e) {
+            BVC_HIP_D(hipMemcpyAsync(entries, P.entries, (size_t)n_e * sizeof(bvc_pileup_entry), hipMemcpyDeviceToHost, ctx->stream));
+            BVC_HIP_D(hipMemcpyAsync(samples, P.samples, (size_t)n_e * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (n_i) BVC_HIP_D(hipMemcpyAsync(indels, P.indels, (size_t)n_i * sizeof(bvc_pileup_indel), hipMemcpyDeviceToHost, ctx->stream));
+        if (P.n_lines > 0) BVC_HIP_D(hipMemcpyAsync(&cout, P.status + 3, 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    BVC_HIP_D(hipMemcpyAsync(entry_off, P.entry_off, (size_t)(T + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    BVC_HIP_D(hipStreamSynchronize(ctx->stream));
+#undef BVC_HIP_D
+    carry_out[0] = (uint8_t)(cout & 7u); carry_out[1] = (uint8_t)(cout >> 8); carry_out[2] = (uint8_t)(cout >> 16);
+    carry_out[3] = (uint8_t)(cout >> 24); carry_out[4] = (uint8_t)((cout >> 3) & 1u);
+    return BVC_OK;
+}
+
 // bvc_lrt_dense_groups and bvc_lrt_dense_groups_packed: `packed` = the tile is one byte per sample in `bases`
 // (base << 6 | qual, include/bvc.h) and `quals` is not used.
 static int lrt_groups_impl(bvc_ctx *ctx, bool packed, int64_t n_sites, int64_t n_samples, int64_t row_stride,
@@ -949,76 +1258,22 @@ static int lrt_groups_impl(bvc_ctx *ctx, bool packed, int64_t n_sites, int64_t n
     if (n_groups < 1 || n_groups > BVC_MAX_GROUPS) return fail(ctx, BVC_ERR_ARG, "n_groups must be 1..32");
     if (!group_of_sample || !grp_results) return fail(ctx, BVC_ERR_ARG, "null group pointer");
     if (n_sites == 0) return BVC_OK;
-    const int n_hist = n_groups + 1;
-
-    // Same two-stage structure as the plain dense call: stage 1 (one pass, n_groups + 1 histograms per site) on the
-    // context's stream; stage 2 (sum, overall LRT, per-group LRT) on the side stream in overlap mode.
     auto run_device = [&](int64_t ns, const int8_t *b, const int8_t *q, const int8_t *r, const uint8_t *g,
                           bvc_site_result *res, bvc_group_result *gres) -> int {
-        const int buf = ctx->overlap ? ctx->flip : 0;
-        if (ctx->overlap) ctx->flip = (ctx->flip + 1) % bvc_ctx::kRing;
-        uint32_t **cp = &ctx->d_cnt[buf];
-        size_t *ccap = &ctx->cnt_cap[buf];
-        uint32_t **gp = &ctx->d_grp[buf];
-        size_t *gcap = &ctx->grp_cap[buf];
-        const size_t cbytes = (size_t)ns * BVC_NCLASS * sizeof(uint32_t), gbytes = cbytes * (size_t)n_hist;
-        if (cbytes > *ccap || gbytes > *gcap) { int rj = join_side(ctx); if (rj != BVC_OK) return rj; }
-        int rc2 = ensure(ctx, reinterpret_cast<void **>(cp), ccap, cbytes);
-        if (rc2 != BVC_OK) return rc2;
-        rc2 = ensure(ctx, reinterpret_cast<void **>(gp), gcap, gbytes);
-        if (rc2 != BVC_OK) return rc2;
         const size_t lbytes = group_labels_bytes(n_samples, ns);       // the call's labels clamped to 0..n_groups + a flag per site
         if (lbytes > ctx->grp_labels_cap) { int rj = join_side(ctx); if (rj != BVC_OK) return rj; }
-        rc2 = ensure(ctx, reinterpret_cast<void **>(&ctx->d_grp_labels), &ctx->grp_labels_cap, lbytes);
+        int rc2 = ensure(ctx, reinterpret_cast<void **>(&ctx->d_grp_labels), &ctx->grp_labels_cap, lbytes);
         if (rc2 != BVC_OK) return rc2;
-        void *em_scratch = nullptr, *emg_scratch = nullptr;
-        rc2 = em_scratch_for(ctx, buf, ns, min_af, &em_scratch);
-        if (rc2 != BVC_OK) return rc2;
-        rc2 = em_scratch_for(ctx, buf, ns, min_af, &emg_scratch, n_groups);
-        if (rc2 != BVC_OK) return rc2;
-        if (ctx->overlap && ctx->em_pending[buf]) {
-            BVC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_em_done[buf], 0));
-            ctx->em_pending[buf] = false;
-        }
-        bvc_ctx::Triple t{nullptr, nullptr, nullptr, nullptr, ns};
-        const bool timed = ctx->profiling && take_timing_events(ctx, t);
-        auto bail = [&](int code) { give_back(ctx, t.a); give_back(ctx, t.b); give_back(ctx, t.c); give_back(ctx, t.d); return code; };
-#define BVC_HIP_T(call)                                                                     \
-    do {                                                                                    \
-        hipError_t e__ = (call);                                                            \
-        if (e__ != hipSuccess) return bail(fail(ctx, BVC_ERR_DEVICE, #call, e__));          \
-    } while (0)
-        if (timed) BVC_HIP_T(hipEventRecord(t.a, ctx->stream));
-        if (packed)
-            BVC_HIP_T(launch_hist_packed_groups(ctx->ls, ctx->stream, ns, n_samples, row_stride, reinterpret_cast<const uint8_t *>(b),
-                                                g, n_groups, *gp, ctx->d_grp_scratch, ctx->d_grp_labels));
-        else
-            BVC_HIP_T(launch_hist_dense(ctx->ls, ctx->stream, ns, n_samples, row_stride, b, q, g, n_groups, *gp, 1, ctx->d_grp_scratch, ctx->d_grp_labels));
-        if (timed) BVC_HIP_T(hipEventRecord(t.b, ctx->stream));
-        hipStream_t s2 = ctx->stream;
-        if (ctx->overlap) {
-            s2 = em_stream(ctx, 2);
-            BVC_HIP_T(hipEventRecord(ctx->ev_hist_done[buf], ctx->stream));
-            BVC_HIP_T(hipStreamWaitEvent(s2, ctx->ev_hist_done[buf], 0));
-        }
-        if (timed) BVC_HIP_T(hipEventRecord(t.c, s2));
-        BVC_HIP_T(launch_sum_groups(s2, ns, n_hist, *gp, *cp));
-        const bool shared = ctx->overlap && n_samples >= 200000;
-        const int per_launch = kGroupSharedWavesPerCu / em_stream_count(ctx, 2) > 2 ? kGroupSharedWavesPerCu / em_stream_count(ctx, 2) : 2;
-        BVC_HIP_T(launch_lrt(ctx->ls, s2, ns, *cp, BVC_NCLASS, r, min_af, ctx->d_lut, nullptr, nullptr, res, shared, per_launch, em_scratch));
-        BVC_HIP_T(launch_lrt_groups(ctx->ls, s2, ns, n_groups, *gp, r, min_af, ctx->d_lut, res, gres, shared, per_launch, emg_scratch));
-        if (timed) {
-            BVC_HIP_T(hipEventRecord(t.d, s2));
-            ctx->ev_pending.push_back(t);
-            t = bvc_ctx::Triple{nullptr, nullptr, nullptr, nullptr, 0};
-            if (ctx->ev_pending.size() > 256) reap_timing(ctx, false);
-        }
-        if (ctx->overlap) {
-            BVC_HIP_T(hipEventRecord(ctx->ev_em_done[buf], s2));
-            ctx->em_pending[buf] = true;
-        }
-#undef BVC_HIP_T
-        return BVC_OK;
+        return run_group_stages(ctx, ns, n_groups, n_samples >= 200000,
+                                [&](uint32_t *gp) {
+                                    if (packed)
+                                        return launch_hist_packed_groups(ctx->ls, ctx->stream, ns, n_samples, row_stride,
+                                                                         reinterpret_cast<const uint8_t *>(b), g, n_groups, gp,
+                                                                         ctx->d_grp_scratch, ctx->d_grp_labels);
+                                    return launch_hist_dense(ctx->ls, ctx->stream, ns, n_samples, row_stride, b, q, g, n_groups, gp, 1,
+                                                             ctx->d_grp_scratch, ctx->d_grp_labels);
+                                },
+                                r, min_af, res, gres);
     };
 
     if (flags & BVC_PTR_DEVICE)
@@ -1098,6 +1353,9 @@ int bvc_debug_report(bvc_ctx *ctx, uint32_t *out24, int reset)
     BVC_HIP(ctx, debug_read_hist(out24, reset != 0));
     BVC_HIP(ctx, debug_read_wave_engine(out24 + 8, reset != 0));
     BVC_HIP(ctx, debug_read_items(out24 + 16, reset != 0));
+    uint32_t pl[8];                                              // pileup_kernel.hip: folded into the histogram unit's count
+    BVC_HIP(ctx, debug_read_pileup(pl, reset != 0));
+    if (pl[0]) { if (out24[0] == 0) for (int i = 1; i < 8; ++i) out24[i] = pl[i]; out24[0] += pl[0]; }
     return BVC_OK;
 }
 #endif

@@ -119,7 +119,35 @@ hipError_t launch_synth_dense(hipStream_t stream, uint64_t seed, int64_t site0, 
                               int64_t n_samples, int64_t row_stride, uint32_t cov_thr16,
                               int8_t *bases, int8_t *quals, int8_t *ref_base);
 
+// ---- pileup_kernel.hip: temp-batch pileup text -> ragged columns; per-group histograms of ragged columns -----------------
+// Device buffers of one tile between bvc_pileup_begin and bvc_pileup_finish (all owned by the context).
+struct PileupTile {
+    const uint8_t *text = nullptr;
+    const uint32_t *line_start = nullptr;    // [n_batches][n_pos + 1]
+    const int32_t *sample0 = nullptr, *n_in_batch = nullptr;
+    int32_t n_batches = 0, n_pos = 0;
+    int64_t n_lines = 0;
+    uint32_t *line_words = nullptr;          // 4 arrays of n_lines words: entries, observations, last base token, inherited indels
+    uint32_t *status = nullptr;              // [0] irregular lines [1] indel entries [2] indel records written [3] carry out
+    int64_t *entry_off = nullptr, *obs_off = nullptr, *totals = nullptr;    // [n_pos + 1], [n_pos + 1], [2]
+    bvc_pileup_entry *entries = nullptr;
+    int32_t *samples = nullptr, *obs_sample = nullptr;
+    int8_t *obs_base = nullptr, *obs_qual = nullptr;
+    int32_t *tally = nullptr;                // [n_pos][32]
+    bvc_pileup_indel *indels = nullptr;
+    uint32_t indel_cap = 0;
+};
+// count pass + prefix sums (fills line_words, entry_off, obs_off, totals, status[0..1])
+hipError_t launch_pileup_count(hipStream_t stream, const PileupTile &P);
+// write pass + the entries that inherit across lines (status[2] and tally must be zero; leaves the carry in status[3])
+hipError_t launch_pileup_write(hipStream_t stream, const PileupTile &P, uint32_t carry_in);
+// counts = [site][n_groups + 1][512] from ragged observations with their sample indices
+hipError_t launch_hist_csr_groups(LaunchState &st, hipStream_t stream, int64_t n_sites, const int64_t *offsets, const int8_t *bases,
+                                  const int8_t *quals, const int32_t *sample_of_obs, const uint8_t *group_of_sample, int64_t n_samples,
+                                  int n_groups, uint32_t *counts);
+
 #ifdef BVC_CHECK_LDS
+hipError_t debug_read_pileup(uint32_t *out8, bool reset);
 // diagnostic builds: each translation unit's violation record (bvc_device.h)
 hipError_t debug_read_hist(uint32_t *out8, bool reset);
 hipError_t debug_read_wave_engine(uint32_t *out8, bool reset);

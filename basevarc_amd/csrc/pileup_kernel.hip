@@ -1,0 +1,411 @@
+// pileup_kernel.hip -- the producer side of the hot path on the device: temp-batch pileup TEXT -> ragged pileup columns,
+// and the per-group histograms of ragged columns.
+//
+// Reference (paths under /root/reference): the position loop of bt_s parses one line of every temp batch per position with
+// strtok_r / atoi (src/BaseVarC.cpp:403-441; writer :509-527), bt_f then walks the position's entries for the depth and strand
+// tallies of the CVG line (:548-590) and builds the (base, qual) vectors BaseType takes (:550-559), for the whole cohort and, with
+// --group, per population group (:617-661).  On the host that is ~140 us of CPU per position of 1e5 samples; the device takes the
+// inflated text as it is.
+//
+// Layout: the text of a tile = for every temp batch b the T lines of the tile's positions, one after the other; the caller gives
+// the offset of every line (it cut the batch's stream at line ends anyway).  One WAVEFRONT per line, 16 bytes of the line per lane
+// and step; token starts from a compare mask, token and entry ranks from wave prefix sums; two passes over the text -- count, then
+// write -- with a prefix sum over the lines (position-major: the entries of a position are those of its lines in batch order, as
+// the reference appends them) in between.  Exactly the observable behaviour of the reference's parser on the lines its writer
+// produces (REGULAR lines: tokens ". ", "b,m,q,r,s " with 1-3 digits per field, or an indel token starting '+', '-' or 'N', each
+// followed by ONE space; as many tokens as the batch has samples): N bases (base code 4) dropped (:427), the fields' bit widths
+// (src/BamProcess.h:32-37), and the long-lived AlleleInfo whose fields an indel entry inherits from the last base token parsed
+// before it -- in the same line, in an earlier line of the tile, or in the tile before (:392, 407-440).  A line that is not regular
+// is only counted: the call then reports BVC_PILEUP_IRREGULAR and the caller parses that tile on the CPU.
+#include <hip/hip_runtime.h>
+
+#include "bvc_device.h"
+#include "bvc_internal.h"
+
+namespace bvc {
+namespace {
+
+constexpr int kParseWaves = 4;                  // lines per workgroup (one wavefront each)
+constexpr uint32_t kTokValid = 0x80u;           // packed base token: bits 0..2 base, 3 strand, 7 valid, 8..15 mapq, 16..23 qual, 24..31 rpr
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)v, d, kWave);
+        if (lane >= d) v += u;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, kWave);
+    return v;
+}
+
+// "b,m,q,r,s " at text[p..] (p < e): five fields of one to three decimal digits, four commas, a space.  Returns the packed token,
+// 0 for any other shape.  Three aligned 8-byte loads cover the 20 bytes of the longest such token wherever p falls (the text
+// buffer is allocated 32 bytes longer than the text).
+__device__ __forceinline__ uint32_t parse_base_token(const uint8_t *__restrict__ text, uint32_t p, uint32_t e)
+{
+    const uint64_t *w = reinterpret_cast<const uint64_t *>(text + (p & ~7u));
+    const uint64_t w0 = w[0], w1 = w[1], w2 = w[2];
+    const uint32_t sh = p & 7u;
+    uint32_t f = 0, nd = 0, acc = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+#pragma unroll
+    for (int i = 0; i < 20; ++i) {
+        const uint32_t k = sh + (uint32_t)i;
+        uint32_t c = (uint32_t)((k < 8u ? w0 >> (8u * k) : (k < 16u ? w1 >> (8u * (k - 8u)) : w2 >> (8u * (k - 16u)))) & 0xFFu);
+        if (p + (uint32_t)i >= e) c = 0x20u;
+        if (c == 0x20u) {
+            if (nd == 0u || f != 4u) return 0u;
+            return (v0 & 7u) | ((acc & 1u) << 3) | kTokValid | ((v1 & 0xFFu) << 8) | ((v2 & 0xFFu) << 16) | ((v3 & 0xFFu) << 24);
+        }
+        if (c == 0x2Cu) {
+            if (nd == 0u || f == 4u) return 0u;
+            if (f == 0u) v0 = acc; else if (f == 1u) v1 = acc; else if (f == 2u) v2 = acc; else v3 = acc;
+            ++f; nd = 0u; acc = 0u;
+        } else {
+            const uint32_t d = c - 0x30u;
+            if (d > 9u || nd == 3u) return 0u;
+            acc = acc * 10u + d; ++nd;
+        }
+    }
+    return 0u;
+}
+
+struct ParseArgs {
+    const uint8_t *text;
+    const uint32_t *line_start;      // [n_batches][n_pos + 1]: offset of line t of batch b; the last = one past the batch's last '\n'
+    const int32_t *sample0;          // [n_batches]
+    const int32_t *n_in_batch;       // [n_batches] tokens of every line of the batch
+    int32_t n_batches, n_pos;
+    uint32_t *line_entries;          // [n_pos * n_batches] position-major: count pass = entries of the line; after the scan = first entry
+    uint32_t *line_obs;              // the same for observations (entries that are not indels)
+    uint32_t *line_last;             // last base token of the line (packed) or 0
+    uint32_t *line_need;             // indel entries in front of the line's first base token: they inherit from an earlier line
+    uint32_t *status;                // [0] irregular lines, [1] indel entries counted, [2] indel records written
+    bvc_pileup_entry *entries;
+    int32_t *samples;
+    int8_t *obs_base, *obs_qual;
+    int32_t *obs_sample;
+    int32_t *tally;                  // [n_pos][32]: [strand << 3 | base] of the base entries, + 16 for the indel entries
+    bvc_pileup_indel *indels;
+    uint32_t indel_cap;
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(kParseWaves * kWave) void pileup_parse_kernel(ParseArgs A)
+{
+    BVC_POISON_LDS();
+    __shared__ uint32_t tal_all[kParseWaves][32];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *tal = tal_all[wave];
+    if (lane < 32) tal[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t *__restrict__ text = A.text;
+    const int64_t n_lines = (int64_t)A.n_pos * A.n_batches;
+    for (int64_t line = (int64_t)blockIdx.x * kParseWaves + wave; line < n_lines; line += (int64_t)gridDim.x * kParseWaves) {
+        const int t = (int)(line / A.n_batches), b = (int)(line - (int64_t)t * A.n_batches);
+        const uint32_t s = A.line_start[(int64_t)b * (A.n_pos + 1) + t];
+        const uint32_t e1 = A.line_start[(int64_t)b * (A.n_pos + 1) + t + 1];
+        bool bad = e1 <= s;
+        const uint32_t e = bad ? s : e1 - 1u;                    // the line is [s, e); text[e] is its '\n'
+        if (!bad) bad = text[e] != 0x0Au || (e > s && text[e - 1u] != 0x20u);
+        const int32_t smp0 = A.sample0[b];
+        uint32_t ent_at = 0, obs_at = 0;
+        if (WRITE) { ent_at = A.line_entries[line]; obs_at = A.line_obs[line]; }
+        uint32_t tok_run = 0, ent_run = 0, obs_run = 0, need = 0, n_ind_line = 0;
+        uint32_t prev_tok = 0;                                   // wave-uniform: last base token of the line so far
+        uint32_t prev_sep = 1u;                                  // wave-uniform: was the byte in front of this step a separator?
+        for (uint32_t off = s & ~15u; off < e; off += 16u * kWave) {
+            const uint32_t a = off + 16u * (uint32_t)lane;
+            u32x4 w = u32x4{0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
+            uint32_t c16 = 0x20u;
+            if (a < e && a + 16u > s) {
+                w = *reinterpret_cast<const u32x4 *>(text + a);
+                if (a + 16u < e) c16 = text[a + 16u];
+            }
+            const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+            uint32_t sep = 0, dot = 0, dig = 0, ind = 0, inside = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t pos = a + (uint32_t)i;
+                uint32_t c = (wv[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                const bool in = pos >= s && pos < e;
+                if (!in) c = 0x20u;
+                inside |= (uint32_t)in << i;
+                sep |= (uint32_t)(c == 0x20u) << i;
+                dot |= (uint32_t)(c == 0x2Eu) << i;
+                dig |= (uint32_t)(c - 0x30u <= 9u) << i;
+                ind |= (uint32_t)(c == 0x2Bu || c == 0x2Du || c == 0x4Eu) << i;
+            }
+            sep |= (uint32_t)(c16 == 0x20u) << 16;
+            const uint32_t left = (uint32_t)__shfl_up((int)sep, 1, kWave);
+            const uint32_t pb = lane == 0 ? prev_sep : (left >> 15) & 1u;
+            const uint32_t after_sep = ((sep << 1) | pb) & 0xFFFFu;
+            const uint32_t start = ~sep & after_sep & 0xFFFFu;
+            // not regular: two separators in a row inside the line, a token that starts with none of [0-9.+-N], a '.' token longer than the dot
+            if ((sep & after_sep & inside) | (start & ~(dot | dig | ind)) | (start & dot & ~(sep >> 1))) bad = true;
+            // ---- first walk over the lane's tokens: what each adds
+            const uint32_t cand = start & (dig | ind);
+            uint32_t ent = 0, obs = 0, n_ind = 0, ind_front = 0, lane_last = 0;
+            for (uint32_t m = cand; m;) {
+                const int i = __builtin_ctz(m);
+                m &= m - 1u;
+                if ((dig >> i) & 1u) {
+                    const uint32_t tok = parse_base_token(text, a + (uint32_t)i, e);
+                    if (tok == 0u) { bad = true; continue; }
+                    lane_last = tok;
+                    if ((tok & 7u) != 4u) { ++ent; ++obs; }      // skip N base, src/BaseVarC.cpp:427
+                } else {
+                    ++ent; ++n_ind;
+                    if (lane_last == 0u) ++ind_front;
+                }
+            }
+            const uint32_t packed = (uint32_t)__builtin_popcount(start) | (ent << 10) | (obs << 20);
+            const uint32_t incl = wave_incl_scan(packed, lane);
+            const uint32_t excl = incl - packed;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint64_t have = __ballot(lane_last != 0u);
+            const bool any_ind = __ballot(n_ind != 0u) != 0ull;
+            uint32_t left_last = 0;                              // last base token of the lanes in front of this one (this step)
+            if (any_ind) {
+                const uint64_t before = have & ((1ull << lane) - 1ull);
+                const int src = before ? 63 - __builtin_clzll(before) : 0;
+                const uint32_t got = (uint32_t)__shfl((int)lane_last, src, kWave);
+                left_last = before ? got : 0u;
+                // indel entries in front of the line's first base token
+                if (prev_tok == 0u) {
+                    const int first = have ? __builtin_ctzll(have) : kWave;
+                    need += wave_sum(lane < first ? n_ind : (lane == first ? ind_front : 0u));
+                }
+                n_ind_line += wave_sum(n_ind);
+            }
+            // ---- second walk: write
+            if (WRITE && !bad) {
+                uint32_t ent_i = ent_at + ent_run + ((excl >> 10) & 0x3FFu);
+                uint32_t obs_i = obs_at + obs_run + ((excl >> 20) & 0x3FFu);
+                const uint32_t tok_i = tok_run + (excl & 0x3FFu);
+                uint32_t cur_last = 0;
+                for (uint32_t m = cand; m;) {
+                    const int i = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const uint32_t p = a + (uint32_t)i;
+                    const int32_t smp = smp0 + (int32_t)(tok_i + (uint32_t)__builtin_popcount(start & ((1u << i) - 1u)));
+                    if ((dig >> i) & 1u) {
+                        const uint32_t tok = parse_base_token(text, p, e);
+                        cur_last = tok;
+                        if ((tok & 7u) == 4u) continue;
+                        *reinterpret_cast<u32x2 *>(&A.entries[ent_i]) =
+                            u32x2{(tok & 7u) | (tok & 0xFFFFFF00u), (tok >> 3) & 1u};
+                        A.samples[ent_i] = smp;
+                        A.obs_base[obs_i] = (int8_t)(tok & 7u);
+                        A.obs_qual[obs_i] = (int8_t)((tok >> 16) & 0xFFu);
+                        A.obs_sample[obs_i] = smp;
+                        atomicAdd(&tal[tok & 15u], 1u);
+                        ++ent_i; ++obs_i;
+                    } else {
+                        // the entry carries the fields of the last base token parsed before it (src/BaseVarC.cpp:431-436)
+                        const uint32_t src = cur_last ? cur_last : (left_last ? left_last : prev_tok);
+                        *reinterpret_cast<u32x2 *>(&A.entries[ent_i]) =
+                            u32x2{(src & 7u) | (src & 0xFFFFFF00u), ((src >> 3) & 1u) | 0x100u};
+                        A.samples[ent_i] = smp;
+                        if (src) atomicAdd(&tal[16u + (src & 15u)], 1u);
+                        uint32_t q = p + 1u;                         // the token's text, for the CVG line's Indels column
+                        while (q < e && text[q] != 0x20u) ++q;
+                        const uint32_t k = atomicAdd(&A.status[2], 1u);
+                        if (k < A.indel_cap) A.indels[k] = bvc_pileup_indel{(int64_t)ent_i, (int64_t)p, (int32_t)(q - p), 0};
+                        ++ent_i;
+                    }
+                }
+            }
+            tok_run += total & 0x3FFu; ent_run += (total >> 10) & 0x3FFu; obs_run += (total >> 20) & 0x3FFu;
+            if (have) prev_tok = (uint32_t)__shfl((int)lane_last, 63 - __builtin_clzll(have), kWave);
+            prev_sep = (uint32_t)__builtin_amdgcn_readlane((int)sep, 63) >> 15 & 1u;
+        }
+        if (tok_run != (uint32_t)A.n_in_batch[b]) bad = true;
+        const bool any_bad = __ballot(bad) != 0ull;
+        if (!WRITE) {
+            if (lane == 0) {
+                A.line_entries[line] = any_bad ? 0u : ent_run;
+                A.line_obs[line] = any_bad ? 0u : obs_run;
+                A.line_last[line] = prev_tok;
+                A.line_need[line] = need;
+                if (any_bad) atomicAdd(&A.status[0], 1u);
+                if (n_ind_line) atomicAdd(&A.status[1], n_ind_line);
+            }
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 32) {
+                const uint32_t v = tal[lane];
+                if (v) atomicAdd(&A.tally[(int64_t)t * 32 + lane], (int32_t)v);
+                tal[lane] = 0u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// Exclusive prefix sums of the lines' entry and observation counts, in place, position-major; the positions' offsets; the totals.
+__global__ __launch_bounds__(1024) void pileup_scan_kernel(int64_t n_lines, int32_t n_batches, int32_t n_pos, uint32_t *__restrict__ line_entries,
+                                                           uint32_t *__restrict__ line_obs, int64_t *__restrict__ entry_off,
+                                                           int64_t *__restrict__ obs_off, int64_t *__restrict__ totals)
+{
+    BVC_POISON_LDS();
+    __shared__ uint64_t part_e[1024], part_o[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n_lines + 1023) / 1024;
+    const int64_t i0 = (int64_t)tid * per, i1 = i0 + per < n_lines ? i0 + per : n_lines;
+    uint64_t se = 0, so = 0;
+    for (int64_t i = i0; i < i1; ++i) { se += line_entries[i]; so += line_obs[i]; }
+    part_e[tid] = se; part_o[tid] = so;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint64_t ue = 0, uo = 0;
+        if (tid >= d) { ue = part_e[tid - d]; uo = part_o[tid - d]; }
+        __syncthreads();
+        part_e[tid] += ue; part_o[tid] += uo;
+        __syncthreads();
+    }
+    uint64_t be = part_e[tid] - se, bo = part_o[tid] - so;      // exclusive base of this thread's run
+    for (int64_t i = i0; i < i1; ++i) {
+        const uint32_t ce = line_entries[i], co = line_obs[i];
+        line_entries[i] = (uint32_t)be; line_obs[i] = (uint32_t)bo;
+        if (i % n_batches == 0) { entry_off[i / n_batches] = (int64_t)be; obs_off[i / n_batches] = (int64_t)bo; }
+        be += ce; bo += co;
+    }
+    if (tid == 1023) {
+        entry_off[n_pos] = (int64_t)part_e[1023]; obs_off[n_pos] = (int64_t)part_o[1023];
+        totals[0] = (int64_t)part_e[1023]; totals[1] = (int64_t)part_o[1023];
+    }
+}
+
+// The indel entries in front of a line's first base token take the fields of the last base token of the lines before it
+// (position-major order: the order the reference parses in), or of the tile before (carry_in).  One thread per line; thread
+// n_lines leaves the tile's own last base token for the next tile.
+__global__ void pileup_patch_kernel(int64_t n_lines, int32_t n_batches, const uint32_t *__restrict__ line_entries,
+                                    const uint32_t *__restrict__ line_last, const uint32_t *__restrict__ line_need, uint32_t carry_in,
+                                    bvc_pileup_entry *__restrict__ entries, int32_t *__restrict__ tally, uint32_t *__restrict__ carry_out)
+{
+    const int64_t line = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (line > n_lines) return;
+    const uint32_t need = line < n_lines ? line_need[line] : 0u;
+    if (line < n_lines && need == 0u) return;
+    uint32_t src = carry_in;
+    for (int64_t j = line - 1; j >= 0; --j) {
+        const uint32_t l = line_last[j];
+        if (l) { src = l; break; }
+    }
+    if (line == n_lines) { *carry_out = src; return; }
+    const uint32_t at = line_entries[line];
+    for (uint32_t k = 0; k < need; ++k)
+        *reinterpret_cast<u32x2 *>(&entries[at + k]) = u32x2{(src & 7u) | (src & 0xFFFFFF00u), ((src >> 3) & 1u) | 0x100u};
+    atomicAdd(&tally[(line / n_batches) * 32 + 16 + (src & 15u)], (int32_t)need);
+}
+
+// ---- per-group histograms of ragged columns ----------------------------------------------------------------------------
+// counts[site][h][512], h = the group of the observation's sample (labels >= n_groups, or a sample index outside the label
+// vector: the "no group" histogram n_groups), as the dense group kernels lay them out.  The reference's group loop runs on each
+// site's COVERED samples (src/BaseVarC.cpp:617-661, vectors of :550-559): this is that loop's input without the dense
+// [site][N] tile in between.  One workgroup per site, one LDS counter per (histogram, class), LDS atomics: a ragged site is
+// 1e1-1e5 observations, far fewer than a dense row, and what bounds a site here is zeroing and folding (k + 1) x 512 counters.
+constexpr int kCsrGroupThreads = 256;
+
+__global__ __launch_bounds__(kCsrGroupThreads) void hist_csr_groups_kernel(
+    int64_t n_sites, const int64_t *__restrict__ offsets, const int8_t *__restrict__ bases, const int8_t *__restrict__ quals,
+    const int32_t *__restrict__ sample_of_obs, const uint8_t *__restrict__ group_of_sample, int64_t n_samples, int n_groups,
+    uint32_t *__restrict__ counts)
+{
+    BVC_POISON_LDS();
+    extern __shared__ __attribute__((aligned(16))) uint32_t ghist[];        // [n_groups + 1][512]
+    const int tid = threadIdx.x;
+    const int words = (n_groups + 1) * BVC_NCLASS;
+    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
+        for (int i = tid; i < words; i += kCsrGroupThreads) ghist[i] = 0u;
+        __syncthreads();
+        const int64_t o0 = offsets[site], o1 = offsets[site + 1];
+        for (int64_t i = o0 + tid; i < o1; i += kCsrGroupThreads) {
+            const uint32_t b = (uint8_t)bases[i], q = (uint8_t)quals[i];
+            if (b < 4u && q < 128u) {
+                const int64_t smp = sample_of_obs[i];
+                uint32_t g = (uint32_t)n_groups;
+                if (smp >= 0 && smp < n_samples) { g = group_of_sample[smp]; if (g > (uint32_t)n_groups) g = (uint32_t)n_groups; }
+                const uint32_t at = g * BVC_NCLASS + ((b << 7) | q);
+                if (BVC_LDS_OK(0x501, at, words)) atomicAdd(&ghist[at], 1u);
+            }
+        }
+        __syncthreads();
+        uint32_t *dst = counts + site * (int64_t)words;
+        for (int i = tid; i < words; i += kCsrGroupThreads) dst[i] = ghist[i];
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+hipError_t launch_pileup_count(hipStream_t stream, const PileupTile &P)
+{
+    ParseArgs A{};
+    A.text = P.text; A.line_start = P.line_start; A.sample0 = P.sample0; A.n_in_batch = P.n_in_batch;
+    A.n_batches = P.n_batches; A.n_pos = P.n_pos;
+    A.line_entries = P.line_words; A.line_obs = P.line_words + P.n_lines; A.line_last = P.line_words + 2 * P.n_lines;
+    A.line_need = P.line_words + 3 * P.n_lines; A.status = P.status;
+    if (P.n_lines <= 0) return hipSuccess;
+    const int64_t blocks = (P.n_lines + kParseWaves - 1) / kParseWaves;
+    hipLaunchKernelGGL(pileup_parse_kernel<false>, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(kParseWaves * kWave), 0, stream, A);
+    hipLaunchKernelGGL(pileup_scan_kernel, dim3(1), dim3(1024), 0, stream, P.n_lines, P.n_batches, P.n_pos, A.line_entries, A.line_obs,
+                       P.entry_off, P.obs_off, P.totals);
+    return hipGetLastError();
+}
+
+hipError_t launch_pileup_write(hipStream_t stream, const PileupTile &P, uint32_t carry_in)
+{
+    ParseArgs A{};
+    A.text = P.text; A.line_start = P.line_start; A.sample0 = P.sample0; A.n_in_batch = P.n_in_batch;
+    A.n_batches = P.n_batches; A.n_pos = P.n_pos;
+    A.line_entries = P.line_words; A.line_obs = P.line_words + P.n_lines; A.line_last = P.line_words + 2 * P.n_lines;
+    A.line_need = P.line_words + 3 * P.n_lines; A.status = P.status;
+    A.entries = P.entries; A.samples = P.samples; A.obs_base = P.obs_base; A.obs_qual = P.obs_qual; A.obs_sample = P.obs_sample;
+    A.tally = P.tally; A.indels = P.indels; A.indel_cap = P.indel_cap;
+    if (P.n_lines <= 0) return hipSuccess;
+    const int64_t blocks = (P.n_lines + kParseWaves - 1) / kParseWaves;
+    hipLaunchKernelGGL(pileup_parse_kernel<true>, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(kParseWaves * kWave), 0, stream, A);
+    const int64_t threads = P.n_lines + 1;
+    hipLaunchKernelGGL(pileup_patch_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, P.n_lines, P.n_batches,
+                       A.line_entries, A.line_last, A.line_need, carry_in, P.entries, P.tally, P.status + 3);
+    return hipGetLastError();
+}
+
+hipError_t launch_hist_csr_groups(LaunchState &st, hipStream_t stream, int64_t n_sites, const int64_t *offsets, const int8_t *bases,
+                                  const int8_t *quals, const int32_t *sample_of_obs, const uint8_t *group_of_sample, int64_t n_samples,
+                                  int n_groups, uint32_t *counts)
+{
+    if (n_sites <= 0) return hipSuccess;
+    const size_t lds = (size_t)(n_groups + 1) * BVC_NCLASS * sizeof(uint32_t);
+    constexpr uint32_t kSlotCsrGroups = 61;
+    if (lds > 48 * 1024 && !(st.attr_done & ((uint64_t)1 << kSlotCsrGroups))) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(hist_csr_groups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)((size_t)(BVC_MAX_GROUPS + 1) * BVC_NCLASS * sizeof(uint32_t)));
+        if (e != hipSuccess) return e;
+        st.attr_done |= (uint64_t)1 << kSlotCsrGroups;
+    }
+    hipLaunchKernelGGL(hist_csr_groups_kernel, dim3((unsigned)(n_sites < 8192 ? n_sites : 8192)), dim3(kCsrGroupThreads), lds, stream, n_sites,
+                       offsets, bases, quals, sample_of_obs, group_of_sample, n_samples, n_groups, counts);
+    return hipGetLastError();
+}
+
+#ifdef BVC_CHECK_LDS
+BVC_DEFINE_DEBUG_READER(debug_read_pileup)
+#endif
+
+}  // namespace bvc

@@ -398,6 +398,33 @@ bool BgzfReader::getline(std::string &line)
     }
 }
 
+size_t BgzfReader::read_lines(size_t n, std::vector<char> &out, uint32_t *starts)
+{
+    size_t got = 0;
+    bool at_line_start = true;                  // the next byte copied begins line `got`
+    const size_t out0 = out.size();
+    size_t pending_from = out0;                 // start (in out) of the line being assembled
+    while (got < n) {
+        if (pos_ >= block_.size() && !load_block()) break;
+        const unsigned char *b = block_.data() + pos_, *end = block_.data() + block_.size();
+        const unsigned char *p = b;
+        const size_t base = out.size();         // where b[0] will land in out
+        while (got < n && p < end) {
+            if (at_line_start) { starts[got] = (uint32_t)(base + (size_t)(p - b)); pending_from = base + (size_t)(p - b); at_line_start = false; }
+            const unsigned char *nl = static_cast<const unsigned char *>(std::memchr(p, '\n', (size_t)(end - p)));
+            if (!nl) { p = end; break; }
+            p = nl + 1;
+            ++got;
+            at_line_start = true;
+        }
+        out.insert(out.end(), reinterpret_cast<const char *>(b), reinterpret_cast<const char *>(p));
+        pos_ += (size_t)(p - b);
+    }
+    if (!at_line_start) out.resize(pending_from);      // the file ended inside a line: drop the fragment
+    starts[got] = (uint32_t)out.size();
+    return got;
+}
+
 bool BgzfReader::seek(uint64_t voffset)
 {
     settle();

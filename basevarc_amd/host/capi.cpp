@@ -60,6 +60,33 @@ int32_t bvchost_merge_subfiles(const char *out_prefix, const char *suffix, int32
     if (!dst.ok() || !merge_subfiles(out_prefix, suffix, thread, dst)) return 0;
     return dst.close() ? 1 : 0;
 }
+// BgzfReader::read_lines, n lines per call until the file ends: the concatenated lines into out (returns their byte count, or -1 when cap is
+// too small / -2 when a `starts` entry does not sit at the beginning of a line), the number of lines in *n_lines.  threads > 0: with read-ahead.
+int64_t bvchost_bgzf_read_lines(const char *path, int64_t n_per_call, int32_t threads, char *out, int64_t cap, int64_t *n_lines)
+{
+    std::unique_ptr<InflatePool> pool(threads > 0 ? new InflatePool(threads) : nullptr);
+    BgzfReader rd(path);
+    if (pool) rd.attach(pool.get());
+    std::vector<char> buf;
+    std::vector<uint32_t> starts((size_t)n_per_call + 1);
+    int64_t total = 0, lines = 0;
+    for (;;) {
+        buf.assign(7, '#');                                 // lines are appended behind what the buffer holds
+        const size_t got = rd.read_lines((size_t)n_per_call, buf, starts.data());
+        for (size_t i = 0; i < got; ++i) {
+            if (starts[i] < 7 || starts[i + 1] <= starts[i] || buf[starts[i + 1] - 1] != '\n') return -2;
+            if (i > 0 && buf[starts[i] - 1] != '\n') return -2;
+        }
+        if (starts[got] != buf.size() || (got > 0 && starts[0] != 7)) return -2;
+        if (total + (int64_t)buf.size() - 7 > cap) return -1;
+        std::memcpy(out + total, buf.data() + 7, buf.size() - 7);
+        total += (int64_t)buf.size() - 7;
+        lines += (int64_t)got;
+        if (got < (size_t)n_per_call) break;
+    }
+    *n_lines = lines;
+    return total;
+}
 long bvchost_zlib_fallbacks(void) { return bgzf_zlib_fallbacks(); }
 long bvchost_crc_errors(void) { return bgzf_crc_errors(); }
 uint32_t bvchost_crc32(const unsigned char *buf, size_t len) { return bgzf_crc32(buf, len); }

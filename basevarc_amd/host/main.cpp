@@ -234,8 +234,21 @@ struct Tile {
     std::vector<int64_t> offsets;
     std::vector<int8_t> bases, quals;
     std::vector<uint8_t> packed;
-    void reset() { n_used = 0; entries = 0; refs.clear(); }
+    // -- a tile whose text the DEVICE parses (bvc_pileup_begin / bvc_pileup_finish): the inflated lines of its positions, batch
+    //    after batch, as they came out of the temp files; what comes back are the columns and tallies the CPU parser would have built
+    bool dev = false;
+    size_t n_pos = 0;                    // positions of the tile (with or without entries)
+    std::vector<int32_t> pos;            // their coordinates
+    std::vector<char> text;
+    std::vector<uint32_t> line_start;    // [n_batches][n_pos + 1]
+    std::vector<int64_t> entry_off;
+    std::vector<int32_t> tally, samples;
+    std::vector<bvc_pileup_entry> ent;
+    std::vector<bvc_pileup_indel> indels;
+    bool dev_parsed = false;             // false after the call: a line was not regular and the tile went through the CPU parser (sites)
+    void reset() { n_used = 0; entries = 0; refs.clear(); dev = false; dev_parsed = false; n_pos = 0; pos.clear(); }
 };
+static_assert(sizeof(bvc_pileup_entry) == sizeof(Entry), "the device parser's entry is the host's");
 
 // A runner's three stages on three threads with three tiles in flight: while libbvc works on tile i the thread that
 // reads the temp batches parses tile i + 1 and the writer formats and compresses the lines of tile i - 1 (the
@@ -268,7 +281,7 @@ struct TileRunner {
     bvc_ctx *ctx = nullptr;
     const Groups *groups = nullptr;
     std::string chr;
-    int32_t n_samples = 0;
+    int32_t n_samples = 0, ithread = 0;
     double min_af = 0;
     BgzfWriter *fvcf = nullptr, *fcvg = nullptr;
 
@@ -281,6 +294,10 @@ struct TileRunner {
     std::string err;                     // first failure of stage 2 or 3
     bool started = false;
     int64_t tiles_one_byte = 0, tiles_two_byte = 0;   // library calls by tile form (stage 2's thread; read after finish())
+    int64_t tiles_dev_parsed = 0, tiles_cpu_parsed = 0;   // tiles of text: parsed on the device / handed back (a line was not regular)
+    std::vector<int32_t> sample0, n_in_batch;         // per temp batch: its first sample and its samples (device-parsed tiles)
+    uint8_t carry[5] = {0, 0, 0, 0, 0};               // the parser's long-lived AlleleInfo between tiles (stage 2's thread)
+    std::atomic<int64_t> sites_done{0};
 
     void fail(const std::string &what)
     {
@@ -295,7 +312,7 @@ struct TileRunner {
         cur = free_q.pop();
         dev_thread = std::thread([this] {
             for (Tile *t; (t = dev_q.pop()) != nullptr;) {
-                if (!failed()) { try { run_device(*t); } catch (const std::exception &e) { fail(e.what()); } }
+                if (!failed()) { try { if (t->dev) run_device_text(*t); else run_device(*t); } catch (const std::exception &e) { fail(e.what()); } }
                 out_q.push(t);
             }
             out_q.close();
@@ -315,7 +332,7 @@ struct TileRunner {
     // stage 1 hands its tile on and takes a free one (waits when both later stages are still busy)
     void flush()
     {
-        if (cur->n_used == 0) return;
+        if (cur->n_used == 0 && !(cur->dev && cur->n_pos)) return;
         dev_q.push(cur);
         cur = free_q.pop();
         if (failed()) { std::lock_guard<std::mutex> g(err_mu); throw std::runtime_error(err); }
@@ -325,7 +342,7 @@ struct TileRunner {
     void finish()
     {
         if (!started) return;
-        if (cur && cur->n_used) dev_q.push(cur);
+        if (cur && (cur->n_used || (cur->dev && cur->n_pos))) dev_q.push(cur);
         dev_q.close();
         dev_thread.join();
         out_thread.join();
@@ -336,6 +353,57 @@ struct TileRunner {
     ~TileRunner()
     {
         if (started) { dev_q.close(); dev_thread.join(); out_thread.join(); }
+    }
+
+    // stage 2 of a tile of TEXT: parse and LRT on the device; the CPU parser only when a line is not what the writer produces
+    void run_device_text(Tile &T)
+    {
+        const int ng = groups ? (int)groups->names.size() : 0;
+        const double t0 = StageClock::now();
+        int64_t n_ent = 0, n_ind = 0;
+        int rc = bvc_pileup_begin(ctx, T.text.data(), (int64_t)T.text.size(), T.line_start.data(), sample0.data(), n_in_batch.data(),
+                                  (int32_t)sample0.size(), (int32_t)T.n_pos, &n_ent, &n_ind);
+        if (rc == BVC_PILEUP_IRREGULAR) {
+            // the reference's rules (strtok_r, atoi) on this tile's lines, position by position, batch by batch; then the ragged call
+            tiles_cpu_parsed += 1;
+            set_parser_carry(carry);
+            const size_t nb = sample0.size();
+            for (size_t t = 0; t < T.n_pos; ++t) {
+                SiteColumn &site = T.slot();
+                site.clear();
+                site.pos = T.pos[t];
+                int32_t j = 0;
+                for (size_t b = 0; b < nb; ++b) {
+                    const uint32_t s0 = T.line_start[b * (T.n_pos + 1) + t], s1 = T.line_start[b * (T.n_pos + 1) + t + 1];
+                    j += parse_pileup_line(T.text.data() + s0, (size_t)(s1 - s0 - 1), j, site);
+                }
+                if (!site.aiv.empty()) { T.refs[T.n_used] = T.refs[t]; ++T.n_used; }
+            }
+            T.refs.resize(T.n_used);
+            get_parser_carry(carry);
+            clk_dev.pack += StageClock::now() - t0;
+            if (T.n_used) run_device(T);
+            return;
+        }
+        if (rc != BVC_OK) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(ctx));
+        tiles_dev_parsed += 1;
+        T.entry_off.resize(T.n_pos + 1);
+        T.tally.resize(T.n_pos * 32);
+        T.ent.resize((size_t)n_ent + 1);
+        T.samples.resize((size_t)n_ent + 1);
+        T.indels.resize((size_t)n_ind + 1);
+        T.res.resize(T.n_pos);
+        T.gres.resize(T.n_pos * (size_t)ng);
+        uint8_t carry_out[5];
+        rc = bvc_pileup_finish(ctx, T.refs.data(), min_af, carry, carry_out, ng ? groups->of_sample.data() : nullptr,
+                               ng ? (int64_t)groups->of_sample.size() : 0, ng, T.entry_off.data(), T.tally.data(), T.ent.data(),
+                               T.samples.data(), T.indels.data(), T.res.data(), ng ? T.gres.data() : nullptr);
+        if (rc != BVC_OK) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(ctx));
+        std::memcpy(carry, carry_out, 5);
+        T.indels.resize((size_t)n_ind);
+        std::sort(T.indels.begin(), T.indels.end(), [](const bvc_pileup_indel &a, const bvc_pileup_indel &b) { return a.entry < b.entry; });
+        T.dev_parsed = true;
+        clk_dev.gpu += StageClock::now() - t0;
     }
 
     // stage 2: the tile in the form libbvc takes, and the call
@@ -430,10 +498,49 @@ struct TileRunner {
     // stage 3: the CVG line of every position, the VCF line of every called one (bt_f, src/BaseVarC.cpp:548-666)
     void write_out(Tile &T)
     {
-        const int64_t ns = (int64_t)T.n_used;
         const int ng = groups ? (int)groups->names.size() : 0;
         StageClock &c = clk_out;
         double t0 = StageClock::now(), t1;
+        if (T.dev && T.dev_parsed) {
+            // the position's slice of the arrays the device returned; its tallies (src/BaseVarC.cpp:560-590) from the 32 counters
+            size_t ii = 0;                                   // next indel record (sorted by entry)
+            std::vector<std::string> ind_text;
+            for (size_t t = 0; t < T.n_pos; ++t) {
+                const int64_t e0 = T.entry_off[t], e1 = T.entry_off[t + 1];
+                if (e1 == e0) continue;                      // no entry: the reference skips the position (:443)
+                const int32_t *ta = &T.tally[t * 32];
+                int32_t cnt[4], fwd[8], rev[8];
+                for (int b = 0; b < 8; ++b) { rev[b] = ta[b] + ta[16 + b]; fwd[b] = ta[8 + b] + ta[24 + b]; }
+                for (int b = 0; b < 4; ++b) cnt[b] = ta[b] + ta[8 + b];
+                ind_text.clear();
+                for (; ii < T.indels.size() && T.indels[ii].entry < e1; ++ii)
+                    ind_text.emplace_back(T.text.data() + T.indels[ii].text_off, (size_t)T.indels[ii].len);
+                SiteView v;
+                v.pos = T.pos[t];
+                v.aiv = reinterpret_cast<const Entry *>(&T.ent[(size_t)e0]);
+                v.sample = &T.samples[(size_t)e0];
+                v.n = (size_t)(e1 - e0);
+                v.cnt = cnt; v.fwd = fwd; v.rev = rev;
+                v.indels = ind_text.data(); v.n_indels = ind_text.size();
+                const bvc_group_result *g = ng ? &T.gres[t * (size_t)ng] : nullptr;
+                const std::string cl = cvg_line(chr, T.refs[t], v, g, ng);
+                t1 = StageClock::now(); c.cvg += t1 - t0; t0 = t1;
+                fcvg->write(cl);
+                t1 = StageClock::now(); c.write += t1 - t0; t0 = t1;
+                if (T.res[t].called) {
+                    std::map<std::string, std::string> info;
+                    if (ng) group_af_info(T.res[t], g, *groups, info);
+                    const std::string vl = vcf_line(T.res[t], chr, T.refs[t], v, info, n_samples);
+                    t1 = StageClock::now(); c.vcf += t1 - t0; t0 = t1;
+                    fvcf->write(vl);
+                    t1 = StageClock::now(); c.write += t1 - t0; t0 = t1;
+                }
+                const int64_t done = ++sites_done;
+                if (!(done % 1000)) std::cerr << "basetype completed " << done << " sites -- thread" << ithread << std::endl;
+            }
+            return;
+        }
+        const int64_t ns = (int64_t)T.n_used;
         for (int64_t s = 0; s < ns; ++s) {
             const bvc_group_result *g = ng ? &T.gres[(size_t)(s * ng)] : nullptr;
             const std::string cl = cvg_line(chr, T.sites[s].pos, T.refs[s], T.sites[s], g, ng);
@@ -578,7 +685,54 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
     size_t lo, hi;
     thread_window(pv.size(), thread, ithread, lo, hi);
     int32_t count = 0;
+    tr.ithread = ithread;
+    // Tiles of TEXT for the device parser (the default with the reference's text batches): BVC_HOST_DEVICE_PARSE=0 keeps the CPU
+    // parser (A/B runs, and what the quality-shift test hook and the binary batch forms use)
+    bool dev_parse = !qual_shift && !(getenv("BVC_HOST_DEVICE_PARSE") && atoi(getenv("BVC_HOST_DEVICE_PARSE")) == 0);
+    for (auto fp : fpiv) if (fp->bin) dev_parse = false;
     const double t_loop = StageClock::now();
+    if (dev_parse) {
+        // per batch: its first sample and its samples, from the names line (tab-terminated names, src/BaseVarC.cpp:495, 503)
+        int32_t j0 = 0;
+        for (auto fp : fpiv) {
+            const int32_t n_in = (int32_t)std::count(fp->names.begin(), fp->names.end(), '\t');
+            tr.sample0.push_back(j0); tr.n_in_batch.push_back(n_in);
+            j0 += n_in;
+        }
+        get_parser_carry(tr.carry);                                     // (zeros: reset_parser_carry above)
+        // a tile: --tile positions at most, and about BVC_HOST_TILE_MB of text (default 32) going by the tile before it
+        const double target = 1048576.0 * (getenv("BVC_HOST_TILE_MB") ? std::max(1, atoi(getenv("BVC_HOST_TILE_MB"))) : 32);
+        double bytes_per_pos = 0;
+        const size_t nb = fpiv.size();
+        for (size_t ip = lo; ip < hi;) {
+            size_t T = (size_t)std::min<int64_t>(tile, (int64_t)(hi - ip));
+            if (bytes_per_pos > 0) T = std::min(T, (size_t)std::max(1.0, target / bytes_per_pos));
+            else T = std::min<size_t>(T, 64);
+            Tile &tl = *tr.cur;
+            tl.dev = true; tl.n_pos = T;
+            tl.text.clear();
+            tl.line_start.resize(nb * (T + 1));
+            double t0 = StageClock::now();
+            for (size_t b = 0; b < nb; ++b) {
+                tl.text.resize((tl.text.size() + 15) & ~(size_t)15, '\n');    // every batch's lines from a 16-byte boundary
+                if (fpiv[b]->rd.read_lines(T, tl.text, &tl.line_start[b * (T + 1)]) != T)
+                    throw std::runtime_error("ERROR: truncated temp batch (it ends before the thread's window does)");
+                if (tl.text.size() > (size_t)0xF0000000u) throw std::runtime_error("ERROR: more than 3.75 GiB of text in one tile: lower --tile");
+            }
+            tr.clk.read += StageClock::now() - t0;
+            tl.refs.resize(T);
+            tl.pos.resize(T);
+            for (size_t k = 0; k < T; ++k) {
+                const int32_t p = pv[ip + k];
+                const char rc = refseq[(size_t)(p - rg_s)];
+                tl.pos[k] = p;
+                tl.refs[k] = rc == 'A' ? 0 : rc == 'C' ? 1 : rc == 'G' ? 2 : rc == 'T' ? 3 : -1;
+            }
+            bytes_per_pos = (double)tl.text.size() / (double)T;
+            tr.flush();
+            ip += T;
+        }
+    } else
     for (size_t ip = lo; ip < hi; ++ip) {
         const int32_t p = pv[ip];
         SiteColumn &site = tr.slot();                                   // parsed in place: no copy into the tile
@@ -606,7 +760,8 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
     const double loop_s = StageClock::now() - t_loop, setup_s = t_loop - t_start;
     if (getenv("BVC_HOST_PROFILE")) {
         std::cerr << "[profile] thread " << ithread << ": library calls on one-byte tiles " << tr.tiles_one_byte << ", on two-byte tiles "
-                  << tr.tiles_two_byte << std::endl;
+                  << tr.tiles_two_byte << "; tiles of text parsed on the device " << tr.tiles_dev_parsed << ", handed back to the CPU parser "
+                  << tr.tiles_cpu_parsed << std::endl;
         const StageClock &c = tr.clk, &d = tr.clk_dev, &o = tr.clk_out;
         std::cerr << "[profile] thread " << ithread << ": stage 1 read+inflate " << c.read << " s, parse " << c.parse << " s | stage 2 pack "
                   << d.pack << " s, libbvc " << d.gpu << " s | stage 3 cvg lines " << o.cvg << " s, vcf lines " << o.vcf

@@ -57,6 +57,14 @@ static inline int atoi_span(const char *&p, const char *end)   // atoi on a fiel
 static thread_local AlleleInfo g_carry;
 
 void reset_parser_carry() { g_carry = AlleleInfo(); g_carry.base = 0; }
+void get_parser_carry(uint8_t out[5])
+{
+    out[0] = g_carry.base; out[1] = g_carry.mapq; out[2] = g_carry.qual; out[3] = g_carry.rpr; out[4] = g_carry.strand;
+}
+void set_parser_carry(const uint8_t in[5])
+{
+    g_carry.base = in[0]; g_carry.mapq = in[1]; g_carry.qual = in[2]; g_carry.rpr = in[3]; g_carry.strand = in[4];
+}
 
 int parse_pileup_line(const char *line, size_t len, int32_t j0, SiteColumn &site)
 {
@@ -293,16 +301,16 @@ std::string vcf_header(const Groups &g, const std::string &reference, const std:
 }
 
 // ---- CVG line: bt_f, src/BaseVarC.cpp:548-610 + group columns :617-663 ------------------------------------
-std::string cvg_line(const std::string &chr, int32_t pos, int8_t ref_base, const SiteColumn &site,
-                     const bvc_group_result *grp, int n_groups)
+std::string cvg_line(const std::string &chr, int8_t ref_base, const SiteView &site, const bvc_group_result *grp, int n_groups)
 {
+    const int32_t pos = site.pos;
     // depth per base (non-indel entries) and forward / reverse counts per base value of EVERY entry -- indel entries
     // take part in the strand tallies with the fields they carry (src/BaseVarC.cpp:575-590 reads a.base and a.strand
     // of all of aiv) -- were taken as the entries were appended (SiteColumn::add); the ref and alt columns are picked
     // from them here.
     const int32_t *cnt = site.cnt, *fwd = site.fwd, *rev = site.rev;
     std::map<std::string, int> indel_m;    // the reference iterates a hash map here (:570-573): order by key instead
-    for (auto const &t : site.indels) indel_m[t] += 1;
+    for (size_t i = 0; i < site.n_indels; ++i) indel_m[site.indels[i]] += 1;
     std::string indels = ".";
     if (!indel_m.empty()) {
         indels.clear();
@@ -371,9 +379,10 @@ static const std::string &bp_field(uint8_t qual)
 }
 
 // ---- VCF line: WriteVcf, src/BaseType.cpp:141-234 ---------------------------------------------------------
-std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int32_t pos, int8_t ref_base,
-                     const SiteColumn &site, std::map<std::string, std::string> &info, int32_t n_samples)
+std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int8_t ref_base, const SiteView &site,
+                     std::map<std::string, std::string> &info, int32_t n_samples)
 {
+    const int32_t pos = site.pos;
     std::string alt_gt[8];                                        // genotype string per base code 0..7
     bool has_gt[8] = {false, false, false, false, false, false, false, false};
     auto is_alt = [&bt](int b) { for (int i = 0; i < bt.n_alt; ++i) if (bt.alt_base[i] == b) return true; return false; };
@@ -383,7 +392,7 @@ std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int32_t 
     std::string samgt;
     size_t k = 0;
     for (int32_t i = 0; i < n_samples; ++i) {
-        if (k >= site.sample.size() || site.sample[k] != i) { samgt += "./.\t"; continue; }
+        if (k >= site.n || site.sample[k] != i) { samgt += "./.\t"; continue; }
         const Entry &a = site.aiv[k++];
         if (!has_gt[a.base]) { alt_gt[a.base] = "./."; has_gt[a.base] = true; }
         const std::string &gt = (a.base == ref_base) ? std::string("0/.") : alt_gt[a.base];

@@ -81,6 +81,25 @@ struct SiteColumn {
     }
 };
 
+// What the emitters read of a position, wherever it lives: a SiteColumn the CPU parser filled, or a position's slice of the arrays
+// the device parser returned (bvc_pileup_finish).
+struct SiteView {
+    int32_t pos = 0;
+    const Entry *aiv = nullptr;
+    const int32_t *sample = nullptr;
+    size_t n = 0;                       // entries
+    const int32_t *cnt = nullptr, *fwd = nullptr, *rev = nullptr;   // [4], [8], [8]
+    const std::string *indels = nullptr;    // indel text of the entries with is_indel = 1, in entry order
+    size_t n_indels = 0;
+};
+inline SiteView view_of(const SiteColumn &c)
+{
+    SiteView v;
+    v.pos = c.pos; v.aiv = c.aiv.data(); v.sample = c.sample.data(); v.n = c.aiv.size();
+    v.cnt = c.cnt; v.fwd = c.fwd; v.rev = c.rev; v.indels = c.indels.data(); v.n_indels = c.indels.size();
+    return v;
+}
+
 // Population groups: name-sorted (std::map order in the reference, src/BaseVarC.cpp:98, 358-362).
 struct Groups {
     std::vector<std::string> names;
@@ -110,6 +129,9 @@ void format_pileup_token(const AlleleInfo *a, std::string &out);           // a 
 int parse_pileup_line(const char *line, size_t len, int32_t j0, SiteColumn &site);
 // The parser carries one AlleleInfo across calls within a thread, as bt_s does; call this at thread start.
 void reset_parser_carry();
+// base, mapq, qual, rpr, strand of that AlleleInfo: tiles parsed on the device and tiles parsed here hand it back and forth
+void get_parser_carry(uint8_t out[5]);
+void set_parser_carry(const uint8_t in[5]);
 
 // ---- temp-batch binary form (additive: `--tmp-format bin`; the text form above stays the default) ----------------
 // Same content as the text form, without the tokenising: a BGZF stream of
@@ -134,11 +156,24 @@ std::string cvg_header(const Groups &g);
 std::string vcf_header(const Groups &g, const std::string &reference, const std::vector<std::string> &sample_names);
 
 // CVG line without the trailing newline handling of groups: pass grp (n_groups records) or nullptr.
-std::string cvg_line(const std::string &chr, int32_t pos, int8_t ref_base, const SiteColumn &site,
-                     const bvc_group_result *grp, int n_groups);
+std::string cvg_line(const std::string &chr, int8_t ref_base, const SiteView &site, const bvc_group_result *grp, int n_groups);
+inline std::string cvg_line(const std::string &chr, int32_t pos, int8_t ref_base, const SiteColumn &site,
+                            const bvc_group_result *grp, int n_groups)
+{
+    SiteView v = view_of(site);
+    v.pos = pos;
+    return cvg_line(chr, ref_base, v, grp, n_groups);
+}
 // VCF line for a called site.  info carries the "<group>_AF" entries; the rest is filled here.
-std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int32_t pos, int8_t ref_base,
-                     const SiteColumn &site, std::map<std::string, std::string> &info, int32_t n_samples);
+std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int8_t ref_base, const SiteView &site,
+                     std::map<std::string, std::string> &info, int32_t n_samples);
+inline std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int32_t pos, int8_t ref_base,
+                            const SiteColumn &site, std::map<std::string, std::string> &info, int32_t n_samples)
+{
+    SiteView v = view_of(site);
+    v.pos = pos;
+    return vcf_line(bt, chr, ref_base, v, info, n_samples);
+}
 // "<group>_AF" values from the group records (src/BaseVarC.cpp:646-658).
 void group_af_info(const bvc_site_result &bt, const bvc_group_result *grp, const Groups &g,
                    std::map<std::string, std::string> &info);

@@ -51,7 +51,7 @@ EXPORTS = [
     "bvc_synchronize", "bvc_set_overlap", "bvc_join", "bvc_set_profiling", "bvc_get_profile", "bvc_lrt_dense", "bvc_lrt_dense_groups",
     "bvc_lrt_csr", "bvc_lrt_csr_comb", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense", "bvc_stream_read_ms", "bvc_set_tuning",
     "bvc_lrt_dense_packed", "bvc_pack_dense", "bvc_hist_dense_packed", "bvc_lrt_dense_groups_packed",
-    "bvc_lrt_csr_packed",
+    "bvc_lrt_csr_packed", "bvc_lrt_csr_groups", "bvc_pileup_begin", "bvc_pileup_finish",
 ]
 
 _lib = None
@@ -113,6 +113,12 @@ def load_library():
     L.bvc_hist_dense_packed.argtypes = [vp, i64, i64, i64, vp, vp, u32]
     L.bvc_lrt_csr_packed.restype = C.c_int
     L.bvc_lrt_csr_packed.argtypes = [vp, i64, vp, vp, vp, dbl, vp, u32]
+    L.bvc_lrt_csr_groups.restype = C.c_int
+    L.bvc_lrt_csr_groups.argtypes = [vp, i64, vp, vp, vp, vp, vp, dbl, vp, i64, i32, vp, vp, u32]
+    L.bvc_pileup_begin.restype = C.c_int
+    L.bvc_pileup_begin.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.bvc_pileup_finish.restype = C.c_int
+    L.bvc_pileup_finish.argtypes = [vp, vp, dbl, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -239,6 +245,69 @@ class Context:
                                              _np_ptr(cb) if cb is not None else None,
                                              _np_ptr(nc) if nc is not None else None, _np_ptr(out), BVC_PTR_HOST))
         return out
+
+    def lrt_csr_groups(self, offsets, bases, quals, sample_of_obs, ref_base, min_af, group_of_sample, n_groups):
+        """The --group loop on ragged sites: per observation its sample index; group_of_sample[n_samples] (>= n_groups: no group)."""
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        b = np.ascontiguousarray(bases, dtype=np.int8)
+        q = np.ascontiguousarray(quals, dtype=np.int8)
+        sm = np.ascontiguousarray(sample_of_obs, dtype=np.int32)
+        r = np.ascontiguousarray(ref_base, dtype=np.int8)
+        g = np.ascontiguousarray(group_of_sample, dtype=np.uint8)
+        n = len(o) - 1
+        out = np.zeros(n, dtype=SITE_DTYPE)
+        gout = np.zeros((n, n_groups), dtype=GROUP_DTYPE)
+        self._check(self._L.bvc_lrt_csr_groups(self._h, n, _np_ptr(o), _np_ptr(b), _np_ptr(q), _np_ptr(sm), _np_ptr(r), float(min_af),
+                                               _np_ptr(g), len(g), int(n_groups), _np_ptr(out), _np_ptr(gout), BVC_PTR_HOST))
+        return out, gout
+
+    def lrt_csr_groups_device(self, offsets_t, bases_t, quals_t, samples_t, ref_t, min_af, group_t, n_groups):
+        import torch
+        ns = offsets_t.numel() - 1
+        res = torch.empty(ns * SITE_DTYPE.itemsize, dtype=torch.uint8, device=bases_t.device)
+        gres = torch.empty(ns * n_groups * GROUP_DTYPE.itemsize, dtype=torch.uint8, device=bases_t.device)
+        self._check(self._L.bvc_lrt_csr_groups(self._h, ns, _dev_ptr(offsets_t), _dev_ptr(bases_t), _dev_ptr(quals_t), _dev_ptr(samples_t),
+                                               _dev_ptr(ref_t), float(min_af), _dev_ptr(group_t), group_t.numel(), int(n_groups),
+                                               _dev_ptr(res), _dev_ptr(gres), BVC_PTR_DEVICE))
+        return res, gres
+
+    def pileup_tile(self, text, line_start, sample0, n_in_batch, ref_base, min_af, carry_in=(0, 0, 0, 0, 0), group_of_sample=None,
+                    n_groups=0):
+        """bvc_pileup_begin + bvc_pileup_finish on one tile of temp-batch pileup text (include/bvc.h).  text: bytes;
+        line_start: uint32 [n_batches, n_positions + 1].  Returns None when a line is not regular (BVC_PILEUP_IRREGULAR), else a
+        dict: entry_off, tally [T, 32], entries (structured), samples, indels (sorted by entry), results, grp_results, carry_out."""
+        ls = np.ascontiguousarray(line_start, dtype=np.uint32)
+        nb, T = ls.shape[0], ls.shape[1] - 1
+        s0 = np.ascontiguousarray(sample0, dtype=np.int32)
+        nib = np.ascontiguousarray(n_in_batch, dtype=np.int32)
+        buf = np.frombuffer(bytes(text), dtype=np.uint8)
+        ne, ni = C.c_int64(0), C.c_int64(0)
+        rc = self._L.bvc_pileup_begin(self._h, _np_ptr(buf) if len(buf) else None, len(buf), _np_ptr(ls), _np_ptr(s0), _np_ptr(nib), nb, T,
+                                      C.byref(ne), C.byref(ni))
+        if rc == 1:
+            return None
+        self._check(rc)
+        ENTRY = np.dtype([("base", "u1"), ("mapq", "u1"), ("qual", "u1"), ("rpr", "u1"), ("strand", "u1"), ("is_indel", "u1"), ("pad", "<u2")])
+        INDEL = np.dtype([("entry", "<i8"), ("text_off", "<i8"), ("len", "<i4"), ("pad", "<i4")])
+        r = np.ascontiguousarray(ref_base, dtype=np.int8)
+        assert r.shape == (T,)
+        entry_off = np.zeros(T + 1, dtype=np.int64)
+        tally = np.zeros((T, 32), dtype=np.int32)
+        entries = np.zeros(max(1, ne.value), dtype=ENTRY)
+        samples = np.zeros(max(1, ne.value), dtype=np.int32)
+        indels = np.zeros(max(1, ni.value), dtype=INDEL)
+        res = np.zeros(T, dtype=SITE_DTYPE)
+        gres = np.zeros((T, max(1, n_groups)), dtype=GROUP_DTYPE)
+        g = np.ascontiguousarray(group_of_sample, dtype=np.uint8) if n_groups else np.zeros(0, dtype=np.uint8)
+        cin = np.asarray(carry_in, dtype=np.uint8)
+        cout = np.zeros(5, dtype=np.uint8)
+        self._check(self._L.bvc_pileup_finish(self._h, _np_ptr(r), float(min_af), _np_ptr(cin), _np_ptr(cout), _np_ptr(g) if n_groups else None,
+                                              len(g), int(n_groups), _np_ptr(entry_off), _np_ptr(tally), _np_ptr(entries), _np_ptr(samples),
+                                              _np_ptr(indels), _np_ptr(res), _np_ptr(gres) if n_groups else None))
+        ind = indels[:ni.value]
+        ind = ind[np.argsort(ind["entry"], kind="stable")]
+        return dict(entry_off=entry_off, tally=tally, entries=entries[:ne.value], samples=samples[:ne.value], indels=ind, results=res,
+                    grp_results=gres if n_groups else None, carry_out=[int(x) for x in cout])
 
     def lrt_csr_packed(self, offsets, packed, ref_base, min_af):
         """Ragged sites at one byte per observation (base << 6 | qual); host arrays, synchronous."""

@@ -39,6 +39,8 @@ extern "C" {
 #define BVC_ERR_DEVICE      -2   /* HIP runtime error; text in bvc_last_error */
 #define BVC_ERR_NO_DEVICE   -3   /* no gfx950 device / device index out of range */
 #define BVC_ERR_ALLOC       -4   /* device or host allocation failed */
+#define BVC_PILEUP_IRREGULAR 1   /* bvc_pileup_begin only, not an error: a line of the tile is not of the shape the reference's
+                                    writer produces; nothing was computed, parse this tile with the reference's own rules */
 
 /* flags for the compute entry points */
 #define BVC_PTR_HOST    0u       /* every data pointer is host memory; the call is synchronous */
@@ -194,6 +196,66 @@ int bvc_lrt_dense_groups_packed(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples
 int bvc_pack_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,
                    const int8_t *bases, const int8_t *quals, int64_t packed_stride, uint8_t *packed,
                    int64_t *n_unrepresentable, uint32_t flags);
+
+/*
+ * Additive: the caller's --group loop on RAGGED columns (src/BaseVarC.cpp:617-661 works on each site's COVERED samples: the
+ * vectors of :550-559 plus, per entry, which sample it came from, :633-636).  bvc_lrt_csr with, per observation, the index of
+ * its sample: sample_of_obs[i] in 0..n_samples-1 (anything else: in no group); group_of_sample[n_samples] as in
+ * bvc_lrt_dense_groups.  grp_results is [n_sites][n_groups].  Same records as bvc_lrt_dense_groups on the dense tile that holds
+ * the same observations, bit for bit (the per-group histograms are the same counts), without building, uploading or reading
+ * n_samples bytes per site: at the coverage of the cohorts this tool is for (6-10 %) that is 10-16 x fewer bytes.
+ */
+int bvc_lrt_csr_groups(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets, const int8_t *bases, const int8_t *quals,
+                       const int32_t *sample_of_obs, const int8_t *ref_base, double min_af,
+                       const uint8_t *group_of_sample, int64_t n_samples, int32_t n_groups,
+                       bvc_site_result *results, bvc_group_result *grp_results, uint32_t flags);
+
+/* ---- the producer of the hot path's input on the device (additive) ------------------------------------------------------ */
+/*
+ * The reference's position loop (bt_s, src/BaseVarC.cpp:403-441) reads one line of every temp-batch file per position and
+ * tokenises it with strtok_r / atoi into the position's entries; bt_f then tallies depths and strands (:548-590), builds the
+ * (base, qual) vectors (:550-559) and calls BaseType on them (:612-613; per group :617-661).  These two calls do all of that for
+ * a TILE of positions from the inflated TEXT of the temp batches (format: writer :509-527): the text goes to the device as it is,
+ * the parsed columns feed the LRT there, and what bt_f and WriteVcf read afterwards comes back.
+ *
+ *   text         the tile's text: for every temp batch the lines of the tile's positions ('\n' after each), anywhere in the buffer
+ *   line_start   [n_batches][n_positions + 1] offsets into text: line t of batch b starts at line_start[b * (n_positions + 1) + t];
+ *                entry n_positions of a batch = one past the '\n' of its last line (lines of a batch are consecutive)
+ *   sample0      [n_batches] index of the batch's first sample (the running j of :407); n_in_batch: samples (= tokens per line)
+ *
+ * bvc_pileup_begin uploads and counts; it returns BVC_OK and the sizes of what bvc_pileup_finish will deliver, or
+ * BVC_PILEUP_IRREGULAR when some line is not what the reference's writer produces (tokens ". ", "b,m,q,r,s " with 1-3 digits a
+ * field, or an indel token starting '+', '-' or 'N'; ONE space after every token; as many tokens as the batch has samples): the
+ * reference's parser gives such lines a meaning too (strtok_r, atoi), which the caller then applies itself (host/pileup.cpp).
+ * bvc_pileup_finish (only after a begin that returned BVC_OK, same context) parses, runs the LRT of every position on the device
+ * (bvc_lrt_csr on the non-indel entries; bvc_lrt_csr_groups when n_groups > 0) and returns
+ *   entry_off  [n_positions + 1]  entries of position t = entries[entry_off[t] .. entry_off[t + 1]), in sample order
+ *   tally      [n_positions][32]  [strand << 3 | base] counts of the base entries, + 16 for the indel entries (:560-590)
+ *   entries / samples             the entry and the sample it belongs to (aiv and the inverse of idx, :428-429)
+ *   indels     [n_indels]         which entries are indel tokens and where their text is (any order)
+ *   results / grp_results         as bvc_lrt_csr / bvc_lrt_csr_groups
+ * carry: base, mapq, qual, rpr, strand of the last base token parsed before the tile / after it -- the reference keeps ONE
+ * AlleleInfo alive across tokens, lines and positions and an indel token only sets is_indel / indel (:392, 407-440), so an indel
+ * entry shows the fields of the last base token before it.
+ * Host pointers only; both calls synchronise the context's stream.
+ */
+typedef struct bvc_pileup_entry {       /* AlleleInfo without its string, src/BamProcess.h:30-39 */
+    uint8_t  base, mapq, qual, rpr, strand, is_indel;
+    uint16_t pad;
+} bvc_pileup_entry;
+typedef struct bvc_pileup_indel {
+    int64_t entry;                      /* index into entries */
+    int64_t text_off;                   /* the token's text in the caller's buffer */
+    int32_t len;
+    int32_t pad;
+} bvc_pileup_indel;
+int bvc_pileup_begin(bvc_ctx *ctx, const char *text, int64_t text_bytes, const uint32_t *line_start,
+                     const int32_t *sample0, const int32_t *n_in_batch, int32_t n_batches, int32_t n_positions,
+                     int64_t *n_entries, int64_t *n_indels);
+int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const uint8_t carry_in[5], uint8_t carry_out[5],
+                      const uint8_t *group_of_sample, int64_t n_samples, int32_t n_groups,
+                      int64_t *entry_off, int32_t *tally, bvc_pileup_entry *entries, int32_t *samples,
+                      bvc_pileup_indel *indels, bvc_site_result *results, bvc_group_result *grp_results);
 
 /* ---- the two stages on their own (used by the parity tests; also valid entry points) -------------- */
 /* Stage 1: counts[s * 512 + base * 128 + qual] = number of covered samples of that class (exact). */

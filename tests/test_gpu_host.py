@@ -25,7 +25,7 @@ def test_basetype_command_on_reference_test_data(tmp_path, thread, grouped, tmp_
     env = None
     if tmp_format == "two_byte_tiles":                            # --group tiles go to libbvc packed (one byte per sample)
         import os                                                 # unless a quality does not fit; this forces the two-byte tiles
-        env = dict(os.environ, BVC_HOST_TWO_BYTE_TILES="1")
+        env = dict(os.environ, BVC_HOST_TWO_BYTE_TILES="1", BVC_HOST_DEVICE_PARSE="0")      # (dense tiles are the CPU parser's path)
     elif tmp_format != "text":                                    # additive: binary temp batches, same outputs
         cmd += ["--tmp-format", tmp_format]
     group_of = None
@@ -194,3 +194,56 @@ def test_a_temp_batch_cut_short_is_an_error_in_both_forms(tmp_path):
         assert r.returncode == 1, (fmt, r.returncode, r.stderr[-500:])
         assert "truncated temp batch" in r.stderr or "malformed temp batch" in r.stderr, r.stderr[-500:]
         assert os.path.exists(victim)
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_device_parsed_tiles_write_what_cpu_parsed_tiles_write(tmp_path, grouped):
+    """The text batches of the reference's test data through both feeds of the compute phase: tiles of text parsed on the device
+    (bvc_pileup_begin / bvc_pileup_finish, the default; with --group the ragged group call) and the CPU parser
+    (BVC_HOST_DEVICE_PARSE=0; with --group dense tiles).  Same VCF and CVG, byte for byte, whatever the tile size (tiles of 1, 37
+    and the default), and the device run really parsed on the device.  One batch file then gets a line the reference's writer never
+    produces (two spaces in a row, which strtok_r skips): that tile -- and only that tile -- goes through the CPU parser, and the
+    outputs are those of the CPU feed on the same files."""
+    import os
+    import re
+    from basevarc_amd import build as b
+    from tests import hostref
+    from tools.host_bench import _bgzf_write
+    exe, _ = b.build_host()
+    fa = hostref.write_fasta(str(tmp_path / "chr17.fa"))
+    lst = hostref.write_bam_list(str(tmp_path / "bam.list"))
+    extra = []
+    if grouped:
+        names = hostref.Pipeline(mapq=20, batch=25, thread=1).names
+        gf = tmp_path / "groups.txt"
+        gf.write_text("".join(f"{n} {['EAS', 'AFR', 'EUR'][i % 3]}\n" for i, n in enumerate(names) if i % 14 != 5))
+        extra += ["-g", str(gf)]
+    base = str(tmp_path / "base")
+    r = _run(exe, base, lst, fa, extra + ["--keep_tmp"], dict(os.environ, BVC_HOST_DEVICE_PARSE="0", BVC_HOST_PROFILE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert sum(int(x) for x in re.findall(r"parsed on the device (\d+)", r.stderr)) == 0
+    want = [gzip.decompress(open(base + k, "rb").read()) for k in (".vcf.gz", ".cvg.gz")]
+    assert want[0].count(b"\n") > 30
+
+    def rerun(tile, env_extra=None):
+        env = dict(os.environ, BVC_HOST_PROFILE="1", **(env_extra or {}))
+        rr = _run(exe, base, lst, fa, extra + ["--keep_tmp", "--rerun"] + (["--tile", str(tile)] if tile else []), env)
+        assert rr.returncode == 0, rr.stderr[-2000:]
+        dev = sum(int(x) for x in re.findall(r"parsed on the device (\d+)", rr.stderr))
+        cpu = sum(int(x) for x in re.findall(r"handed back to the CPU parser (\d+)", rr.stderr))
+        return [gzip.decompress(open(base + k, "rb").read()) for k in (".vcf.gz", ".cvg.gz")], dev, cpu
+    for tile in (0, 37, 1):
+        got, dev, cpu = rerun(tile)
+        assert got == want, tile
+        assert dev > 0 and cpu == 0, (tile, dev, cpu)
+    # a line with a run of two spaces in batch 1 of thread 0: the same columns to strtok_r, not a line the device parses
+    victim = f"{base}.tmp.thread.0/batch.1"
+    raw = gzip.decompress(open(victim, "rb").read()).split(b"\n")
+    k = next(i for i, l in enumerate(raw) if i > 2000 and l.count(b",") >= 8)
+    raw[k] = raw[k].replace(b" ", b"  ", 1)
+    tmp = str(tmp_path / "victim.raw")
+    open(tmp, "wb").write(b"\n".join(raw))
+    _bgzf_write(tmp, victim)
+    got, dev, cpu = rerun(64)
+    assert got == want
+    assert cpu == 1 and dev > 10, (dev, cpu)

@@ -1,0 +1,291 @@
+"""Round 5 (GPU): the producer side on the device and the ragged group loop.
+
+* bvc_pileup_begin / bvc_pileup_finish: a tile of temp-batch pileup TEXT (the reference's own format, writer
+  src/BaseVarC.cpp:509-527) parsed on the device must give the columns the reference's position loop builds from it
+  (src/BaseVarC.cpp:403-441: entries in sample order, N bases dropped, bit-field widths, indel entries inheriting the fields of the last
+  base token parsed before them -- across lines, positions and tiles), the tallies bt_f takes (:560-590) and the records of
+  bvc_lrt_csr on those columns.  Checked against the Python restatement of that parser (oracle/emit_oracle.py Parser) on the
+  reference's test data and on fuzzed regular lines; lines the reference's writer cannot produce must be REPORTED, not guessed.
+* bvc_lrt_csr_groups: the caller's --group loop (src/BaseVarC.cpp:617-661) on ragged columns, against the oracle's group loop and,
+  byte for byte, against the dense group call on the tile that holds the same observations.
+"""
+import numpy as np
+import pytest
+
+from oracle import emit_oracle as eo
+from oracle import orc
+from tests.test_gpu_parity import AF_ATOL, assert_site_matches
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from basevarc_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+# ------------------------------------------------------------------------------------------------ pileup text on the device
+def tile_of(batch_lines):
+    """batch_lines[b] = list of T lines (no newline).  Returns (text, line_start [nb, T + 1])."""
+    nb, T = len(batch_lines), len(batch_lines[0])
+    text = bytearray()
+    ls = np.zeros((nb, T + 1), dtype=np.uint32)
+    for b, lines in enumerate(batch_lines):
+        while len(text) % 16 != (b * 5) % 16:                      # chunks at every alignment
+            text += b"#"
+        for t, l in enumerate(lines):
+            ls[b, t] = len(text)
+            text += l.encode() + b"\n"
+        ls[b, T] = len(text)
+    return bytes(text), ls
+
+
+def reference_columns(batch_lines, parser):
+    """What bt_s builds per position: (aiv, sample) with the restated parser, lines taken position by position, batch by batch."""
+    nb, T = len(batch_lines), len(batch_lines[0])
+    return [parser.parse([batch_lines[b][t] for b in range(nb)]) for t in range(T)]
+
+
+def check_tile(ctx, batch_lines, n_in_batch, ref, min_af, parser, carry_in, where=""):
+    text, ls = tile_of(batch_lines)
+    sample0 = np.concatenate([[0], np.cumsum(n_in_batch)[:-1]]).astype(np.int32)
+    out = ctx.pileup_tile(text, ls, sample0, n_in_batch, ref, min_af, carry_in=carry_in)
+    assert out is not None, where + ": reported as irregular"
+    cols = reference_columns(batch_lines, parser)
+    T = len(cols)
+    eoff = out["entry_off"]
+    assert eoff[0] == 0 and eoff[T] == len(out["entries"]) == sum(len(a) for a, _ in cols), where
+    indel_texts = {int(r["entry"]): text[int(r["text_off"]):int(r["text_off"]) + int(r["len"])].decode() for r in out["indels"]}
+    assert len(indel_texts) == len(out["indels"])
+    sites = []
+    for t, (aiv, sample) in enumerate(cols):
+        e = out["entries"][eoff[t]:eoff[t + 1]]
+        assert len(e) == len(aiv), (where, t)
+        assert out["samples"][eoff[t]:eoff[t + 1]].tolist() == sample, (where, t)
+        tally = np.zeros(32, dtype=np.int64)
+        for k, a in enumerate(aiv):
+            got = tuple(int(e[k][f]) for f in ("base", "mapq", "qual", "rpr", "strand", "is_indel"))
+            assert got == (a["base"], a["mapq"], a["qual"], a["rpr"], a["strand"], a["is_indel"]), (where, t, k, got, a)
+            tally[(16 if a["is_indel"] else 0) + (a["strand"] << 3 | a["base"])] += 1
+            if a["is_indel"]:
+                assert indel_texts[int(eoff[t]) + k] == a["indel"], (where, t, k)
+        assert out["tally"][t].tolist() == tally.tolist(), (where, t)
+        b = np.array([a["base"] for a in aiv if not a["is_indel"]], dtype=np.int8)
+        q = np.array([a["qual"] for a in aiv if not a["is_indel"]], dtype=np.uint8).astype(np.int8)
+        sites.append((b, q))
+    assert set(indel_texts) == {int(eoff[t]) + k for t, (aiv, _) in enumerate(cols) for k, a in enumerate(aiv) if a["is_indel"]}
+    # the records: bvc_lrt_csr on the same columns, byte for byte
+    offs = np.concatenate([[0], np.cumsum([len(b) for b, _ in sites])]).astype(np.int64)
+    allb = np.concatenate([b for b, _ in sites] + [np.zeros(0, np.int8)])
+    allq = np.concatenate([q for _, q in sites] + [np.zeros(0, np.int8)])
+    want = ctx.lrt_csr(offs, allb if len(allb) else np.zeros(1, np.int8), allq if len(allq) else np.zeros(1, np.int8), ref, min_af)
+    assert out["results"].tobytes() == want.tobytes(), where
+    ai = parser.ai
+    assert out["carry_out"] == [ai["base"], ai["mapq"], ai["qual"], ai["rpr"], ai["strand"]], where
+    return out, sites
+
+
+def random_token(rng, p_data, p_indel, wide=False):
+    u = rng.random()
+    if u < p_data:
+        hi = 1000 if wide else 100
+        base = int(rng.integers(0, 8 if wide else 5))
+        return f"{base},{rng.integers(0, hi if wide else 61)},{rng.integers(0, hi if wide else 42)},{rng.integers(0, hi)},{rng.integers(0, 10 if wide else 2)}"
+    if u < p_data + p_indel:
+        kind = rng.integers(3)
+        if kind == 0:
+            return "N"
+        seq = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 30))))
+        return ("+" if kind == 1 else "-") + seq
+    return "."
+
+
+@pytest.mark.parametrize("shape", ["sparse", "dense", "indel_heavy", "wide_fields", "tiny_batches"])
+def test_device_parse_of_fuzzed_regular_lines_equals_the_restated_parser(ctx, shape):
+    """Regular lines of every kind the writer can produce, at every alignment: tokens crossing the 16-byte lanes and the 1 KiB steps,
+    indel tokens first in a line / after an N base / in runs, fields of three digits (bit-field wrap: base & 7, strand & 1, the
+    others mod 256), batches of one sample, empty positions; three consecutive tiles share one parser state (the carry)."""
+    rng = np.random.default_rng({"sparse": 1, "dense": 2, "indel_heavy": 3, "wide_fields": 4, "tiny_batches": 5}[shape])
+    p_data, p_indel, wide = {"sparse": (0.08, 0.004, False), "dense": (0.9, 0.02, False), "indel_heavy": (0.2, 0.3, False),
+                             "wide_fields": (0.5, 0.05, True), "tiny_batches": (0.3, 0.05, False)}[shape]
+    n_in_batch = np.array({"tiny_batches": [1, 2, 1, 3, 1, 1, 7, 1]}.get(shape, [700, 37, 1, 300]), dtype=np.int32)
+    parser = eo.Parser()
+    carry = [0, 0, 0, 0, 0]
+    for tile in range(3):
+        T = [13, 1, 40][tile]
+        batch_lines = [["".join(random_token(rng, p_data if (t + tile) % 7 else 0.0, p_indel, wide) + " " for _ in range(n)) for t in range(T)]
+                       for n in n_in_batch]
+        ref = rng.integers(0, 4, T).astype(np.int8)
+        out, _ = check_tile(ctx, batch_lines, n_in_batch, ref, 0.001, parser, carry, where=f"{shape} tile {tile}")
+        carry = out["carry_out"]
+
+
+def test_device_parse_of_the_reference_test_data_batches(ctx):
+    """BASELINE configs[0]'s own temp batches (100 BAMs, chr17:41197700-41276155, -q 20; written by the restated bt_r): every tile of
+    2048 positions of one thread's window, batch = 30 samples, against the restated parser; records against bvc_lrt_csr."""
+    from tests import hostref
+    P = hostref.Pipeline(mapq=20, batch=30, thread=1)
+    files = P.batch_files()
+    nb = 1 + (P.n - 1) // P.batch
+    per_batch = [files[(0, ib)].split("\n")[1:-1] for ib in range(nb)]
+    n_in_batch = np.array([min(P.batch, P.n - ib * P.batch) for ib in range(nb)], dtype=np.int32)
+    assert all(len(pb) == len(P.pv) for pb in per_batch)
+    parser = eo.Parser()
+    carry = [0, 0, 0, 0, 0]
+    n_entries = 0
+    for t0 in range(0, len(P.pv), 2048)[:12]:
+        t1 = min(len(P.pv), t0 + 2048)
+        ref = np.array(["ACGT".index(P.refseq[p - P.rg_s]) for p in P.pv[t0:t1]], dtype=np.int8)
+        out, _ = check_tile(ctx, [pb[t0:t1] for pb in per_batch], n_in_batch, ref, P.min_af, parser, carry, where=f"test data tile {t0}")
+        carry = out["carry_out"]
+        n_entries += len(out["entries"])
+    assert n_entries > 100000
+
+
+def test_lines_the_writer_cannot_produce_are_reported_not_guessed(ctx):
+    """strtok_r / atoi give a meaning to lines the reference's writer never produces (runs of spaces, missing fields, signs, a last token
+    without its space ...).  The device does not imitate that: every such tile is reported (BVC_PILEUP_IRREGULAR -> None here) and the
+    host program then parses it with the reference's rules on the CPU (tests/test_gpu_host.py).  A regular tile beside each is accepted."""
+    good = ["1,30,25,7,1 . . 0,60,40,12,0 ", ". . . +ACG "]
+    n = np.array([4], dtype=np.int32)
+    ref = np.zeros(2, dtype=np.int8)
+
+    def run(lines, nib=n):
+        text, ls = tile_of([lines])
+        return ctx.pileup_tile(text, ls, [0], nib, ref, 0.001)
+    assert run(good) is not None
+    for bad_line in ["1,30,25,7,1  . . 0,60,40,12,0 ",      # two spaces
+                     " 1,30,25,7,1 . . 0,60,40,12,0 ",      # leading space
+                     "1,30,25,7,1 . . 0,60,40,12,0",        # no space behind the last token
+                     "1,30,25,7 . . 0,60,40,12,0 ",         # four fields
+                     "1,30,25,7,1,9 . . 0,60,40,12,0 ",     # six fields
+                     "1,30,2555,7,1 . . 0,60,40,12,0 ",     # four digits
+                     "1,30,,7,1 . . 0,60,40,12,0 ",         # empty field
+                     "1,30,25,7,1 .x . 0,60,40,12,0 ",      # a '.' token with a tail
+                     "1,30,25,7,1 A . 0,60,40,12,0 ",       # a token of no known kind
+                     "1,30,25,7,1 . 0,60,40,12,0 ",         # three tokens for four samples
+                     "1,30,25,7,1 . . . 0,60,40,12,0 ",     # five
+                     "1,30,2x,7,1 . . 0,60,40,12,0 ",       # a letter in a field
+                     ""]:
+        assert run([bad_line, good[1]]) is None, bad_line
+        assert run([good[0], bad_line]) is None, bad_line
+    assert run(good) is not None                             # the context is as usable as before
+    # a batch of no samples has empty lines
+    text, ls = tile_of([good, ["", ""]])
+    out = ctx.pileup_tile(text, ls, [0, 4], np.array([4, 0], dtype=np.int32), ref, 0.001)
+    assert out is not None and len(out["entries"]) == 3
+
+
+def test_empty_tiles_and_positions_without_entries(ctx):
+    out = ctx.pileup_tile(b"", np.zeros((0, 1), dtype=np.uint32), [], [], np.zeros(0, dtype=np.int8), 0.001, carry_in=[3, 9, 8, 7, 1])
+    assert out is not None and out["entry_off"].tolist() == [0] and out["carry_out"] == [3, 9, 8, 7, 1]
+    lines = [". . . ", "4,1,1,1,1 . . ", ". N . "]            # nothing, an N base only (dropped, but it IS the last base token), an indel
+    text, ls = tile_of([lines])
+    out = ctx.pileup_tile(text, ls, [5], [3], np.zeros(3, dtype=np.int8), 0.001, carry_in=[2, 50, 33, 6, 1])
+    assert out["entry_off"].tolist() == [0, 0, 0, 1] and out["samples"].tolist() == [6]
+    e = out["entries"][0]
+    assert (int(e["base"]), int(e["mapq"]), int(e["qual"]), int(e["rpr"]), int(e["strand"]), int(e["is_indel"])) == (4, 1, 1, 1, 1, 1)
+    assert out["results"]["called"].tolist() == [0, 0, 0] and out["carry_out"] == [4, 1, 1, 1, 1]
+    # the same indel first in the tile: the carry of the tile before
+    text, ls = tile_of([[". N . "]])
+    out = ctx.pileup_tile(text, ls, [5], [3], np.zeros(1, dtype=np.int8), 0.001, carry_in=[2, 50, 33, 6, 1])
+    e = out["entries"][0]
+    assert (int(e["base"]), int(e["mapq"]), int(e["qual"]), int(e["rpr"]), int(e["strand"]), int(e["is_indel"])) == (2, 50, 33, 6, 1, 1)
+    assert out["tally"][0][16 + (1 << 3 | 2)] == 1 and out["tally"][0].sum() == 1 and out["carry_out"] == [2, 50, 33, 6, 1]
+
+
+# ------------------------------------------------------------------------------------------------ the group loop on ragged columns
+def ragged_group_case(rng, n_sites, n_samples, k, coverage, ungrouped=0.1):
+    labels = rng.integers(0, k, n_samples).astype(np.uint8)
+    labels[rng.random(n_samples) < ungrouped] = 255
+    sites = []
+    for s in range(n_sites):
+        cov = coverage if s % 9 else 0.0                                 # some sites without a single observation
+        who = np.nonzero(rng.random(n_samples) < cov)[0].astype(np.int32)
+        ref = int(rng.integers(0, 4))
+        af = float(rng.choice([0.0, 0.0, 0.02, 0.3]))
+        alt = (ref + 1 + int(rng.integers(0, 3))) % 4
+        b = np.where(rng.random(len(who)) < af, alt, ref).astype(np.int8)
+        q = rng.integers(5, 42, len(who)).astype(np.int8)
+        err = rng.random(len(who)) < 10.0 ** (-q / 10.0)
+        b[err] = (b[err] + 1 + rng.integers(0, 3, int(err.sum()))) % 4
+        if s % 11 == 3 and len(who) > 4:
+            b[:2] = 5                                                    # entries that are no A/C/G/T: skipped (src/BaseVarC.cpp:551-559)
+        sites.append((who, b, q, ref))
+    return labels, sites
+
+
+@pytest.mark.parametrize("k", [1, 5, 32])
+def test_csr_groups_against_the_oracles_group_loop_and_the_dense_group_call(ctx, k):
+    rng = np.random.default_rng(100 + k)
+    n_samples = 6000
+    labels, sites = ragged_group_case(rng, 130, n_samples, k, coverage=0.08)
+    m = min(0.001, 100.0 / n_samples)
+    offs = np.concatenate([[0], np.cumsum([len(w) for w, _, _, _ in sites])]).astype(np.int64)
+    allb = np.concatenate([b for _, b, _, _ in sites]); allq = np.concatenate([q for _, _, q, _ in sites])
+    alls = np.concatenate([w for w, _, _, _ in sites])
+    ref = np.array([r for _, _, _, r in sites], dtype=np.int8)
+    res, gres = ctx.lrt_csr_groups(offs, allb, allq, alls, ref, m, labels, k)
+    # the dense tile with the same observations: the same bytes
+    B = np.full((len(sites), n_samples), -1, dtype=np.int8); Q = np.zeros((len(sites), n_samples), dtype=np.int8)
+    for s, (w, b, q, _) in enumerate(sites):
+        B[s, w] = b; Q[s, w] = q
+    dres, dgres = ctx.lrt_dense_groups(B, Q, ref, m, labels, k)
+    assert res.tobytes() == dres.tobytes() and gres.tobytes() == dgres.tobytes()
+    ran = called = 0
+    for s, (w, b, q, r) in enumerate(sites):
+        o, gd, ga, gr, gp = orc.dense_site_groups(B[s], Q[s], r, m, labels, k)
+        assert_site_matches(res[s], o, where=f"k={k} site {s}", path_strict=False)
+        called += o["called"]
+        for g in range(k):
+            assert gres[s, g]["depth"].tolist() == gd[g].tolist(), (s, g)
+            assert int(gres[s, g]["ran"]) == int(gr[g]) and int(gres[s, g]["present"]) == int(gp[g]), (s, g)
+            ran += int(gr[g])
+            for i in range(o["n_alt"]):
+                if gp[g] >> i & 1:
+                    assert abs(float(gres[s, g]["af"][i]) - float(ga[g][i])) <= AF_ATOL, (s, g, i)
+    assert called > 10 and ran > 10
+    # device pointers: the same records
+    import torch
+    from basevarc_amd.lib import results_from_tensor
+    d = [torch.from_numpy(x).cuda() for x in (offs, allb, allq, alls, ref, labels)]
+    rt, gt = ctx.lrt_csr_groups_device(d[0], d[1], d[2], d[3], d[4], m, d[5], k)
+    ctx.synchronize()
+    assert results_from_tensor(rt).tobytes() == res.tobytes() and gt.cpu().numpy().tobytes() == gres.tobytes()
+
+
+def test_csr_groups_sample_indices_outside_the_label_vector_are_in_no_group(ctx):
+    offs = np.array([0, 6], dtype=np.int64)
+    b = np.array([0, 0, 1, 1, 0, 1], dtype=np.int8); q = np.full(6, 30, dtype=np.int8)
+    smp = np.array([0, 1, 2, -1, 7, 1000000], dtype=np.int32)
+    labels = np.array([0, 1, 0, 1], dtype=np.uint8)
+    res, gres = ctx.lrt_csr_groups(offs, b, q, smp, np.zeros(1, np.int8), 0.001, labels, 2)
+    assert res[0]["depth"].tolist() == [3, 3, 0, 0]
+    assert gres[0, 0]["depth"].tolist() == [1, 1, 0, 0] and gres[0, 1]["depth"].tolist() == [1, 0, 0, 0]
+
+
+def test_device_parse_with_groups_feeds_the_ragged_group_loop(ctx):
+    """bvc_pileup_finish with n_groups > 0 = the parse + bvc_lrt_csr_groups on its columns (sample indices from the token positions)."""
+    rng = np.random.default_rng(9)
+    n_in_batch = np.array([200, 200, 77], dtype=np.int32)
+    N = int(n_in_batch.sum())
+    labels = rng.integers(0, 4, N).astype(np.uint8); labels[::13] = 255
+    T = 60
+    batch_lines = [["".join(random_token(rng, 0.5, 0.02) + " " for _ in range(n)) for _ in range(T)] for n in n_in_batch]
+    text, ls = tile_of(batch_lines)
+    ref = rng.integers(0, 4, T).astype(np.int8)
+    out = ctx.pileup_tile(text, ls, [0, 200, 400], n_in_batch, ref, 0.001, group_of_sample=labels, n_groups=3)
+    cols = reference_columns(batch_lines, eo.Parser())
+    offs, bb, qq, ss = [0], [], [], []
+    for aiv, sample in cols:
+        for a, j in zip(aiv, sample):
+            if not a["is_indel"]:
+                bb.append(a["base"]); qq.append(a["qual"]); ss.append(j)
+        offs.append(len(bb))
+    res, gres = ctx.lrt_csr_groups(np.array(offs, np.int64), np.array(bb, np.int8), np.array(qq, np.int8), np.array(ss, np.int32), ref, 0.001,
+                                   labels, 3)
+    assert out["results"].tobytes() == res.tobytes() and out["grp_results"].tobytes() == gres.tobytes()
+    assert res["called"].sum() > 5 and gres["ran"].sum() > 5

@@ -767,3 +767,31 @@ def test_thread_windows_device_map_and_merge_order_give_position_ordered_output(
         assert pos == sorted(pos) and len(set(pos)) == len(pos)
         assert len(pos) == (psize if suffix == ".cvg.gz" else len(range(0, psize, 97)))
         assert not any(os.path.exists(f"{out}.{i}{suffix}") for i in range(thread))
+
+
+def test_read_lines_hands_over_whole_lines_with_their_starts(H, tmp_path):
+    """BgzfReader::read_lines (what the tiles the device parses are filled with): n lines per call, appended with their newlines,
+    the start of every line noted -- across BGZF block ends, for lines longer than a block, empty lines, a last line without a
+    newline (not returned), with and without read-ahead: the concatenation is the file up to its last newline."""
+    H.bvchost_bgzf_write.restype = C.c_int
+    H.bvchost_bgzf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int, C.c_int]
+    H.bvchost_bgzf_read_lines.restype = C.c_int64
+    H.bvchost_bgzf_read_lines.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]
+    rng = np.random.default_rng(12)
+    cases = []
+    lines = [". " * int(rng.integers(0, 4000)) for _ in range(300)] + ["", "", "x" * 200000, ""] + ["1,2,3,4,5 " * 10] * 50
+    cases.append(("".join(l + "\n" for l in lines)).encode())
+    cases.append(cases[0] + b"a last line without its newline")
+    cases.append(b"")
+    cases.append(b"\n")
+    cases.append(b"no newline at all")
+    for ci, data in enumerate(cases):
+        f = str(tmp_path / f"rl{ci}.gz").encode()
+        assert H.bvchost_bgzf_write(f, data, len(data), 65537, 6, 0) == 1
+        want = data[:data.rfind(b"\n") + 1]
+        for n_per_call in (1, 7, 1000):
+            for threads in (0, 2):
+                out = C.create_string_buffer(len(data) + 16)
+                nl = C.c_int64(0)
+                got = H.bvchost_bgzf_read_lines(f, n_per_call, threads, out, len(data) + 16, C.byref(nl))
+                assert got == len(want) and out.raw[:got] == want and nl.value == want.count(b"\n"), (ci, n_per_call, threads, got)
