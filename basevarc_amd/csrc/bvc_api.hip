@@ -491,6 +491,7 @@ int bvc_create(bvc_ctx **out, int device)
     ctx->ls.group_pipe = env_int("BVC_GROUP_PIPE", 0, 1, 1);
     ctx->ls.group_log2c = env_int("BVC_GROUP_LOG2C", 0, 5, -1);
     ctx->ls.group_big_lds = env_int("BVC_GROUP_BIG_LDS", 0, 1, 1);
+    ctx->ls.group_h16 = env_int("BVC_GROUP_H16", 0, 1, 0);
     ctx->ls.em_streams = env_int("BVC_EM_STREAMS", 0, 3, 0);
     ctx->ls.em_engine = env_int("BVC_EM_ENGINE", 0, 1, 0);
 #ifdef BVC_DIAG_KNOBS
@@ -1371,6 +1372,7 @@ int bvc_set_tuning(bvc_ctx *ctx, const char *key, int value)
     if (std::strcmp(key, "group_pipe") == 0 && (value == 0 || value == 1)) { ctx->ls.group_pipe = value; return BVC_OK; }
     if (std::strcmp(key, "group_copies_log2") == 0 && value >= -1 && value <= 5) { ctx->ls.group_log2c = value; return BVC_OK; }
     if (std::strcmp(key, "group_big_lds") == 0 && (value == 0 || value == 1)) { ctx->ls.group_big_lds = value; return BVC_OK; }
+    if (std::strcmp(key, "group_h16") == 0 && (value == 0 || value == 1)) { ctx->ls.group_h16 = value; return BVC_OK; }
     if (std::strcmp(key, "em_engine") == 0 && value >= 0 && value <= 1) { ctx->ls.em_engine = value; return BVC_OK; }
     if (std::strcmp(key, "em_tiny_regions") == 0 && value >= 0 && value <= 1) { ctx->ls.em_tiny_regions = value; return BVC_OK; }
     if (std::strcmp(key, "em_prune") == 0 && value >= 0 && value <= 1) { ctx->ls.em_prune = value; return BVC_OK; }

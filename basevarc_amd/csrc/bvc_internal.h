@@ -22,6 +22,8 @@ struct LaunchState {
     int group_big_lds = 1;     // any-order group histograms, 4 groups and more: 1 = one 1024-thread workgroup per CU with 256 slots x
                                // 16 / 8 / 4 copies per histogram (up to 9 / 18 / 36 histograms in 144 KiB of LDS; two-byte rows packed in
                                // registers), 0 = 512-thread workgroups of <= 64 KiB
+    int group_h16 = 0;         // any-order group histograms on packed rows / packed-in-registers rows: 1 = 32 conflict-free copies of
+                               // 16-bit counter pairs (hist_kernel.hip "H16"), 0 = 16 copies of 32-bit counters
     int em_engine = 0;         // stage 2: 0 = item engine (em_items.hip; em_kernel.hip takes the sites it leaves),
                                // 1 = one wavefront per site for every site (em_kernel.hip): A/B runs.  The two agree to
                                // rounding (1e-15 on AF), not bit for bit: a call's records never depend on the call's

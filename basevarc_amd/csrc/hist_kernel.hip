@@ -1057,6 +1057,129 @@ __device__ __forceinline__ uint32_t shl_half(uint32_t w, uint32_t shift)
     return r;
 }
 
+// 1 << (byte BYTE of `amounts`) in one instruction (SDWA byte select on the shift amount).
+template <int BYTE>
+__device__ __forceinline__ uint32_t one_shl_byte(uint32_t amounts, uint32_t one)
+{
+    uint32_t r;
+    if (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(amounts), "v"(one));
+    if (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(amounts), "v"(one));
+    if (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(amounts), "v"(one));
+    if (BYTE == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(amounts), "v"(one));
+    return r;
+}
+
+__device__ __forceinline__ void lds_add_value(uint32_t lds_byte_address, uint32_t v)
+{
+#ifdef BVC_CHECK_LDS
+    if (!BVC_LDS_OK(3, lds_byte_address, lds_bytes_of_workgroup() - 3u)) return;
+#endif
+    __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)lds_byte_address, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ---- round 5: 32 conflict-free copies with TWO 16-bit counters per LDS word (H16) --------------------------------------------
+// The 16-copy forms above put two lanes of every 32-lane group on one bank whenever their slots have the same parity (bank =
+// copy + 16 * (slot & 1)): SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 49 % (profiles/r04_pmc_summary.md).  Here slots 2j and 2j + 1
+// share a word -- the add is 1 << 16 * (slot & 1) -- so [histogram][128 slot pairs][32 copies] takes the same 96 KiB at k = 5 and the
+// bank of an update is lane mod 32 whatever the data, as in hist_dense_kernel.  A copy's counter sees at most N / 32 samples of a
+// site: N <= kH16MaxSamples (the launcher keeps the 16-copy kernels beyond it).  Cost: the value of the add (1.5 VALU instructions
+// per sample: one mask-and-shift per four samples, one SDWA shift per sample).
+constexpr int64_t kH16MaxSamples = 2000000;
+constexpr int kH16Threads = 1024;
+
+// the four samples of one packed word and their four labels
+__device__ __forceinline__ void count_word_h16(uint32_t pw, uint32_t gw, uint32_t copy4, uint32_t one)
+{
+    const uint32_t lo = __builtin_amdgcn_perm(gw, pw, 0x05010400u);   // [g1 p1 g0 p0]
+    const uint32_t hi = __builtin_amdgcn_perm(gw, pw, 0x07030602u);   // [g3 p3 g2 p2]
+    const uint32_t amounts = (pw & 0x01010101u) << 4;                 // 16 * (slot & 1) per sample
+    // word address = (slot >> 1) * 128 + copy * 4 = ((slot << 6) & ~127) | copy << 2   (the histograms start at LDS address 0)
+    lds_add_value((shl_half<0>(lo, 6) & 0xFFFFFF80u) | copy4, one_shl_byte<0>(amounts, one));
+    lds_add_value((shl_half<1>(lo, 6) & 0xFFFFFF80u) | copy4, one_shl_byte<1>(amounts, one));
+    lds_add_value((shl_half<0>(hi, 6) & 0xFFFFFF80u) | copy4, one_shl_byte<2>(amounts, one));
+    lds_add_value((shl_half<1>(hi, 6) & 0xFFFFFF80u) | copy4, one_shl_byte<3>(amounts, one));
+}
+
+// Fold of one site: thread per slot pair; writes every class of every histogram (qualities 63..127 have no slot: zero).
+__device__ __forceinline__ void fold_h16(uint32_t *hist, int n_hist, uint32_t *__restrict__ dst, int tid)
+{
+    for (int pk = tid; pk < n_hist * 128; pk += kH16Threads) {
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            u32x4 *p = reinterpret_cast<u32x4 *>(&hist[pk * 32 + 4 * ((j + pk) & 7)]);
+            const u32x4 x = *p;
+            lo += (x.x & 0xFFFFu) + (x.y & 0xFFFFu) + (x.z & 0xFFFFu) + (x.w & 0xFFFFu);
+            hi += (x.x >> 16) + (x.y >> 16) + (x.z >> 16) + (x.w >> 16);
+            *p = u32x4{0u, 0u, 0u, 0u};
+        }
+        const int h = pk >> 7, r = pk & 127, b = r >> 5, q = (2 * r) & 63;
+        uint32_t *d = dst + h * BVC_NCLASS + b * 128 + q;
+        d[0] = lo;
+        d[1] = q + 1 == 63 ? 0u : hi;                                // slot 63 of an allele: "no observation"
+        d[64] = 0u; d[65] = 0u;
+    }
+}
+
+// hist_packed_groups_kernel's job (labels in any order, packed rows) with the H16 counters; 16-byte aligned rows only.
+__global__ __launch_bounds__(kH16Threads) void hist_packed_groups_h16_kernel(
+    int64_t n_sites, int64_t n_samples, int64_t row_stride, const uint8_t *__restrict__ packed,
+    const uint8_t *__restrict__ hist_of_sample, int n_groups, uint32_t *__restrict__ grp_counts,
+    const int64_t *__restrict__ bounds)
+{
+    BVC_POISON_LDS();
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [hist][128 slot pairs][32 copies]
+    if (bounds[0] == 0) return;                                   // ordered by group: hist_packed_ranges_kernel has the call
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int THREADS = kH16Threads;
+    const int tid = threadIdx.x;
+    const int n_hist = n_groups + 1;
+    const int words = n_hist * 128 * 32;
+    const uint32_t copy4 = lds_address(hist) + (((uint32_t)tid & 31u) << 2);
+    uint32_t one = 1u;
+    asm volatile("" : "+v"(one));                                 // a VGPR for the SDWA shifts
+    for (int i = tid * 4; i < words; i += THREADS * 4)
+        *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    const int64_t n16 = n_samples >> 4;
+    const u32x4 *gv = reinterpret_cast<const u32x4 *>(hist_of_sample);
+    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
+        const uint8_t *row = packed + site * row_stride;
+        const u32x4 *rv = reinterpret_cast<const u32x4 *>(row);
+        constexpr int64_t kBlockChunks = 2 * (int64_t)THREADS;
+        for (int64_t cb = 0; cb < n16; cb += kBlockChunks) {
+            u32x4 p[2], g[2];
+            if (cb + kBlockChunks <= n16) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int64_t c = cb + tid + (int64_t)u * THREADS;
+                    p[u] = __builtin_nontemporal_load(&rv[c]); g[u] = gv[c];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int64_t c = cb + tid + (int64_t)u * THREADS;
+                    p[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // past the end: slot 255 ...
+                    g[u] = u32x4{0u, 0u, 0u, 0u};                                       // ... of histogram 0
+                    if (c < n16) { p[u] = __builtin_nontemporal_load(&rv[c]); g[u] = gv[c]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                count_word_h16(p[u].x, g[u].x, copy4, one); count_word_h16(p[u].y, g[u].y, copy4, one);
+                count_word_h16(p[u].z, g[u].z, copy4, one); count_word_h16(p[u].w, g[u].w, copy4, one);
+            }
+        }
+        for (int64_t i = (n16 << 4) + tid; i < n_samples; i += THREADS) {
+            const uint32_t slot = ((uint32_t)hist_of_sample[i] << 8) | row[i];
+            lds_add_value(((slot >> 1) << 7) + copy4, 1u << (16u * (slot & 1u)));
+        }
+        __syncthreads();
+        fold_h16(hist, n_hist, grp_counts + site * n_hist * BVC_NCLASS, tid);
+        __syncthreads();
+    }
+}
+
 // Labels in any order on packed rows: LDS [hist][256 slots][copies], copies = 1 << LOG2C as many as fit 64 KiB (8 at
 // k = 5, against 4 of the two-byte kernel: half the bank conflicts), counter byte address =
 // (label << 8 | packed byte) << (2 + LOG2C) | copy << 2.  The 16-bit (label, byte) pairs of two samples are put
@@ -1334,6 +1457,7 @@ enum KernelSlot : uint32_t {
     kSlotCsrPacked0 = 44, kSlotCsrPacked1 = 45,
     kSlotPackedGroupsBig = 46,  // + (4 - log2 copies): 46..48
     kSlotGroupSlots = 49,       // + (4 - log2 copies): 49..51
+    kSlotPackedGroupsH16 = 52, kSlotGroupSlotsH16 = 53,
 };
 constexpr size_t kBigLdsBytes = 144 * 1024;      // a workgroup may take the CU's whole LDS (160 KiB); stage 2 keeps 16 KiB beside it
 
@@ -1492,6 +1616,15 @@ hipError_t launch_hist_packed_groups(LaunchState &st, hipStream_t stream, int64_
     // sites), underneath stage 2 -- the way the calls run -- 5 % faster (0.90 against 0.95) and stage 2 itself a fifth
     // (profiles/r03_group_anyorder_experiments.txt).  The same form of the two-byte kernel (8 copies, 96 KiB) LOSES 15 %
     // underneath stage 2 and is not kept.
+    // round 5: two 16-bit counters per word, 32 conflict-free copies (same LDS as 16 copies of words); st.group_h16 picks it
+    const size_t hlds = (size_t)n_hist * 128 * 32 * sizeof(uint32_t);
+    if (st.group_h16 && st.group_big_lds && aligned && log2c < 4 && hlds <= kBigLdsBytes && n_samples <= kH16MaxSamples) {
+        e = raise_lds(st, kSlotPackedGroupsH16, reinterpret_cast<const void *>(hist_packed_groups_h16_kernel), kBigLdsBytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(hist_packed_groups_h16_kernel, dim3((unsigned)(n_sites < 4096 ? n_sites : 4096)), dim3(kH16Threads), hlds, stream,
+                           n_sites, n_samples, row_stride, packed, hist_of_sample, n_groups, counts, group_scratch);
+        return hipGetLastError();
+    }
     int bl = 4;                                                  // 16 / 8 / 4 copies in one workgroup's LDS: up to 9 / 18 / 36 histograms
     while (bl > 2 && ((size_t)n_hist * kPackedSlots << bl) * sizeof(uint32_t) > kBigLdsBytes) --bl;
     if (st.group_big_lds && aligned && log2c < bl && ((size_t)n_hist * kPackedSlots << bl) * sizeof(uint32_t) <= kBigLdsBytes) {
