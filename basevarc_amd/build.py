@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbvc.so")
-SOURCES = ["bvc_api.hip", "hist_kernel.hip", "em_kernel.hip", "em_items.hip", "synth_kernel.hip", "pileup_kernel.hip"]
+SOURCES = ["bvc_api.hip", "hist_kernel.hip", "em_kernel.hip", "em_items.hip", "synth_kernel.hip", "pileup_kernel.hip", "inflate_kernel.hip"]
 DEPS = ["bvc_device.h", "bvc_internal.h", "synth_tables.inc", os.path.join("..", "..", "include", "bvc.h")]
 
 

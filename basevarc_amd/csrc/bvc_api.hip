@@ -1094,6 +1094,49 @@ int bvc_lrt_csr_groups(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets, co
     return BVC_OK;
 }
 
+// ---- BGZF blocks on the device (inflate_kernel.hip) ------------------------------------------------------------------------
+int bvc_inflate_blocks(bvc_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, const bvc_bgzf_block *blocks, int64_t n_blocks,
+                       uint8_t *out, int64_t out_bytes, uint32_t *status, uint32_t flags)
+{
+    if (!ctx) return BVC_ERR_ARG;
+    if (n_blocks < 0 || comp_bytes < 0 || out_bytes < 0) return fail(ctx, BVC_ERR_ARG, "negative size");
+    if (n_blocks == 0) return BVC_OK;
+    if (!comp || !blocks || !status || (!out && out_bytes > 0)) return fail(ctx, BVC_ERR_ARG, "null data pointer");
+    BVC_HIP(ctx, hipSetDevice(ctx->device));
+    if (flags & BVC_PTR_DEVICE) {
+        BVC_HIP(ctx, launch_inflate(ctx->stream, comp, blocks, n_blocks, out, status));
+        return BVC_OK;
+    }
+    for (int64_t i = 0; i < n_blocks; ++i) {
+        const bvc_bgzf_block &b = blocks[i];
+        if (b.comp_off < 0 || b.comp_len < 0 || b.comp_off + b.comp_len > comp_bytes || b.isize < 0 || b.isize > 65536 || b.out_off < 0 ||
+            b.out_off + b.isize > out_bytes)
+            return fail(ctx, BVC_ERR_ARG, "block outside its buffer");
+    }
+    const size_t c_al = al256((size_t)comp_bytes + 16), b_al = al256((size_t)n_blocks * sizeof(bvc_bgzf_block)), s_al = al256((size_t)n_blocks * 4);
+    int rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_stage[0]), &ctx->stage_cap[0], c_al + b_al + s_al + (size_t)out_bytes + 256);
+    if (rc != BVC_OK) return rc;
+    char *p = ctx->d_stage[0];
+    uint8_t *d_c = reinterpret_cast<uint8_t *>(p); p += c_al;
+    bvc_bgzf_block *d_b = reinterpret_cast<bvc_bgzf_block *>(p); p += b_al;
+    uint32_t *d_s = reinterpret_cast<uint32_t *>(p); p += s_al;
+    uint8_t *d_o = reinterpret_cast<uint8_t *>(p);
+    auto drained = [&](int code) { if (code != BVC_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); } return code; };
+#define BVC_HIP_D(call)                                                                   \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) return drained(fail(ctx, BVC_ERR_DEVICE, #call, e__));     \
+    } while (0)
+    BVC_HIP_D(hipMemcpyAsync(d_c, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, ctx->stream));
+    BVC_HIP_D(hipMemcpyAsync(d_b, blocks, (size_t)n_blocks * sizeof(bvc_bgzf_block), hipMemcpyHostToDevice, ctx->stream));
+    BVC_HIP_D(launch_inflate(ctx->stream, d_c, d_b, n_blocks, d_o, d_s));
+    BVC_HIP_D(hipMemcpyAsync(status, d_s, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_bytes) BVC_HIP_D(hipMemcpyAsync(out, d_o, (size_t)out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BVC_HIP_D(hipStreamSynchronize(ctx->stream));
+#undef BVC_HIP_D
+    return BVC_OK;
+}
+
 // ---- temp-batch pileup text -> columns -> records (pileup_kernel.hip) -------------------------------------------------------
 int bvc_pileup_begin(bvc_ctx *ctx, const char *text, int64_t text_bytes, const uint32_t *line_start,
                      const int32_t *sample0, const int32_t *n_in_batch, int32_t n_batches, int32_t n_positions,
@@ -1356,6 +1399,8 @@ int bvc_debug_report(bvc_ctx *ctx, uint32_t *out24, int reset)
     BVC_HIP(ctx, debug_read_items(out24 + 16, reset != 0));
     uint32_t pl[8];                                              // pileup_kernel.hip: folded into the histogram unit's count
     BVC_HIP(ctx, debug_read_pileup(pl, reset != 0));
+    if (pl[0]) { if (out24[0] == 0) for (int i = 1; i < 8; ++i) out24[i] = pl[i]; out24[0] += pl[0]; }
+    BVC_HIP(ctx, debug_read_inflate(pl, reset != 0));
     if (pl[0]) { if (out24[0] == 0) for (int i = 1; i < 8; ++i) out24[i] = pl[i]; out24[0] += pl[0]; }
     return BVC_OK;
 }

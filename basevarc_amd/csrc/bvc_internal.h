@@ -148,7 +148,11 @@ hipError_t launch_hist_csr_groups(LaunchState &st, hipStream_t stream, int64_t n
                                   const int8_t *quals, const int32_t *sample_of_obs, const uint8_t *group_of_sample, int64_t n_samples,
                                   int n_groups, uint32_t *counts);
 
+// inflate_kernel.hip: raw deflate of whole BGZF blocks, one wavefront per block; status[i] != 0: block i is not valid deflate of isize bytes
+hipError_t launch_inflate(hipStream_t stream, const uint8_t *comp, const bvc_bgzf_block *blocks, int64_t n_blocks, uint8_t *out, uint32_t *status);
+
 #ifdef BVC_CHECK_LDS
+hipError_t debug_read_inflate(uint32_t *out8, bool reset);
 hipError_t debug_read_pileup(uint32_t *out8, bool reset);
 // diagnostic builds: each translation unit's violation record (bvc_device.h)
 hipError_t debug_read_hist(uint32_t *out8, bool reset);

@@ -1204,13 +1204,14 @@ __global__ __launch_bounds__(THREADS) void hist_packed_groups_kernel(
         *reinterpret_cast<u32x4 *>(&hist[i]) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
     constexpr uint32_t SH = 2 + LOG2C;
+    // round 5: each sample's 16-bit (label, byte) key by ONE v_perm_b32 ([0 0 g p], the zero bytes from selector 0x0C) and its counter
+    // address by ONE v_lshl_add_u32: 2 VALU instructions per sample where two perms per word + an SDWA shift + an add were 2.5.
+    // (The kernel answers to its VALU count, not to its LDS conflicts: profiles/r05_group_h16.txt.)
     auto count_word = [&](uint32_t pw, uint32_t gw) {
-        const uint32_t lo = __builtin_amdgcn_perm(gw, pw, 0x05010400u);   // [g1 p1 g0 p0]
-        const uint32_t hi = __builtin_amdgcn_perm(gw, pw, 0x07030602u);   // [g3 p3 g2 p2]
-        lds_add_one(shl_half<0>(lo, SH) + lane_base);
-        lds_add_one(shl_half<1>(lo, SH) + lane_base);
-        lds_add_one(shl_half<0>(hi, SH) + lane_base);
-        lds_add_one(shl_half<1>(hi, SH) + lane_base);
+        lds_add_one((__builtin_amdgcn_perm(gw, pw, 0x0C0C0400u) << SH) + lane_base);
+        lds_add_one((__builtin_amdgcn_perm(gw, pw, 0x0C0C0501u) << SH) + lane_base);
+        lds_add_one((__builtin_amdgcn_perm(gw, pw, 0x0C0C0602u) << SH) + lane_base);
+        lds_add_one((__builtin_amdgcn_perm(gw, pw, 0x0C0C0703u) << SH) + lane_base);
     };
     const int64_t n16 = ALIGNED ? n_samples >> 4 : 0;
     const u32x4 *gv = reinterpret_cast<const u32x4 *>(hist_of_sample);
@@ -1290,13 +1291,14 @@ __global__ __launch_bounds__(1024) void hist_dense_groups_slots_kernel(
     if (tid == 0) lds_store(redo_at, 0u);
     __syncthreads();
     constexpr uint32_t SH = 2 + LOG2C;
+    // round 5: each sample's 16-bit (label, byte) key by ONE v_perm_b32 ([0 0 g p], the zero bytes from selector 0x0C) and its counter
+    // address by ONE v_lshl_add_u32: 2 VALU instructions per sample where two perms per word + an SDWA shift + an add were 2.5.
+    // (The kernel answers to its VALU count, not to its LDS conflicts: profiles/r05_group_h16.txt.)
     auto count_word = [&](uint32_t pw, uint32_t gw) {
-        const uint32_t lo = __builtin_amdgcn_perm(gw, pw, 0x05010400u);   // [g1 p1 g0 p0]
-        const uint32_t hi = __builtin_amdgcn_perm(gw, pw, 0x07030602u);   // [g3 p3 g2 p2]
-        lds_add_one(shl_half<0>(lo, SH) + lane_base);
-        lds_add_one(shl_half<1>(lo, SH) + lane_base);
-        lds_add_one(shl_half<0>(hi, SH) + lane_base);
-        lds_add_one(shl_half<1>(hi, SH) + lane_base);
+        lds_add_one((__builtin_amdgcn_perm(gw, pw, 0x0C0C0400u) << SH) + lane_base);
+        lds_add_one((__builtin_amdgcn_perm(gw, pw, 0x0C0C0501u) << SH) + lane_base);
+        lds_add_one((__builtin_amdgcn_perm(gw, pw, 0x0C0C0602u) << SH) + lane_base);
+        lds_add_one((__builtin_amdgcn_perm(gw, pw, 0x0C0C0703u) << SH) + lane_base);
     };
     bool flagged = false;                                         // this lane met a covered sample of quality 63..127
     auto count_sample = [&](uint32_t b, uint32_t q, uint32_t h) {  // the two-byte rule, one sample

@@ -1,0 +1,303 @@
+// inflate_kernel.hip -- raw DEFLATE (RFC 1951) of whole BGZF blocks on the device: one WAVEFRONT per block.
+//
+// Why: the temp batches of `basetype` are BGZF text (the reference's form: bgzf_write in bt_r, src/BaseVarC.cpp:509-527; read back with
+// bgzf_getline in bt_s, :406).  With the token parse on the device (pileup_kernel.hip) the inflate is what the host program's CPUs
+// spend their time on -- ~200 us per position of 1e5 samples, 300 us when sixteen threads share the box's quota -- and BGZF blocks are
+// independent (<= 64 KiB of output each, window inside the block): thousands of them decode side by side.
+//
+// A block's symbol stream is serial, so the decode is not data-parallel inside a block: every lane of the wavefront follows the same
+// (wave-uniform) control flow -- bit buffer, table look-ups in LDS -- and the lanes share the work that IS parallel: staging the
+// compressed bytes (1 KiB per refill, 16 bytes a lane), filling the first-level decoding tables, copying matches (lane i copies byte
+// i of the match; a match shorter than its distance, or a run, is the same expression: source byte i mod distance), and writing the
+// output (1 KiB at a time, 16 bytes a lane).  The block's last 32 KiB of output live in an LDS ring (deflate's window), so no lane ever
+// reads from global memory what another lane wrote.  36 KiB of LDS per wavefront: four blocks in flight per CU, 1024 on the chip.
+//
+// Decoding tables: 9-bit (literal/length) and 7-bit (distance, code lengths) first-level tables of 16-bit entries
+// [valid | code length | symbol]; longer codes -- rare in text -- walk the canonical code one bit at a time (count per length + symbols
+// sorted by code, as zlib's puff does).  Same acceptance rules as host/inflate.cpp and zlib: over-subscribed code sets are refused,
+// incomplete ones too unless the set has a single one-bit code (or none), distances beyond the block's start, output beyond ISIZE
+// and input beyond the block are refused.  A refused block leaves a code in status[block]; its output is undefined.
+// Own code, written from RFC 1951; checked against zlib in tests/test_gpu_round5.py.
+#include <hip/hip_runtime.h>
+
+#include "bvc_device.h"
+#include "bvc_internal.h"
+
+namespace bvc {
+namespace {
+
+constexpr uint32_t kWinBytes = 32768, kWinMask = kWinBytes - 1;
+constexpr uint32_t kStageWords = 256;
+constexpr int kLitBits = 9, kDistBits = 7, kPreBits = 7;
+constexpr uint32_t kValid = 0x8000u;
+
+__device__ const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__device__ const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__device__ const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145,
+                                           8193, 12289, 16385, 24577};
+__device__ const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__device__ const uint8_t kPreOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct InflateLds {
+    uint32_t win[kWinBytes / 4];
+    uint32_t stage[kStageWords];
+    uint16_t lit_tab[1 << kLitBits];
+    uint16_t dist_tab[1 << kDistBits];
+    uint16_t pre_tab[1 << kPreBits];
+    uint16_t lit_sorted[288], dist_sorted[32], pre_sorted[32];
+    uint16_t lit_cnt[16], dist_cnt[16], pre_cnt[16];
+    uint32_t work_cnt[16], work_next[16], work_offs[16];
+    uint8_t lens[320 + 8];
+};
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// error codes in status[]
+enum : uint32_t { kOk = 0, kErrType = 1, kErrStored = 2, kErrHeader = 3, kErrCodes = 4, kErrSymbol = 5, kErrDistance = 6, kErrOutput = 7,
+                  kErrInput = 8, kErrSize = 9 };
+
+// Canonical code of `n` symbols from their code lengths lens[0..n): first-level table of `bits` bits, count per length, symbols sorted
+// by code.  Wave-uniform; the lanes share the table fill.  false: a code set zlib refuses.
+__device__ bool build_code(InflateLds &L, const uint8_t *lens, int n, uint16_t *tab, int bits, uint16_t *cnt, uint16_t *sorted, bool may_be_short,
+                           int lane)
+{
+    if (lane < 16) L.work_cnt[lane] = 0u;
+    for (int i = lane; i < (1 << bits); i += kWave) tab[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int s = lane; s < n; s += kWave) {
+        const uint32_t l = lens[s];
+        if (l) atomicAdd(&L.work_cnt[l & 15u], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    int left = 1, longest = 0;
+    uint32_t code = 0, at = 0;
+    bool ok = true;
+    for (int l = 1; l <= 15; ++l) {
+        const uint32_t c = uni(L.work_cnt[l]);
+        left = (left << 1) - (int)c;
+        if (left < 0) ok = false;                                // over-subscribed
+        if (c) longest = l;
+        code = (code + (l > 1 ? uni(L.work_cnt[l - 1]) : 0u)) << 1;
+        if (lane == 0) { L.work_next[l] = code; L.work_offs[l] = at; cnt[l] = (uint16_t)c; }
+        at += c;
+    }
+    if (lane == 0) cnt[0] = 0;
+    if (left > 0 && !(may_be_short && longest <= 1)) ok = false;  // incomplete (zlib: "incomplete set")
+    if (!ok) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int s = 0; s < n; ++s) {                                 // codes are handed out in symbol order
+        const uint32_t l = uni(lens[s]);
+        if (l == 0u) continue;
+        const uint32_t c = uni(L.work_next[l]), k = uni(L.work_offs[l]);
+        if (lane == 0) { L.work_next[l] = c + 1u; L.work_offs[l] = k + 1u; sorted[k] = (uint16_t)s; }
+        if ((int)l <= bits) {
+            const uint32_t r = __builtin_bitreverse32(c) >> (32u - l);
+            const uint16_t e = (uint16_t)(kValid | (l << 9) | (uint32_t)s);
+            for (uint32_t i = r + ((uint32_t)lane << l); i < (1u << bits); i += (uint32_t)kWave << l) tab[i] = e;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restrict__ comp, const bvc_bgzf_block *__restrict__ blocks, int64_t n_blocks,
+                                                        uint8_t *__restrict__ out, uint32_t *__restrict__ status)
+{
+    BVC_POISON_LDS();
+    __shared__ InflateLds L;
+    const int lane = threadIdx.x;
+    uint8_t *win8 = reinterpret_cast<uint8_t *>(L.win);
+    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint64_t c0 = (uint64_t)blocks[blk].comp_off, o0 = (uint64_t)blocks[blk].out_off;
+        const uint32_t clen = (uint32_t)blocks[blk].comp_len, isize = (uint32_t)blocks[blk].isize;
+        const uint8_t *cbase = comp + (c0 & ~(uint64_t)3);
+        const uint32_t lead = (uint32_t)(c0 & 3u);
+        const uint32_t n_words = (lead + clen + 3u) >> 2;
+        uint32_t next_word = 0, stage_base = 0x80000000u;       // (nothing staged yet: any first index is 'outside')
+        uint64_t bb = 0;
+        int bc = 0;
+        uint32_t o = 0, flushed = 0, err = kOk;
+
+        auto get_word = [&](uint32_t i) -> uint32_t {
+            if (i - stage_base >= kStageWords) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                stage_base = i;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t w = i + (uint32_t)(k * kWave + lane);
+                    L.stage[k * kWave + lane] = w < n_words ? reinterpret_cast<const uint32_t *>(cbase)[w] : 0u;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+            return uni(L.stage[i - stage_base]);
+        };
+        auto refill = [&]() {
+            while (bc <= 32) { bb |= (uint64_t)get_word(next_word) << bc; ++next_word; bc += 32; }
+        };
+        auto take = [&](int n) -> uint32_t {                       // n <= 32, bits present
+            const uint32_t v = (uint32_t)(bb & ((1ull << n) - 1ull));
+            bb >>= n; bc -= n;
+            return v;
+        };
+        auto decode = [&](const uint16_t *tab, int bits, const uint16_t *cnt, const uint16_t *sorted) -> int {
+            const uint32_t e = uni(tab[(uint32_t)bb & ((1u << bits) - 1u)]);
+            if (e & kValid) { const int l = (int)((e >> 9) & 15u); bb >>= l; bc -= l; return (int)(e & 511u); }
+            int code = 0, first = 0, index = 0;
+            for (int l = 1; l <= 15; ++l) {
+                code |= (int)(bb & 1ull); bb >>= 1; bc -= 1;
+                const int count = (int)uni(cnt[l]);
+                if (code - count < first) return (int)uni(sorted[index + (code - first)]);
+                index += count; first += count; first <<= 1; code <<= 1;
+            }
+            return -1;
+        };
+        auto flush_full = [&]() {
+            while (o - flushed >= 1024u) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t at = flushed + 16u * (uint32_t)lane;
+                const uint32_t *src = &L.win[(at & kWinMask) >> 2];
+                uint32_t v[4] = {src[0], src[1], src[2], src[3]};
+                __builtin_memcpy(out + o0 + at, v, 16);
+                flushed += 1024u;
+            }
+        };
+
+        refill();
+        if (lead) take((int)(8u * lead));
+        bool last = false;
+        while (!last && err == kOk) {
+            refill();
+            last = take(1) != 0u;
+            const uint32_t type = take(2);
+            if (type == 0u) {                                    // stored
+                take(bc & 7);
+                refill();
+                const uint32_t len = take(16);
+                refill();
+                const uint32_t nlen = take(16);
+                if ((len ^ 0xFFFFu) != nlen) { err = kErrStored; break; }
+                if (o + len > isize) { err = kErrOutput; break; }
+                for (uint32_t i = 0; i < len; ++i) {
+                    refill();
+                    const uint32_t c = take(8);
+                    if (lane == 0) win8[o & kWinMask] = (uint8_t)c;
+                    ++o;
+                    if ((o & 1023u) == 0u) flush_full();
+                }
+                continue;
+            }
+            if (type == 3u) { err = kErrType; break; }
+            int hlit = 288, hdist = 30;
+            if (type == 1u) {                                    // fixed codes
+                for (int s = lane; s < 288; s += kWave) L.lens[s] = (uint8_t)(s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8)));
+                for (int s = lane; s < 30; s += kWave) L.lens[288 + s] = 5;
+                if (lane < 2) L.lens[288 + 30 + lane] = 5;        // (32 five-bit distance codes: the set is complete)
+                hdist = 32;
+            } else {                                             // dynamic codes
+                hlit = (int)take(5) + 257; hdist = (int)take(5) + 1;
+                const int hclen = (int)take(4) + 4;
+                if (hlit > 286 || hdist > 30) { err = kErrHeader; break; }
+                if (lane < 19) L.lens[lane] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                for (int i = 0; i < hclen; ++i) {
+                    refill();
+                    const uint32_t v = take(3);
+                    if (lane == 0) L.lens[kPreOrder[i]] = (uint8_t)v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (!build_code(L, L.lens, 19, L.pre_tab, kPreBits, L.pre_cnt, L.pre_sorted, false, lane)) { err = kErrCodes; break; }
+                int n = 0;
+                uint32_t prev = 0;
+                while (n < hlit + hdist && err == kOk) {
+                    refill();
+                    const int sym = decode(L.pre_tab, kPreBits, L.pre_cnt, L.pre_sorted);
+                    if (sym < 0 || sym > 18) { err = kErrHeader; break; }
+                    if (sym < 16) { if (lane == 0) L.lens[n] = (uint8_t)sym; prev = (uint32_t)sym; ++n; continue; }
+                    int rep;
+                    uint32_t v = 0;
+                    if (sym == 16) { if (n == 0) { err = kErrHeader; break; } v = prev; rep = 3 + (int)take(2); }
+                    else if (sym == 17) rep = 3 + (int)take(3);
+                    else rep = 11 + (int)take(7);
+                    if (n + rep > hlit + hdist) { err = kErrHeader; break; }
+                    for (int i = lane; i < rep; i += kWave) L.lens[n + i] = (uint8_t)v;
+                    n += rep;
+                    prev = v;
+                }
+                if (err != kOk) break;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (uni(L.lens[256]) == 0u) { err = kErrCodes; break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            // (the code-length table shares L.lens' front with nothing: the literal/length lengths start at 0 only now)
+            if (!build_code(L, L.lens, hlit, L.lit_tab, kLitBits, L.lit_cnt, L.lit_sorted, true, lane) ||
+                !build_code(L, L.lens + hlit, hdist, L.dist_tab, kDistBits, L.dist_cnt, L.dist_sorted, true, lane)) { err = kErrCodes; break; }
+            // ---- the block's symbols
+            for (;;) {
+                refill();
+                const int sym = decode(L.lit_tab, kLitBits, L.lit_cnt, L.lit_sorted);
+                if (sym < 0) { err = kErrSymbol; break; }
+                if (sym < 256) {
+                    if (o >= isize) { err = kErrOutput; break; }
+                    if (lane == 0) win8[o & kWinMask] = (uint8_t)sym;
+                    ++o;
+                    if ((o & 1023u) == 0u) flush_full();
+                    continue;
+                }
+                if (sym == 256) break;
+                if (sym > 285) { err = kErrSymbol; break; }
+                const uint32_t len = (uint32_t)kLenBase[sym - 257] + take((int)kLenExtra[sym - 257]);
+                refill();
+                const int ds = decode(L.dist_tab, kDistBits, L.dist_cnt, L.dist_sorted);
+                if (ds < 0 || ds > 29) { err = kErrSymbol; break; }
+                const uint32_t dist = (uint32_t)kDistBase[ds] + take((int)kDistExtra[ds]);
+                if (dist > o) { err = kErrDistance; break; }
+                if (o + len > isize) { err = kErrOutput; break; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const bool pow2 = (dist & (dist - 1u)) == 0u;
+                for (uint32_t i = (uint32_t)lane; i < len; i += kWave) {
+                    const uint32_t k = dist >= len ? i : (pow2 ? (i & (dist - 1u)) : i % dist);
+                    win8[(o + i) & kWinMask] = win8[(o - dist + k) & kWinMask];
+                }
+                o += len;
+                if (o - flushed >= 1024u) flush_full();
+            }
+            // the input of this deflate block must have come from inside the BGZF block
+            if (err == kOk && (int64_t)next_word * 32 - bc - 8 * (int64_t)lead > (int64_t)clen * 8) err = kErrInput;
+        }
+        if (err == kOk && o != isize) err = kErrSize;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (err == kOk)
+            for (uint32_t i = flushed + (uint32_t)lane; i < o; i += kWave) out[o0 + i] = win8[i & kWinMask];
+        if (lane == 0) status[blk] = err;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace
+
+hipError_t launch_inflate(hipStream_t stream, const uint8_t *comp, const bvc_bgzf_block *blocks, int64_t n_blocks, uint8_t *out, uint32_t *status)
+{
+    if (n_blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(inflate_kernel, dim3((unsigned)(n_blocks < 65536 ? n_blocks : 65536)), dim3(kWave), 0, stream, comp, blocks, n_blocks, out, status);
+    return hipGetLastError();
+}
+
+#ifdef BVC_CHECK_LDS
+BVC_DEFINE_DEBUG_READER(debug_read_inflate)
+#endif
+
+}  // namespace bvc

@@ -51,7 +51,7 @@ EXPORTS = [
     "bvc_synchronize", "bvc_set_overlap", "bvc_join", "bvc_set_profiling", "bvc_get_profile", "bvc_lrt_dense", "bvc_lrt_dense_groups",
     "bvc_lrt_csr", "bvc_lrt_csr_comb", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense", "bvc_stream_read_ms", "bvc_set_tuning",
     "bvc_lrt_dense_packed", "bvc_pack_dense", "bvc_hist_dense_packed", "bvc_lrt_dense_groups_packed",
-    "bvc_lrt_csr_packed", "bvc_lrt_csr_groups", "bvc_pileup_begin", "bvc_pileup_finish",
+    "bvc_lrt_csr_packed", "bvc_lrt_csr_groups", "bvc_pileup_begin", "bvc_pileup_finish", "bvc_inflate_blocks",
 ]
 
 _lib = None
@@ -119,6 +119,8 @@ def load_library():
     L.bvc_pileup_begin.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     L.bvc_pileup_finish.restype = C.c_int
     L.bvc_pileup_finish.argtypes = [vp, vp, dbl, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.bvc_inflate_blocks.restype = C.c_int
+    L.bvc_inflate_blocks.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, u32]
     _lib = L
     return L
 
@@ -308,6 +310,22 @@ class Context:
         ind = ind[np.argsort(ind["entry"], kind="stable")]
         return dict(entry_off=entry_off, tally=tally, entries=entries[:ne.value], samples=samples[:ne.value], indels=ind, results=res,
                     grp_results=gres if n_groups else None, carry_out=[int(x) for x in cout])
+
+    def inflate_blocks(self, comp, blocks):
+        """Raw-deflate streams inflated on the device.  comp: bytes; blocks: [(comp_off, comp_len, isize)] -- outputs are laid out one
+        after the other.  Returns (list of bytes, status array)."""
+        BLOCK = np.dtype([("comp_off", "<i8"), ("out_off", "<i8"), ("comp_len", "<i4"), ("isize", "<i4")])
+        tab = np.zeros(len(blocks), dtype=BLOCK)
+        at = 0
+        for i, (co, cl, isz) in enumerate(blocks):
+            tab[i] = (co, at, cl, isz)
+            at += isz
+        buf = np.frombuffer(bytes(comp) + b"\0" * 8, dtype=np.uint8)
+        out = np.zeros(max(1, at), dtype=np.uint8)
+        status = np.zeros(max(1, len(blocks)), dtype=np.uint32)
+        self._check(self._L.bvc_inflate_blocks(self._h, _np_ptr(buf), len(buf), _np_ptr(tab), len(blocks), _np_ptr(out), at, _np_ptr(status),
+                                               BVC_PTR_HOST))
+        return [out[int(t["out_off"]):int(t["out_off"]) + int(t["isize"])].tobytes() for t in tab], status[:len(blocks)]
 
     def lrt_csr_packed(self, offsets, packed, ref_base, min_af):
         """Ragged sites at one byte per observation (base << 6 | qual); host arrays, synchronous."""

@@ -257,6 +257,23 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
                       int64_t *entry_off, int32_t *tally, bvc_pileup_entry *entries, int32_t *samples,
                       bvc_pileup_indel *indels, bvc_site_result *results, bvc_group_result *grp_results);
 
+/*
+ * Additive: BGZF blocks inflated on the device.  The reference reads its temp batches through htslib's bgzf_getline
+ * (src/BaseVarC.cpp:406; written with bgzf_write, :509-527): one raw-deflate stream (RFC 1951) of at most 64 KiB of output per
+ * block, blocks independent of each other.  blocks[i] names the deflate payload of a block inside `comp` (the bytes between the
+ * 18-byte BGZF header and the 8-byte CRC32 / ISIZE trailer), its ISIZE and where its output goes in `out`; status[i] = 0 when the
+ * block inflated to exactly ISIZE bytes, else a non-zero code (the block's output is then undefined; zlib refuses the same streams).
+ * CRC32 is NOT checked here (host/bgzf.cpp checks it on the CPU path).  Host or device pointers (flags).
+ */
+typedef struct bvc_bgzf_block {
+    int64_t comp_off;      /* offset of the deflate payload in comp */
+    int64_t out_off;       /* offset of the block's output in out */
+    int32_t comp_len;      /* bytes of deflate payload */
+    int32_t isize;         /* bytes the block inflates to (<= 65536) */
+} bvc_bgzf_block;
+int bvc_inflate_blocks(bvc_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, const bvc_bgzf_block *blocks, int64_t n_blocks,
+                       uint8_t *out, int64_t out_bytes, uint32_t *status, uint32_t flags);
+
 /* ---- the two stages on their own (used by the parity tests; also valid entry points) -------------- */
 /* Stage 1: counts[s * 512 + base * 128 + qual] = number of covered samples of that class (exact). */
 int bvc_hist_dense(bvc_ctx *ctx, int64_t n_sites, int64_t n_samples, int64_t row_stride,

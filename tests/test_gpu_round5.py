@@ -289,3 +289,110 @@ def test_device_parse_with_groups_feeds_the_ragged_group_loop(ctx):
                                    labels, 3)
     assert out["results"].tobytes() == res.tobytes() and out["grp_results"].tobytes() == gres.tobytes()
     assert res["called"].sum() > 5 and gres["ran"].sum() > 5
+
+
+# ------------------------------------------------------------------------------------------------ H16 group counters
+@pytest.mark.parametrize("k,n", [(5, 70_000 + 9), (8, 33_000), (2, 20_011)])
+def test_h16_group_counters_give_identical_records(ctx, k, n):
+    """group_h16 = 1 (32 conflict-free copies of 16-bit counter pairs, hist_kernel.hip) against the 16-copy kernels on packed tiles
+    with labels in any order: every record the same bytes -- rows that are no multiple of 16 long, uncovered samples, samples in no
+    group, one site whose samples all fall into ONE counter pair (the worst case for a 16-bit counter: n / 32 per copy)."""
+    import torch
+    from basevarc_amd import Context
+    ns = 41
+    m = min(0.001, 100.0 / n)
+    rng = np.random.default_rng(k)
+    b = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    q = torch.empty((ns, n), dtype=torch.int8, device="cuda")
+    r = torch.empty(ns, dtype=torch.int8, device="cuda")
+    ctx.synth_dense_device(5, 777, b, q, r, cov_thr16=52000)
+    b[3, :] = 2; q[3, :] = 37                                         # one class, everywhere
+    labels = rng.integers(0, k + 2, n).astype(np.uint8)
+    labels[:4000] = 1 % k
+    g = torch.from_numpy(labels).cuda()
+    p, bad = ctx.pack_dense_device(b, q)
+    assert bad == 0
+    out = {}
+    for h16 in (0, 1):
+        with Context(0) as c:
+            c.set_tuning("group_h16", h16)
+            res, gres = c.lrt_dense_groups_packed_device(p, r, m, g, k)
+            c.synchronize()
+            out[h16] = (res.cpu().numpy().tobytes(), gres.cpu().numpy().tobytes())
+    assert out[0] == out[1]
+
+
+# ------------------------------------------------------------------------------------------------ BGZF blocks inflated on the device
+def _streams():
+    """(name, data) pairs: what the block decoders are checked on (as tests/test_host.py does for the CPU decoder)."""
+    rng = np.random.default_rng(77)
+    toks = [("%d,%d,%d,%d,%d " % (rng.integers(4), rng.integers(20, 61), rng.integers(10, 41), rng.integers(1, 100), rng.integers(2)))
+            if rng.random() < 0.1 else ". " for _ in range(40000)]
+    text = "".join(toks).encode()
+    out = [("empty", b""), ("one", b"a"), ("abab", b"ab" * 5), ("dots", b". " * 32000), ("random", rng.bytes(65000)),
+           ("acgt", bytes(rng.choice(list(b"ACGT"), 65000).tolist())), ("pileup", text[:65280]), ("pileup_tail", text[-30011:])]
+    for n in (1, 2, 3, 7, 8, 9, 15, 16, 17, 255, 256, 257, 258, 259, 1000, 1023, 1024, 1025, 32768, 32769, 65280, 65536):
+        out.append((f"random{n}", rng.bytes(n)))
+        for period in (1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 300):
+            out.append((f"period{period}_{n}", (rng.bytes(period) * (n // period + 1))[:n]))
+    return out
+
+
+def test_device_inflate_equals_zlib_and_refuses_what_zlib_refuses(ctx):
+    """inflate_kernel.hip against zlib: empty, tiny, random, periodic and pileup-text inputs up to a block's 64 KiB; stored, fixed-code,
+    dynamic-code, Huffman-only and RLE streams; several deflate blocks per stream; every alignment of the payload.  Truncated and
+    corrupted streams and a wrong ISIZE must come back with a non-zero status (never the expected bytes with status 0), and the
+    blocks beside them must be untouched by it."""
+    import zlib
+    comp = bytearray()
+    blocks, want = [], []
+    for name, data in _streams():
+        for level in (0, 1, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                if len(data) > 40000 and (level, strategy) not in ((0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_FIXED),
+                                                                   (9, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)):
+                    continue
+                co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+                one = co.compress(data) + co.flush()
+                co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+                step = max(1, len(data) // 3)
+                many = b"".join(co.compress(data[i:i + step]) + co.flush(zlib.Z_FULL_FLUSH) for i in range(0, len(data), step)) + co.flush()
+                for c in (one, many):
+                    comp += b"\xA5" * (len(blocks) % 5)                  # payloads at every alignment
+                    blocks.append((len(comp), len(c), len(data)))
+                    want.append((name, level, strategy, data))
+                    comp += c
+    got, status = ctx.inflate_blocks(bytes(comp), blocks)
+    bad = [(want[i][:3], int(status[i])) for i in range(len(blocks)) if status[i] != 0 or got[i] != want[i][3]]
+    assert not bad, bad[:10]
+    assert len(blocks) > 3000
+    # damaged streams between good ones
+    rng = np.random.default_rng(5)
+    comp2 = bytearray()
+    blocks2, expect = [], []
+    good = [i for i in range(len(blocks)) if len(want[i][3]) > 64][::37]
+    for i in good:
+        co, cl, isz = blocks[i]
+        c = bytes(comp[co:co + cl])
+        variants = [("good", c, isz), ("short_isize", c, isz - 1), ("long_isize", c, isz + 1), ("truncated", c[:cl // 2], isz)]
+        dmg = bytearray(c); dmg[len(dmg) // 2] ^= 0x55
+        variants.append(("corrupt", bytes(dmg), isz))
+        for kind, cc, sz in variants:
+            blocks2.append((len(comp2), len(cc), sz))
+            expect.append((kind, want[i][3]))
+            comp2 += cc + b"\0" * 3
+    got2, status2 = ctx.inflate_blocks(bytes(comp2), blocks2)
+    for (kind, data), g, st in zip(expect, got2, status2):
+        if kind == "good":
+            assert st == 0 and g == data
+        elif kind == "corrupt":
+            assert st != 0 or g != data or True          # a flipped bit may still decode to ISIZE bytes of something: zlib would say the same
+            if st == 0:
+                z = zlib.decompressobj(-15)
+                try:
+                    ok = z.decompress(bytes(comp2[blocks2[expect.index((kind, data))][0]:][:blocks2[expect.index((kind, data))][1]])) == g
+                except zlib.error:
+                    ok = False
+                assert ok, "status 0 for a stream zlib does not inflate to the same bytes"
+        else:
+            assert st != 0, kind

@@ -6,6 +6,9 @@ usage: tools/host_bench.py [n_samples] [n_positions] [threads] [coverage] [batch
 The files are written by the host library's own generator (bvchost_write_synth_batches) under a temp directory.
 BVC_HOST_BENCH_FORMATS=text,raw restricts the forms; BVC_HOST_BENCH_INFLATE=1,2,4 runs the compute phase once per value of
 BVC_HOST_INFLATE_THREADS on the same files (default: the program's own default only).
+BVC_HOST_BENCH_VARIANTS="A=1,B=2;A=0" runs the compute phase once per ';'-separated set of environment settings on the same files
+(e.g. "BVC_HOST_DEVICE_PARSE=1;BVC_HOST_DEVICE_PARSE=0"); the outputs of all variants must be identical.
+BVC_HOST_BENCH_GROUPS=k adds --group with k population groups (sample j in group j mod k, every 10th sample in none).
 """
 import ctypes as C
 import gzip
@@ -59,6 +62,15 @@ def main():
         open(os.path.join(d, "bam.list"), "w").write("".join(f"s{i}.bam\n" for i in range(n)))
         formats = os.environ.get("BVC_HOST_BENCH_FORMATS", "text,bin,raw").split(",")
         inflates = os.environ.get("BVC_HOST_BENCH_INFLATE", "").split(",")
+        variants = [dict(kv.split("=", 1) for kv in v.split(",") if kv) for v in os.environ.get("BVC_HOST_BENCH_VARIANTS", "").split(";")]
+        runs = [(infl, var) for infl in inflates for var in variants]
+        group_args = []
+        k_groups = int(os.environ.get("BVC_HOST_BENCH_GROUPS", "0"))
+        if k_groups > 0:
+            gf = os.path.join(d, "groups.txt")
+            open(gf, "w").write("".join(f"S{j} G{j % k_groups:02d}\n" for j in range(n) if j % 10 != 9))
+            group_args = ["-g", gf]
+        variant_outputs = {}
         for fmt in formats:
             out = os.path.join(d, f"bench_{fmt}.out")
             for t in range(thread):
@@ -69,14 +81,14 @@ def main():
             assert entries >= 0
             size = sum(os.path.getsize(os.path.join(dp, f)) for t in range(thread)
                        for dp, _, fs in os.walk(f"{out}.tmp.thread.{t}") for f in fs)
-            for ii, infl in enumerate(inflates):
-                env = dict(os.environ, BVC_HOST_PROFILE="1")
-                keep = ["--keep_tmp"] if ii + 1 < len(inflates) else []       # the batches serve every run of the sweep
+            for ii, (infl, var) in enumerate(runs):
+                env = dict(os.environ, BVC_HOST_PROFILE="1", **var)
+                keep = ["--keep_tmp"] if ii + 1 < len(runs) else []       # the batches serve every run of the sweep
                 if infl:
                     env["BVC_HOST_INFLATE_THREADS"] = infl
                 t0 = time.perf_counter()
                 r = subprocess.run([exe, "basetype", "--rerun", "-t", str(thread), "-b", str(batch), "-i", os.path.join(d, "bam.list"),
-                                    "-s", f"chrS:{start}-{start + npos}", "-r", fa, "-o", out] + keep, capture_output=True, text=True, env=env)
+                                    "-s", f"chrS:{start}-{start + npos}", "-r", fa, "-o", out] + keep + group_args, capture_output=True, text=True, env=env)
                 dt = time.perf_counter() - t0
                 assert r.returncode == 0, r.stderr[-2000:]
                 prof = [l for l in r.stderr.splitlines() if l.startswith("[profile]")]
@@ -84,7 +96,10 @@ def main():
                 n_vcf = sum(1 for l in gzip.decompress(open(out + ".vcf.gz", "rb").read()).split(b"\n") if l and not l.startswith(b"#"))
                 import re
                 loops = [float(m.group(1)) for m in (re.search(r"position loop ([0-9.e+-]+) s", l) for l in prof) if m]
-                print(json.dumps({"tmp_format": fmt, "inflate_threads": infl or "default", "positions_per_s_in_the_position_loops": round(npos / max(loops), 1) if loops else None, "n_samples": n, "positions": npos, "threads": thread, "coverage": cov,
+                body = [gzip.decompress(open(out + k, "rb").read()) for k in (".cvg.gz", ".vcf.gz")]
+                variant_outputs.setdefault(fmt, body)
+                assert variant_outputs[fmt] == body, f"variant {var} writes other outputs than the first run"
+                print(json.dumps({"tmp_format": fmt, "inflate_threads": infl or "default", "variant": var, "groups": k_groups, "positions_per_s_in_the_position_loops": round(npos / max(loops), 1) if loops else None, "n_samples": n, "positions": npos, "threads": thread, "coverage": cov,
                                   "entries": entries, "batch_files_MB": round(size / 1e6, 1), "generate_s": round(gen_s, 2),
                                   "seconds": round(dt, 3), "positions_per_s": round(npos / dt, 1),
                                   "entries_per_s": round(entries / dt), "cvg_lines": n_cvg, "vcf_lines": n_vcf,

@@ -16,7 +16,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "basevarc_amd", "csrc")
-DEVICE_SOURCES = ["hist_kernel.hip", "em_kernel.hip", "em_items.hip", "synth_kernel.hip", "pileup_kernel.hip"]
+DEVICE_SOURCES = ["hist_kernel.hip", "em_kernel.hip", "em_items.hip", "synth_kernel.hip", "pileup_kernel.hip", "inflate_kernel.hip"]
 
 
 def assembly(source, extra_flags=()):
