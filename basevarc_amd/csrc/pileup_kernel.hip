@@ -85,11 +85,13 @@ struct ParseArgs {
     const int32_t *sample0;          // [n_batches]
     const int32_t *n_in_batch;       // [n_batches] tokens of every line of the batch
     int32_t n_batches, n_pos;
+    int32_t line_stride;             // elements of line_start per batch (n_pos + 1 when the caller built the table)
+    const int32_t *n_pos_dev;        // not null: the number of positions is decided on the device (tiles inflated there) and read from here
     uint32_t *line_entries;          // [n_pos * n_batches] position-major: count pass = entries of the line; after the scan = first entry
     uint32_t *line_obs;              // the same for observations (entries that are not indels)
     uint32_t *line_last;             // last base token of the line (packed) or 0
     uint32_t *line_need;             // indel entries in front of the line's first base token: they inherit from an earlier line
-    uint32_t *status;                // [0] irregular lines, [1] indel entries counted, [2] indel records written
+    uint32_t *status;                // [0] irregular lines, [1] indel entries counted, [2] indel records written, [4] bytes of indel tokens
     bvc_pileup_entry *entries;
     int32_t *samples;
     int8_t *obs_base, *obs_qual;
@@ -111,18 +113,18 @@ __global__ __launch_bounds__(kParseWaves * kWave) void pileup_parse_kernel(Parse
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     const uint8_t *__restrict__ text = A.text;
-    const int64_t n_lines = (int64_t)A.n_pos * A.n_batches;
+    const int64_t n_lines = (int64_t)(A.n_pos_dev ? *A.n_pos_dev : A.n_pos) * A.n_batches;
     for (int64_t line = (int64_t)blockIdx.x * kParseWaves + wave; line < n_lines; line += (int64_t)gridDim.x * kParseWaves) {
         const int t = (int)(line / A.n_batches), b = (int)(line - (int64_t)t * A.n_batches);
-        const uint32_t s = A.line_start[(int64_t)b * (A.n_pos + 1) + t];
-        const uint32_t e1 = A.line_start[(int64_t)b * (A.n_pos + 1) + t + 1];
+        const uint32_t s = A.line_start[(int64_t)b * A.line_stride + t];
+        const uint32_t e1 = A.line_start[(int64_t)b * A.line_stride + t + 1];
         bool bad = e1 <= s;
         const uint32_t e = bad ? s : e1 - 1u;                    // the line is [s, e); text[e] is its '\n'
         if (!bad) bad = text[e] != 0x0Au || (e > s && text[e - 1u] != 0x20u);
         const int32_t smp0 = A.sample0[b];
         uint32_t ent_at = 0, obs_at = 0;
         if (WRITE) { ent_at = A.line_entries[line]; obs_at = A.line_obs[line]; }
-        uint32_t tok_run = 0, ent_run = 0, obs_run = 0, need = 0, n_ind_line = 0;
+        uint32_t tok_run = 0, ent_run = 0, obs_run = 0, need = 0, n_ind_line = 0, ind_bytes = 0;
         uint32_t prev_tok = 0;                                   // wave-uniform: last base token of the line so far
         uint32_t prev_sep = 1u;                                  // wave-uniform: was the byte in front of this step a separator?
         for (uint32_t off = s & ~15u; off < e; off += 16u * kWave) {
@@ -168,6 +170,11 @@ __global__ __launch_bounds__(kParseWaves * kWave) void pileup_parse_kernel(Parse
                 } else {
                     ++ent; ++n_ind;
                     if (lane_last == 0u) ++ind_front;
+                    if (!WRITE) {                                // the token's length: the caller sizes the buffer for the Indels column's text
+                        uint32_t q = a + (uint32_t)i + 1u;
+                        while (q < e && text[q] != 0x20u) ++q;
+                        ind_bytes += q - (a + (uint32_t)i);
+                    }
                 }
             }
             const uint32_t packed = (uint32_t)__builtin_popcount(start) | (ent << 10) | (obs << 20);
@@ -234,7 +241,9 @@ __global__ __launch_bounds__(kParseWaves * kWave) void pileup_parse_kernel(Parse
         if (tok_run != (uint32_t)A.n_in_batch[b]) bad = true;
         const bool any_bad = __ballot(bad) != 0ull;
         if (!WRITE) {
+            const uint32_t ind_bytes_line = n_ind_line ? wave_sum(ind_bytes) : 0u;      // (n_ind_line is wave-uniform)
             if (lane == 0) {
+                if (ind_bytes_line) atomicAdd(&A.status[4], ind_bytes_line);
                 A.line_entries[line] = any_bad ? 0u : ent_run;
                 A.line_obs[line] = any_bad ? 0u : obs_run;
                 A.line_last[line] = prev_tok;
@@ -257,11 +266,13 @@ __global__ __launch_bounds__(kParseWaves * kWave) void pileup_parse_kernel(Parse
 }
 
 // Exclusive prefix sums of the lines' entry and observation counts, in place, position-major; the positions' offsets; the totals.
-__global__ __launch_bounds__(1024) void pileup_scan_kernel(int64_t n_lines, int32_t n_batches, int32_t n_pos, uint32_t *__restrict__ line_entries,
+__global__ __launch_bounds__(1024) void pileup_scan_kernel(int64_t n_lines, int32_t n_batches, int32_t n_pos, const int32_t *__restrict__ n_pos_dev,
+                                                           uint32_t *__restrict__ line_entries,
                                                            uint32_t *__restrict__ line_obs, int64_t *__restrict__ entry_off,
                                                            int64_t *__restrict__ obs_off, int64_t *__restrict__ totals)
 {
     BVC_POISON_LDS();
+    if (n_pos_dev) { n_pos = *n_pos_dev; n_lines = (int64_t)n_pos * n_batches; }
     __shared__ uint64_t part_e[1024], part_o[1024];
     const int tid = threadIdx.x;
     const int64_t per = (n_lines + 1023) / 1024;
@@ -353,36 +364,165 @@ __global__ __launch_bounds__(kCsrGroupThreads) void hist_csr_groups_kernel(
 
 }  // namespace
 
-hipError_t launch_pileup_count(hipStream_t stream, const PileupTile &P)
+static ParseArgs parse_args_of(const PileupTile &P)
 {
     ParseArgs A{};
     A.text = P.text; A.line_start = P.line_start; A.sample0 = P.sample0; A.n_in_batch = P.n_in_batch;
-    A.n_batches = P.n_batches; A.n_pos = P.n_pos;
-    A.line_entries = P.line_words; A.line_obs = P.line_words + P.n_lines; A.line_last = P.line_words + 2 * P.n_lines;
-    A.line_need = P.line_words + 3 * P.n_lines; A.status = P.status;
-    if (P.n_lines <= 0) return hipSuccess;
-    const int64_t blocks = (P.n_lines + kParseWaves - 1) / kParseWaves;
+    A.n_batches = P.n_batches; A.n_pos = P.n_pos; A.line_stride = P.line_stride; A.n_pos_dev = P.n_pos_dev;
+    A.line_entries = P.line_words; A.line_obs = P.line_words + P.n_lines_cap; A.line_last = P.line_words + 2 * P.n_lines_cap;
+    A.line_need = P.line_words + 3 * P.n_lines_cap; A.status = P.status;
+    A.entries = P.entries; A.samples = P.samples; A.obs_base = P.obs_base; A.obs_qual = P.obs_qual; A.obs_sample = P.obs_sample;
+    A.tally = P.tally; A.indels = P.indels; A.indel_cap = P.indel_cap;
+    return A;
+}
+
+hipError_t launch_pileup_count(hipStream_t stream, const PileupTile &P)
+{
+    const ParseArgs A = parse_args_of(P);
+    const int64_t n_lines = (int64_t)P.n_pos * P.n_batches;       // (an upper bound when the device decides the positions)
+    if (n_lines <= 0) return hipSuccess;
+    const int64_t blocks = (n_lines + kParseWaves - 1) / kParseWaves;
     hipLaunchKernelGGL(pileup_parse_kernel<false>, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(kParseWaves * kWave), 0, stream, A);
-    hipLaunchKernelGGL(pileup_scan_kernel, dim3(1), dim3(1024), 0, stream, P.n_lines, P.n_batches, P.n_pos, A.line_entries, A.line_obs,
-                       P.entry_off, P.obs_off, P.totals);
+    hipLaunchKernelGGL(pileup_scan_kernel, dim3(1), dim3(1024), 0, stream, n_lines, P.n_batches, P.n_pos, P.n_pos_dev, A.line_entries,
+                       A.line_obs, P.entry_off, P.obs_off, P.totals);
     return hipGetLastError();
 }
 
 hipError_t launch_pileup_write(hipStream_t stream, const PileupTile &P, uint32_t carry_in)
 {
-    ParseArgs A{};
-    A.text = P.text; A.line_start = P.line_start; A.sample0 = P.sample0; A.n_in_batch = P.n_in_batch;
-    A.n_batches = P.n_batches; A.n_pos = P.n_pos;
-    A.line_entries = P.line_words; A.line_obs = P.line_words + P.n_lines; A.line_last = P.line_words + 2 * P.n_lines;
-    A.line_need = P.line_words + 3 * P.n_lines; A.status = P.status;
-    A.entries = P.entries; A.samples = P.samples; A.obs_base = P.obs_base; A.obs_qual = P.obs_qual; A.obs_sample = P.obs_sample;
-    A.tally = P.tally; A.indels = P.indels; A.indel_cap = P.indel_cap;
-    if (P.n_lines <= 0) return hipSuccess;
-    const int64_t blocks = (P.n_lines + kParseWaves - 1) / kParseWaves;
+    ParseArgs A = parse_args_of(P);
+    A.n_pos_dev = nullptr;                                       // the caller knows the positions by now
+    const int64_t n_lines = (int64_t)P.n_pos * P.n_batches;
+    if (n_lines <= 0) return hipSuccess;
+    const int64_t blocks = (n_lines + kParseWaves - 1) / kParseWaves;
     hipLaunchKernelGGL(pileup_parse_kernel<true>, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(kParseWaves * kWave), 0, stream, A);
-    const int64_t threads = P.n_lines + 1;
-    hipLaunchKernelGGL(pileup_patch_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, P.n_lines, P.n_batches,
+    const int64_t threads = n_lines + 1;
+    hipLaunchKernelGGL(pileup_patch_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, n_lines, P.n_batches,
                        A.line_entries, A.line_last, A.line_need, carry_in, P.entries, P.tally, P.status + 3);
+    return hipGetLastError();
+}
+
+// ---- tiles whose text is inflated on the device: where the lines are, and how many positions every batch has whole ---------
+// A batch's region of the text buffer = what the tile before left of it + the output of its new blocks.  One wavefront per
+// 1 KiB segment of a region counts its newlines; one thread per batch adds them up (the batch's whole lines) and the tile's
+// positions are the fewest any batch has (at most max_pos); the segments then note where each of those lines starts.
+struct RegionArgs {
+    const uint8_t *text;
+    const bvc_pileup_region *regions;      // [n_batches]
+    const uint32_t *seg_base;              // [n_batches + 1] first segment of each region
+    int32_t n_batches, max_pos, line_stride;
+    uint32_t *seg_nl;                      // [segments] newlines of the segment; after the scan: newlines of the region before it
+    int32_t *lines;                        // [n_batches] whole lines of the region
+    int32_t *n_pos;                        // the tile's positions
+    uint32_t *line_start;                  // [n_batches][line_stride]
+};
+
+constexpr int kSegBytes = 1024;
+
+template <bool FILL>
+__global__ __launch_bounds__(kParseWaves * kWave) void region_lines_kernel(RegionArgs A)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t n_seg = A.seg_base[A.n_batches];
+    for (int64_t seg = (int64_t)blockIdx.x * kParseWaves + wave; seg < n_seg; seg += (int64_t)gridDim.x * kParseWaves) {
+        int lo = 0, hi = A.n_batches;                            // the region of this segment
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)A.seg_base[mid] <= seg) lo = mid; else hi = mid; }
+        const int b = lo;
+        const uint32_t r0 = A.regions[b].start, r1 = r0 + A.regions[b].len;
+        const uint32_t s0 = r0 + (uint32_t)(seg - A.seg_base[b]) * kSegBytes;
+        const uint32_t at = s0 + 16u * (uint32_t)lane;
+        uint32_t nl = 0;                                         // bit i: byte at + i is a newline inside the region
+        if (at < r1) {
+            // (the region starts where the caller put it: bytes, not 16-byte words)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) nl |= (uint32_t)(at + (uint32_t)i < r1 && A.text[at + (uint32_t)i] == 0x0Au) << i;
+        }
+        const uint32_t incl = wave_incl_scan((uint32_t)__builtin_popcount(nl), lane);
+        if (!FILL) {
+            if (lane == 63) A.seg_nl[seg] = incl;
+        } else {
+            const int32_t T = *A.n_pos;
+            uint32_t rank = A.seg_nl[seg] + incl - (uint32_t)__builtin_popcount(nl);       // newlines of the region before this lane's bytes
+            if (seg == (int64_t)A.seg_base[b] && lane == 0) A.line_start[(int64_t)b * A.line_stride] = r0;
+            for (uint32_t m = nl; m; m &= m - 1u) {
+                ++rank;                                          // the line behind this newline is line `rank`
+                if ((int32_t)rank <= T) A.line_start[(int64_t)b * A.line_stride + rank] = at + (uint32_t)__builtin_ctz(m) + 1u;
+            }
+        }
+    }
+}
+
+__global__ void region_scan_kernel(RegionArgs A)
+{
+    __shared__ int32_t least;
+    if (threadIdx.x == 0) least = A.max_pos;
+    __syncthreads();
+    for (int b = threadIdx.x; b < A.n_batches; b += blockDim.x) {
+        uint32_t run = 0;
+        for (uint32_t s = A.seg_base[b]; s < A.seg_base[b + 1]; ++s) { const uint32_t c = A.seg_nl[s]; A.seg_nl[s] = run; run += c; }
+        A.lines[b] = (int32_t)run;
+        atomicMin(&least, (int32_t)run);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *A.n_pos = A.n_batches > 0 ? least : 0;
+}
+
+// what the tile before left of every batch, to the front of the batch's region in the other text buffer
+__global__ void region_carry_kernel(const uint8_t *__restrict__ old_text, uint8_t *__restrict__ text, const bvc_pileup_region *__restrict__ regions)
+{
+    const bvc_pileup_region r = regions[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < r.left_len; i += blockDim.x) text[r.start + i] = old_text[r.left_src + i];
+}
+
+// the text of the indel tokens, gathered for the caller (tiles whose text never was on the host): any order; each record's text_off
+// becomes its offset in `dst`
+__global__ void indel_text_kernel(const uint8_t *__restrict__ text, bvc_pileup_indel *__restrict__ indels, const uint32_t *__restrict__ n_written,
+                                  uint32_t cap_records, uint8_t *__restrict__ dst, uint32_t dst_cap, uint32_t *__restrict__ used)
+{
+    const uint32_t n = *n_written < cap_records ? *n_written : cap_records;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t len = (uint32_t)indels[k].len, from = (uint32_t)indels[k].text_off;
+        const uint32_t at = atomicAdd(used, len);
+        if (at + len <= dst_cap)
+            for (uint32_t i = 0; i < len; ++i) dst[at + i] = text[from + i];
+        indels[k].text_off = (int64_t)at;
+    }
+}
+
+hipError_t launch_region_lines(hipStream_t stream, const PileupTile &P, const uint8_t *old_text, const bvc_pileup_region *regions,
+                               const uint32_t *seg_base, int64_t n_segments, uint32_t *seg_nl, int32_t *lines, int32_t max_pos)
+{
+    if (P.n_batches <= 0) return hipSuccess;
+    RegionArgs A{};
+    A.text = P.text; A.regions = regions; A.seg_base = seg_base; A.n_batches = P.n_batches; A.max_pos = max_pos; A.line_stride = P.line_stride;
+    A.seg_nl = seg_nl; A.lines = lines; A.n_pos = const_cast<int32_t *>(P.n_pos_dev); A.line_start = const_cast<uint32_t *>(P.line_start);
+    if (old_text)
+        hipLaunchKernelGGL(region_carry_kernel, dim3((unsigned)P.n_batches), dim3(256), 0, stream, old_text, const_cast<uint8_t *>(P.text), regions);
+    return hipGetLastError();
+    (void)n_segments; (void)A;
+}
+
+hipError_t launch_region_index(hipStream_t stream, const PileupTile &P, const bvc_pileup_region *regions, const uint32_t *seg_base,
+                               int64_t n_segments, uint32_t *seg_nl, int32_t *lines, int32_t max_pos)
+{
+    if (P.n_batches <= 0) return hipSuccess;
+    RegionArgs A{};
+    A.text = P.text; A.regions = regions; A.seg_base = seg_base; A.n_batches = P.n_batches; A.max_pos = max_pos; A.line_stride = P.line_stride;
+    A.seg_nl = seg_nl; A.lines = lines; A.n_pos = const_cast<int32_t *>(P.n_pos_dev); A.line_start = const_cast<uint32_t *>(P.line_start);
+    const int64_t blocks = (n_segments + kParseWaves - 1) / kParseWaves;
+    const unsigned grid = (unsigned)(blocks < 65536 ? (blocks > 0 ? blocks : 1) : 65536);
+    hipLaunchKernelGGL(region_lines_kernel<false>, dim3(grid), dim3(kParseWaves * kWave), 0, stream, A);
+    hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(256), 0, stream, A);
+    hipLaunchKernelGGL(region_lines_kernel<true>, dim3(grid), dim3(kParseWaves * kWave), 0, stream, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_indel_text(hipStream_t stream, const PileupTile &P, uint8_t *dst, uint32_t dst_cap, uint32_t *used)
+{
+    if (P.indel_cap == 0) return hipSuccess;
+    hipLaunchKernelGGL(indel_text_kernel, dim3((P.indel_cap + 255) / 256), dim3(256), 0, stream, P.text, P.indels, P.status + 2, P.indel_cap, dst,
+                       dst_cap, used);
     return hipGetLastError();
 }
 

@@ -370,7 +370,7 @@ def test_device_inflate_equals_zlib_and_refuses_what_zlib_refuses(ctx):
     rng = np.random.default_rng(5)
     comp2 = bytearray()
     blocks2, expect = [], []
-    good = [i for i in range(len(blocks)) if len(want[i][3]) > 64][::37]
+    good = [i for i in range(len(blocks)) if 64 < len(want[i][3]) < 65536][::37]
     for i in good:
         co, cl, isz = blocks[i]
         c = bytes(comp[co:co + cl])
