@@ -56,6 +56,14 @@ struct bvc_ctx {
     // bvc_pileup_begin / bvc_pileup_finish: the tile's text, its line tables and counts, its parsed columns and records
     char *d_pl_text = nullptr, *d_pl_meta = nullptr, *d_pl_out = nullptr;
     size_t pl_text_cap = 0, pl_meta_cap = 0, pl_out_cap = 0;
+    // tiles inflated on the device (bvc_pileup_begin_bgzf): two text buffers (what a tile leaves of a batch is carried from one to the
+    // other), the compressed bytes, what the calls left of every batch
+    char *d_pz_text[2] = {nullptr, nullptr}, *d_pz_comp = nullptr;
+    size_t pz_text_cap[2] = {0, 0}, pz_comp_cap = 0;
+    int pz_cur = 0;                    // the buffer that holds the leftovers
+    std::vector<uint32_t> pz_left_src, pz_left_len;
+    int64_t pl_text_bytes = 0, pl_indel_bytes = 0;
+    bool pl_on_device_text = false;
     PileupTile pl;                     // the tile between the two calls
     bool pl_begun = false;
     int64_t pl_entries = 0, pl_obs = 0, pl_indels = 0;
@@ -574,6 +582,8 @@ void bvc_destroy(bvc_ctx *ctx)
     if (ctx->d_pl_text) (void)hipFree(ctx->d_pl_text);
     if (ctx->d_pl_meta) (void)hipFree(ctx->d_pl_meta);
     if (ctx->d_pl_out) (void)hipFree(ctx->d_pl_out);
+    for (int k = 0; k < 2; ++k) if (ctx->d_pz_text[k]) (void)hipFree(ctx->d_pz_text[k]);
+    if (ctx->d_pz_comp) (void)hipFree(ctx->d_pz_comp);
     delete ctx;
 }
 
@@ -1179,7 +1189,7 @@ int bvc_pileup_begin(bvc_ctx *ctx, const char *text, int64_t text_bytes, const u
     P.entry_off = reinterpret_cast<int64_t *>(p); p += off_al;
     P.obs_off = reinterpret_cast<int64_t *>(p); p += off_al;
     P.tally = reinterpret_cast<int32_t *>(p);
-    P.n_batches = n_batches; P.n_pos = n_positions; P.n_lines = n_lines;
+    P.n_batches = n_batches; P.n_pos = n_positions; P.n_lines_cap = n_lines; P.line_stride = n_positions + 1;
     auto drained = [&](int code) { if (code != BVC_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); } return code; };
 #define BVC_HIP_D(call)                                                                   \
     do {                                                                                  \
@@ -1203,17 +1213,180 @@ int bvc_pileup_begin(bvc_ctx *ctx, const char *text, int64_t text_bytes, const u
     if (st[0] != 0) return BVC_PILEUP_IRREGULAR;
     ctx->pl_entries = tot[0]; ctx->pl_obs = tot[1]; ctx->pl_indels = st[1];
     ctx->pl_begun = true;
+    ctx->pl_on_device_text = false; ctx->pl_indel_bytes = 0;
     *n_entries = tot[0]; *n_indels = st[1];
+    return BVC_OK;
+}
+
+int bvc_pileup_begin_bgzf(bvc_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, const bvc_bgzf_block *blocks,
+                          const int32_t *blocks_of_batch, const int32_t *skip_bytes, const int32_t *sample0, const int32_t *n_in_batch,
+                          int32_t n_batches, int32_t max_positions, int32_t reset, int32_t *n_positions, int32_t *lines_of_batch,
+                          int64_t *n_entries, int64_t *n_indels, int64_t *indel_text_bytes)
+{
+    if (!ctx) return BVC_ERR_ARG;
+    ctx->pl_begun = false;
+    if (n_batches < 0 || max_positions < 0 || comp_bytes < 0 || !n_positions || !n_entries || !n_indels || !indel_text_bytes)
+        return fail(ctx, BVC_ERR_ARG, "bad argument");
+    if (n_batches > 0 && (!blocks_of_batch || !sample0 || !n_in_batch || !lines_of_batch)) return fail(ctx, BVC_ERR_ARG, "null data pointer");
+    if (max_positions > (int32_t)(0x7FFFFFFF / 64)) return fail(ctx, BVC_ERR_ARG, "too many positions in one call (split the tile)");
+    BVC_HIP(ctx, hipSetDevice(ctx->device));
+    *n_positions = 0; *n_entries = 0; *n_indels = 0; *indel_text_bytes = 0;
+    const size_t nb = (size_t)n_batches;
+    if (reset || ctx->pz_left_len.size() != nb) { ctx->pz_left_len.assign(nb, 0u); ctx->pz_left_src.assign(nb, 0u); }
+    int64_t n_blocks = 0;
+    for (size_t b = 0; b < nb; ++b) { if (blocks_of_batch[b] < 0 || n_in_batch[b] < 0) return fail(ctx, BVC_ERR_ARG, "negative count"); n_blocks += blocks_of_batch[b]; }
+    if (n_blocks > 0 && (!comp || !blocks)) return fail(ctx, BVC_ERR_ARG, "null data pointer");
+    // layout of the new text buffer: per batch [left over | its new blocks' output], every region from a 16-byte boundary
+    std::vector<bvc_bgzf_block> blk((size_t)n_blocks);
+    std::vector<bvc_pileup_region> reg(nb);
+    std::vector<uint32_t> seg_base(nb + 1);
+    std::vector<uint32_t> region_end(nb);
+    uint64_t at = 0;
+    int64_t bi = 0;
+    uint32_t segs = 0;
+    for (size_t b = 0; b < nb; ++b) {
+        at = (at + 15) & ~(uint64_t)15;
+        const uint32_t left = ctx->pz_left_len[b];
+        uint64_t fresh = 0;
+        for (int32_t k = 0; k < blocks_of_batch[b]; ++k, ++bi) {
+            const bvc_bgzf_block &in = blocks[bi];
+            if (in.comp_off < 0 || in.comp_len < 0 || in.comp_off + in.comp_len > comp_bytes || in.isize < 0 || in.isize > 65536)
+                return fail(ctx, BVC_ERR_ARG, "block outside its buffer");
+            blk[(size_t)bi] = in;
+            blk[(size_t)bi].out_off = (int64_t)(at + left + fresh);
+            fresh += (uint64_t)in.isize;
+        }
+        uint32_t skip = 0;
+        if (skip_bytes && left == 0 && skip_bytes[b] > 0) skip = (uint32_t)skip_bytes[b];
+        if (skip > fresh) return fail(ctx, BVC_ERR_ARG, "skip_bytes beyond the batch's first blocks");
+        if (at + left + fresh > (uint64_t)0xFFFFFF00u) return fail(ctx, BVC_ERR_ARG, "more than 4 GiB of text in one tile (send fewer blocks)");
+        reg[b].start = (uint32_t)at + skip; reg[b].len = left + (uint32_t)fresh - skip; reg[b].left_src = ctx->pz_left_src[b]; reg[b].left_len = left;
+        region_end[b] = reg[b].start + reg[b].len;
+        seg_base[b] = segs;
+        segs += (reg[b].len + 1023u) / 1024u;
+        at += left + fresh;
+    }
+    seg_base[nb] = segs;
+    const uint64_t text_bytes = at;
+    const int nw = 1 - ctx->pz_cur;
+    const size_t T = (size_t)max_positions;
+    const int64_t n_lines_cap = (int64_t)max_positions * n_batches;
+    const size_t ls_al = al256(nb * (T + 1) * 4), b_al = al256(nb * 4 + 4), lw_al = al256((size_t)n_lines_cap * 16), st_al = 256;
+    const size_t off_al = al256((T + 1) * 8), tal_al = al256(T * 32 * 4);
+    const size_t blk_al = al256((size_t)n_blocks * sizeof(bvc_bgzf_block)), bst_al = al256((size_t)n_blocks * 4), reg_al = al256(nb * sizeof(bvc_pileup_region));
+    const size_t sb_al = al256((nb + 1) * 4), sn_al = al256((size_t)segs * 4 + 4);
+    int rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_pz_text[nw]), &ctx->pz_text_cap[nw], (size_t)text_bytes + 64);
+    if (rc == BVC_OK) rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_pz_comp), &ctx->pz_comp_cap, (size_t)comp_bytes + 64);
+    if (rc == BVC_OK)
+        rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_pl_meta), &ctx->pl_meta_cap,
+                    ls_al + 2 * b_al + lw_al + st_al + 2 * off_al + tal_al + blk_al + bst_al + reg_al + sb_al + sn_al + 3 * b_al);
+    if (rc != BVC_OK) return rc;
+    char *p = ctx->d_pl_meta;
+    PileupTile &P = ctx->pl;
+    P = PileupTile{};
+    P.text = reinterpret_cast<const uint8_t *>(ctx->d_pz_text[nw]);
+    uint32_t *d_ls = reinterpret_cast<uint32_t *>(p); p += ls_al;
+    int32_t *d_s0 = reinterpret_cast<int32_t *>(p); p += b_al;
+    int32_t *d_nib = reinterpret_cast<int32_t *>(p); p += b_al;
+    P.line_start = d_ls; P.sample0 = d_s0; P.n_in_batch = d_nib;
+    P.line_words = reinterpret_cast<uint32_t *>(p); p += lw_al;
+    P.status = reinterpret_cast<uint32_t *>(p);
+    P.totals = reinterpret_cast<int64_t *>(p + 64);
+    int32_t *d_T = reinterpret_cast<int32_t *>(p + 128); p += st_al;
+    P.entry_off = reinterpret_cast<int64_t *>(p); p += off_al;
+    P.obs_off = reinterpret_cast<int64_t *>(p); p += off_al;
+    P.tally = reinterpret_cast<int32_t *>(p); p += tal_al;
+    bvc_bgzf_block *d_blk = reinterpret_cast<bvc_bgzf_block *>(p); p += blk_al;
+    uint32_t *d_bst = reinterpret_cast<uint32_t *>(p); p += bst_al;
+    bvc_pileup_region *d_reg = reinterpret_cast<bvc_pileup_region *>(p); p += reg_al;
+    uint32_t *d_sb = reinterpret_cast<uint32_t *>(p); p += sb_al;
+    uint32_t *d_sn = reinterpret_cast<uint32_t *>(p); p += sn_al;
+    int32_t *d_lines = reinterpret_cast<int32_t *>(p); p += b_al;
+    uint32_t *d_ends = reinterpret_cast<uint32_t *>(p); p += b_al;
+    P.n_batches = n_batches; P.n_pos = max_positions; P.n_lines_cap = n_lines_cap; P.line_stride = max_positions + 1; P.n_pos_dev = d_T;
+    auto drained = [&](int code) { if (code != BVC_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); } return code; };
+#define BVC_HIP_D(call)                                                                   \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) return drained(fail(ctx, BVC_ERR_DEVICE, #call, e__));     \
+    } while (0)
+    BVC_HIP_D(hipMemsetAsync(P.status, 0, st_al + 2 * off_al + tal_al, ctx->stream));
+    std::vector<uint32_t> bst((size_t)n_blocks);
+    std::vector<uint32_t> ends(nb);
+    uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t tot[2] = {0, 0};
+    int32_t Tgot = 0;
+    if (nb > 0) {
+        if (n_blocks > 0) {
+            BVC_HIP_D(hipMemcpyAsync(ctx->d_pz_comp, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, ctx->stream));
+            BVC_HIP_D(hipMemcpyAsync(d_blk, blk.data(), (size_t)n_blocks * sizeof(bvc_bgzf_block), hipMemcpyHostToDevice, ctx->stream));
+        }
+        BVC_HIP_D(hipMemcpyAsync(d_reg, reg.data(), nb * sizeof(bvc_pileup_region), hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP_D(hipMemcpyAsync(d_sb, seg_base.data(), (nb + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP_D(hipMemcpyAsync(d_s0, sample0, nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP_D(hipMemcpyAsync(d_nib, n_in_batch, nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP_D(launch_region_carry(ctx->stream, reinterpret_cast<const uint8_t *>(ctx->d_pz_text[ctx->pz_cur]),
+                                      reinterpret_cast<uint8_t *>(ctx->d_pz_text[nw]), d_reg, n_batches));
+        if (n_blocks > 0)
+            BVC_HIP_D(launch_inflate(ctx->stream, reinterpret_cast<const uint8_t *>(ctx->d_pz_comp), d_blk, n_blocks,
+                                     reinterpret_cast<uint8_t *>(ctx->d_pz_text[nw]), d_bst));
+        BVC_HIP_D(launch_region_index(ctx->stream, P, d_reg, d_sb, (int64_t)segs, d_sn, d_lines, max_positions));
+        BVC_HIP_D(launch_region_ends(ctx->stream, P, d_ends));
+        BVC_HIP_D(launch_pileup_count(ctx->stream, P));
+        if (n_blocks > 0) BVC_HIP_D(hipMemcpyAsync(bst.data(), d_bst, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, ctx->stream));
+        BVC_HIP_D(hipMemcpyAsync(lines_of_batch, d_lines, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+        BVC_HIP_D(hipMemcpyAsync(ends.data(), d_ends, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+        BVC_HIP_D(hipMemcpyAsync(&Tgot, d_T, 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    BVC_HIP_D(hipMemcpyAsync(st, P.status, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+    BVC_HIP_D(hipMemcpyAsync(tot, P.totals, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
+    BVC_HIP_D(hipStreamSynchronize(ctx->stream));
+#undef BVC_HIP_D
+    for (int64_t i = 0; i < n_blocks; ++i)
+        if (bst[(size_t)i] != 0) {
+            ctx->pz_left_len.assign(nb, 0u);                     // the stream of this window is broken: nothing to carry on with
+            return fail(ctx, BVC_ERR_DATA, "a BGZF block of a temp batch is not valid deflate of its ISIZE bytes");
+        }
+    // what this tile leaves of every batch: from the end of its last line to the end of its region
+    for (size_t b = 0; b < nb; ++b) { ctx->pz_left_src[b] = ends[b]; ctx->pz_left_len[b] = region_end[b] - ends[b]; }
+    ctx->pz_cur = nw;
+    P.n_pos = Tgot; P.n_pos_dev = nullptr;
+    ctx->pl_text_bytes = (int64_t)text_bytes;
+    ctx->pl_on_device_text = true;
+    *n_positions = Tgot;
+    if (Tgot == 0) return BVC_OK;
+    if (st[0] != 0) return BVC_PILEUP_IRREGULAR;
+    ctx->pl_entries = tot[0]; ctx->pl_obs = tot[1]; ctx->pl_indels = st[1]; ctx->pl_indel_bytes = st[4];
+    ctx->pl_begun = true;
+    *n_entries = tot[0]; *n_indels = st[1]; *indel_text_bytes = st[4];
+    return BVC_OK;
+}
+
+int bvc_pileup_text(bvc_ctx *ctx, char *text, int64_t text_cap, int64_t *text_bytes_needed, uint32_t *line_start)
+{
+    if (!ctx || !text_bytes_needed) return BVC_ERR_ARG;
+    if (!ctx->pl_on_device_text) return fail(ctx, BVC_ERR_ARG, "bvc_pileup_text without a tile from bvc_pileup_begin_bgzf");
+    *text_bytes_needed = ctx->pl_text_bytes;
+    if (!text) return BVC_OK;
+    if (text_cap < ctx->pl_text_bytes || !line_start) return fail(ctx, BVC_ERR_ARG, "text buffer too small / null line table");
+    BVC_HIP(ctx, hipSetDevice(ctx->device));
+    const PileupTile &P = ctx->pl;
+    if (ctx->pl_text_bytes) BVC_HIP(ctx, hipMemcpyAsync(text, P.text, (size_t)ctx->pl_text_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (P.n_batches > 0)
+        BVC_HIP(ctx, hipMemcpy2DAsync(line_start, (size_t)(P.n_pos + 1) * 4, P.line_start, (size_t)P.line_stride * 4, (size_t)(P.n_pos + 1) * 4,
+                                      (size_t)P.n_batches, hipMemcpyDeviceToHost, ctx->stream));
+    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BVC_OK;
 }
 
 int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const uint8_t carry_in[5], uint8_t carry_out[5],
                       const uint8_t *group_of_sample, int64_t n_samples, int32_t n_groups,
                       int64_t *entry_off, int32_t *tally, bvc_pileup_entry *entries, int32_t *samples,
-                      bvc_pileup_indel *indels, bvc_site_result *results, bvc_group_result *grp_results)
+                      bvc_pileup_indel *indels, char *indel_text, bvc_site_result *results, bvc_group_result *grp_results)
 {
     if (!ctx) return BVC_ERR_ARG;
     if (!ctx->pl_begun) return fail(ctx, BVC_ERR_ARG, "bvc_pileup_finish without a bvc_pileup_begin that returned BVC_OK");
+    if (ctx->pl_on_device_text && ctx->pl_indels > 0 && !indel_text) return fail(ctx, BVC_ERR_ARG, "indel_text is needed: the tile's text is on the device only");
     ctx->pl_begun = false;
     PileupTile &P = ctx->pl;
     const int64_t T = P.n_pos, n_e = ctx->pl_entries, n_o = ctx->pl_obs, n_i = ctx->pl_indels;
@@ -1227,7 +1400,9 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
     const size_t os_al = al256((size_t)n_o * 4 + 16), i_al = al256((size_t)n_i * sizeof(bvc_pileup_indel) + 16), r_al = al256((size_t)T + 16);
     const size_t res_al = al256((size_t)T * sizeof(bvc_site_result)), g_al = al256((size_t)(n_groups ? n_samples : 0) + 16);
     const size_t gres_al = al256((size_t)T * (size_t)n_groups * sizeof(bvc_group_result));
-    int rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_pl_out), &ctx->pl_out_cap, e_al + s_al + 2 * o_al + os_al + i_al + r_al + res_al + g_al + gres_al + 256);
+    const size_t it_al = al256((size_t)(indel_text ? ctx->pl_indel_bytes : 0) + 16);
+    int rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_pl_out), &ctx->pl_out_cap,
+                    e_al + s_al + 2 * o_al + os_al + i_al + r_al + res_al + g_al + gres_al + it_al + 256);
     if (rc != BVC_OK) return rc;
     char *p = ctx->d_pl_out;
     P.entries = reinterpret_cast<bvc_pileup_entry *>(p); p += e_al;
@@ -1240,7 +1415,8 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
     int8_t *d_ref = reinterpret_cast<int8_t *>(p); p += r_al;
     bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(p); p += res_al;
     uint8_t *d_g = reinterpret_cast<uint8_t *>(p); p += g_al;
-    bvc_group_result *d_gres = reinterpret_cast<bvc_group_result *>(p);
+    bvc_group_result *d_gres = reinterpret_cast<bvc_group_result *>(p); p += gres_al;
+    uint8_t *d_itext = reinterpret_cast<uint8_t *>(p);
     const uint32_t cin = (uint32_t)(carry_in[0] & 7u) | ((uint32_t)(carry_in[4] & 1u) << 3) | 0x80u | ((uint32_t)carry_in[1] << 8) |
                          ((uint32_t)carry_in[2] << 16) | ((uint32_t)carry_in[3] << 24);
     auto drained = [&](int code) {
@@ -1261,7 +1437,7 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
     if (T > 0) {
         BVC_HIP_D(hipMemcpyAsync(d_ref, ref_base, (size_t)T, hipMemcpyHostToDevice, ctx->stream));
         if (n_groups > 0 && n_samples > 0) BVC_HIP_D(hipMemcpyAsync(d_g, group_of_sample, (size_t)n_samples, hipMemcpyHostToDevice, ctx->stream));
-        if (P.n_lines > 0) BVC_HIP_D(launch_pileup_write(ctx->stream, P, cin));
+        if ((int64_t)P.n_pos * P.n_batches > 0) BVC_HIP_D(launch_pileup_write(ctx->stream, P, cin));
         if (n_groups > 0)
             rc = run_csr_groups_device(ctx, T, P.obs_off, P.obs_base, P.obs_qual, P.obs_sample, d_ref, min_af, d_g, n_samples, n_groups, d_res, d_gres);
         else
@@ -1276,8 +1452,12 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
             BVC_HIP_D(hipMemcpyAsync(entries, P.entries, (size_t)n_e * sizeof(bvc_pileup_entry), hipMemcpyDeviceToHost, ctx->stream));
             BVC_HIP_D(hipMemcpyAsync(samples, P.samples, (size_t)n_e * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
+        if (n_i && indel_text) {
+            BVC_HIP_D(launch_indel_text(ctx->stream, P, d_itext, (uint32_t)ctx->pl_indel_bytes, P.status + 5));
+            if (ctx->pl_indel_bytes) BVC_HIP_D(hipMemcpyAsync(indel_text, d_itext, (size_t)ctx->pl_indel_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        }
         if (n_i) BVC_HIP_D(hipMemcpyAsync(indels, P.indels, (size_t)n_i * sizeof(bvc_pileup_indel), hipMemcpyDeviceToHost, ctx->stream));
-        if (P.n_lines > 0) BVC_HIP_D(hipMemcpyAsync(&cout, P.status + 3, 4, hipMemcpyDeviceToHost, ctx->stream));
+        if ((int64_t)P.n_pos * P.n_batches > 0) BVC_HIP_D(hipMemcpyAsync(&cout, P.status + 3, 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     BVC_HIP_D(hipMemcpyAsync(entry_off, P.entry_off, (size_t)(T + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     BVC_HIP_D(hipStreamSynchronize(ctx->stream));

@@ -125,12 +125,15 @@ hipError_t launch_synth_dense(hipStream_t stream, uint64_t seed, int64_t site0, 
 // Device buffers of one tile between bvc_pileup_begin and bvc_pileup_finish (all owned by the context).
 struct PileupTile {
     const uint8_t *text = nullptr;
-    const uint32_t *line_start = nullptr;    // [n_batches][n_pos + 1]
+    const uint32_t *line_start = nullptr;    // [n_batches][line_stride]
     const int32_t *sample0 = nullptr, *n_in_batch = nullptr;
-    int32_t n_batches = 0, n_pos = 0;
-    int64_t n_lines = 0;
-    uint32_t *line_words = nullptr;          // 4 arrays of n_lines words: entries, observations, last base token, inherited indels
+    int32_t n_batches = 0, n_pos = 0;        // n_pos: the tile's positions (an upper bound while n_pos_dev decides)
+    int32_t line_stride = 0;                 // elements of line_start per batch
+    const int32_t *n_pos_dev = nullptr;      // tiles inflated on the device: the positions, decided there
+    int64_t n_lines_cap = 0;                 // lines the per-line arrays are laid out for
+    uint32_t *line_words = nullptr;          // 4 arrays of n_lines_cap words: entries, observations, last base token, inherited indels
     uint32_t *status = nullptr;              // [0] irregular lines [1] indel entries [2] indel records written [3] carry out
+                                             // [4] bytes of indel tokens [5] bytes of indel text gathered
     int64_t *entry_off = nullptr, *obs_off = nullptr, *totals = nullptr;    // [n_pos + 1], [n_pos + 1], [2]
     bvc_pileup_entry *entries = nullptr;
     int32_t *samples = nullptr, *obs_sample = nullptr;
@@ -139,6 +142,16 @@ struct PileupTile {
     bvc_pileup_indel *indels = nullptr;
     uint32_t indel_cap = 0;
 };
+// A batch's region of the text buffer of a tile inflated on the device: [start, start + len) = left_len bytes the tile before left
+// (at left_src of the other text buffer) + the output of the batch's new blocks.
+struct bvc_pileup_region { uint32_t start, len, left_src, left_len; };
+hipError_t launch_region_carry(hipStream_t stream, const uint8_t *old_text, uint8_t *text, const bvc_pileup_region *regions, int32_t n_batches);
+// newlines of every region -> lines[b], the tile's positions (*P.n_pos_dev = min(lines, max_pos)), line_start of those positions
+hipError_t launch_region_index(hipStream_t stream, const PileupTile &P, const bvc_pileup_region *regions, const uint32_t *seg_base,
+                               int64_t n_segments, uint32_t *seg_nl, int32_t *lines, int32_t max_pos);
+hipError_t launch_region_ends(hipStream_t stream, const PileupTile &P, uint32_t *ends);
+// the text of the indel tokens gathered into dst (records' text_off become offsets into it); *used = bytes
+hipError_t launch_indel_text(hipStream_t stream, const PileupTile &P, uint8_t *dst, uint32_t dst_cap, uint32_t *used);
 // count pass + prefix sums (fills line_words, entry_off, obs_off, totals, status[0..1])
 hipError_t launch_pileup_count(hipStream_t stream, const PileupTile &P);
 // write pass + the entries that inherit across lines (status[2] and tally must be zero; leaves the carry in status[3])

@@ -191,6 +191,8 @@ __global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restric
                     ++o;
                     if ((o & 1023u) == 0u) flush_full();
                 }
+                // (the bytes of a stored block must have come from inside the BGZF block too)
+                if ((int64_t)next_word * 32 - bc - 8 * (int64_t)lead > (int64_t)clen * 8) err = kErrInput;
                 continue;
             }
             if (type == 3u) { err = kErrType; break; }

@@ -444,7 +444,6 @@ __global__ __launch_bounds__(kParseWaves * kWave) void region_lines_kernel(Regio
         } else {
             const int32_t T = *A.n_pos;
             uint32_t rank = A.seg_nl[seg] + incl - (uint32_t)__builtin_popcount(nl);       // newlines of the region before this lane's bytes
-            if (seg == (int64_t)A.seg_base[b] && lane == 0) A.line_start[(int64_t)b * A.line_stride] = r0;
             for (uint32_t m = nl; m; m &= m - 1u) {
                 ++rank;                                          // the line behind this newline is line `rank`
                 if ((int32_t)rank <= T) A.line_start[(int64_t)b * A.line_stride + rank] = at + (uint32_t)__builtin_ctz(m) + 1u;
@@ -462,6 +461,7 @@ __global__ void region_scan_kernel(RegionArgs A)
         uint32_t run = 0;
         for (uint32_t s = A.seg_base[b]; s < A.seg_base[b + 1]; ++s) { const uint32_t c = A.seg_nl[s]; A.seg_nl[s] = run; run += c; }
         A.lines[b] = (int32_t)run;
+        A.line_start[(int64_t)b * A.line_stride] = A.regions[b].start;   // (also of a batch whose region is empty: it has no segment to do it)
         atomicMin(&least, (int32_t)run);
     }
     __syncthreads();
@@ -490,17 +490,11 @@ __global__ void indel_text_kernel(const uint8_t *__restrict__ text, bvc_pileup_i
     }
 }
 
-hipError_t launch_region_lines(hipStream_t stream, const PileupTile &P, const uint8_t *old_text, const bvc_pileup_region *regions,
-                               const uint32_t *seg_base, int64_t n_segments, uint32_t *seg_nl, int32_t *lines, int32_t max_pos)
+hipError_t launch_region_carry(hipStream_t stream, const uint8_t *old_text, uint8_t *text, const bvc_pileup_region *regions, int32_t n_batches)
 {
-    if (P.n_batches <= 0) return hipSuccess;
-    RegionArgs A{};
-    A.text = P.text; A.regions = regions; A.seg_base = seg_base; A.n_batches = P.n_batches; A.max_pos = max_pos; A.line_stride = P.line_stride;
-    A.seg_nl = seg_nl; A.lines = lines; A.n_pos = const_cast<int32_t *>(P.n_pos_dev); A.line_start = const_cast<uint32_t *>(P.line_start);
-    if (old_text)
-        hipLaunchKernelGGL(region_carry_kernel, dim3((unsigned)P.n_batches), dim3(256), 0, stream, old_text, const_cast<uint8_t *>(P.text), regions);
+    if (n_batches <= 0) return hipSuccess;
+    hipLaunchKernelGGL(region_carry_kernel, dim3((unsigned)n_batches), dim3(256), 0, stream, old_text, text, regions);
     return hipGetLastError();
-    (void)n_segments; (void)A;
 }
 
 hipError_t launch_region_index(hipStream_t stream, const PileupTile &P, const bvc_pileup_region *regions, const uint32_t *seg_base,
@@ -515,6 +509,22 @@ hipError_t launch_region_index(hipStream_t stream, const PileupTile &P, const bv
     hipLaunchKernelGGL(region_lines_kernel<false>, dim3(grid), dim3(kParseWaves * kWave), 0, stream, A);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(256), 0, stream, A);
     hipLaunchKernelGGL(region_lines_kernel<true>, dim3(grid), dim3(kParseWaves * kWave), 0, stream, A);
+    return hipGetLastError();
+}
+
+// ends[b] = where the tile's last line of batch b ends (the start of what the tile leaves of the batch)
+__global__ void region_ends_kernel(const uint32_t *__restrict__ line_start, int32_t line_stride, const int32_t *__restrict__ n_pos, int32_t n_batches,
+                                   uint32_t *__restrict__ ends)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_batches) ends[b] = line_start[(int64_t)b * line_stride + *n_pos];
+}
+
+hipError_t launch_region_ends(hipStream_t stream, const PileupTile &P, uint32_t *ends)
+{
+    if (P.n_batches <= 0) return hipSuccess;
+    hipLaunchKernelGGL(region_ends_kernel, dim3((unsigned)((P.n_batches + 255) / 256)), dim3(256), 0, stream, P.line_start, P.line_stride, P.n_pos_dev,
+                       P.n_batches, ends);
     return hipGetLastError();
 }
 

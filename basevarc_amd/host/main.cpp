@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -355,38 +356,36 @@ struct TileRunner {
         if (started) { dev_q.close(); dev_thread.join(); out_thread.join(); }
     }
 
-    // stage 2 of a tile of TEXT: parse and LRT on the device; the CPU parser only when a line is not what the writer produces
-    void run_device_text(Tile &T)
+    // A tile whose lines are in T.text / T.line_start through the reference's own rules (strtok_r, atoi) on the CPU, position by position,
+    // batch by batch; then the ragged call.  (A line of the tile is not what the reference's writer produces.)
+    void cpu_parse_tile(Tile &T)
+    {
+        const double t0 = StageClock::now();
+        tiles_cpu_parsed += 1;
+        set_parser_carry(carry);
+        const size_t nb = sample0.size();
+        for (size_t t = 0; t < T.n_pos; ++t) {
+            SiteColumn &site = T.slot();
+            site.clear();
+            site.pos = T.pos[t];
+            int32_t j = 0;
+            for (size_t b = 0; b < nb; ++b) {
+                const uint32_t s0 = T.line_start[b * (T.n_pos + 1) + t], s1 = T.line_start[b * (T.n_pos + 1) + t + 1];
+                j += parse_pileup_line(T.text.data() + s0, (size_t)(s1 - s0 - 1), j, site);
+            }
+            if (!site.aiv.empty()) { T.refs[T.n_used] = T.refs[t]; ++T.n_used; }
+        }
+        T.refs.resize(T.n_used);
+        get_parser_carry(carry);
+        clk_dev.pack += StageClock::now() - t0;
+        if (T.n_used) run_device(T);
+    }
+
+    // bvc_pileup_finish into the tile's arrays (after a begin that returned BVC_OK).  text_on_device: the indel tokens' text comes back
+    // in T.text (the tile's own text never was on the host).
+    void finish_tile(Tile &T, int64_t n_ent, int64_t n_ind, int64_t ind_bytes, bool text_on_device)
     {
         const int ng = groups ? (int)groups->names.size() : 0;
-        const double t0 = StageClock::now();
-        int64_t n_ent = 0, n_ind = 0;
-        int rc = bvc_pileup_begin(ctx, T.text.data(), (int64_t)T.text.size(), T.line_start.data(), sample0.data(), n_in_batch.data(),
-                                  (int32_t)sample0.size(), (int32_t)T.n_pos, &n_ent, &n_ind);
-        if (rc == BVC_PILEUP_IRREGULAR) {
-            // the reference's rules (strtok_r, atoi) on this tile's lines, position by position, batch by batch; then the ragged call
-            tiles_cpu_parsed += 1;
-            set_parser_carry(carry);
-            const size_t nb = sample0.size();
-            for (size_t t = 0; t < T.n_pos; ++t) {
-                SiteColumn &site = T.slot();
-                site.clear();
-                site.pos = T.pos[t];
-                int32_t j = 0;
-                for (size_t b = 0; b < nb; ++b) {
-                    const uint32_t s0 = T.line_start[b * (T.n_pos + 1) + t], s1 = T.line_start[b * (T.n_pos + 1) + t + 1];
-                    j += parse_pileup_line(T.text.data() + s0, (size_t)(s1 - s0 - 1), j, site);
-                }
-                if (!site.aiv.empty()) { T.refs[T.n_used] = T.refs[t]; ++T.n_used; }
-            }
-            T.refs.resize(T.n_used);
-            get_parser_carry(carry);
-            clk_dev.pack += StageClock::now() - t0;
-            if (T.n_used) run_device(T);
-            return;
-        }
-        if (rc != BVC_OK) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(ctx));
-        tiles_dev_parsed += 1;
         T.entry_off.resize(T.n_pos + 1);
         T.tally.resize(T.n_pos * 32);
         T.ent.resize((size_t)n_ent + 1);
@@ -394,15 +393,30 @@ struct TileRunner {
         T.indels.resize((size_t)n_ind + 1);
         T.res.resize(T.n_pos);
         T.gres.resize(T.n_pos * (size_t)ng);
+        if (text_on_device) T.text.resize((size_t)ind_bytes + 1);
         uint8_t carry_out[5];
-        rc = bvc_pileup_finish(ctx, T.refs.data(), min_af, carry, carry_out, ng ? groups->of_sample.data() : nullptr,
-                               ng ? (int64_t)groups->of_sample.size() : 0, ng, T.entry_off.data(), T.tally.data(), T.ent.data(),
-                               T.samples.data(), T.indels.data(), T.res.data(), ng ? T.gres.data() : nullptr);
+        const int rc = bvc_pileup_finish(ctx, T.refs.data(), min_af, carry, carry_out, ng ? groups->of_sample.data() : nullptr,
+                                         ng ? (int64_t)groups->of_sample.size() : 0, ng, T.entry_off.data(), T.tally.data(), T.ent.data(),
+                                         T.samples.data(), T.indels.data(), text_on_device ? T.text.data() : nullptr, T.res.data(),
+                                         ng ? T.gres.data() : nullptr);
         if (rc != BVC_OK) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(ctx));
         std::memcpy(carry, carry_out, 5);
         T.indels.resize((size_t)n_ind);
         std::sort(T.indels.begin(), T.indels.end(), [](const bvc_pileup_indel &a, const bvc_pileup_indel &b) { return a.entry < b.entry; });
         T.dev_parsed = true;
+        tiles_dev_parsed += 1;
+    }
+
+    // stage 2 of a tile of TEXT: parse and LRT on the device; the CPU parser only when a line is not what the writer produces
+    void run_device_text(Tile &T)
+    {
+        const double t0 = StageClock::now();
+        int64_t n_ent = 0, n_ind = 0;
+        const int rc = bvc_pileup_begin(ctx, T.text.data(), (int64_t)T.text.size(), T.line_start.data(), sample0.data(), n_in_batch.data(),
+                                        (int32_t)sample0.size(), (int32_t)T.n_pos, &n_ent, &n_ind);
+        if (rc == BVC_PILEUP_IRREGULAR) { cpu_parse_tile(T); return; }
+        if (rc != BVC_OK) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(ctx));
+        finish_tile(T, n_ent, n_ind, 0, false);
         clk_dev.gpu += StageClock::now() - t0;
     }
 
@@ -559,6 +573,112 @@ struct TileRunner {
     }
 };
 
+// ---- temp batches as RAW BGZF blocks (the device inflates them: bvc_pileup_begin_bgzf) ------------------------------------------
+// One block of a temp-batch file as it is on disk: its deflate payload and the size it inflates to.
+struct RawBlock { std::vector<unsigned char> payload; uint32_t isize = 0; };
+
+// The blocks of the temp-batch files of a thread, read ahead of the tiles by a thread of their own into one FIFO per batch.
+class RawBlockFeed {
+ public:
+    explicit RawBlockFeed(const std::vector<std::string> &paths, size_t ahead_per_batch) : ahead_(ahead_per_batch)
+    {
+        for (auto const &f : paths) {
+            FILE *fp = std::fopen(f.c_str(), "rb");
+            if (!fp) throw std::runtime_error("ERROR: can not open " + f);
+            fps_.push_back(fp);
+        }
+        q_.resize(paths.size());
+        eof_.assign(paths.size(), false);
+        th_ = std::thread([this] { run(); });
+    }
+    ~RawBlockFeed()
+    {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_room_.notify_all();
+        th_.join();
+        for (auto fp : fps_) std::fclose(fp);
+    }
+    // the next block of batch b; false when the file has ended (throws on a damaged file)
+    bool pop(size_t b, RawBlock &out)
+    {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_data_.wait(g, [&] { return !q_[b].empty() || eof_[b] || !err_.empty(); });
+        if (!err_.empty()) throw std::runtime_error(err_);
+        if (q_[b].empty()) return false;
+        out = std::move(q_[b].front());
+        q_[b].pop_front();
+        g.unlock();
+        cv_room_.notify_one();
+        return true;
+    }
+ private:
+    void run()
+    {
+        try {
+            for (;;) {
+                bool any = false, all_eof = true;
+                for (size_t b = 0; b < fps_.size(); ++b) {
+                    {
+                        std::unique_lock<std::mutex> g(mu_);
+                        if (stop_) return;
+                        if (eof_[b]) continue;
+                        all_eof = false;
+                        if (q_[b].size() >= ahead_) continue;
+                    }
+                    RawBlock blk;
+                    const bool got = read_block(fps_[b], blk);
+                    {
+                        std::lock_guard<std::mutex> g(mu_);
+                        if (got) q_[b].push_back(std::move(blk)); else eof_[b] = true;
+                    }
+                    cv_data_.notify_all();
+                    any = true;
+                }
+                if (all_eof) return;
+                if (!any) {
+                    std::unique_lock<std::mutex> g(mu_);
+                    cv_room_.wait(g, [&] {
+                        if (stop_) return true;
+                        for (size_t b = 0; b < q_.size(); ++b) if (!eof_[b] && q_[b].size() < ahead_) return true;
+                        return false;
+                    });
+                }
+            }
+        } catch (const std::exception &e) {
+            { std::lock_guard<std::mutex> g(mu_); err_ = e.what(); }
+            cv_data_.notify_all();
+        }
+    }
+    // the next non-empty block of the file (SAM specification 4.1: 18-byte header with the 'BC' subfield, payload, CRC32, ISIZE)
+    static bool read_block(FILE *fp, RawBlock &blk)
+    {
+        for (;;) {
+            unsigned char h[18];
+            const size_t n = std::fread(h, 1, 18, fp);
+            if (n == 0) return false;
+            if (n != 18 || h[0] != 0x1f || h[1] != 0x8b || h[12] != 'B' || h[13] != 'C') throw std::runtime_error("ERROR: a temp batch is not BGZF");
+            const size_t bsize = ((size_t)h[16] | ((size_t)h[17] << 8)) + 1;
+            if (bsize < 18 + 8) throw std::runtime_error("ERROR: a temp batch is not BGZF");
+            blk.payload.resize(bsize - 18 - 8);
+            unsigned char t[8];
+            if ((blk.payload.size() && std::fread(blk.payload.data(), 1, blk.payload.size(), fp) != blk.payload.size()) || std::fread(t, 1, 8, fp) != 8)
+                throw std::runtime_error("ERROR: truncated temp batch (it ends inside a BGZF block)");
+            blk.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+            if (blk.isize > 65536) throw std::runtime_error("ERROR: a temp batch is not BGZF (a block of more than 64 KiB)");
+            if (blk.isize != 0) return true;                      // (empty blocks: the EOF marker)
+        }
+    }
+    std::vector<FILE *> fps_;
+    std::vector<std::deque<RawBlock>> q_;
+    std::vector<bool> eof_;
+    size_t ahead_;
+    std::mutex mu_;
+    std::condition_variable cv_data_, cv_room_;
+    bool stop_ = false;
+    std::string err_;
+    std::thread th_;
+};
+
 // One temp-batch file of a thread, in either form (detected from its first bytes).
 struct BatchInput {
     BgzfReader rd;
@@ -691,6 +811,8 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
     bool dev_parse = !qual_shift && !(getenv("BVC_HOST_DEVICE_PARSE") && atoi(getenv("BVC_HOST_DEVICE_PARSE")) == 0);
     for (auto fp : fpiv) if (fp->bin) dev_parse = false;
     const double t_loop = StageClock::now();
+    // ... and with the blocks of the temp batches inflated on the device too (the default): BVC_HOST_DEVICE_INFLATE=0 inflates on the CPU
+    const bool dev_inflate = dev_parse && !(getenv("BVC_HOST_DEVICE_INFLATE") && atoi(getenv("BVC_HOST_DEVICE_INFLATE")) == 0);
     if (dev_parse) {
         // per batch: its first sample and its samples, from the names line (tab-terminated names, src/BaseVarC.cpp:495, 503)
         int32_t j0 = 0;
@@ -700,6 +822,110 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
             j0 += n_in;
         }
         get_parser_carry(tr.carry);                                     // (zeros: reset_parser_carry above)
+    }
+    if (dev_inflate) {
+        // The files go to the device as they are: this thread reads raw blocks (a thread of the feed's own keeps a few ahead per batch),
+        // hands every batch's next blocks to bvc_pileup_begin_bgzf -- as many as its lines are short of the tile's target, counted from what
+        // the calls report back -- and the tile is the positions every batch has whole.  Stage 3 (CVG / VCF lines) runs beside it.
+        const size_t nb = fpiv.size();
+        std::vector<int32_t> skip(nb);
+        for (size_t b = 0; b < nb; ++b) skip[b] = (int32_t)fpiv[b]->names.size() + 1;      // the names line and its newline
+        for (auto fp : fpiv) delete fp;
+        fpiv.clear();
+        const double tile_mb = getenv("BVC_HOST_TILE_MB") ? std::max(1, atoi(getenv("BVC_HOST_TILE_MB"))) : 32;
+        const double blocks_per_batch = std::max(1.0, tile_mb * 1048576.0 / (65280.0 * (double)std::max<size_t>(1, nb)));
+        RawBlockFeed feed(ftmp_v, (size_t)(2 * blocks_per_batch) + 4);
+        std::vector<double> lines_per_block(nb, 0.0);                   // running estimate per batch
+        std::vector<int64_t> blocks_sent(nb, 0), lines_seen(nb, 0);
+        std::vector<int32_t> left_lines(nb, 0), lines(nb, 0), send(nb, 0);
+        std::vector<char> ended(nb, 0);
+        std::vector<unsigned char> comp;
+        std::vector<bvc_bgzf_block> blocks;
+        bool first = true;
+        int64_t target = 1;                                             // positions the next tile should hold
+        for (size_t ip = lo; ip < hi;) {
+            const double t0 = StageClock::now();
+            // every batch's new blocks: enough for `target` lines going by its lines per block so far (the first call: the names line and
+            // one block of positions); a batch found without a whole line gets one block more than that
+            comp.clear(); blocks.clear();
+            bool any_new = false;
+            for (size_t b = 0; b < nb; ++b) {
+                int64_t want = 0;
+                if (first) { want = 1 + skip[b] / 60000; }
+                else if (left_lines[b] < target) {
+                    const double lpb = lines_per_block[b] > 0 ? lines_per_block[b] : 1.0;
+                    want = (int64_t)std::ceil((double)(target - left_lines[b]) / lpb);
+                    if (want < 1) want = 1;
+                }
+                int32_t took = 0;
+                RawBlock rb;
+                while (took < want && !ended[b]) {
+                    if (!feed.pop(b, rb)) { ended[b] = 1; break; }
+                    bvc_bgzf_block blk;
+                    blk.comp_off = (int64_t)comp.size(); blk.out_off = 0; blk.comp_len = (int32_t)rb.payload.size(); blk.isize = (int32_t)rb.isize;
+                    comp.insert(comp.end(), rb.payload.begin(), rb.payload.end());
+                    comp.resize((comp.size() + 3) & ~(size_t)3);
+                    blocks.push_back(blk);
+                    ++took;
+                }
+                send[b] = took;
+                blocks_sent[b] += took;
+                any_new = any_new || took > 0;
+            }
+            tr.clk.read += StageClock::now() - t0;
+            const double t1 = StageClock::now();
+            Tile &tl = *tr.cur;
+            const int32_t max_pos = (int32_t)std::min<int64_t>((int64_t)(hi - ip), std::max<int64_t>(2 * target, 64));
+            int32_t T = 0;
+            int64_t n_ent = 0, n_ind = 0, ind_bytes = 0;
+            const int rc = bvc_pileup_begin_bgzf(tr.ctx, comp.empty() ? nullptr : comp.data(), (int64_t)comp.size(), blocks.data(), send.data(),
+                                                 first ? skip.data() : nullptr, tr.sample0.data(), tr.n_in_batch.data(), (int32_t)nb, max_pos,
+                                                 first ? 1 : 0, &T, lines.data(), &n_ent, &n_ind, &ind_bytes);
+            first = false;
+            if (rc < 0) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(tr.ctx) + " (BVC_HOST_DEVICE_INFLATE=0 inflates on the CPU)");
+            for (size_t b = 0; b < nb; ++b) {
+                lines_seen[b] += lines[b] - left_lines[b];
+                if (blocks_sent[b] > 0) lines_per_block[b] = (double)lines_seen[b] / (double)blocks_sent[b];
+                left_lines[b] = lines[b] - T;
+            }
+            if (T == 0) {
+                // some batch has no whole line yet: it gets more blocks next time round (left_lines < target); nothing new and nothing
+                // whole means its file has ended before the window has
+                if (!any_new) throw std::runtime_error("ERROR: truncated temp batch (it ends before the thread's window does)");
+                continue;
+            }
+            tl.dev = true; tl.n_pos = (size_t)T;
+            tl.refs.resize((size_t)T);
+            tl.pos.resize((size_t)T);
+            for (int32_t k = 0; k < T; ++k) {
+                const int32_t p = pv[ip + (size_t)k];
+                const char rcc = refseq[(size_t)(p - rg_s)];
+                tl.pos[(size_t)k] = p;
+                tl.refs[(size_t)k] = rcc == 'A' ? 0 : rcc == 'C' ? 1 : rcc == 'G' ? 2 : rcc == 'T' ? 3 : -1;
+            }
+            if (rc == BVC_PILEUP_IRREGULAR) {
+                int64_t need = 0;
+                if (bvc_pileup_text(tr.ctx, nullptr, 0, &need, nullptr) != BVC_OK) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(tr.ctx));
+                tl.text.resize((size_t)need + 1);
+                tl.line_start.resize(nb * ((size_t)T + 1));
+                if (bvc_pileup_text(tr.ctx, tl.text.data(), need, &need, tl.line_start.data()) != BVC_OK)
+                    throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(tr.ctx));
+                tr.cpu_parse_tile(tl);
+            } else {
+                tr.finish_tile(tl, n_ent, n_ind, ind_bytes, true);
+            }
+            tr.clk_dev.gpu += StageClock::now() - t1;
+            // the tile after this one: the positions that ~tile_mb of text hold, going by the batch with the fewest lines per block
+            double lpb_min = 1e30;
+            for (size_t b = 0; b < nb; ++b) if (lines_per_block[b] > 0) lpb_min = std::min(lpb_min, lines_per_block[b]);
+            if (lpb_min < 1e30) target = std::max<int64_t>(1, std::min<int64_t>(tile, (int64_t)(blocks_per_batch * lpb_min)));
+            ip += (size_t)T;
+            // straight to stage 3 (this thread did stage 2's work itself)
+            if (tr.failed()) { std::lock_guard<std::mutex> g(tr.err_mu); throw std::runtime_error(tr.err); }
+            tr.out_q.push(tr.cur);
+            tr.cur = tr.free_q.pop();
+        }
+    } else if (dev_parse) {
         // a tile: --tile positions at most, and about BVC_HOST_TILE_MB of text (default 32) going by the tile before it
         const double target = 1048576.0 * (getenv("BVC_HOST_TILE_MB") ? std::max(1, atoi(getenv("BVC_HOST_TILE_MB"))) : 32);
         double bytes_per_pos = 0;

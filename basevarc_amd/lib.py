@@ -51,7 +51,7 @@ EXPORTS = [
     "bvc_synchronize", "bvc_set_overlap", "bvc_join", "bvc_set_profiling", "bvc_get_profile", "bvc_lrt_dense", "bvc_lrt_dense_groups",
     "bvc_lrt_csr", "bvc_lrt_csr_comb", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense", "bvc_stream_read_ms", "bvc_set_tuning",
     "bvc_lrt_dense_packed", "bvc_pack_dense", "bvc_hist_dense_packed", "bvc_lrt_dense_groups_packed",
-    "bvc_lrt_csr_packed", "bvc_lrt_csr_groups", "bvc_pileup_begin", "bvc_pileup_finish", "bvc_inflate_blocks",
+    "bvc_lrt_csr_packed", "bvc_lrt_csr_groups", "bvc_pileup_begin", "bvc_pileup_finish", "bvc_inflate_blocks", "bvc_pileup_begin_bgzf", "bvc_pileup_text",
 ]
 
 _lib = None
@@ -118,7 +118,12 @@ def load_library():
     L.bvc_pileup_begin.restype = C.c_int
     L.bvc_pileup_begin.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     L.bvc_pileup_finish.restype = C.c_int
-    L.bvc_pileup_finish.argtypes = [vp, vp, dbl, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.bvc_pileup_finish.argtypes = [vp, vp, dbl, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.bvc_pileup_begin_bgzf.restype = C.c_int
+    L.bvc_pileup_begin_bgzf.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(i32), vp, C.POINTER(i64), C.POINTER(i64),
+                                        C.POINTER(i64)]
+    L.bvc_pileup_text.restype = C.c_int
+    L.bvc_pileup_text.argtypes = [vp, vp, i64, C.POINTER(i64), vp]
     L.bvc_inflate_blocks.restype = C.c_int
     L.bvc_inflate_blocks.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, u32]
     _lib = L
@@ -289,15 +294,19 @@ class Context:
         if rc == 1:
             return None
         self._check(rc)
+        return self._pileup_finish(T, ne.value, ni.value, 0, ref_base, min_af, carry_in, group_of_sample, n_groups)
+
+    def _pileup_finish(self, T, n_entries, n_indels, indel_text_bytes, ref_base, min_af, carry_in, group_of_sample, n_groups):
         ENTRY = np.dtype([("base", "u1"), ("mapq", "u1"), ("qual", "u1"), ("rpr", "u1"), ("strand", "u1"), ("is_indel", "u1"), ("pad", "<u2")])
         INDEL = np.dtype([("entry", "<i8"), ("text_off", "<i8"), ("len", "<i4"), ("pad", "<i4")])
         r = np.ascontiguousarray(ref_base, dtype=np.int8)
         assert r.shape == (T,)
         entry_off = np.zeros(T + 1, dtype=np.int64)
         tally = np.zeros((T, 32), dtype=np.int32)
-        entries = np.zeros(max(1, ne.value), dtype=ENTRY)
-        samples = np.zeros(max(1, ne.value), dtype=np.int32)
-        indels = np.zeros(max(1, ni.value), dtype=INDEL)
+        entries = np.zeros(max(1, n_entries), dtype=ENTRY)
+        samples = np.zeros(max(1, n_entries), dtype=np.int32)
+        indels = np.zeros(max(1, n_indels), dtype=INDEL)
+        itext = np.zeros(max(1, indel_text_bytes), dtype=np.uint8)
         res = np.zeros(T, dtype=SITE_DTYPE)
         gres = np.zeros((T, max(1, n_groups)), dtype=GROUP_DTYPE)
         g = np.ascontiguousarray(group_of_sample, dtype=np.uint8) if n_groups else np.zeros(0, dtype=np.uint8)
@@ -305,11 +314,41 @@ class Context:
         cout = np.zeros(5, dtype=np.uint8)
         self._check(self._L.bvc_pileup_finish(self._h, _np_ptr(r), float(min_af), _np_ptr(cin), _np_ptr(cout), _np_ptr(g) if n_groups else None,
                                               len(g), int(n_groups), _np_ptr(entry_off), _np_ptr(tally), _np_ptr(entries), _np_ptr(samples),
-                                              _np_ptr(indels), _np_ptr(res), _np_ptr(gres) if n_groups else None))
-        ind = indels[:ni.value]
+                                              _np_ptr(indels), _np_ptr(itext) if indel_text_bytes else None, _np_ptr(res),
+                                              _np_ptr(gres) if n_groups else None))
+        ind = indels[:n_indels]
         ind = ind[np.argsort(ind["entry"], kind="stable")]
-        return dict(entry_off=entry_off, tally=tally, entries=entries[:ne.value], samples=samples[:ne.value], indels=ind, results=res,
-                    grp_results=gres if n_groups else None, carry_out=[int(x) for x in cout])
+        return dict(entry_off=entry_off, tally=tally, entries=entries[:n_entries], samples=samples[:n_entries], indels=ind, results=res,
+                    grp_results=gres if n_groups else None, carry_out=[int(x) for x in cout], indel_text=itext[:indel_text_bytes].tobytes())
+
+    def pileup_begin_bgzf(self, comp, blocks, blocks_of_batch, skip_bytes, sample0, n_in_batch, max_positions, reset):
+        """bvc_pileup_begin_bgzf.  comp: bytes; blocks: [(comp_off, comp_len, isize)] batch after batch.  Returns a dict with rc
+        (0, 1 = irregular, negative = error), T, lines (per batch) and the sizes bvc_pileup_finish needs."""
+        BLOCK = np.dtype([("comp_off", "<i8"), ("out_off", "<i8"), ("comp_len", "<i4"), ("isize", "<i4")])
+        tab = np.zeros(max(1, len(blocks)), dtype=BLOCK)
+        for i, (co, cl, isz) in enumerate(blocks):
+            tab[i] = (co, 0, cl, isz)
+        buf = np.frombuffer(bytes(comp) + b"\0" * 8, dtype=np.uint8)
+        bob = np.ascontiguousarray(blocks_of_batch, dtype=np.int32)
+        nb = len(bob)
+        sk = np.ascontiguousarray(skip_bytes, dtype=np.int32) if skip_bytes is not None else None
+        s0 = np.ascontiguousarray(sample0, dtype=np.int32)
+        nib = np.ascontiguousarray(n_in_batch, dtype=np.int32)
+        lines = np.zeros(max(1, nb), dtype=np.int32)
+        T, ne, ni, nt = C.c_int32(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        rc = self._L.bvc_pileup_begin_bgzf(self._h, _np_ptr(buf), len(buf) - 8, _np_ptr(tab), _np_ptr(bob), _np_ptr(sk) if sk is not None else None,
+                                           _np_ptr(s0), _np_ptr(nib), nb, int(max_positions), int(bool(reset)), C.byref(T), _np_ptr(lines),
+                                           C.byref(ne), C.byref(ni), C.byref(nt))
+        return dict(rc=rc, T=T.value, lines=lines[:nb].copy(), n_entries=ne.value, n_indels=ni.value, indel_text_bytes=nt.value,
+                    error=self._L.bvc_last_error(self._h).decode() if rc < 0 else "")
+
+    def pileup_text(self, n_batches, T):
+        need = C.c_int64(0)
+        self._check(self._L.bvc_pileup_text(self._h, None, 0, C.byref(need), None))
+        text = np.zeros(max(1, need.value), dtype=np.uint8)
+        ls = np.zeros((n_batches, T + 1), dtype=np.uint32)
+        self._check(self._L.bvc_pileup_text(self._h, _np_ptr(text), need.value, C.byref(need), _np_ptr(ls)))
+        return text[:need.value].tobytes(), ls
 
     def inflate_blocks(self, comp, blocks):
         """Raw-deflate streams inflated on the device.  comp: bytes; blocks: [(comp_off, comp_len, isize)] -- outputs are laid out one

@@ -39,6 +39,7 @@ extern "C" {
 #define BVC_ERR_DEVICE      -2   /* HIP runtime error; text in bvc_last_error */
 #define BVC_ERR_NO_DEVICE   -3   /* no gfx950 device / device index out of range */
 #define BVC_ERR_ALLOC       -4   /* device or host allocation failed */
+#define BVC_ERR_DATA        -5   /* bvc_pileup_begin_bgzf: a BGZF block is not valid deflate of its ISIZE bytes */
 #define BVC_PILEUP_IRREGULAR 1   /* bvc_pileup_begin only, not an error: a line of the tile is not of the shape the reference's
                                     writer produces; nothing was computed, parse this tile with the reference's own rules */
 
@@ -210,6 +211,23 @@ int bvc_lrt_csr_groups(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets, co
                        const uint8_t *group_of_sample, int64_t n_samples, int32_t n_groups,
                        bvc_site_result *results, bvc_group_result *grp_results, uint32_t flags);
 
+/*
+ * Additive: BGZF blocks inflated on the device.  The reference reads its temp batches through htslib's bgzf_getline
+ * (src/BaseVarC.cpp:406; written with bgzf_write, :509-527): one raw-deflate stream (RFC 1951) of at most 64 KiB of output per
+ * block, blocks independent of each other.  blocks[i] names the deflate payload of a block inside `comp` (the bytes between the
+ * 18-byte BGZF header and the 8-byte CRC32 / ISIZE trailer), its ISIZE and where its output goes in `out`; status[i] = 0 when the
+ * block inflated to exactly ISIZE bytes, else a non-zero code (the block's output is then undefined; zlib refuses the same streams).
+ * CRC32 is NOT checked here (host/bgzf.cpp checks it on the CPU path).  Host or device pointers (flags).
+ */
+typedef struct bvc_bgzf_block {
+    int64_t comp_off;      /* offset of the deflate payload in comp */
+    int64_t out_off;       /* offset of the block's output in out */
+    int32_t comp_len;      /* bytes of deflate payload */
+    int32_t isize;         /* bytes the block inflates to (<= 65536) */
+} bvc_bgzf_block;
+int bvc_inflate_blocks(bvc_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, const bvc_bgzf_block *blocks, int64_t n_blocks,
+                       uint8_t *out, int64_t out_bytes, uint32_t *status, uint32_t flags);
+
 /* ---- the producer of the hot path's input on the device (additive) ------------------------------------------------------ */
 /*
  * The reference's position loop (bt_s, src/BaseVarC.cpp:403-441) reads one line of every temp-batch file per position and
@@ -255,24 +273,31 @@ int bvc_pileup_begin(bvc_ctx *ctx, const char *text, int64_t text_bytes, const u
 int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const uint8_t carry_in[5], uint8_t carry_out[5],
                       const uint8_t *group_of_sample, int64_t n_samples, int32_t n_groups,
                       int64_t *entry_off, int32_t *tally, bvc_pileup_entry *entries, int32_t *samples,
-                      bvc_pileup_indel *indels, bvc_site_result *results, bvc_group_result *grp_results);
-
+                      bvc_pileup_indel *indels, char *indel_text, bvc_site_result *results, bvc_group_result *grp_results);
 /*
- * Additive: BGZF blocks inflated on the device.  The reference reads its temp batches through htslib's bgzf_getline
- * (src/BaseVarC.cpp:406; written with bgzf_write, :509-527): one raw-deflate stream (RFC 1951) of at most 64 KiB of output per
- * block, blocks independent of each other.  blocks[i] names the deflate payload of a block inside `comp` (the bytes between the
- * 18-byte BGZF header and the 8-byte CRC32 / ISIZE trailer), its ISIZE and where its output goes in `out`; status[i] = 0 when the
- * block inflated to exactly ISIZE bytes, else a non-zero code (the block's output is then undefined; zlib refuses the same streams).
- * CRC32 is NOT checked here (host/bgzf.cpp checks it on the CPU path).  Host or device pointers (flags).
+ * The same from the COMPRESSED temp batches: the BGZF blocks go to the device as they are in the files (a fifth of the bytes of
+ * their text), are inflated there (bvc_inflate_blocks) and the text never exists on the host.  The caller no longer knows where the
+ * lines are, so the call decides the tile's positions itself: every batch's text so far = what the previous call left of it (kept
+ * on the device) + its new blocks; the tile = the lines EVERY batch has whole, at most max_positions.
+ *   blocks            the new blocks of all batches, batch after batch (out_off is ignored); blocks_of_batch[b] = how many are b's
+ *   skip_bytes        NULL, or per batch the bytes at the start of its FIRST block that are not position lines (the sample-names
+ *                     line, src/BaseVarC.cpp:495, 503); only read where the batch has nothing left over
+ *   reset             non-zero: forget what earlier calls left (a new window of positions)
+ *   n_positions       out: the tile's positions T (0: some batch has no whole line yet -- send more of its blocks; lines_of_batch
+ *                     says which); lines_of_batch[b]: whole lines batch b had (before the T of this tile are taken away)
+ *   indel_text_bytes  out: size of the buffer bvc_pileup_finish's indel_text needs (the indel tokens' text: records' text_off are
+ *                     then offsets into it; with bvc_pileup_begin indel_text may be NULL and text_off stays an offset into text)
+ * Returns BVC_OK, BVC_PILEUP_IRREGULAR (the tile's T positions are decided and consumed, but some line is not regular: fetch the text
+ * with bvc_pileup_text and parse it with the reference's rules), BVC_ERR_DATA or another error.  CRC32 of the blocks is NOT checked
+ * on this path.
  */
-typedef struct bvc_bgzf_block {
-    int64_t comp_off;      /* offset of the deflate payload in comp */
-    int64_t out_off;       /* offset of the block's output in out */
-    int32_t comp_len;      /* bytes of deflate payload */
-    int32_t isize;         /* bytes the block inflates to (<= 65536) */
-} bvc_bgzf_block;
-int bvc_inflate_blocks(bvc_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, const bvc_bgzf_block *blocks, int64_t n_blocks,
-                       uint8_t *out, int64_t out_bytes, uint32_t *status, uint32_t flags);
+int bvc_pileup_begin_bgzf(bvc_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, const bvc_bgzf_block *blocks,
+                          const int32_t *blocks_of_batch, const int32_t *skip_bytes, const int32_t *sample0, const int32_t *n_in_batch,
+                          int32_t n_batches, int32_t max_positions, int32_t reset, int32_t *n_positions, int32_t *lines_of_batch,
+                          int64_t *n_entries, int64_t *n_indels, int64_t *indel_text_bytes);
+/* After bvc_pileup_begin_bgzf: the tile's text (text_bytes from *text_bytes_needed: call with text = NULL first) and its line table
+ * [n_batches][n_positions + 1] as bvc_pileup_begin takes it. */
+int bvc_pileup_text(bvc_ctx *ctx, char *text, int64_t text_cap, int64_t *text_bytes_needed, uint32_t *line_start);
 
 /* ---- the two stages on their own (used by the parity tests; also valid entry points) -------------- */
 /* Stage 1: counts[s * 512 + base * 128 + qual] = number of covered samples of that class (exact). */

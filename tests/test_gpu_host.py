@@ -198,9 +198,9 @@ def test_a_temp_batch_cut_short_is_an_error_in_both_forms(tmp_path):
 
 @pytest.mark.parametrize("grouped", [False, True])
 def test_device_parsed_tiles_write_what_cpu_parsed_tiles_write(tmp_path, grouped):
-    """The text batches of the reference's test data through both feeds of the compute phase: tiles of text parsed on the device
-    (bvc_pileup_begin / bvc_pileup_finish, the default; with --group the ragged group call) and the CPU parser
-    (BVC_HOST_DEVICE_PARSE=0; with --group dense tiles).  Same VCF and CVG, byte for byte, whatever the tile size (tiles of 1, 37
+    """The text batches of the reference's test data through the feeds of the compute phase: the BGZF blocks inflated AND parsed on the
+    device (bvc_pileup_begin_bgzf, the default), tiles of text inflated on the CPU and parsed on the device (BVC_HOST_DEVICE_INFLATE=0,
+    bvc_pileup_begin; with --group both use the ragged group call), and the CPU parser (BVC_HOST_DEVICE_PARSE=0; with --group dense tiles).  Same VCF and CVG, byte for byte, whatever the tile size (tiles of 1, 37
     and the default), and the device run really parsed on the device.  One batch file then gets a line the reference's writer never
     produces (two spaces in a row, which strtok_r skips): that tile -- and only that tile -- goes through the CPU parser, and the
     outputs are those of the CPU feed on the same files."""
@@ -232,10 +232,14 @@ def test_device_parsed_tiles_write_what_cpu_parsed_tiles_write(tmp_path, grouped
         dev = sum(int(x) for x in re.findall(r"parsed on the device (\d+)", rr.stderr))
         cpu = sum(int(x) for x in re.findall(r"handed back to the CPU parser (\d+)", rr.stderr))
         return [gzip.decompress(open(base + k, "rb").read()) for k in (".vcf.gz", ".cvg.gz")], dev, cpu
+    # the device feed in both its forms: blocks inflated on the device too (the default), and inflated on the CPU (tiles of text)
     for tile in (0, 37, 1):
-        got, dev, cpu = rerun(tile)
-        assert got == want, tile
-        assert dev > 0 and cpu == 0, (tile, dev, cpu)
+        for inflate in ("1", "0"):
+            got, dev, cpu = rerun(tile, {"BVC_HOST_DEVICE_INFLATE": inflate})
+            assert got == want, (tile, inflate)
+            assert dev > 0 and cpu == 0, (tile, inflate, dev, cpu)
+    got, dev, cpu = rerun(0, {"BVC_HOST_TILE_MB": "1"})              # small tiles by bytes: many calls, batches at different paces
+    assert got == want and dev > 0 and cpu == 0
     # a line with a run of two spaces in batch 1 of thread 0: the same columns to strtok_r, not a line the device parses
     victim = f"{base}.tmp.thread.0/batch.1"
     raw = gzip.decompress(open(victim, "rb").read()).split(b"\n")
@@ -244,6 +248,7 @@ def test_device_parsed_tiles_write_what_cpu_parsed_tiles_write(tmp_path, grouped
     tmp = str(tmp_path / "victim.raw")
     open(tmp, "wb").write(b"\n".join(raw))
     _bgzf_write(tmp, victim)
-    got, dev, cpu = rerun(64)
-    assert got == want
-    assert cpu == 1 and dev > 10, (dev, cpu)
+    for inflate in ("1", "0"):
+        got, dev, cpu = rerun(64, {"BVC_HOST_DEVICE_INFLATE": inflate})
+        assert got == want, inflate
+        assert cpu == 1 and dev > 10, (inflate, dev, cpu)

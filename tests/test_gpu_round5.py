@@ -396,3 +396,151 @@ def test_device_inflate_equals_zlib_and_refuses_what_zlib_refuses(ctx):
                 assert ok, "status 0 for a stream zlib does not inflate to the same bytes"
         else:
             assert st != 0, kind
+
+
+# ------------------------------------------------------------------------------------------------ tiles from COMPRESSED temp batches
+def _bgzf_payloads(data, rng, sizes):
+    """data cut into deflate payloads the way a BGZF writer cuts a stream into blocks (block ends fall anywhere, also inside a line)."""
+    import zlib
+    out, at = [], 0
+    while at < len(data):
+        n = int(rng.choice(sizes))
+        chunk = data[at:at + n]
+        co = zlib.compressobj(int(rng.choice([1, 6, 9])), zlib.DEFLATED, -15)
+        out.append((co.compress(chunk) + co.flush(), len(chunk)))
+        at += n
+    return out
+
+
+def _columns_check(out, cols, ref, min_af, ctx, where):
+    """out: a finished tile; cols: [(aiv, sample)] per position of the tile from the restated parser."""
+    T = len(cols)
+    eoff = out["entry_off"]
+    assert eoff[T] == len(out["entries"]) == sum(len(a) for a, _ in cols), where
+    texts = {int(r["entry"]): out["indel_text"][int(r["text_off"]):int(r["text_off"]) + int(r["len"])].decode() for r in out["indels"]}
+    bb, qq, offs = [], [], [0]
+    for t, (aiv, sample) in enumerate(cols):
+        e = out["entries"][eoff[t]:eoff[t + 1]]
+        assert out["samples"][eoff[t]:eoff[t + 1]].tolist() == sample, (where, t)
+        tally = np.zeros(32, dtype=np.int64)
+        for k, a in enumerate(aiv):
+            got = tuple(int(e[k][f]) for f in ("base", "mapq", "qual", "rpr", "strand", "is_indel"))
+            assert got == (a["base"], a["mapq"], a["qual"], a["rpr"], a["strand"], a["is_indel"]), (where, t, k, got, a)
+            tally[(16 if a["is_indel"] else 0) + (a["strand"] << 3 | a["base"])] += 1
+            if a["is_indel"]:
+                assert texts[int(eoff[t]) + k] == a["indel"], (where, t, k)
+            else:
+                bb.append(a["base"]); qq.append(a["qual"])
+        offs.append(len(bb))
+        assert out["tally"][t].tolist() == tally.tolist(), (where, t)
+    b = np.array(bb if bb else [0], dtype=np.int8); q = np.array(qq if qq else [0], dtype=np.uint8).astype(np.int8)
+    want = ctx.lrt_csr(np.array(offs, np.int64), b, q, ref, min_af)
+    assert out["results"].tobytes() == want.tobytes(), where
+
+
+@pytest.mark.parametrize("shape", ["sparse", "dense", "tiny_blocks"])
+def test_tiles_from_compressed_batches_equal_the_restated_parser(ctx, shape):
+    """bvc_pileup_begin_bgzf: the batches' BGZF blocks go to the device as they are, a few per call and batch (0..3, so that batches
+    run ahead of and fall behind each other), block ends anywhere (inside lines, inside tokens); the tile = the lines every batch has
+    whole.  Position by position the columns, tallies, indel texts and records are those of the restated parser on the same lines, the
+    carry runs through all tiles, every line is used exactly once, and a call that finds some batch without a whole line says so."""
+    rng = np.random.default_rng({"sparse": 21, "dense": 22, "tiny_blocks": 23}[shape])
+    p_data, p_indel = {"sparse": (0.08, 0.004), "dense": (0.8, 0.03), "tiny_blocks": (0.3, 0.05)}[shape]
+    n_in_batch = np.array([300, 41, 1, 120], dtype=np.int32)
+    sample0 = np.concatenate([[0], np.cumsum(n_in_batch)[:-1]]).astype(np.int32)
+    n_lines = {"sparse": 900, "dense": 260, "tiny_blocks": 150}[shape]
+    sizes = {"sparse": [65280, 30000, 5000], "dense": [65280, 40000, 777], "tiny_blocks": [1, 2, 17, 300, 2000]}[shape]
+    batch_lines = [["".join(random_token(rng, p_data if t % 9 else 0.0, p_indel) + " " for _ in range(n)) for t in range(n_lines)] for n in n_in_batch]
+    names = ["".join(f"S{sample0[b] + j}\t" for j in range(n)) + "\n" for b, n in enumerate(n_in_batch)]
+    payloads = [_bgzf_payloads((names[b] + "".join(l + "\n" for l in batch_lines[b])).encode(), rng, sizes) for b in range(len(n_in_batch))]
+    nxt = [0] * len(payloads)
+    parser = eo.Parser()
+    carry = [0, 0, 0, 0, 0]
+    done = 0
+    first, zero_tiles, tiles = True, 0, 0
+    while done < n_lines:
+        comp, blocks, bob = bytearray(), [], []
+        for b, pl in enumerate(payloads):
+            k = int(rng.integers(0, 4)) if shape != "tiny_blocks" else int(rng.integers(0, 40))
+            if first:
+                k = max(k, 1)
+            take = pl[nxt[b]:nxt[b] + k]
+            nxt[b] += len(take)
+            for c, isz in take:
+                comp += b"\x5A" * int(rng.integers(0, 4))
+                blocks.append((len(comp), len(c), isz))
+                comp += c
+            bob.append(len(take))
+        if all(n >= len(pl) for n, pl in zip(nxt, payloads)) is False and sum(bob) == 0:
+            continue
+        max_pos = int(rng.choice([3, 50, 1000]))
+        r = ctx.pileup_begin_bgzf(bytes(comp), blocks, bob, [len(n) for n in names] if first else None, sample0, n_in_batch, max_pos, first)
+        first = False
+        assert r["rc"] == 0, r
+        T = r["T"]
+        assert T == min(int(r["lines"].min()), max_pos)
+        tiles += 1
+        if T == 0:
+            zero_tiles += 1
+            continue
+        ref = rng.integers(0, 4, T).astype(np.int8)
+        out = ctx._pileup_finish(T, r["n_entries"], r["n_indels"], r["indel_text_bytes"], ref, 0.001, carry, None, 0)
+        cols = [parser.parse([batch_lines[b][done + t] for b in range(len(n_in_batch))]) for t in range(T)]
+        _columns_check(out, cols, ref, 0.001, ctx, f"{shape} positions {done}..{done + T}")
+        ai = parser.ai
+        assert out["carry_out"] == [ai["base"], ai["mapq"], ai["qual"], ai["rpr"], ai["strand"]]
+        carry = out["carry_out"]
+        done += T
+        assert tiles < 5000
+    assert done == n_lines and all(n == len(pl) for n, pl in zip(nxt, payloads))
+    # nothing is left: a call without new blocks finds no line
+    r = ctx.pileup_begin_bgzf(b"", [], [0] * len(payloads), None, sample0, n_in_batch, 10, False)
+    assert r["rc"] == 0 and r["T"] == 0 and r["lines"].tolist() == [0] * len(payloads)
+
+
+def test_compressed_tiles_report_irregular_lines_and_broken_blocks(ctx):
+    import zlib
+    n_in_batch = np.array([4, 2], dtype=np.int32)
+    lines0 = ["1,30,25,7,1 . . 0,60,40,12,0 ", ". . . +ACG ", "1,30,25,7,1  . . 0,60,40,12,0 ", ". . . . "]     # the third has two spaces in a row
+    lines1 = [". 2,22,33,44,0 ", ". . ", "N . ", "3,1,2,3,1 . "]
+    names = ["a\tb\tc\td\t\n", "e\tf\t\n"]
+
+    def payload(b, lines):
+        data = (names[b] + "".join(l + "\n" for l in lines)).encode()
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        return co.compress(data) + co.flush(), len(data)
+    p0, p1 = payload(0, lines0), payload(1, lines1)
+    comp = p0[0] + p1[0]
+    blocks = [(0, len(p0[0]), p0[1]), (len(p0[0]), len(p1[0]), p1[1])]
+    skip = [len(n) for n in names]
+    # two positions at a time: the first tile is regular, the second holds the line with the run of spaces
+    r = ctx.pileup_begin_bgzf(comp, blocks, [1, 1], skip, [0, 4], n_in_batch, 2, True)
+    assert r["rc"] == 0 and r["T"] == 2 and r["lines"].tolist() == [4, 4]
+    out = ctx._pileup_finish(2, r["n_entries"], r["n_indels"], r["indel_text_bytes"], np.zeros(2, np.int8), 0.001, [0] * 5, None, 0)
+    assert out["samples"].tolist() == [0, 3, 5, 3] and out["indel_text"] == b"+ACG"
+    r = ctx.pileup_begin_bgzf(b"", [], [0, 0], None, [0, 4], n_in_batch, 2, False)
+    assert r["rc"] == 1 and r["T"] == 2                           # BVC_PILEUP_IRREGULAR: the tile is decided, the caller parses it
+    text, ls = ctx.pileup_text(2, 2)
+    got = [[text[ls[b, t]:ls[b, t + 1]].decode() for t in range(2)] for b in range(2)]
+    assert got == [[l + "\n" for l in lines0[2:]], [l + "\n" for l in lines1[2:]]]
+    for _ in range(3):                                            # all four positions are used up, and stay so (empty regions carry nothing)
+        r = ctx.pileup_begin_bgzf(b"", [], [0, 0], None, [0, 4], n_in_batch, 2, False)
+        assert r["rc"] == 0 and r["T"] == 0 and r["lines"].tolist() == [0, 0]
+    # one batch ends before the other: the tile is then empty however much the other has, call after call
+    r = ctx.pileup_begin_bgzf(p1[0], [(0, len(p1[0]), p1[1])], [0, 1], [0, skip[1]], [0, 4], n_in_batch, 5, True)
+    assert r["rc"] == 0 and r["T"] == 0 and r["lines"].tolist() == [0, 4]
+    r = ctx.pileup_begin_bgzf(b"", [], [0, 0], None, [0, 4], n_in_batch, 5, False)
+    assert r["rc"] == 0 and r["T"] == 0 and r["lines"].tolist() == [0, 4]
+    # a block that is not deflate: an error, not a guess
+    bad = bytearray(p0[0]); bad[len(bad) // 2] ^= 0x10; bad = bytes(bad)
+    try:
+        zlib.decompressobj(-15).decompress(bad)
+        broken = False
+    except zlib.error:
+        broken = True
+    r = ctx.pileup_begin_bgzf(bad + p1[0], [(0, len(bad), p0[1]), (len(bad), len(p1[0]), p1[1])], [1, 1], skip, [0, 4], n_in_batch, 2, True)
+    if broken:
+        assert r["rc"] == -5 and "deflate" in r["error"]
+    # and the context goes on with good data
+    r = ctx.pileup_begin_bgzf(comp, blocks, [1, 1], skip, [0, 4], n_in_batch, 100, True)
+    assert r["rc"] == 1 and r["T"] == 4
