@@ -47,6 +47,7 @@ struct InflateLds {
     uint16_t lit_sorted[288], dist_sorted[32], pre_sorted[32];
     uint16_t lit_cnt[16], dist_cnt[16], pre_cnt[16];
     uint32_t work_cnt[16], work_next[16], work_offs[16];
+    uint32_t len_code[32], dist_code[32];       // base | extra bits << 16 of the length / distance symbols (a global load per match otherwise)
     uint8_t lens[320 + 8];
 };
 
@@ -111,6 +112,10 @@ __global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restric
     __shared__ InflateLds L;
     const int lane = threadIdx.x;
     uint8_t *win8 = reinterpret_cast<uint8_t *>(L.win);
+    if (lane < 29) L.len_code[lane] = (uint32_t)kLenBase[lane] | ((uint32_t)kLenExtra[lane] << 16);
+    if (lane < 30) L.dist_code[lane] = (uint32_t)kDistBase[lane] | ((uint32_t)kDistExtra[lane] << 16);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const uint64_t c0 = (uint64_t)blocks[blk].comp_off, o0 = (uint64_t)blocks[blk].out_off;
         const uint32_t clen = (uint32_t)blocks[blk].comp_len, isize = (uint32_t)blocks[blk].isize;
@@ -258,11 +263,13 @@ __global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restric
                 }
                 if (sym == 256) break;
                 if (sym > 285) { err = kErrSymbol; break; }
-                const uint32_t len = (uint32_t)kLenBase[sym - 257] + take((int)kLenExtra[sym - 257]);
+                const uint32_t lc = uni(L.len_code[sym - 257]);
+                const uint32_t len = (lc & 0xFFFFu) + take((int)(lc >> 16));
                 refill();
                 const int ds = decode(L.dist_tab, kDistBits, L.dist_cnt, L.dist_sorted);
                 if (ds < 0 || ds > 29) { err = kErrSymbol; break; }
-                const uint32_t dist = (uint32_t)kDistBase[ds] + take((int)kDistExtra[ds]);
+                const uint32_t dc = uni(L.dist_code[ds]);
+                const uint32_t dist = (dc & 0xFFFFu) + take((int)(dc >> 16));
                 if (dist > o) { err = kErrDistance; break; }
                 if (o + len > isize) { err = kErrOutput; break; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
