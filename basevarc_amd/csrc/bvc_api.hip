@@ -17,7 +17,13 @@ using namespace bvc;
 
 struct bvc_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream the entry points work on: own_stream until bvc_set_stream names another
+    hipStream_t own_stream = nullptr;  // created with the context.  A BLOCKING stream: ordered against the device's default stream as the
+                                       // default stream itself is (callers that prepare buffers there need no extra synchronisation), but the
+                                       // streams of different contexts run side by side -- sixteen threads of the host program, each with
+                                       // its context, were one queue when every context worked on the default stream
+    hipEvent_t ev_wait = nullptr;      // blocking-sync event: the long waits of the pileup calls SLEEP on it (wait_stream) where
+                                       // hipStreamSynchronize polls -- a host program with a thread per context on a CPU quota cannot afford that
     QualLut *d_lut = nullptr;
     // [sites][512] scratch between the two stages.  Overlap mode cycles through kRing buffers: with three, the
     // histogram pass of call i+1 waits only for the EM of call i-2 (long finished), never for the one running
@@ -64,6 +70,10 @@ struct bvc_ctx {
     std::vector<uint32_t> pz_left_src, pz_left_len;
     int64_t pl_text_bytes = 0, pl_indel_bytes = 0;
     bool pl_on_device_text = false;
+    // pinned host memory the pileup calls bounce their transfers through: a copy from or to pageable memory makes the calling thread
+    // wait inside the runtime -- spinning -- for the whole transfer; from pinned memory it is a DMA the thread sleeps behind (wait_stream)
+    char *h_up = nullptr, *h_down = nullptr;
+    size_t up_cap = 0, down_cap = 0;
     PileupTile pl;                     // the tile between the two calls
     bool pl_begun = false;
     int64_t pl_entries = 0, pl_obs = 0, pl_indels = 0;
@@ -85,6 +95,13 @@ int fail(bvc_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
         if (e != hipSuccess) { ctx->err += ": "; ctx->err += hipGetErrorString(e); }
     }
     return code;
+}
+
+// Waits for the context's stream without spinning: the thread sleeps until the event behind everything enqueued so far fires.
+inline hipError_t wait_stream(bvc_ctx *ctx)
+{
+    hipError_t e = hipEventRecord(ctx->ev_wait, ctx->stream);
+    return e == hipSuccess ? hipEventSynchronize(ctx->ev_wait) : e;
 }
 
 #define BVC_HIP(ctx, call)                                                         \
@@ -437,6 +454,56 @@ int run_group_stages(bvc_ctx *ctx, int64_t ns, int n_groups, bool long_rows, Sta
     return BVC_OK;
 }
 
+// Transfers of one call through the context's pinned buffers: h2d copies the caller's bytes into pinned memory and enqueues the DMA,
+// d2h enqueues a DMA into pinned memory and deliver() -- after the stream has been waited for -- copies the bytes to the caller.
+struct PinIO {
+    bvc_ctx *ctx;
+    size_t up_used = 0, down_used = 0;
+    struct Out { void *dst; const char *src; size_t n; };
+    std::vector<Out> outs;
+    explicit PinIO(bvc_ctx *c) : ctx(c) {}
+    static size_t al(size_t n) { return (n + 63) & ~(size_t)63; }
+    int reserve(size_t up_bytes, size_t down_bytes)
+    {
+        auto grow = [&](char **buf, size_t *cap, size_t need) -> int {
+            if (need <= *cap) return BVC_OK;
+            if (*buf) {
+                if (wait_stream(ctx) != hipSuccess) return fail(ctx, BVC_ERR_DEVICE, "wait before growing a pinned buffer");
+                (void)hipHostFree(*buf);
+                *buf = nullptr; *cap = 0;
+            }
+            const size_t want = need + need / 4 + 4096;
+            if (hipHostMalloc(reinterpret_cast<void **>(buf), want, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(ctx, BVC_ERR_ALLOC, "pinned host allocation failed");
+            }
+            *cap = want;
+            return BVC_OK;
+        };
+        int rc = grow(&ctx->h_up, &ctx->up_cap, up_bytes);
+        return rc == BVC_OK ? grow(&ctx->h_down, &ctx->down_cap, down_bytes) : rc;
+    }
+    hipError_t h2d(void *dev, const void *host, size_t n)
+    {
+        if (n == 0) return hipSuccess;
+        if (up_used + n > ctx->up_cap) return hipErrorOutOfMemory;
+        char *p = ctx->h_up + up_used;
+        std::memcpy(p, host, n);
+        up_used += al(n);
+        return hipMemcpyAsync(dev, p, n, hipMemcpyHostToDevice, ctx->stream);
+    }
+    hipError_t d2h(void *host, const void *dev, size_t n)
+    {
+        if (n == 0) return hipSuccess;
+        if (down_used + n > ctx->down_cap) return hipErrorOutOfMemory;
+        char *p = ctx->h_down + down_used;
+        down_used += al(n);
+        outs.push_back(Out{host, p, n});
+        return hipMemcpyAsync(p, dev, n, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    void deliver() { for (auto const &o : outs) std::memcpy(o.dst, o.src, o.n); outs.clear(); }
+};
+
 int check_common(bvc_ctx *ctx, int64_t n_sites, const void *a, const void *b, const void *c, const void *d)
 {
     if (!ctx) return BVC_ERR_ARG;
@@ -533,7 +600,9 @@ int bvc_create(bvc_ctx **out, int device)
     int prio_least = 0, prio_greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_least = 0; }
     const int side_prio = env_int("BVC_SIDE_PRIORITY", 0, 1, 1) ? prio_least : 0;
-    bool ok = hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, side_prio) == hipSuccess &&
+    bool ok = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamDefault) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_wait, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess &&
+              hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, side_prio) == hipSuccess &&
               hipStreamCreateWithPriority(&ctx->side_b, hipStreamNonBlocking, side_prio) == hipSuccess &&
               hipStreamCreateWithPriority(&ctx->side_c, hipStreamNonBlocking, side_prio) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking) == hipSuccess &&
@@ -545,6 +614,7 @@ int bvc_create(bvc_ctx **out, int device)
     for (int b = 0; b < 2 && ok; ++b) ok = hipEventCreateWithFlags(&ctx->ev_upload[b], hipEventDisableTiming) == hipSuccess;
     for (int b = 0; b < 2 && ok; ++b) ok = hipEventCreateWithFlags(&ctx->ev_set_free[b], hipEventDisableTiming) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); bvc_destroy(ctx); return BVC_ERR_DEVICE; }
+    ctx->stream = ctx->own_stream;
     *out = ctx;
     return BVC_OK;
 }
@@ -558,6 +628,8 @@ void bvc_destroy(bvc_ctx *ctx)
     if (ctx->side_b) { (void)hipStreamSynchronize(ctx->side_b); (void)hipStreamDestroy(ctx->side_b); }
     if (ctx->side_c) { (void)hipStreamSynchronize(ctx->side_c); (void)hipStreamDestroy(ctx->side_c); }
     if (ctx->copy) { (void)hipStreamSynchronize(ctx->copy); (void)hipStreamDestroy(ctx->copy); }
+    if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
+    if (ctx->ev_wait) (void)hipEventDestroy(ctx->ev_wait);
     for (int b = 0; b < bvc_ctx::kRing; ++b) {
         if (ctx->ev_hist_done[b]) (void)hipEventDestroy(ctx->ev_hist_done[b]);
         if (ctx->ev_em_done[b]) (void)hipEventDestroy(ctx->ev_em_done[b]);
@@ -582,6 +654,8 @@ void bvc_destroy(bvc_ctx *ctx)
     if (ctx->d_pl_text) (void)hipFree(ctx->d_pl_text);
     if (ctx->d_pl_meta) (void)hipFree(ctx->d_pl_meta);
     if (ctx->d_pl_out) (void)hipFree(ctx->d_pl_out);
+    if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+    if (ctx->h_down) (void)hipHostFree(ctx->h_down);
     for (int k = 0; k < 2; ++k) if (ctx->d_pz_text[k]) (void)hipFree(ctx->d_pz_text[k]);
     if (ctx->d_pz_comp) (void)hipFree(ctx->d_pz_comp);
     delete ctx;
@@ -1208,7 +1282,7 @@ int bvc_pileup_begin(bvc_ctx *ctx, const char *text, int64_t text_bytes, const u
     int64_t tot[2] = {0, 0};
     BVC_HIP_D(hipMemcpyAsync(st, P.status, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
     BVC_HIP_D(hipMemcpyAsync(tot, P.totals, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
-    BVC_HIP_D(hipStreamSynchronize(ctx->stream));
+    BVC_HIP_D(wait_stream(ctx));
 #undef BVC_HIP_D
     if (st[0] != 0) return BVC_PILEUP_IRREGULAR;
     ctx->pl_entries = tot[0]; ctx->pl_obs = tot[1]; ctx->pl_indels = st[1];
@@ -1310,6 +1384,10 @@ int bvc_pileup_begin_bgzf(bvc_ctx *ctx, const uint8_t *comp, int64_t comp_bytes,
         hipError_t e__ = (call);                                                          \
         if (e__ != hipSuccess) return drained(fail(ctx, BVC_ERR_DEVICE, #call, e__));     \
     } while (0)
+    PinIO io(ctx);
+    rc = io.reserve((size_t)comp_bytes + (size_t)n_blocks * sizeof(bvc_bgzf_block) + nb * (sizeof(bvc_pileup_region) + 12) + 1024,
+                    (size_t)n_blocks * 4 + nb * 8 + 1024);
+    if (rc != BVC_OK) return rc;
     BVC_HIP_D(hipMemsetAsync(P.status, 0, st_al + 2 * off_al + tal_al, ctx->stream));
     std::vector<uint32_t> bst((size_t)n_blocks);
     std::vector<uint32_t> ends(nb);
@@ -1318,13 +1396,13 @@ int bvc_pileup_begin_bgzf(bvc_ctx *ctx, const uint8_t *comp, int64_t comp_bytes,
     int32_t Tgot = 0;
     if (nb > 0) {
         if (n_blocks > 0) {
-            BVC_HIP_D(hipMemcpyAsync(ctx->d_pz_comp, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, ctx->stream));
-            BVC_HIP_D(hipMemcpyAsync(d_blk, blk.data(), (size_t)n_blocks * sizeof(bvc_bgzf_block), hipMemcpyHostToDevice, ctx->stream));
+            BVC_HIP_D(io.h2d(ctx->d_pz_comp, comp, (size_t)comp_bytes));
+            BVC_HIP_D(io.h2d(d_blk, blk.data(), (size_t)n_blocks * sizeof(bvc_bgzf_block)));
         }
-        BVC_HIP_D(hipMemcpyAsync(d_reg, reg.data(), nb * sizeof(bvc_pileup_region), hipMemcpyHostToDevice, ctx->stream));
-        BVC_HIP_D(hipMemcpyAsync(d_sb, seg_base.data(), (nb + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-        BVC_HIP_D(hipMemcpyAsync(d_s0, sample0, nb * 4, hipMemcpyHostToDevice, ctx->stream));
-        BVC_HIP_D(hipMemcpyAsync(d_nib, n_in_batch, nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP_D(io.h2d(d_reg, reg.data(), nb * sizeof(bvc_pileup_region)));
+        BVC_HIP_D(io.h2d(d_sb, seg_base.data(), (nb + 1) * 4));
+        BVC_HIP_D(io.h2d(d_s0, sample0, nb * 4));
+        BVC_HIP_D(io.h2d(d_nib, n_in_batch, nb * 4));
         BVC_HIP_D(launch_region_carry(ctx->stream, reinterpret_cast<const uint8_t *>(ctx->d_pz_text[ctx->pz_cur]),
                                       reinterpret_cast<uint8_t *>(ctx->d_pz_text[nw]), d_reg, n_batches));
         if (n_blocks > 0)
@@ -1333,14 +1411,15 @@ int bvc_pileup_begin_bgzf(bvc_ctx *ctx, const uint8_t *comp, int64_t comp_bytes,
         BVC_HIP_D(launch_region_index(ctx->stream, P, d_reg, d_sb, (int64_t)segs, d_sn, d_lines, max_positions));
         BVC_HIP_D(launch_region_ends(ctx->stream, P, d_ends));
         BVC_HIP_D(launch_pileup_count(ctx->stream, P));
-        if (n_blocks > 0) BVC_HIP_D(hipMemcpyAsync(bst.data(), d_bst, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, ctx->stream));
-        BVC_HIP_D(hipMemcpyAsync(lines_of_batch, d_lines, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-        BVC_HIP_D(hipMemcpyAsync(ends.data(), d_ends, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-        BVC_HIP_D(hipMemcpyAsync(&Tgot, d_T, 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (n_blocks > 0) BVC_HIP_D(io.d2h(bst.data(), d_bst, (size_t)n_blocks * 4));
+        BVC_HIP_D(io.d2h(lines_of_batch, d_lines, nb * 4));
+        BVC_HIP_D(io.d2h(ends.data(), d_ends, nb * 4));
+        BVC_HIP_D(io.d2h(&Tgot, d_T, 4));
     }
-    BVC_HIP_D(hipMemcpyAsync(st, P.status, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
-    BVC_HIP_D(hipMemcpyAsync(tot, P.totals, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
-    BVC_HIP_D(hipStreamSynchronize(ctx->stream));
+    BVC_HIP_D(io.d2h(st, P.status, sizeof st));
+    BVC_HIP_D(io.d2h(tot, P.totals, sizeof tot));
+    BVC_HIP_D(wait_stream(ctx));
+    io.deliver();
 #undef BVC_HIP_D
     for (int64_t i = 0; i < n_blocks; ++i)
         if (bst[(size_t)i] != 0) {
@@ -1375,7 +1454,7 @@ int bvc_pileup_text(bvc_ctx *ctx, char *text, int64_t text_cap, int64_t *text_by
     if (P.n_batches > 0)
         BVC_HIP(ctx, hipMemcpy2DAsync(line_start, (size_t)(P.n_pos + 1) * 4, P.line_start, (size_t)P.line_stride * 4, (size_t)(P.n_pos + 1) * 4,
                                       (size_t)P.n_batches, hipMemcpyDeviceToHost, ctx->stream));
-    BVC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BVC_HIP(ctx, wait_stream(ctx));
     return BVC_OK;
 }
 
@@ -1434,9 +1513,14 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
         if (e__ != hipSuccess) return drained(fail(ctx, BVC_ERR_DEVICE, #call, e__));     \
     } while (0)
     uint32_t cout = cin;
+    PinIO io(ctx);
+    rc = io.reserve((size_t)T + (size_t)(n_groups > 0 ? n_samples : 0) + 1024,
+                    (size_t)T * (sizeof(bvc_site_result) + 32 * 4 + 8 + (size_t)n_groups * sizeof(bvc_group_result)) +
+                        (size_t)n_e * (sizeof(bvc_pileup_entry) + 4) + (size_t)n_i * sizeof(bvc_pileup_indel) + (size_t)ctx->pl_indel_bytes + 4096);
+    if (rc != BVC_OK) return rc;
     if (T > 0) {
-        BVC_HIP_D(hipMemcpyAsync(d_ref, ref_base, (size_t)T, hipMemcpyHostToDevice, ctx->stream));
-        if (n_groups > 0 && n_samples > 0) BVC_HIP_D(hipMemcpyAsync(d_g, group_of_sample, (size_t)n_samples, hipMemcpyHostToDevice, ctx->stream));
+        BVC_HIP_D(io.h2d(d_ref, ref_base, (size_t)T));
+        if (n_groups > 0 && n_samples > 0) BVC_HIP_D(io.h2d(d_g, group_of_sample, (size_t)n_samples));
         if ((int64_t)P.n_pos * P.n_batches > 0) BVC_HIP_D(launch_pileup_write(ctx->stream, P, cin));
         if (n_groups > 0)
             rc = run_csr_groups_device(ctx, T, P.obs_off, P.obs_base, P.obs_qual, P.obs_sample, d_ref, min_af, d_g, n_samples, n_groups, d_res, d_gres);
@@ -1444,23 +1528,24 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
             rc = run_csr_device(ctx, T, P.obs_off, P.obs_base, P.obs_qual, d_ref, min_af, nullptr, nullptr, d_res);
         if (rc == BVC_OK) rc = join_side(ctx);
         if (rc != BVC_OK) return drained(rc);
-        BVC_HIP_D(hipMemcpyAsync(results, d_res, (size_t)T * sizeof(bvc_site_result), hipMemcpyDeviceToHost, ctx->stream));
+        BVC_HIP_D(io.d2h(results, d_res, (size_t)T * sizeof(bvc_site_result)));
         if (n_groups > 0)
-            BVC_HIP_D(hipMemcpyAsync(grp_results, d_gres, (size_t)T * (size_t)n_groups * sizeof(bvc_group_result), hipMemcpyDeviceToHost, ctx->stream));
-        BVC_HIP_D(hipMemcpyAsync(tally, P.tally, (size_t)T * 32 * 4, hipMemcpyDeviceToHost, ctx->stream));
+            BVC_HIP_D(io.d2h(grp_results, d_gres, (size_t)T * (size_t)n_groups * sizeof(bvc_group_result)));
+        BVC_HIP_D(io.d2h(tally, P.tally, (size_t)T * 32 * 4));
         if (n_e) {
-            BVC_HIP_D(hipMemcpyAsync(entries, P.entries, (size_t)n_e * sizeof(bvc_pileup_entry), hipMemcpyDeviceToHost, ctx->stream));
-            BVC_HIP_D(hipMemcpyAsync(samples, P.samples, (size_t)n_e * 4, hipMemcpyDeviceToHost, ctx->stream));
+            BVC_HIP_D(io.d2h(entries, P.entries, (size_t)n_e * sizeof(bvc_pileup_entry)));
+            BVC_HIP_D(io.d2h(samples, P.samples, (size_t)n_e * 4));
         }
         if (n_i && indel_text) {
             BVC_HIP_D(launch_indel_text(ctx->stream, P, d_itext, (uint32_t)ctx->pl_indel_bytes, P.status + 5));
-            if (ctx->pl_indel_bytes) BVC_HIP_D(hipMemcpyAsync(indel_text, d_itext, (size_t)ctx->pl_indel_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            if (ctx->pl_indel_bytes) BVC_HIP_D(io.d2h(indel_text, d_itext, (size_t)ctx->pl_indel_bytes));
         }
-        if (n_i) BVC_HIP_D(hipMemcpyAsync(indels, P.indels, (size_t)n_i * sizeof(bvc_pileup_indel), hipMemcpyDeviceToHost, ctx->stream));
-        if ((int64_t)P.n_pos * P.n_batches > 0) BVC_HIP_D(hipMemcpyAsync(&cout, P.status + 3, 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (n_i) BVC_HIP_D(io.d2h(indels, P.indels, (size_t)n_i * sizeof(bvc_pileup_indel)));
+        if ((int64_t)P.n_pos * P.n_batches > 0) BVC_HIP_D(io.d2h(&cout, P.status + 3, 4));
     }
-    BVC_HIP_D(hipMemcpyAsync(entry_off, P.entry_off, (size_t)(T + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    BVC_HIP_D(hipStreamSynchronize(ctx->stream));
+    BVC_HIP_D(io.d2h(entry_off, P.entry_off, (size_t)(T + 1) * 8));
+    BVC_HIP_D(wait_stream(ctx));
+    io.deliver();
 #undef BVC_HIP_D
     carry_out[0] = (uint8_t)(cout & 7u); carry_out[1] = (uint8_t)(cout >> 8); carry_out[2] = (uint8_t)(cout >> 16);
     carry_out[3] = (uint8_t)(cout >> 24); carry_out[4] = (uint8_t)((cout >> 3) & 1u);

@@ -9,16 +9,26 @@
 // (wave-uniform) control flow -- bit buffer, table look-ups in LDS -- and the lanes share the work that IS parallel: staging the
 // compressed bytes (1 KiB per refill, 16 bytes a lane), filling the first-level decoding tables, copying matches (lane i copies byte
 // i of the match; a match shorter than its distance, or a run, is the same expression: source byte i mod distance), and writing the
-// output (1 KiB at a time, 16 bytes a lane).  The block's last 32 KiB of output live in an LDS ring (deflate's window), so no lane ever
-// reads from global memory what another lane wrote.  36 KiB of LDS per wavefront: four blocks in flight per CU, 1024 on the chip.
+// output (1 KiB at a time, 16 bytes a lane).  The block's last 4 KiB of output live in an LDS ring: nearly every match of pileup text
+// reaches back less than that (a line is 1-2 KiB) and is copied LDS to LDS; a match that reaches further back -- deflate allows 32 KiB
+// -- reads its source from the block's output in global memory, which left the ring at least 3 KiB ago (loads behind a
+// release fence: the bytes were written by this wavefront's own stores).  10 KiB of LDS per wavefront instead of the 36 KiB a whole
+// window takes: sixteen blocks in flight per CU instead of four, and the decode is a chain of LDS round trips that only other
+// wavefronts can hide (round 5, pileup text at 10 % coverage deflated at zlib's level 6: 3.0 ms per block
+// either way; 8192 blocks in 9.7 ms = 55 GB/s of text with the 4 KiB ring, 45 with 8 KiB, 34 with 16, 22 with all 32: profiles/r05_inflate.txt).
 //
-// Decoding tables: 9-bit (literal/length) and 7-bit (distance, code lengths) first-level tables of 16-bit entries
-// [valid | code length | symbol]; longer codes -- rare in text -- walk the canonical code one bit at a time (count per length + symbols
-// sorted by code, as zlib's puff does).  Same acceptance rules as host/inflate.cpp and zlib: over-subscribed code sets are refused,
+// Decoding tables: 9-bit (literal/length) and 7-bit (distance, code lengths) first-level tables of 32-bit entries
+// [valid | code length | kind | extra bits | value] -- a length's or distance's base and extra-bit count ride in the entry, so a
+// match is two look-ups, not four; longer codes -- rare in text -- walk the canonical code one bit at a time (count per length +
+// symbols sorted by code, as zlib's puff does).  Same acceptance rules as host/inflate.cpp and zlib: over-subscribed code sets are refused,
 // incomplete ones too unless the set has a single one-bit code (or none), distances beyond the block's start, output beyond ISIZE
 // and input beyond the block are refused.  A refused block leaves a code in status[block]; its output is undefined.
 // Own code, written from RFC 1951; checked against zlib in tests/test_gpu_round5.py.
 #include <hip/hip_runtime.h>
+
+#ifndef BVC_INFLATE_WINDOW
+#define BVC_INFLATE_WINDOW 4096
+#endif
 
 #include "bvc_device.h"
 #include "bvc_internal.h"
@@ -26,10 +36,13 @@
 namespace bvc {
 namespace {
 
-constexpr uint32_t kWinBytes = 32768, kWinMask = kWinBytes - 1;
+constexpr uint32_t kWinBytes = BVC_INFLATE_WINDOW, kWinMask = kWinBytes - 1;
+static_assert((kWinBytes & kWinMask) == 0 && kWinBytes >= 4096 && kWinBytes <= 32768, "the LDS ring: a power of two, 4..32 KiB");
 constexpr uint32_t kStageWords = 256;
 constexpr int kLitBits = 9, kDistBits = 7, kPreBits = 7;
-constexpr uint32_t kValid = 0x8000u;
+constexpr uint32_t kValid = 0x80000000u;
+// entry: bit 31 valid, 27..30 code length, 24..25 kind, 16..19 extra bits, 0..15 value (literal / length base / distance base / symbol)
+constexpr uint32_t kKindLiteral = 0u << 24, kKindEnd = 1u << 24, kKindLength = 2u << 24, kKindBad = 3u << 24, kKindMask = 3u << 24;
 
 __device__ const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __device__ const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -41,9 +54,9 @@ __device__ const uint8_t kPreOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 
 struct InflateLds {
     uint32_t win[kWinBytes / 4];
     uint32_t stage[kStageWords];
-    uint16_t lit_tab[1 << kLitBits];
-    uint16_t dist_tab[1 << kDistBits];
-    uint16_t pre_tab[1 << kPreBits];
+    uint32_t lit_tab[1 << kLitBits];
+    uint32_t dist_tab[1 << kDistBits];
+    uint32_t pre_tab[1 << kPreBits];
     uint16_t lit_sorted[288], dist_sorted[32], pre_sorted[32];
     uint16_t lit_cnt[16], dist_cnt[16], pre_cnt[16];
     uint32_t work_cnt[16], work_next[16], work_offs[16];
@@ -59,8 +72,9 @@ enum : uint32_t { kOk = 0, kErrType = 1, kErrStored = 2, kErrHeader = 3, kErrCod
 
 // Canonical code of `n` symbols from their code lengths lens[0..n): first-level table of `bits` bits, count per length, symbols sorted
 // by code.  Wave-uniform; the lanes share the table fill.  false: a code set zlib refuses.
-__device__ bool build_code(InflateLds &L, const uint8_t *lens, int n, uint16_t *tab, int bits, uint16_t *cnt, uint16_t *sorted, bool may_be_short,
-                           int lane)
+template <class Entry>
+__device__ bool build_code(InflateLds &L, const uint8_t *lens, int n, uint32_t *tab, int bits, uint16_t *cnt, uint16_t *sorted, bool may_be_short,
+                           int lane, Entry entry_of)
 {
     if (lane < 16) L.work_cnt[lane] = 0u;
     for (int i = lane; i < (1 << bits); i += kWave) tab[i] = 0;
@@ -96,7 +110,7 @@ __device__ bool build_code(InflateLds &L, const uint8_t *lens, int n, uint16_t *
         if (lane == 0) { L.work_next[l] = c + 1u; L.work_offs[l] = k + 1u; sorted[k] = (uint16_t)s; }
         if ((int)l <= bits) {
             const uint32_t r = __builtin_bitreverse32(c) >> (32u - l);
-            const uint16_t e = (uint16_t)(kValid | (l << 9) | (uint32_t)s);
+            const uint32_t e = kValid | (l << 27) | entry_of((uint32_t)s);
             for (uint32_t i = r + ((uint32_t)lane << l); i < (1u << bits); i += (uint32_t)kWave << l) tab[i] = e;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -150,17 +164,32 @@ __global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restric
             bb >>= n; bc -= n;
             return v;
         };
-        auto decode = [&](const uint16_t *tab, int bits, const uint16_t *cnt, const uint16_t *sorted) -> int {
+        // what an entry says beside the code length, by symbol
+        auto lit_entry = [&](uint32_t s) -> uint32_t {
+            if (s < 256u) return kKindLiteral | s;
+            if (s == 256u) return kKindEnd;
+            if (s > 285u) return kKindBad;
+            const uint32_t lc = L.len_code[s - 257u];
+            return kKindLength | (lc & 0xFFFFu) | ((lc >> 16) << 16);
+        };
+        auto dist_entry = [&](uint32_t s) -> uint32_t {
+            if (s > 29u) return kKindBad;
+            const uint32_t dc = L.dist_code[s];
+            return (dc & 0xFFFFu) | ((dc >> 16) << 16);
+        };
+        auto pre_entry = [&](uint32_t s) -> uint32_t { return s; };
+        // the next symbol's entry (valid bit set), or 0 when the bits are no code of the set
+        auto decode = [&](const uint32_t *tab, int bits, const uint16_t *cnt, const uint16_t *sorted, auto entry_of) -> uint32_t {
             const uint32_t e = uni(tab[(uint32_t)bb & ((1u << bits) - 1u)]);
-            if (e & kValid) { const int l = (int)((e >> 9) & 15u); bb >>= l; bc -= l; return (int)(e & 511u); }
+            if (e & kValid) { const int l = (int)((e >> 27) & 15u); bb >>= l; bc -= l; return e; }
             int code = 0, first = 0, index = 0;
             for (int l = 1; l <= 15; ++l) {
                 code |= (int)(bb & 1ull); bb >>= 1; bc -= 1;
                 const int count = (int)uni(cnt[l]);
-                if (code - count < first) return (int)uni(sorted[index + (code - first)]);
+                if (code - count < first) return kValid | uni(entry_of((uint32_t)uni(sorted[index + (code - first)])));
                 index += count; first += count; first <<= 1; code <<= 1;
             }
-            return -1;
+            return 0u;
         };
         auto flush_full = [&]() {
             while (o - flushed >= 1024u) {
@@ -221,13 +250,14 @@ __global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restric
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
-                if (!build_code(L, L.lens, 19, L.pre_tab, kPreBits, L.pre_cnt, L.pre_sorted, false, lane)) { err = kErrCodes; break; }
+                if (!build_code(L, L.lens, 19, L.pre_tab, kPreBits, L.pre_cnt, L.pre_sorted, false, lane, pre_entry)) { err = kErrCodes; break; }
                 int n = 0;
                 uint32_t prev = 0;
                 while (n < hlit + hdist && err == kOk) {
                     refill();
-                    const int sym = decode(L.pre_tab, kPreBits, L.pre_cnt, L.pre_sorted);
-                    if (sym < 0 || sym > 18) { err = kErrHeader; break; }
+                    const uint32_t pe = decode(L.pre_tab, kPreBits, L.pre_cnt, L.pre_sorted, pre_entry);
+                    const int sym = (int)(pe & 0xFFFFu);
+                    if (pe == 0u || sym > 18) { err = kErrHeader; break; }
                     if (sym < 16) { if (lane == 0) L.lens[n] = (uint8_t)sym; prev = (uint32_t)sym; ++n; continue; }
                     int rep;
                     uint32_t v = 0;
@@ -247,37 +277,48 @@ __global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restric
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             // (the code-length table shares L.lens' front with nothing: the literal/length lengths start at 0 only now)
-            if (!build_code(L, L.lens, hlit, L.lit_tab, kLitBits, L.lit_cnt, L.lit_sorted, true, lane) ||
-                !build_code(L, L.lens + hlit, hdist, L.dist_tab, kDistBits, L.dist_cnt, L.dist_sorted, true, lane)) { err = kErrCodes; break; }
+            if (!build_code(L, L.lens, hlit, L.lit_tab, kLitBits, L.lit_cnt, L.lit_sorted, true, lane, lit_entry) ||
+                !build_code(L, L.lens + hlit, hdist, L.dist_tab, kDistBits, L.dist_cnt, L.dist_sorted, true, lane, dist_entry)) { err = kErrCodes; break; }
             // ---- the block's symbols
             for (;;) {
                 refill();
-                const int sym = decode(L.lit_tab, kLitBits, L.lit_cnt, L.lit_sorted);
-                if (sym < 0) { err = kErrSymbol; break; }
-                if (sym < 256) {
+                const uint32_t e = decode(L.lit_tab, kLitBits, L.lit_cnt, L.lit_sorted, lit_entry);
+                if (e == 0u) { err = kErrSymbol; break; }
+                const uint32_t kind = e & kKindMask;
+                if (kind == kKindLiteral) {
                     if (o >= isize) { err = kErrOutput; break; }
-                    if (lane == 0) win8[o & kWinMask] = (uint8_t)sym;
+                    if (lane == 0) win8[o & kWinMask] = (uint8_t)e;
                     ++o;
                     if ((o & 1023u) == 0u) flush_full();
                     continue;
                 }
-                if (sym == 256) break;
-                if (sym > 285) { err = kErrSymbol; break; }
-                const uint32_t lc = uni(L.len_code[sym - 257]);
-                const uint32_t len = (lc & 0xFFFFu) + take((int)(lc >> 16));
+                if (kind == kKindEnd) break;
+                if (kind == kKindBad) { err = kErrSymbol; break; }
+                const uint32_t len = (e & 0xFFFFu) + take((int)((e >> 16) & 15u));
                 refill();
-                const int ds = decode(L.dist_tab, kDistBits, L.dist_cnt, L.dist_sorted);
-                if (ds < 0 || ds > 29) { err = kErrSymbol; break; }
-                const uint32_t dc = uni(L.dist_code[ds]);
-                const uint32_t dist = (dc & 0xFFFFu) + take((int)(dc >> 16));
+                const uint32_t d = decode(L.dist_tab, kDistBits, L.dist_cnt, L.dist_sorted, dist_entry);
+                if (d == 0u || (d & kKindMask)) { err = kErrSymbol; break; }
+                const uint32_t dist = (d & 0xFFFFu) + take((int)((d >> 16) & 15u));
                 if (dist > o) { err = kErrDistance; break; }
                 if (o + len > isize) { err = kErrOutput; break; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
-                const bool pow2 = (dist & (dist - 1u)) == 0u;
-                for (uint32_t i = (uint32_t)lane; i < len; i += kWave) {
-                    const uint32_t k = dist >= len ? i : (pow2 ? (i & (dist - 1u)) : i % dist);
-                    win8[(o + i) & kWinMask] = win8[(o - dist + k) & kWinMask];
+                if (dist + len + 64u <= kWinBytes) {
+                    // source and destination are in the ring (and stay there while the match is written)
+                    const bool pow2 = (dist & (dist - 1u)) == 0u;
+                    for (uint32_t i = (uint32_t)lane; i < len; i += kWave) {
+                        const uint32_t k = dist >= len ? i : (pow2 ? (i & (dist - 1u)) : i % dist);
+                        win8[(o + i) & kWinMask] = win8[(o - dist + k) & kWinMask];
+                    }
+                } else {
+                    // the source has left the ring: it is in the block's output in global memory, written by this wavefront's flushes at
+                    // least kWinBytes - 2 * 258 - 64 bytes of output ago (dist > len here: no overlap with the destination)
+                    // (workgroup scope: the stores and the loads are this wavefront's own and go through the same L1 and L2 -- the fence is
+                    // a wait for the stores in flight; at agent scope it is a write-back of the XCD's L2 and the loads bypass it: 5 x slower)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    const uint8_t *src = out + o0 + (o - dist);
+                    for (uint32_t i = (uint32_t)lane; i < len; i += kWave)
+                        win8[(o + i) & kWinMask] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 o += len;
                 if (o - flushed >= 1024u) flush_full();

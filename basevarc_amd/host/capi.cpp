@@ -1,5 +1,7 @@
 // capi.cpp -- C entry points of the host-side pieces, for tests and for callers in other languages.
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -321,54 +323,66 @@ int64_t bvchost_write_synth_batches(const char *out_prefix, int32_t n_samples, i
                                 z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); };
     const int32_t nb = 1 + (n_samples - 1) / batch;
     const size_t window = (size_t)n_pos % thread + (size_t)n_pos / thread;
-    int64_t entries = 0;
-    std::string out, payload;
-    for (int32_t t = 0; t < thread; ++t) {
-        const size_t lo = std::min((size_t)n_pos, (size_t)t * window);
-        const size_t hi = t == thread - 1 ? (size_t)n_pos : std::min((size_t)n_pos, (size_t)(t + 1) * window);
-        for (int32_t ib = 0; ib < nb; ++ib) {
-            const int32_t j0 = ib * batch, j1 = std::min(n_samples, (ib + 1) * batch);
-            // bin: 0 text, 1 binary deflated, 2 binary stored ("raw")
-            BgzfWriter fp(std::string(out_prefix) + ".tmp.thread." + std::to_string(t) + "/batch." + std::to_string(ib), bin == 2 ? 0 : 1);
-            if (!fp.ok()) return -1;
-            std::string names;
-            for (int32_t j = j0; j < j1; ++j) names += "S" + std::to_string(j) + "\t";
-            names += "\n";
-            out.clear();
-            if (bin) bin_batch_header((uint32_t)(j1 - j0), names, out); else out = names;
-            fp.write(out);
-            for (size_t p = lo; p < hi; ++p) {
-                out.clear(); payload.clear();
-                for (int32_t j = j0; j < j1; ++j) {
-                    const uint64_t h = mix(seed * 0x100000001B3ULL + p * 0x9E3779B1ULL + (uint64_t)j);
-                    const bool covered = (int32_t)(h % 1000) < cov_permille;
-                    AlleleInfo a;
-                    if (covered) {
-                        a.mapq = (uint8_t)(20 + (h >> 24) % 41); a.qual = (uint8_t)(10 + (h >> 32) % 31);
-                        // a sequencing error with the probability the quality states, so that sites are monomorphic
-                        // the way real ones mostly are (every 64th position carries a real ALT at frequency 2 %)
-                        const bool err = (double)((h >> 10) % 1000000) < 1e6 * std::pow(10.0, -0.1 * a.qual);
-                        const bool alt = (p % 64) == 7 && ((h >> 44) % 50) == 0;
-                        a.base = err ? (uint8_t)(1 + (h >> 20) % 3) : (alt ? 2 : 0);
-                        a.rpr = (uint8_t)(1 + (h >> 40) % 150); a.strand = (uint8_t)((h >> 50) & 1);
-                        ++entries;
-                    }
-                    if (bin) { if (covered) bin_batch_entry(a, (uint32_t)(j - j0), payload); }
-                    else format_pileup_token(covered ? &a : nullptr, out);
-                }
-                if (bin) {
-                    const uint32_t n = (uint32_t)payload.size();
-                    for (int k = 0; k < 4; ++k) out.push_back((char)((n >> (8 * k)) & 0xff));
-                    out += payload;
-                } else {
-                    out += "\n";
-                }
+    // text and binary batches at zlib's level 6, what bt_r (host/main.cpp) and the reference's bgzf_write write; "raw": stored.
+    // BVC_SYNTH_LEVEL overrides it (round 4's records were taken on level-1 files).
+    const int level = bin == 2 ? 0 : (getenv("BVC_SYNTH_LEVEL") ? atoi(getenv("BVC_SYNTH_LEVEL")) : 6);
+    std::atomic<int64_t> entries(0);
+    std::atomic<int> failed(0), next_t(0);
+    auto work = [&]() {
+        std::string out, payload;
+        for (int32_t t; (t = next_t++) < thread;) {
+            const size_t lo = std::min((size_t)n_pos, (size_t)t * window);
+            const size_t hi = t == thread - 1 ? (size_t)n_pos : std::min((size_t)n_pos, (size_t)(t + 1) * window);
+            int64_t mine = 0;
+            for (int32_t ib = 0; ib < nb; ++ib) {
+                const int32_t j0 = ib * batch, j1 = std::min(n_samples, (ib + 1) * batch);
+                // bin: 0 text, 1 binary deflated, 2 binary stored ("raw")
+                BgzfWriter fp(std::string(out_prefix) + ".tmp.thread." + std::to_string(t) + "/batch." + std::to_string(ib), level);
+                if (!fp.ok()) { failed = 1; return; }
+                std::string names;
+                for (int32_t j = j0; j < j1; ++j) names += "S" + std::to_string(j) + "\t";
+                names += "\n";
+                out.clear();
+                if (bin) bin_batch_header((uint32_t)(j1 - j0), names, out); else out = names;
                 fp.write(out);
+                for (size_t p = lo; p < hi; ++p) {
+                    out.clear(); payload.clear();
+                    for (int32_t j = j0; j < j1; ++j) {
+                        const uint64_t h = mix(seed * 0x100000001B3ULL + p * 0x9E3779B1ULL + (uint64_t)j);
+                        const bool covered = (int32_t)(h % 1000) < cov_permille;
+                        AlleleInfo a;
+                        if (covered) {
+                            a.mapq = (uint8_t)(20 + (h >> 24) % 41); a.qual = (uint8_t)(10 + (h >> 32) % 31);
+                            // a sequencing error with the probability the quality states, so that sites are monomorphic
+                            // the way real ones mostly are (every 64th position carries a real ALT at frequency 2 %)
+                            const bool err = (double)((h >> 10) % 1000000) < 1e6 * std::pow(10.0, -0.1 * a.qual);
+                            const bool alt = (p % 64) == 7 && ((h >> 44) % 50) == 0;
+                            a.base = err ? (uint8_t)(1 + (h >> 20) % 3) : (alt ? 2 : 0);
+                            a.rpr = (uint8_t)(1 + (h >> 40) % 150); a.strand = (uint8_t)((h >> 50) & 1);
+                            ++mine;
+                        }
+                        if (bin) { if (covered) bin_batch_entry(a, (uint32_t)(j - j0), payload); }
+                        else format_pileup_token(covered ? &a : nullptr, out);
+                    }
+                    if (bin) {
+                        const uint32_t n = (uint32_t)payload.size();
+                        for (int k = 0; k < 4; ++k) out.push_back((char)((n >> (8 * k)) & 0xff));
+                        out += payload;
+                    } else {
+                        out += "\n";
+                    }
+                    fp.write(out);
+                }
+                if (!fp.close()) { failed = 1; return; }
             }
-            if (!fp.close()) return -1;
+            entries += mine;
         }
-    }
-    return entries;
+    };
+    // the threads' files are independent: written side by side (generating 1e5-sample batches was minutes on one thread)
+    std::vector<std::thread> ws;
+    for (int i = 0; i < std::max(1, std::min<int>(thread, 16)); ++i) ws.emplace_back(work);
+    for (auto &w : ws) w.join();
+    return failed ? -1 : entries.load();
 }
 
 }  // extern "C"

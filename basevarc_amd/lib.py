@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libbvc.so")
+_LIB = os.environ.get("BVC_LIBBVC") or os.path.join(_HERE, "libbvc.so")      # (BVC_LIBBVC: a variant build for A/B runs, tools/)
 
 BVC_PTR_HOST = 0
 BVC_PTR_DEVICE = 1

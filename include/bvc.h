@@ -98,7 +98,8 @@ int  bvc_device_count(void);
 int  bvc_create(bvc_ctx **out, int device);
 void bvc_destroy(bvc_ctx *ctx);
 const char *bvc_last_error(const bvc_ctx *ctx);
-/* Run on the caller's HIP stream (hipStream_t passed as void*; NULL = the device's default stream). */
+/* Run on the caller's HIP stream (hipStream_t passed as void*; NULL = the device's default stream).  A new context works on a
+ * stream of its own (a blocking stream: ordered against the device's default stream, concurrent with other contexts' streams). */
 int  bvc_set_stream(bvc_ctx *ctx, void *hip_stream);
 int  bvc_synchronize(bvc_ctx *ctx);
 /*

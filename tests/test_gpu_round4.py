@@ -18,7 +18,7 @@ import pytest
 
 from oracle import orc
 from tests.sitegen import caller_min_af, random_site
-from tests.test_gpu_parity import AF_ATOL, assert_site_matches, pad_rows, path_counts_match
+from tests.test_gpu_parity import AF_ATOL, assert_path_difference_is_a_tie, assert_site_matches, pad_rows, path_counts_match
 
 pytestmark = pytest.mark.gpu
 

@@ -87,7 +87,9 @@ def main():
                 if infl:
                     env["BVC_HOST_INFLATE_THREADS"] = infl
                 t0 = time.perf_counter()
-                r = subprocess.run([exe, "basetype", "--rerun", "-t", str(thread), "-b", str(batch), "-i", os.path.join(d, "bam.list"),
+                import shlex
+                prefix = shlex.split(os.environ.get("BVC_HOST_BENCH_PREFIX", ""))     # e.g. "rocprofv3 --kernel-trace --stats -d <dir> --"
+                r = subprocess.run(prefix + [exe, "basetype", "--rerun", "-t", str(thread), "-b", str(batch), "-i", os.path.join(d, "bam.list"),
                                     "-s", f"chrS:{start}-{start + npos}", "-r", fa, "-o", out] + keep + group_args, capture_output=True, text=True, env=env)
                 dt = time.perf_counter() - t0
                 assert r.returncode == 0, r.stderr[-2000:]

@@ -11,7 +11,7 @@ export BVC_HOST_BENCH_FORMATS=text
 export BVC_HOST_BENCH_VARIANTS="${BVC_HOST_BENCH_VARIANTS:-BVC_HOST_DEVICE_INFLATE=1;BVC_HOST_DEVICE_INFLATE=0;BVC_HOST_DEVICE_PARSE=0}"
 for t in ${@:-1 4 16}; do
   for g in 0 5; do
-    BVC_HOST_BENCH_GROUPS=$g timeout -k 10 900 python tools/host_bench.py 100000 $((1500 * t)) $t 0.1 500 > $O/host_1e5_t${t}_g$g.jsonl 2> $O/host_1e5_t${t}_g$g.err
+    BVC_HOST_BENCH_GROUPS=$g timeout -k 10 900 python tools/host_bench.py 100000 $((${POS_PER_THREAD:-1500} * t)) $t 0.1 500 > $O/host_1e5_t${t}_g$g.jsonl 2> $O/host_1e5_t${t}_g$g.err
     echo "threads $t groups $g rc=$?" | tee -a $O/progress
   done
 done
