@@ -573,6 +573,32 @@ struct TileRunner {
     }
 };
 
+// At most BVC_HOST_DEVICE_SLOTS (default 8) threads per device are inside the device's part of a tile (bvc_pileup_begin_bgzf ..
+// bvc_pileup_finish) at a time: past eight, the calls of more threads only get in each other's way (profiles/r05_host/README.txt: 4.9e4
+// positions/s with 8 threads, 3.7e4 with 16, 2.4e4 with 32); the threads beyond them gather their next blocks and format their lines.
+class DeviceSlots {
+ public:
+    void acquire(int device)
+    {
+        std::unique_lock<std::mutex> g(mu_);
+        if (limit_ < 0) limit_ = getenv("BVC_HOST_DEVICE_SLOTS") ? std::max(1, atoi(getenv("BVC_HOST_DEVICE_SLOTS"))) : 8;
+        if ((size_t)device >= used_.size()) used_.resize((size_t)device + 1, 0);
+        cv_.wait(g, [&] { return used_[(size_t)device] < limit_; });
+        used_[(size_t)device] += 1;
+    }
+    void release(int device)
+    {
+        { std::lock_guard<std::mutex> g(mu_); used_[(size_t)device] -= 1; }
+        cv_.notify_all();
+    }
+ private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<int> used_;
+    int limit_ = -1;
+};
+static DeviceSlots g_device_slots;
+
 // ---- temp batches as RAW BGZF blocks (the device inflates them: bvc_pileup_begin_bgzf) ------------------------------------------
 // One block of a temp-batch file as it is on disk: its deflate payload and the size it inflates to.
 struct RawBlock { std::vector<unsigned char> payload; uint32_t isize = 0; };
@@ -873,6 +899,8 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
                 any_new = any_new || took > 0;
             }
             tr.clk.read += StageClock::now() - t0;
+            g_device_slots.acquire(device);
+            struct SlotGuard { int d; ~SlotGuard() { g_device_slots.release(d); } } slot_guard{device};
             const double t1 = StageClock::now();
             Tile &tl = *tr.cur;
             const int32_t max_pos = (int32_t)std::min<int64_t>((int64_t)(hi - ip), std::max<int64_t>(2 * target, 64));
