@@ -1424,7 +1424,8 @@ int bvc_pileup_begin_bgzf(bvc_ctx *ctx, const uint8_t *comp, int64_t comp_bytes,
     for (int64_t i = 0; i < n_blocks; ++i)
         if (bst[(size_t)i] != 0) {
             ctx->pz_left_len.assign(nb, 0u);                     // the stream of this window is broken: nothing to carry on with
-            return fail(ctx, BVC_ERR_DATA, "a BGZF block of a temp batch is not valid deflate of its ISIZE bytes");
+            return fail(ctx, BVC_ERR_DATA, bst[(size_t)i] == 10 ? "a BGZF block of a temp batch fails its CRC32"
+                                                                : "a BGZF block of a temp batch is not valid deflate of its ISIZE bytes");
         }
     // what this tile leaves of every batch: from the end of its last line to the end of its region
     for (size_t b = 0; b < nb; ++b) { ctx->pz_left_src[b] = ends[b]; ctx->pz_left_len[b] = region_end[b] - ends[b]; }

@@ -22,7 +22,8 @@
 // match is two look-ups, not four; longer codes -- rare in text -- walk the canonical code one bit at a time (count per length +
 // symbols sorted by code, as zlib's puff does).  Same acceptance rules as host/inflate.cpp and zlib: over-subscribed code sets are refused,
 // incomplete ones too unless the set has a single one-bit code (or none), distances beyond the block's start, output beyond ISIZE
-// and input beyond the block are refused.  A refused block leaves a code in status[block]; its output is undefined.
+// and input beyond the block are refused.  A refused block leaves a code in status[block]; its output is undefined.  A second kernel
+// (crc32_kernel, below) computes the CRC32 of every block's output where the caller asks for the comparison, as htslib does.
 // Own code, written from RFC 1951; checked against zlib in tests/test_gpu_round5.py.
 #include <hip/hip_runtime.h>
 
@@ -68,7 +69,7 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 
 // error codes in status[]
 enum : uint32_t { kOk = 0, kErrType = 1, kErrStored = 2, kErrHeader = 3, kErrCodes = 4, kErrSymbol = 5, kErrDistance = 6, kErrOutput = 7,
-                  kErrInput = 8, kErrSize = 9 };
+                  kErrInput = 8, kErrSize = 9, kErrCrc = 10 };
 
 // Canonical code of `n` symbols from their code lengths lens[0..n): first-level table of `bits` bits, count per length, symbols sorted
 // by code.  Wave-uniform; the lanes share the table fill.  false: a code set zlib refuses.
@@ -337,12 +338,99 @@ __global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restric
     }
 }
 
+
+// ---- CRC32 of the inflated blocks (RFC 1952; htslib checks it for every BGZF block it reads) ---------------------------------
+// One wavefront per block: every lane takes a slice of the block's output (slices cut at absolute 16-byte boundaries: aligned 16-byte
+// loads), runs the byte-wise table CRC over it, and the 64 slice CRCs are combined in order -- crc(A || B) = crc(A) * x^(8 |B|) mod P
+// xor crc(B) in GF(2)[x] (zlib's crc32_combine; the powers x^(2^k) mod P are compile-time constants).
+constexpr uint32_t kCrcPoly = 0xEDB88320u;
+constexpr uint32_t crc_multmodp(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if ((a & (m - 1u)) == 0u) break; }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ kCrcPoly : b >> 1;
+    }
+    return p;
+}
+struct CrcPowers { uint32_t v[32]; };
+constexpr CrcPowers crc_powers()
+{
+    CrcPowers t{};
+    uint32_t p = 1u << 30;                                       // x^1
+    t.v[0] = p;
+    for (int i = 1; i < 32; ++i) { p = crc_multmodp(p, p); t.v[i] = p; }
+    return t;
+}
+__device__ const CrcPowers kCrcPowers = crc_powers();
+
+// x^(8 n) mod P
+__device__ uint32_t crc_shift_op(uint32_t n)
+{
+    uint32_t p = 1u << 31;
+    int k = 3;
+    while (n) { if (n & 1u) p = crc_multmodp(kCrcPowers.v[k & 31], p); n >>= 1; ++k; }
+    return p;
+}
+
+__global__ __launch_bounds__(kWave) void crc32_kernel(const bvc_bgzf_block *__restrict__ blocks, int64_t n_blocks, const uint8_t *__restrict__ out,
+                                                      uint32_t *__restrict__ status)
+{
+    BVC_POISON_LDS();
+    __shared__ uint32_t tab[256];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += kWave) {
+        uint32_t c = (uint32_t)i;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? kCrcPoly ^ (c >> 1) : c >> 1;
+        tab[i] = c;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        if (blocks[blk].check_crc == 0u || status[blk] != 0u) continue;
+        const uint64_t o0 = (uint64_t)blocks[blk].out_off;
+        const uint32_t n = (uint32_t)blocks[blk].isize;
+        // slice boundaries: o0 rounded down to 16, then every `per` bytes (a multiple of 16), clamped to the block
+        const uint64_t base = o0 & ~(uint64_t)15;
+        const uint32_t span = (uint32_t)(o0 - base) + n;
+        const uint32_t per = ((span + kWave - 1) / kWave + 15u) & ~15u;
+        const uint64_t lo64 = base + (uint64_t)per * (uint32_t)lane, hi64 = lo64 + per;
+        const uint64_t lo = lo64 < o0 ? o0 : (lo64 > o0 + n ? o0 + n : lo64), hi = hi64 < o0 ? o0 : (hi64 > o0 + n ? o0 + n : hi64);
+        uint32_t c = 0xFFFFFFFFu;
+        uint64_t at = lo;
+        while (at < hi && (at & 15u)) { c = tab[(c ^ out[at]) & 255u] ^ (c >> 8); ++at; }
+        for (; at + 16 <= hi; at += 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(out + at);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) c = tab[(c ^ (w[j] >> (8 * b))) & 255u] ^ (c >> 8);
+        }
+        for (; at < hi; ++at) c = tab[(c ^ out[at]) & 255u] ^ (c >> 8);
+        const uint32_t mine = ~c;                                // the slice's CRC32 (0 for an empty slice)
+        const uint32_t len = (uint32_t)(hi - lo);
+        // in order: acc = acc * x^(8 len_k) xor crc_k; the slices behind the first are `per` bytes but the last (and the empty ones)
+        const uint32_t op_full = crc_shift_op(per);
+        uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)mine, 0);
+        for (int k = 1; k < kWave; ++k) {
+            const uint32_t lk = (uint32_t)__shfl((int)len, k, kWave), ck = (uint32_t)__shfl((int)mine, k, kWave);
+            if (lk == 0u) continue;
+            acc = crc_multmodp(lk == per ? op_full : crc_shift_op(lk), acc) ^ ck;
+        }
+        if (lane == 0 && acc != blocks[blk].crc32) status[blk] = kErrCrc;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_inflate(hipStream_t stream, const uint8_t *comp, const bvc_bgzf_block *blocks, int64_t n_blocks, uint8_t *out, uint32_t *status)
 {
     if (n_blocks <= 0) return hipSuccess;
     hipLaunchKernelGGL(inflate_kernel, dim3((unsigned)(n_blocks < 65536 ? n_blocks : 65536)), dim3(kWave), 0, stream, comp, blocks, n_blocks, out, status);
+    // (blocks with check_crc: the CRC32 of what was just written against the trailer's)
+    hipLaunchKernelGGL(crc32_kernel, dim3((unsigned)(n_blocks < 65536 ? n_blocks : 65536)), dim3(kWave), 0, stream, blocks, n_blocks, out, status);
     return hipGetLastError();
 }
 

@@ -601,7 +601,7 @@ static DeviceSlots g_device_slots;
 
 // ---- temp batches as RAW BGZF blocks (the device inflates them: bvc_pileup_begin_bgzf) ------------------------------------------
 // One block of a temp-batch file as it is on disk: its deflate payload and the size it inflates to.
-struct RawBlock { std::vector<unsigned char> payload; uint32_t isize = 0; };
+struct RawBlock { std::vector<unsigned char> payload; uint32_t isize = 0, crc32 = 0; };
 
 // The blocks of the temp-batch files of a thread, read ahead of the tiles by a thread of their own into one FIFO per batch.
 class RawBlockFeed {
@@ -689,6 +689,7 @@ class RawBlockFeed {
             unsigned char t[8];
             if ((blk.payload.size() && std::fread(blk.payload.data(), 1, blk.payload.size(), fp) != blk.payload.size()) || std::fread(t, 1, 8, fp) != 8)
                 throw std::runtime_error("ERROR: truncated temp batch (it ends inside a BGZF block)");
+            blk.crc32 = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
             blk.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
             if (blk.isize > 65536) throw std::runtime_error("ERROR: a temp batch is not BGZF (a block of more than 64 KiB)");
             if (blk.isize != 0) return true;                      // (empty blocks: the EOF marker)
@@ -861,6 +862,7 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
         const double tile_mb = getenv("BVC_HOST_TILE_MB") ? std::max(1, atoi(getenv("BVC_HOST_TILE_MB"))) : 32;
         const double blocks_per_batch = std::max(1.0, tile_mb * 1048576.0 / (65280.0 * (double)std::max<size_t>(1, nb)));
         RawBlockFeed feed(ftmp_v, (size_t)(2 * blocks_per_batch) + 4);
+        static const bool check_crc = getenv("BVC_HOST_NO_CRC") == nullptr;     // (the CRC32 of every block is compared on the device, as htslib does)
         std::vector<double> lines_per_block(nb, 0.0);                   // running estimate per batch
         std::vector<int64_t> blocks_sent(nb, 0), lines_seen(nb, 0);
         std::vector<int32_t> left_lines(nb, 0), lines(nb, 0), send(nb, 0);
@@ -889,6 +891,7 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
                     if (!feed.pop(b, rb)) { ended[b] = 1; break; }
                     bvc_bgzf_block blk;
                     blk.comp_off = (int64_t)comp.size(); blk.out_off = 0; blk.comp_len = (int32_t)rb.payload.size(); blk.isize = (int32_t)rb.isize;
+                    blk.crc32 = rb.crc32; blk.check_crc = check_crc ? 1u : 0u;
                     comp.insert(comp.end(), rb.payload.begin(), rb.payload.end());
                     comp.resize((comp.size() + 3) & ~(size_t)3);
                     blocks.push_back(blk);

@@ -324,10 +324,11 @@ class Context:
     def pileup_begin_bgzf(self, comp, blocks, blocks_of_batch, skip_bytes, sample0, n_in_batch, max_positions, reset):
         """bvc_pileup_begin_bgzf.  comp: bytes; blocks: [(comp_off, comp_len, isize)] batch after batch.  Returns a dict with rc
         (0, 1 = irregular, negative = error), T, lines (per batch) and the sizes bvc_pileup_finish needs."""
-        BLOCK = np.dtype([("comp_off", "<i8"), ("out_off", "<i8"), ("comp_len", "<i4"), ("isize", "<i4")])
+        BLOCK = np.dtype([("comp_off", "<i8"), ("out_off", "<i8"), ("comp_len", "<i4"), ("isize", "<i4"), ("crc32", "<u4"), ("check_crc", "<u4")])
         tab = np.zeros(max(1, len(blocks)), dtype=BLOCK)
-        for i, (co, cl, isz) in enumerate(blocks):
-            tab[i] = (co, 0, cl, isz)
+        for i, blk in enumerate(blocks):
+            co, cl, isz = blk[:3]
+            tab[i] = (co, 0, cl, isz, blk[3] if len(blk) > 3 else 0, 1 if len(blk) > 3 else 0)
         buf = np.frombuffer(bytes(comp) + b"\0" * 8, dtype=np.uint8)
         bob = np.ascontiguousarray(blocks_of_batch, dtype=np.int32)
         nb = len(bob)
@@ -353,11 +354,12 @@ class Context:
     def inflate_blocks(self, comp, blocks):
         """Raw-deflate streams inflated on the device.  comp: bytes; blocks: [(comp_off, comp_len, isize)] -- outputs are laid out one
         after the other.  Returns (list of bytes, status array)."""
-        BLOCK = np.dtype([("comp_off", "<i8"), ("out_off", "<i8"), ("comp_len", "<i4"), ("isize", "<i4")])
+        BLOCK = np.dtype([("comp_off", "<i8"), ("out_off", "<i8"), ("comp_len", "<i4"), ("isize", "<i4"), ("crc32", "<u4"), ("check_crc", "<u4")])
         tab = np.zeros(len(blocks), dtype=BLOCK)
         at = 0
-        for i, (co, cl, isz) in enumerate(blocks):
-            tab[i] = (co, at, cl, isz)
+        for i, blk in enumerate(blocks):                        # (comp_off, comp_len, isize[, crc32]): with a CRC it is compared
+            co, cl, isz = blk[:3]
+            tab[i] = (co, at, cl, isz, blk[3] if len(blk) > 3 else 0, 1 if len(blk) > 3 else 0)
             at += isz
         buf = np.frombuffer(bytes(comp) + b"\0" * 8, dtype=np.uint8)
         out = np.zeros(max(1, at), dtype=np.uint8)

@@ -509,7 +509,7 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
     tmp_q = torch.empty((slice_sites, stride), dtype=torch.int8, device=dev)
     for t in range(n_csr_tiles):
         r = torch.empty(csr_sites, dtype=torch.int8, device=dev)
-        parts_b, parts_q, counts = [], [], []
+        parts_b, parts_q, parts_s, counts = [], [], [], []
         for c0 in range(0, csr_sites, slice_sites):
             ns = min(slice_sites, csr_sites - c0)
             bb, qq = tmp_b[:ns, :n], tmp_q[:ns, :n]
@@ -519,18 +519,19 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
             m = bb >= 0
             counts.append(m.sum(dim=1))
             parts_b.append(bb[m]); parts_q.append(qq[m])
+            parts_s.append(torch.nonzero(m)[:, 1].to(torch.int32))          # which sample an observation is of (the ragged group call)
         cnt = torch.cat(counts).to(torch.int64)
         offs = torch.zeros(csr_sites + 1, dtype=torch.int64, device=dev)
         offs[1:] = torch.cumsum(cnt, 0)
-        csr.append((offs, torch.cat(parts_b), torch.cat(parts_q), r))
-        del parts_b, parts_q, counts
+        csr.append((offs, torch.cat(parts_b), torch.cat(parts_q), r, torch.cat(parts_s)))
+        del parts_b, parts_q, parts_s, counts
     del tmp_b, tmp_q
     torch.cuda.synchronize()
     covered = float(sum(int(c[0][-1].item()) for c in csr)) / len(csr)
     res = [torch.empty(csr_sites * SITE_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in csr]
 
     def fn_csr(j):
-        o, b, q, r = csr[j % len(csr)]
+        o, b, q, r, _ = csr[j % len(csr)]
         ctx.lrt_csr_device(o, b, q, r, min_af, res[j % len(csr)])
     n_calls = max(8, 160000 // csr_sites)
     dt, prof = timed_calls(ctx, fn_csr, n_calls)
@@ -552,7 +553,7 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
     csr_check = None
     if a.cpu_sites != 0 and not a.no_verify:                     # 16 sites of CSR tile 0 against the oracle's histogram form
         from oracle import orc
-        o, b, q, r = csr[0]
+        o, b, q, r, _ = csr[0]
         oh = o.cpu().numpy()
         bad = 0
         pick = np.linspace(0, csr_sites - 1, 16).astype(int)
@@ -583,8 +584,40 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
     }
     # ---- host-pointer callers (BVC_PTR_HOST): bound by the host link, so they get the one-byte forms.  Never the
     # reported `value` (inputs are not resident); the roofline of this leg is PCIe, 63 GB/s.
+    # ---- the --group loop on the same ragged sites (bvc_lrt_csr_groups, k = 5, labels interleaved, every 10th sample in no group):
+    # what the host program calls per tile with --group since round 5 (src/BaseVarC.cpp:617-661 on the covered samples only)
+    kg = 5
+    lab = (np.arange(n) % kg).astype(np.uint8)
+    lab[9::10] = 255
+    g_t = torch.from_numpy(lab).to(dev)
+
+    def fn_csrg(j):
+        o, b, q, r, sm = csr[j % len(csr)]
+        fn_csrg.out = ctx.lrt_csr_groups_device(o, b, q, sm, r, min_af, g_t, kg)
+    ctx.join()
+    n_calls_g = max(8, 80000 // csr_sites)
+    dtg, profg = timed_calls(ctx, fn_csrg, n_calls_g)
+    fn_csrg(0)                                                   # (the records compared below: tile 0's)
+    ctx.join(); ctx.synchronize()
+    hist_g_ms = profg["hist_ms"] / max(1, profg["hist_launches"])
+    em_g_ms = profg["em_ms"] / max(1, profg["em_launches"])
+    alg_g = 6.0 * covered                                        # base + quality + 4-byte sample index per COVERED sample
+    same_overall = bool(_same_but_run_counts(results_from_tensor(fn_csrg.out[0]).copy(), rec))
+    legs[f"csr_groups{kg}_coverage10pct"] = {
+        "workload": f"ragged (CSR) sites with population groups, bvc_lrt_csr_groups: N = {n} samples at {cov:.0%} coverage, k = {kg} groups "
+                    f"(labels interleaved, a tenth of the samples in none), {n_calls_g} calls of {csr_sites} sites",
+        "value": n_calls_g * csr_sites / dtg, "unit": "sites/s", "ms_per_call": dtg / n_calls_g * 1e3,
+        "overall_records_identical_to_bvc_lrt_csr": same_overall,
+        "stage2_ms_per_call": em_g_ms, "bound_by": "stage 2 of the overall and the per-group calls (FP64 VALU issue)",
+        "roofline": {"bound": "hbm", "kernel": "hist_csr_groups_kernel", "achieved": alg_g / (hist_g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": alg_g / (hist_g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": hist_g_ms,
+                     "launches_timed": int(profg["hist_launches"]), "algorithmic_bytes_per_launch": alg_g,
+                     "note": "6 bytes per covered observation: base, quality and the 4-byte index of its sample; one workgroup per site, "
+                             "LDS atomics into (k + 1) x 512 counters -- the leg is bound by stage 2, not by this kernel"},
+    }
+    del g_t
     hp = {}
-    o, b, q, r = csr[0]
+    o, b, q, r, _ = csr[0]
     pk_h = ((b.to(torch.uint8) << 6) | q.to(torch.uint8)).cpu().numpy()
     o_h, r_h = o.cpu().numpy(), r.cpu().numpy()
     ctx.join(); ctx.synchronize()

@@ -218,13 +218,15 @@ int bvc_lrt_csr_groups(bvc_ctx *ctx, int64_t n_sites, const int64_t *offsets, co
  * block, blocks independent of each other.  blocks[i] names the deflate payload of a block inside `comp` (the bytes between the
  * 18-byte BGZF header and the 8-byte CRC32 / ISIZE trailer), its ISIZE and where its output goes in `out`; status[i] = 0 when the
  * block inflated to exactly ISIZE bytes, else a non-zero code (the block's output is then undefined; zlib refuses the same streams).
- * CRC32 is NOT checked here (host/bgzf.cpp checks it on the CPU path).  Host or device pointers (flags).
+ * With check_crc the CRC32 of the output is computed on the device too and compared.  Host or device pointers (flags).
  */
 typedef struct bvc_bgzf_block {
     int64_t comp_off;      /* offset of the deflate payload in comp */
     int64_t out_off;       /* offset of the block's output in out */
     int32_t comp_len;      /* bytes of deflate payload */
     int32_t isize;         /* bytes the block inflates to (<= 65536) */
+    uint32_t crc32;        /* CRC32 of the inflated bytes (the block's trailer, RFC 1952) */
+    uint32_t check_crc;    /* non-zero: compare (htslib does for every block it reads); a mismatch is status 10 */
 } bvc_bgzf_block;
 int bvc_inflate_blocks(bvc_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, const bvc_bgzf_block *blocks, int64_t n_blocks,
                        uint8_t *out, int64_t out_bytes, uint32_t *status, uint32_t flags);
@@ -289,8 +291,8 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
  *   indel_text_bytes  out: size of the buffer bvc_pileup_finish's indel_text needs (the indel tokens' text: records' text_off are
  *                     then offsets into it; with bvc_pileup_begin indel_text may be NULL and text_off stays an offset into text)
  * Returns BVC_OK, BVC_PILEUP_IRREGULAR (the tile's T positions are decided and consumed, but some line is not regular: fetch the text
- * with bvc_pileup_text and parse it with the reference's rules), BVC_ERR_DATA or another error.  CRC32 of the blocks is NOT checked
- * on this path.
+ * with bvc_pileup_text and parse it with the reference's rules), BVC_ERR_DATA (a block is not valid deflate of its ISIZE bytes, or -- check_crc -- fails its CRC32)
+ * or another error.
  */
 int bvc_pileup_begin_bgzf(bvc_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, const bvc_bgzf_block *blocks,
                           const int32_t *blocks_of_batch, const int32_t *skip_bytes, const int32_t *sample0, const int32_t *n_in_batch,

@@ -47,7 +47,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert "traffic_note" in rf
     assert len(d["per_rank"]) == 1 and d["per_rank"][0]["sites"] == 8000 and d["per_rank"][0]["calls_per_step"] == 4
     # every leg's rate and roofline fraction once more as the LAST key of the line (a reader that keeps the tail of stdout sees them)
-    assert list(d.keys())[-1] == "legs_summary" and len(json.dumps(d["legs_summary"])) < 700
+    assert list(d.keys())[-1] == "legs_summary" and len(json.dumps(d["legs_summary"])) < 800
     assert set(d["legs_summary"]) == set(d["legs"])
     for name, (value, frac) in d["legs_summary"].items():
         assert value > 0 and 0 < frac < 1, name
@@ -55,7 +55,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
             assert value == pytest.approx(d["legs"][name]["value"], rel=1e-3) and frac == pytest.approx(d["legs"][name]["roofline"]["frac"], rel=1e-3)
     # the other single-GPU configurations ride along as sub-records with their own roofline
     legs = d["legs"]
-    for name in ("config1_1e4x1e4", "config4_groups5_interleaved", "config4_groups5_ordered", "csr_coverage10pct"):
+    assert legs["csr_groups5_coverage10pct"]["overall_records_identical_to_bvc_lrt_csr"] is True
+    for name in ("config1_1e4x1e4", "config4_groups5_interleaved", "config4_groups5_ordered", "csr_coverage10pct", "csr_groups5_coverage10pct"):
         assert legs[name]["value"] > 0 and 0 < legs[name]["roofline"]["frac"] < 1, name
     # the additive packed layout (one byte per sample) rides along too, and must give the two-byte path's records
     pk = legs["packed_1_byte_per_sample"]

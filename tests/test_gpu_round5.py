@@ -339,7 +339,8 @@ def _streams():
 
 
 def test_device_inflate_equals_zlib_and_refuses_what_zlib_refuses(ctx):
-    """inflate_kernel.hip against zlib: empty, tiny, random, periodic and pileup-text inputs up to a block's 64 KiB; stored, fixed-code,
+    """inflate_kernel.hip (and crc32_kernel: two blocks in three carry their CRC32, as BGZF trailers do, and it is compared on the device)
+    against zlib: empty, tiny, random, periodic and pileup-text inputs up to a block's 64 KiB; stored, fixed-code,
     dynamic-code, Huffman-only and RLE streams; several deflate blocks per stream; every alignment of the payload.  Truncated and
     corrupted streams and a wrong ISIZE must come back with a non-zero status (never the expected bytes with status 0), and the
     blocks beside them must be untouched by it."""
@@ -359,7 +360,7 @@ def test_device_inflate_equals_zlib_and_refuses_what_zlib_refuses(ctx):
                 many = b"".join(co.compress(data[i:i + step]) + co.flush(zlib.Z_FULL_FLUSH) for i in range(0, len(data), step)) + co.flush()
                 for c in (one, many):
                     comp += b"\xA5" * (len(blocks) % 5)                  # payloads at every alignment
-                    blocks.append((len(comp), len(c), len(data)))
+                    blocks.append((len(comp), len(c), len(data), zlib.crc32(data) & 0xffffffff) if len(blocks) % 3 else (len(comp), len(c), len(data)))
                     want.append((name, level, strategy, data))
                     comp += c
     got, status = ctx.inflate_blocks(bytes(comp), blocks)
@@ -372,13 +373,16 @@ def test_device_inflate_equals_zlib_and_refuses_what_zlib_refuses(ctx):
     blocks2, expect = [], []
     good = [i for i in range(len(blocks)) if 64 < len(want[i][3]) < 65536][::37]
     for i in good:
-        co, cl, isz = blocks[i]
+        co, cl, isz = blocks[i][:3]
         c = bytes(comp[co:co + cl])
-        variants = [("good", c, isz), ("short_isize", c, isz - 1), ("long_isize", c, isz + 1), ("truncated", c[:cl // 2], isz)]
+        variants = [("good", c, isz), ("short_isize", c, isz - 1), ("long_isize", c, isz + 1), ("truncated", c[:cl // 2], isz), ("wrong_crc", c, isz)]
         dmg = bytearray(c); dmg[len(dmg) // 2] ^= 0x55
         variants.append(("corrupt", bytes(dmg), isz))
         for kind, cc, sz in variants:
-            blocks2.append((len(comp2), len(cc), sz))
+            if kind in ("good", "wrong_crc"):                  # with the CRC32 of the data (its lowest bit flipped: the one thing wrong)
+                blocks2.append((len(comp2), len(cc), sz, (zlib.crc32(want[i][3]) & 0xffffffff) ^ (1 if kind == "wrong_crc" else 0)))
+            else:
+                blocks2.append((len(comp2), len(cc), sz))
             expect.append((kind, want[i][3]))
             comp2 += cc + b"\0" * 3
     got2, status2 = ctx.inflate_blocks(bytes(comp2), blocks2)
@@ -394,6 +398,8 @@ def test_device_inflate_equals_zlib_and_refuses_what_zlib_refuses(ctx):
                 except zlib.error:
                     ok = False
                 assert ok, "status 0 for a stream zlib does not inflate to the same bytes"
+        elif kind == "wrong_crc":
+            assert st == 10, (kind, st)
         else:
             assert st != 0, kind
 

@@ -16,7 +16,8 @@ n_blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cov = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
 level = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 rng = np.random.default_rng(3)
-BLOCK = np.dtype([("comp_off", "<i8"), ("out_off", "<i8"), ("comp_len", "<i4"), ("isize", "<i4")])
+BLOCK = np.dtype([("comp_off", "<i8"), ("out_off", "<i8"), ("comp_len", "<i4"), ("isize", "<i4"), ("crc32", "<u4"), ("check_crc", "<u4")])
+CHECK = int(os.environ.get("BVC_BENCH_CRC", "1"))
 # 64 different blocks of text, repeated: the kernel does not care, the host's generator is the slow part
 texts = []
 for k in range(64):
@@ -31,7 +32,7 @@ comp = bytearray()
 tab = np.zeros(n_blocks, dtype=BLOCK)
 for i in range(n_blocks):
     c = comps[i % 64]
-    tab[i] = (len(comp), i * 65280, len(c), 65280)
+    tab[i] = (len(comp), i * 65280, len(c), 65280, zlib.crc32(texts[i % 64]) & 0xffffffff, CHECK)
     comp += c + b"\0" * ((-len(c)) % 4)
 ctx = Context(0)
 dev = torch.device("cuda:0")
