@@ -330,34 +330,68 @@ __global__ void pileup_patch_kernel(int64_t n_lines, int32_t n_batches, const ui
 // site's COVERED samples (src/BaseVarC.cpp:617-661, vectors of :550-559): this is that loop's input without the dense
 // [site][N] tile in between.  One workgroup per site, one LDS counter per (histogram, class), LDS atomics: a ragged site is
 // 1e1-1e5 observations, far fewer than a dense row, and what bounds a site here is zeroing and folding (k + 1) x 512 counters.
-constexpr int kCsrGroupThreads = 256;
+constexpr int kCsrGroupThreads = 512;
 
+// One workgroup per site; LDS [histogram][class][copy] with as many copies (a power of two, copy = lane mod copies) as fit 64 KiB --
+// 4 at k = 5 -- so that the handful of hot classes of a pileup (the reference base at ~30 qualities, per group) are not ONE counter
+// each for 512 lanes.  6 algorithmic bytes per observation (base, quality, sample index) + a label byte gathered from the L2-resident
+// label vector.
 __global__ __launch_bounds__(kCsrGroupThreads) void hist_csr_groups_kernel(
     int64_t n_sites, const int64_t *__restrict__ offsets, const int8_t *__restrict__ bases, const int8_t *__restrict__ quals,
     const int32_t *__restrict__ sample_of_obs, const uint8_t *__restrict__ group_of_sample, int64_t n_samples, int n_groups,
-    uint32_t *__restrict__ counts)
+    int log2c, uint32_t *__restrict__ counts)
 {
     BVC_POISON_LDS();
-    extern __shared__ __attribute__((aligned(16))) uint32_t ghist[];        // [n_groups + 1][512]
+    extern __shared__ __attribute__((aligned(16))) uint32_t ghist[];        // [n_groups + 1][512][1 << log2c]
     const int tid = threadIdx.x;
-    const int words = (n_groups + 1) * BVC_NCLASS;
-    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
-        for (int i = tid; i < words; i += kCsrGroupThreads) ghist[i] = 0u;
-        __syncthreads();
-        const int64_t o0 = offsets[site], o1 = offsets[site + 1];
-        for (int64_t i = o0 + tid; i < o1; i += kCsrGroupThreads) {
-            const uint32_t b = (uint8_t)bases[i], q = (uint8_t)quals[i];
-            if (b < 4u && q < 128u) {
-                const int64_t smp = sample_of_obs[i];
-                uint32_t g = (uint32_t)n_groups;
-                if (smp >= 0 && smp < n_samples) { g = group_of_sample[smp]; if (g > (uint32_t)n_groups) g = (uint32_t)n_groups; }
-                const uint32_t at = g * BVC_NCLASS + ((b << 7) | q);
-                if (BVC_LDS_OK(0x501, at, words)) atomicAdd(&ghist[at], 1u);
-            }
+    const int n_hist = n_groups + 1;
+    const int classes = n_hist * BVC_NCLASS;
+    const int words = classes << log2c;
+    const uint32_t copy = (uint32_t)tid & ((1u << log2c) - 1u);
+    auto one = [&](uint32_t b, uint32_t q, int64_t smp) {
+        if (b < 4u && q < 128u) {
+            uint32_t g = (uint32_t)n_groups;
+            if (smp >= 0 && smp < n_samples) { g = group_of_sample[smp]; if (g > (uint32_t)n_groups) g = (uint32_t)n_groups; }
+            const uint32_t at = ((g * BVC_NCLASS + ((b << 7) | q)) << log2c) | copy;
+            if (BVC_LDS_OK(0x501, at, words)) atomicAdd(&ghist[at], 1u);
         }
+    };
+    for (int i = tid * 4; i < words; i += kCsrGroupThreads * 4) *reinterpret_cast<u32x4 *>(&ghist[i]) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
+        const int64_t o0 = offsets[site], o1 = offsets[site + 1];
+        // consecutive lanes take consecutive observations: their sample indices ascend, so a wavefront's 64 label gathers fall into
+        // a handful of cache lines (at 10 % coverage ~640 bytes of the label vector) -- with 16 observations per lane they were 64
+        // different lines per gather instruction and the kernel ran at the L1 miss rate (round 5: 1.9 ms against 1.5 per 4000 sites of
+        // 1e5 observations).  Four observations per lane and trip, their loads issued together.
+        constexpr int U = 4;
+        int64_t i = o0 + tid;
+        for (; i + (int64_t)(U - 1) * kCsrGroupThreads < o1; i += (int64_t)U * kCsrGroupThreads) {
+            uint32_t b[U], q[U], lab[U];
+            int32_t sm[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t at = i + (int64_t)u * kCsrGroupThreads;
+                b[u] = (uint8_t)bases[at]; q[u] = (uint8_t)quals[at]; sm[u] = sample_of_obs[at];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) lab[u] = sm[u] >= 0 && (int64_t)sm[u] < n_samples ? group_of_sample[sm[u]] : (uint32_t)n_groups;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (b[u] < 4u && q[u] < 128u) {
+                    const uint32_t g = lab[u] > (uint32_t)n_groups ? (uint32_t)n_groups : lab[u];
+                    const uint32_t at = ((g * BVC_NCLASS + ((b[u] << 7) | q[u])) << log2c) | copy;
+                    if (BVC_LDS_OK(0x502, at, words)) atomicAdd(&ghist[at], 1u);
+                }
+        }
+        for (; i < o1; i += kCsrGroupThreads) one((uint8_t)bases[i], (uint8_t)quals[i], sample_of_obs[i]);
         __syncthreads();
-        uint32_t *dst = counts + site * (int64_t)words;
-        for (int i = tid; i < words; i += kCsrGroupThreads) dst[i] = ghist[i];
+        uint32_t *dst = counts + site * (int64_t)classes;
+        for (int key = tid; key < classes; key += kCsrGroupThreads) {
+            uint32_t sum = 0;
+            for (int v = 0; v < (1 << log2c); ++v) { const int at = (key << log2c) + ((v + key) & ((1 << log2c) - 1)); sum += ghist[at]; ghist[at] = 0u; }
+            dst[key] = sum;
+        }
         __syncthreads();
     }
 }
@@ -541,7 +575,9 @@ hipError_t launch_hist_csr_groups(LaunchState &st, hipStream_t stream, int64_t n
                                   int n_groups, uint32_t *counts)
 {
     if (n_sites <= 0) return hipSuccess;
-    const size_t lds = (size_t)(n_groups + 1) * BVC_NCLASS * sizeof(uint32_t);
+    int log2c = 0;                                               // copies: as many as fit 64 KiB
+    while (log2c < 5 && ((size_t)(n_groups + 1) * BVC_NCLASS * sizeof(uint32_t) << (log2c + 1)) <= 64 * 1024) ++log2c;
+    const size_t lds = (size_t)(n_groups + 1) * BVC_NCLASS * sizeof(uint32_t) << log2c;
     constexpr uint32_t kSlotCsrGroups = 61;
     if (lds > 48 * 1024 && !(st.attr_done & ((uint64_t)1 << kSlotCsrGroups))) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(hist_csr_groups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -550,7 +586,7 @@ hipError_t launch_hist_csr_groups(LaunchState &st, hipStream_t stream, int64_t n
         st.attr_done |= (uint64_t)1 << kSlotCsrGroups;
     }
     hipLaunchKernelGGL(hist_csr_groups_kernel, dim3((unsigned)(n_sites < 8192 ? n_sites : 8192)), dim3(kCsrGroupThreads), lds, stream, n_sites,
-                       offsets, bases, quals, sample_of_obs, group_of_sample, n_samples, n_groups, counts);
+                       offsets, bases, quals, sample_of_obs, group_of_sample, n_samples, n_groups, log2c, counts);
     return hipGetLastError();
 }
 
