@@ -60,8 +60,8 @@ struct bvc_ctx {
     hipEvent_t ev_upload[2] = {nullptr, nullptr};
     hipEvent_t ev_set_free[2] = {nullptr, nullptr};   // ragged host calls: the kernels that read staging set k have finished
     // bvc_pileup_begin / bvc_pileup_finish: the tile's text, its line tables and counts, its parsed columns and records
-    char *d_pl_text = nullptr, *d_pl_meta = nullptr, *d_pl_out = nullptr;
-    size_t pl_text_cap = 0, pl_meta_cap = 0, pl_out_cap = 0;
+    char *d_pl_text = nullptr, *d_pl_meta = nullptr, *d_pl_out = nullptr, *d_pl_called = nullptr;
+    size_t pl_text_cap = 0, pl_meta_cap = 0, pl_out_cap = 0, pl_called_cap = 0;
     // tiles inflated on the device (bvc_pileup_begin_bgzf): two text buffers (what a tile leaves of a batch is carried from one to the
     // other), the compressed bytes, what the calls left of every batch
     char *d_pz_text[2] = {nullptr, nullptr}, *d_pz_comp = nullptr;
@@ -654,6 +654,7 @@ void bvc_destroy(bvc_ctx *ctx)
     if (ctx->d_pl_text) (void)hipFree(ctx->d_pl_text);
     if (ctx->d_pl_meta) (void)hipFree(ctx->d_pl_meta);
     if (ctx->d_pl_out) (void)hipFree(ctx->d_pl_out);
+    if (ctx->d_pl_called) (void)hipFree(ctx->d_pl_called);
     if (ctx->h_up) (void)hipHostFree(ctx->h_up);
     if (ctx->h_down) (void)hipHostFree(ctx->h_down);
     for (int k = 0; k < 2; ++k) if (ctx->d_pz_text[k]) (void)hipFree(ctx->d_pz_text[k]);
@@ -1459,10 +1460,13 @@ int bvc_pileup_text(bvc_ctx *ctx, char *text, int64_t text_cap, int64_t *text_by
     return BVC_OK;
 }
 
-int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const uint8_t carry_in[5], uint8_t carry_out[5],
-                      const uint8_t *group_of_sample, int64_t n_samples, int32_t n_groups,
-                      int64_t *entry_off, int32_t *tally, bvc_pileup_entry *entries, int32_t *samples,
-                      bvc_pileup_indel *indels, char *indel_text, bvc_site_result *results, bvc_group_result *grp_results)
+// bvc_pileup_finish (called_off = null: the entries of every position) and bvc_pileup_finish_called (the entries of the called
+// positions only, compacted on the device; called_cap = room in entries / samples)
+static int pileup_finish_impl(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const uint8_t carry_in[5], uint8_t carry_out[5],
+                              const uint8_t *group_of_sample, int64_t n_samples, int32_t n_groups,
+                              int64_t *entry_off, int32_t *tally, int64_t *called_off, int64_t called_cap, bvc_pileup_entry *entries,
+                              int32_t *samples, bvc_pileup_indel *indels, char *indel_text, bvc_site_result *results,
+                              bvc_group_result *grp_results)
 {
     if (!ctx) return BVC_ERR_ARG;
     if (!ctx->pl_begun) return fail(ctx, BVC_ERR_ARG, "bvc_pileup_finish without a bvc_pileup_begin that returned BVC_OK");
@@ -1472,7 +1476,9 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
     const int64_t T = P.n_pos, n_e = ctx->pl_entries, n_o = ctx->pl_obs, n_i = ctx->pl_indels;
     if (!carry_in || !carry_out || !entry_off) return fail(ctx, BVC_ERR_ARG, "null pointer");
     if (T > 0 && (!ref_base || !tally || !results)) return fail(ctx, BVC_ERR_ARG, "null pointer");
-    if ((n_e > 0 && (!entries || !samples)) || (n_i > 0 && !indels)) return fail(ctx, BVC_ERR_ARG, "null pointer");
+    const bool called_only = called_off != nullptr;
+    if ((n_e > 0 && !called_only && (!entries || !samples)) || (n_i > 0 && !indels)) return fail(ctx, BVC_ERR_ARG, "null pointer");
+    if (called_only && (called_cap < 0 || (called_cap > 0 && (!entries || !samples)))) return fail(ctx, BVC_ERR_ARG, "null pointer");
     if (n_groups < 0 || n_groups > BVC_MAX_GROUPS) return fail(ctx, BVC_ERR_ARG, "n_groups must be 0..32");
     if (n_groups > 0 && (!grp_results || n_samples < 0 || (n_samples > 0 && !group_of_sample))) return fail(ctx, BVC_ERR_ARG, "null group pointer");
     BVC_HIP(ctx, hipSetDevice(ctx->device));
@@ -1481,8 +1487,9 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
     const size_t res_al = al256((size_t)T * sizeof(bvc_site_result)), g_al = al256((size_t)(n_groups ? n_samples : 0) + 16);
     const size_t gres_al = al256((size_t)T * (size_t)n_groups * sizeof(bvc_group_result));
     const size_t it_al = al256((size_t)(indel_text ? ctx->pl_indel_bytes : 0) + 16);
+    const size_t co_al = al256(called_only ? (size_t)(T + 1) * 8 : 0);
     int rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_pl_out), &ctx->pl_out_cap,
-                    e_al + s_al + 2 * o_al + os_al + i_al + r_al + res_al + g_al + gres_al + it_al + 256);
+                    e_al + s_al + 2 * o_al + os_al + i_al + r_al + res_al + g_al + gres_al + it_al + co_al + 256);
     if (rc != BVC_OK) return rc;
     char *p = ctx->d_pl_out;
     P.entries = reinterpret_cast<bvc_pileup_entry *>(p); p += e_al;
@@ -1496,7 +1503,8 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
     bvc_site_result *d_res = reinterpret_cast<bvc_site_result *>(p); p += res_al;
     uint8_t *d_g = reinterpret_cast<uint8_t *>(p); p += g_al;
     bvc_group_result *d_gres = reinterpret_cast<bvc_group_result *>(p); p += gres_al;
-    uint8_t *d_itext = reinterpret_cast<uint8_t *>(p);
+    uint8_t *d_itext = reinterpret_cast<uint8_t *>(p); p += it_al;
+    int64_t *d_called_off = reinterpret_cast<int64_t *>(p);
     const uint32_t cin = (uint32_t)(carry_in[0] & 7u) | ((uint32_t)(carry_in[4] & 1u) << 3) | 0x80u | ((uint32_t)carry_in[1] << 8) |
                          ((uint32_t)carry_in[2] << 16) | ((uint32_t)carry_in[3] << 24);
     auto drained = [&](int code) {
@@ -1517,7 +1525,8 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
     PinIO io(ctx);
     rc = io.reserve((size_t)T + (size_t)(n_groups > 0 ? n_samples : 0) + 1024,
                     (size_t)T * (sizeof(bvc_site_result) + 32 * 4 + 8 + (size_t)n_groups * sizeof(bvc_group_result)) +
-                        (size_t)n_e * (sizeof(bvc_pileup_entry) + 4) + (size_t)n_i * sizeof(bvc_pileup_indel) + (size_t)ctx->pl_indel_bytes + 4096);
+                        (size_t)(called_only ? 0 : n_e) * (sizeof(bvc_pileup_entry) + 4) + (called_only ? (size_t)(T + 1) * 8 : 0) +
+                        (size_t)n_i * sizeof(bvc_pileup_indel) + (size_t)ctx->pl_indel_bytes + 4096);
     if (rc != BVC_OK) return rc;
     if (T > 0) {
         BVC_HIP_D(io.h2d(d_ref, ref_base, (size_t)T));
@@ -1533,9 +1542,13 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
         if (n_groups > 0)
             BVC_HIP_D(io.d2h(grp_results, d_gres, (size_t)T * (size_t)n_groups * sizeof(bvc_group_result)));
         BVC_HIP_D(io.d2h(tally, P.tally, (size_t)T * 32 * 4));
-        if (n_e) {
+        if (n_e && !called_only) {
             BVC_HIP_D(io.d2h(entries, P.entries, (size_t)n_e * sizeof(bvc_pileup_entry)));
             BVC_HIP_D(io.d2h(samples, P.samples, (size_t)n_e * 4));
+        }
+        if (called_only) {
+            BVC_HIP_D(launch_called_scan(ctx->stream, P, d_res, d_called_off));
+            BVC_HIP_D(io.d2h(called_off, d_called_off, (size_t)(T + 1) * 8));
         }
         if (n_i && indel_text) {
             BVC_HIP_D(launch_indel_text(ctx->stream, P, d_itext, (uint32_t)ctx->pl_indel_bytes, P.status + 5));
@@ -1547,10 +1560,49 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
     BVC_HIP_D(io.d2h(entry_off, P.entry_off, (size_t)(T + 1) * 8));
     BVC_HIP_D(wait_stream(ctx));
     io.deliver();
+    if (called_only && T == 0) called_off[0] = 0;
+    if (called_only && T > 0 && called_off[T] > 0) {
+        // the second trip: the called positions' entries, gathered on the device (typically a few per cent of the tile's)
+        const int64_t n_c = called_off[T];
+        if (n_c > called_cap) return fail(ctx, BVC_ERR_ARG, "called_cap is smaller than the entries of the called positions (n_entries of the begin call always suffices)");
+        const size_t ce_al = al256((size_t)n_c * sizeof(bvc_pileup_entry));
+        rc = ensure(ctx, reinterpret_cast<void **>(&ctx->d_pl_called), &ctx->pl_called_cap, ce_al + al256((size_t)n_c * 4));
+        if (rc != BVC_OK) return rc;
+        bvc_pileup_entry *d_ce = reinterpret_cast<bvc_pileup_entry *>(ctx->d_pl_called);
+        int32_t *d_cs = reinterpret_cast<int32_t *>(ctx->d_pl_called + ce_al);
+        io.down_used = 0;
+        rc = io.reserve(0, (size_t)n_c * (sizeof(bvc_pileup_entry) + 4) + 4096);
+        if (rc != BVC_OK) return rc;
+        BVC_HIP_D(launch_called_gather(ctx->stream, P, d_called_off, d_ce, d_cs));
+        BVC_HIP_D(io.d2h(entries, d_ce, (size_t)n_c * sizeof(bvc_pileup_entry)));
+        BVC_HIP_D(io.d2h(samples, d_cs, (size_t)n_c * 4));
+        BVC_HIP_D(wait_stream(ctx));
+        io.deliver();
+    }
 #undef BVC_HIP_D
     carry_out[0] = (uint8_t)(cout & 7u); carry_out[1] = (uint8_t)(cout >> 8); carry_out[2] = (uint8_t)(cout >> 16);
     carry_out[3] = (uint8_t)(cout >> 24); carry_out[4] = (uint8_t)((cout >> 3) & 1u);
     return BVC_OK;
+}
+
+int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const uint8_t carry_in[5], uint8_t carry_out[5],
+                      const uint8_t *group_of_sample, int64_t n_samples, int32_t n_groups,
+                      int64_t *entry_off, int32_t *tally, bvc_pileup_entry *entries, int32_t *samples,
+                      bvc_pileup_indel *indels, char *indel_text, bvc_site_result *results, bvc_group_result *grp_results)
+{
+    return pileup_finish_impl(ctx, ref_base, min_af, carry_in, carry_out, group_of_sample, n_samples, n_groups, entry_off, tally, nullptr, 0,
+                              entries, samples, indels, indel_text, results, grp_results);
+}
+
+int bvc_pileup_finish_called(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const uint8_t carry_in[5], uint8_t carry_out[5],
+                             const uint8_t *group_of_sample, int64_t n_samples, int32_t n_groups,
+                             int64_t *entry_off, int32_t *tally, int64_t *called_off, int64_t called_cap, bvc_pileup_entry *entries,
+                             int32_t *samples, bvc_pileup_indel *indels, char *indel_text, bvc_site_result *results,
+                             bvc_group_result *grp_results)
+{
+    if (ctx && !called_off) return fail(ctx, BVC_ERR_ARG, "null pointer");
+    return pileup_finish_impl(ctx, ref_base, min_af, carry_in, carry_out, group_of_sample, n_samples, n_groups, entry_off, tally, called_off,
+                              called_cap, entries, samples, indels, indel_text, results, grp_results);
 }
 
 // bvc_lrt_dense_groups and bvc_lrt_dense_groups_packed: `packed` = the tile is one byte per sample in `bases`

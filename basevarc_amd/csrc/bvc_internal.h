@@ -152,6 +152,10 @@ hipError_t launch_region_index(hipStream_t stream, const PileupTile &P, const bv
 hipError_t launch_region_ends(hipStream_t stream, const PileupTile &P, uint32_t *ends);
 // the text of the indel tokens gathered into dst (records' text_off become offsets into it); *used = bytes
 hipError_t launch_indel_text(hipStream_t stream, const PileupTile &P, uint8_t *dst, uint32_t dst_cap, uint32_t *used);
+// the entries of the called positions, compacted: called_off [n_pos + 1] (exclusive prefix; the last word is the total)
+hipError_t launch_called_scan(hipStream_t stream, const PileupTile &P, const bvc_site_result *results, int64_t *called_off);
+hipError_t launch_called_gather(hipStream_t stream, const PileupTile &P, const int64_t *called_off, bvc_pileup_entry *out_entries,
+                                int32_t *out_samples);
 // count pass + prefix sums (fills line_words, entry_off, obs_off, totals, status[0..1])
 hipError_t launch_pileup_count(hipStream_t stream, const PileupTile &P);
 // write pass + the entries that inherit across lines (status[2] and tally must be zero; leaves the carry in status[3])

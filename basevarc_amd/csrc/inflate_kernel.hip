@@ -28,7 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #ifndef BVC_INFLATE_WINDOW
-#define BVC_INFLATE_WINDOW 4096
+#define BVC_INFLATE_WINDOW 8192
 #endif
 
 #include "bvc_device.h"
@@ -38,8 +38,9 @@ namespace bvc {
 namespace {
 
 constexpr uint32_t kWinBytes = BVC_INFLATE_WINDOW, kWinMask = kWinBytes - 1;
+constexpr uint32_t kDump = kWinBytes;                          // byte index of the dump area in InflateLds::win
+constexpr bool kWholeWindow = kWinBytes == 32768;              // every distance deflate allows is inside the ring
 static_assert((kWinBytes & kWinMask) == 0 && kWinBytes >= 4096 && kWinBytes <= 32768, "the LDS ring: a power of two, 4..32 KiB");
-constexpr uint32_t kStageWords = 256;
 constexpr int kLitBits = 9, kDistBits = 7, kPreBits = 7;
 constexpr uint32_t kValid = 0x80000000u;
 // entry: bit 31 valid, 27..30 code length, 24..25 kind, 16..19 extra bits, 0..15 value (literal / length base / distance base / symbol)
@@ -53,8 +54,7 @@ __device__ const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5
 __device__ const uint8_t kPreOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct InflateLds {
-    uint32_t win[kWinBytes / 4];
-    uint32_t stage[kStageWords];
+    uint32_t win[kWinBytes / 4 + kWave / 4];     // the ring, and behind it the bytes a lane with nothing to write writes to (kDump)
     uint32_t lit_tab[1 << kLitBits];
     uint32_t dist_tab[1 << kDistBits];
     uint32_t pre_tab[1 << kPreBits];
@@ -66,6 +66,14 @@ struct InflateLds {
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// a or b without a branch: both are computed (the compiler would otherwise sink `a`'s arithmetic into a lane-dependent branch)
+__device__ __forceinline__ uint32_t pick(bool c, uint32_t a, uint32_t b)
+{
+    asm volatile("" : "+v"(a), "+v"(b));
+    return c ? a : b;
+}
+// lane `k` (wave-uniform) of v
+__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)k); }
 
 // error codes in status[]
 enum : uint32_t { kOk = 0, kErrType = 1, kErrStored = 2, kErrHeader = 3, kErrCodes = 4, kErrSymbol = 5, kErrDistance = 6, kErrOutput = 7,
@@ -120,6 +128,188 @@ __device__ bool build_code(InflateLds &L, const uint8_t *lens, int n, uint32_t *
     return true;
 }
 
+// ---- the fast path of the symbol loop, hand-written --------------------------------------------------------------------------
+// A wavefront alone on its SIMD issues one instruction in four cycles and pays more for every taken branch; the symbol loop is a
+// serial chain of scalar steps, so its time IS its instruction count plus the LDS round trips it waits for (round 5: the compiler's
+// loop ran ~130 instructions and ~26 branches per symbol -- uniform branches structurised into mask moves because other parts of the
+// kernel branch on the lane -- and a block took 3.3 ms whatever the LDS latency was).  The same walk in ~10 instructions a literal
+// and ~55 a match:
+//   cw0              lane j: word wbase + j of the block (the bit reader's window, see the kernel); bp: the batch's first bit in it
+//   le / de / view   lane j: the literal/length entry, the distance entry and the 32 bits of the stream that start j bits after bp
+//   off              bits of the batch consumed (the next symbol starts at lane `off`); the stream is at bp + off
+//   o                bytes of output so far
+// Literals are collected in a lane mask and written together (EXEC = the mask: lane j writes its entry's byte at its rank).  A match
+// with len <= 63, dist >= len, dist <= o, o + len <= isize (and inside the ring) is copied here, lane i byte i, its LDS read left IN
+// FLIGHT while the next symbols are decoded: the write follows when the next match (or the way out) asks for it -- LDS operations of
+// a wavefront are performed in order, so a later read sees it.  A batch that is used up is followed by the next one (two cross-lane
+// reads of cw0 and the two table look-ups) without leaving.  The way out, `what`: 1 a match decoded and not copied (len, dist), 2 a
+// symbol the fast path does not take (a code longer than the first-level table, end of block, a bad symbol: at `off`, not
+// consumed), 3 a KiB of output is ready to leave the ring, 4 the reader's window must move on (bp >= 1920, off = 0), 7 literals
+// beyond ISIZE.  The ring is kWinBytes at LDS address 0, the tables where InflateLds has them.
+// Temporaries with fixed names: s[84:85] (the literal mask: its halves are named); everything else is the compiler's choice.
+constexpr uint32_t kLitTabOff = (kWinBytes / 4 + kWave / 4) * 4, kDistTabOff = kLitTabOff + (4u << kLitBits);
+__device__ __forceinline__ void fast_symbols(uint32_t cw0, uint32_t lane, uint32_t isize, uint32_t flushed, uint32_t &le, uint32_t &de,
+                                             uint32_t &view, uint32_t &bp, uint32_t &off, uint32_t &o, uint32_t &what, uint32_t &len,
+                                             uint32_t &dist)
+{
+    uint32_t e, l, t, p, xb, x, msk, d, pl, va, vb, vc, vs, vt;
+    uint64_t m64;
+    const uint32_t mask = kWinMask;
+    // (EXEC is all ones in this kernel: it is set back to -1, not saved)
+#define BVC_EMIT_LITERALS(done)                                                             \
+    "s_cmp_eq_u64 s[84:85], 0\n"                                                            \
+    "s_cbranch_scc1 " done "\n"                                                             \
+    "s_bcnt1_i32_b64 %[x], s[84:85]\n"                                                      \
+    "s_add_u32 %[t], %[o], %[x]\n"                                                          \
+    "s_cmp_gt_u32 %[t], %[isize]\n"                                                         \
+    "s_cbranch_scc1 9f\n"                                                                   \
+    "v_mbcnt_lo_u32_b32 %[vc], s84, 0\n"                                                    \
+    "v_mbcnt_hi_u32_b32 %[vc], s85, %[vc]\n"                                                \
+    "v_add_u32 %[vc], %[o], %[vc]\n"                                                        \
+    "v_and_b32 %[vc], %[mask], %[vc]\n"                                                     \
+    "s_mov_b64 exec, s[84:85]\n"                                                            \
+    "ds_write_b8 %[vc], %[le]\n"                                                            \
+    "s_mov_b64 exec, -1\n"                                                                  \
+    "s_mov_b32 %[o], %[t]\n"                                                                \
+    "s_mov_b64 s[84:85], 0\n"
+    // the write of the copy whose read is in flight
+#define BVC_FINISH_COPY(done)                                                               \
+    "s_cmp_eq_u32 %[pl], 0\n"                                                               \
+    "s_cbranch_scc1 " done "\n"                                                             \
+    "s_bfm_b64 exec, %[pl], 0\n"                                                            \
+    "s_waitcnt lgkmcnt(0)\n"                                                                \
+    "ds_write_b8 %[vb], %[va]\n"                                                            \
+    "s_mov_b64 exec, -1\n"                                                                  \
+    "s_mov_b32 %[pl], 0\n"
+#if BVC_INFLATE_WINDOW == 32768
+#define BVC_NEAR_CHECK ""
+#else
+#define BVC_NEAR_CHECK "s_add_u32 %[x], %[dist], %[len]\n s_cmp_gt_u32 %[x], %[lim]\n s_cbranch_scc1 4f\n"
+#endif
+    asm volatile(
+        "s_mov_b64 s[84:85], 0\n"
+        "s_mov_b32 %[pl], 0\n"
+        "1:\n"
+        "s_cmp_gt_u32 %[off], 63\n"
+        "s_cbranch_scc1 8f\n"
+        "v_readlane_b32 %[e], %[le], %[off]\n"
+        "s_and_b32 %[t], %[e], 0x83000000\n"
+        "s_bfe_u32 %[l], %[e], 0x4001b\n"
+        "s_cmp_eq_u32 %[t], 0x80000000\n"
+        "s_cbranch_scc0 2f\n"
+        "s_lshl_b64 %[m], 1, %[off]\n"
+        "s_or_b64 s[84:85], s[84:85], %[m]\n"
+        "s_add_u32 %[off], %[off], %[l]\n"
+        "s_branch 1b\n"
+        "2:\n"                                          // not a literal of the first-level table
+        "s_cmp_eq_u32 %[t], 0x82000000\n"
+        "s_cbranch_scc0 7f\n"
+        // a length: its extra bits, the distance code, its extra bits.  The lanes read are off + ... in ascending order; one past 63
+        // reads some other lane's entry, which nobody uses: the LAST position is checked and the symbol left to the next batch.
+        "s_add_u32 %[p], %[off], %[l]\n"
+        "s_bfe_u32 %[xb], %[e], 0x40010\n"
+        "v_readlane_b32 %[x], %[view], %[p]\n"
+        "s_bfm_b32 %[msk], %[xb], 0\n"
+        "s_and_b32 %[x], %[x], %[msk]\n"
+        "s_and_b32 %[len], %[e], 0xffff\n"
+        "s_add_u32 %[len], %[len], %[x]\n"
+        "s_add_u32 %[p], %[p], %[xb]\n"
+        "v_readlane_b32 %[d], %[de], %[p]\n"
+        "s_bfe_u32 %[l], %[d], 0x4001b\n"
+        "s_add_u32 %[p], %[p], %[l]\n"
+        "s_cmp_gt_u32 %[p], 63\n"
+        "s_cbranch_scc1 8f\n"
+        "s_and_b32 %[t], %[d], 0x83000000\n"
+        "s_cmp_eq_u32 %[t], 0x80000000\n"
+        "s_cbranch_scc0 7f\n"
+        "s_bfe_u32 %[xb], %[d], 0x40010\n"
+        "v_readlane_b32 %[x], %[view], %[p]\n"
+        "s_bfm_b32 %[msk], %[xb], 0\n"
+        "s_and_b32 %[x], %[x], %[msk]\n"
+        "s_and_b32 %[dist], %[d], 0xffff\n"
+        "s_add_u32 %[dist], %[dist], %[x]\n"
+        "s_add_u32 %[off], %[p], %[xb]\n"               // the symbol is consumed
+        BVC_EMIT_LITERALS("3f")
+        "3:\n"
+        BVC_FINISH_COPY("12f")
+        "12:\n"
+        "s_cmp_gt_u32 %[len], 63\n"                     // (whatever says no: the caller copies the match, with its own checks)
+        "s_cbranch_scc1 4f\n"
+        "s_cmp_lt_u32 %[dist], %[len]\n"
+        "s_cbranch_scc1 4f\n"
+        "s_cmp_gt_u32 %[dist], %[o]\n"
+        "s_cbranch_scc1 4f\n"
+        "s_add_u32 %[t], %[o], %[len]\n"
+        "s_cmp_gt_u32 %[t], %[isize]\n"
+        "s_cbranch_scc1 4f\n"
+        BVC_NEAR_CHECK
+        "s_sub_u32 %[x], %[o], %[dist]\n"               // the copy: lane i < len moves byte i; the read is left in flight
+        "v_add_u32 %[va], %[x], %[lane]\n"
+        "v_and_b32 %[va], %[mask], %[va]\n"
+        "v_add_u32 %[vb], %[o], %[lane]\n"
+        "v_and_b32 %[vb], %[mask], %[vb]\n"
+        "s_bfm_b64 exec, %[len], 0\n"
+        "ds_read_u8 %[va], %[va]\n"
+        "s_mov_b64 exec, -1\n"
+        "s_mov_b32 %[pl], %[len]\n"
+        "s_mov_b32 %[o], %[t]\n"
+        "s_sub_u32 %[x], %[o], %[flushed]\n"            // a KiB to flush?
+        "s_cmp_ge_u32 %[x], 0x400\n"
+        "s_cbranch_scc0 1b\n"
+        "s_mov_b32 %[what], 3\n"
+        "s_branch 6f\n"
+        "4:\n"
+        "s_mov_b32 %[what], 1\n"
+        "s_branch 6f\n"
+        "7:\n"                                          // a symbol for the caller
+        BVC_EMIT_LITERALS("5f")
+        "5:\n"
+        "s_mov_b32 %[what], 2\n"
+        "s_branch 6f\n"
+        "8:\n"                                          // the batch is used up: its literals, then the next one
+        "s_mov_b32 %[what], 3\n"
+        BVC_EMIT_LITERALS("13f")
+        "s_sub_u32 %[x], %[o], %[flushed]\n"
+        "s_cmp_ge_u32 %[x], 0x400\n"
+        "s_cbranch_scc1 6f\n"
+        "13:\n"
+        "s_add_u32 %[bp], %[bp], %[off]\n"
+        "s_mov_b32 %[off], 0\n"
+        "s_mov_b32 %[what], 4\n"
+        "s_cmp_ge_u32 %[bp], 1920\n"
+        "s_cbranch_scc1 6f\n"
+        "s_lshr_b32 %[x], %[bp], 5\n"                   // lane j: the 32 bits from bit bp + j, out of two words of the window
+        "s_and_b32 %[t], %[bp], 31\n"
+        "v_add_u32 %[vt], %[t], %[lane]\n"
+        "v_lshrrev_b32 %[vs], 5, %[vt]\n"
+        "v_add_lshl_u32 %[vs], %[vs], %[x], 2\n"
+        "ds_bpermute_b32 %[vc], %[vs], %[cw0]\n"
+        "ds_bpermute_b32 %[vs], %[vs], %[cw0] offset:4\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_alignbit_b32 %[view], %[vs], %[vc], %[vt]\n"
+        "v_lshlrev_b32 %[vs], 2, %[view]\n"             // both first-level tables
+        "v_and_b32 %[vc], 0x7fc, %[vs]\n"
+        "v_and_b32 %[vs], 0x1fc, %[vs]\n"
+        "ds_read_b32 %[le], %[vc] offset:%[lit_off]\n"
+        "ds_read_b32 %[de], %[vs] offset:%[dist_off]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_branch 1b\n"
+        "9:\n"
+        "s_mov_b32 %[what], 7\n"
+        "6:\n"
+        BVC_FINISH_COPY("14f")
+        "14:\n"
+        : [le] "+v"(le), [de] "+v"(de), [view] "+v"(view), [bp] "+s"(bp), [off] "+s"(off), [o] "+s"(o), [what] "=&s"(what), [len] "=&s"(len),
+          [dist] "=&s"(dist), [e] "=&s"(e), [l] "=&s"(l), [t] "=&s"(t), [p] "=&s"(p), [xb] "=&s"(xb), [x] "=&s"(x), [msk] "=&s"(msk),
+          [d] "=&s"(d), [pl] "=&s"(pl), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [vs] "=&v"(vs), [vt] "=&v"(vt), [m] "=&s"(m64)
+        : [cw0] "v"(cw0), [lane] "v"(lane), [isize] "s"(isize), [flushed] "s"(flushed), [mask] "s"(mask), [lim] "s"(kWinBytes - 64u),
+          [lit_off] "i"(kLitTabOff), [dist_off] "i"(kDistTabOff)
+        : "memory", "scc", "vcc", "s84", "s85");
+#undef BVC_NEAR_CHECK
+#undef BVC_FINISH_COPY
+#undef BVC_EMIT_LITERALS
+}
+
 __global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restrict__ comp, const bvc_bgzf_block *__restrict__ blocks, int64_t n_blocks,
                                                         uint8_t *__restrict__ out, uint32_t *__restrict__ status)
 {
@@ -127,6 +317,11 @@ __global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restric
     __shared__ InflateLds L;
     const int lane = threadIdx.x;
     uint8_t *win8 = reinterpret_cast<uint8_t *>(L.win);
+    // (fast_symbols addresses the ring from LDS address 0: L is the kernel's only LDS object and the ring its first member)
+    if (uni((uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void *)L.win)) != 0u) {
+        for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) status[blk] = kErrType;
+        return;
+    }
     if (lane < 29) L.len_code[lane] = (uint32_t)kLenBase[lane] | ((uint32_t)kLenExtra[lane] << 16);
     if (lane < 30) L.dist_code[lane] = (uint32_t)kDistBase[lane] | ((uint32_t)kDistExtra[lane] << 16);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -134,37 +329,56 @@ __global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restric
     for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const uint64_t c0 = (uint64_t)blocks[blk].comp_off, o0 = (uint64_t)blocks[blk].out_off;
         const uint32_t clen = (uint32_t)blocks[blk].comp_len, isize = (uint32_t)blocks[blk].isize;
-        const uint8_t *cbase = comp + (c0 & ~(uint64_t)3);
+        const uint32_t *cbase32 = reinterpret_cast<const uint32_t *>(comp + (c0 & ~(uint64_t)3));
         const uint32_t lead = (uint32_t)(c0 & 3u);
         const uint32_t n_words = (lead + clen + 3u) >> 2;
-        uint32_t next_word = 0, stage_base = 0x80000000u;       // (nothing staged yet: any first index is 'outside')
-        uint64_t bb = 0;
-        int bc = 0;
         uint32_t o = 0, flushed = 0, err = kOk;
 
-        auto get_word = [&](uint32_t i) -> uint32_t {
-            if (i - stage_base >= kStageWords) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                stage_base = i;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t w = i + (uint32_t)(k * kWave + lane);
-                    L.stage[k * kWave + lane] = w < n_words ? reinterpret_cast<const uint32_t *>(cbase)[w] : 0u;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+        // ---- the bit reader: the block's next 64 words live in a VGPR (lane j: word wbase + j; the 64 after them in a second one, loaded
+        // ahead), the position is wave-uniform; a word is a v_readlane away, so reading bits costs no memory round trip.  When the
+        // position passes word 60 the window moves on by 60 words (two cross-lane shuffles and the next load).
+        uint32_t wbase = 0, bp = 8u * lead;                       // bp: bits from word wbase, < 1920 after ensure()
+        if (n_words == 0u) { if (lane == 0) status[blk] = kErrInput; continue; }
+        auto load_words = [&](uint32_t first) -> uint32_t {        // (no branch: see the symbol loop)
+            const uint32_t w = first + (uint32_t)lane;
+            const uint32_t v = cbase32[w < n_words ? w : n_words - 1u];
+            return w < n_words ? v : 0u;
+        };
+        uint32_t cw0 = load_words(0u), cw1 = load_words(64u);
+        // (the words are WAITED for where they are loaded, not where they are first read)
+        auto settle = [&]() { asm volatile("" : "+v"(cw0), "+v"(cw1)); };
+        settle();
+        auto ensure = [&]() {
+            while (bp >= 1920u) {
+                const uint32_t from = ((uint32_t)lane + 60u) & 63u;
+                const uint32_t a = (uint32_t)__shfl((int)cw0, (int)from), b = (uint32_t)__shfl((int)cw1, (int)from);
+                cw0 = lane < 4 ? a : b;
+                wbase += 60u;
+                cw1 = load_words(wbase + 64u);
+                bp -= 1920u;
+                settle();
             }
-            return uni(L.stage[i - stage_base]);
         };
-        auto refill = [&]() {
-            while (bc <= 32) { bb |= (uint64_t)get_word(next_word) << bc; ++next_word; bc += 32; }
+        auto seek = [&](uint64_t abs_bits) {
+            wbase = (uint32_t)(abs_bits / 1920u) * 60u;
+            bp = (uint32_t)(abs_bits - (uint64_t)wbase * 32u);
+            cw0 = load_words(wbase); cw1 = load_words(wbase + 64u);
+            settle();
         };
-        auto take = [&](int n) -> uint32_t {                       // n <= 32, bits present
-            const uint32_t v = (uint32_t)(bb & ((1ull << n) - 1ull));
-            bb >>= n; bc -= n;
+        auto word_at = [&](uint32_t k) -> uint32_t { return rl(cw0, k); }; // k <= 63
+        auto peek = [&]() -> uint32_t {                            // the next 32 bits (bp < 2048)
+            const uint32_t k = bp >> 5, b = bp & 31u;
+            const uint64_t v = ((uint64_t)word_at(k + 1u) << 32) | word_at(k);
+            return (uint32_t)(v >> b);
+        };
+        auto take = [&](uint32_t n) -> uint32_t {                  // n <= 16
+            ensure();
+            const uint32_t v = peek() & ((1u << n) - 1u);
+            bp += n;
             return v;
         };
+        auto consumed_bits = [&]() -> int64_t { return (int64_t)wbase * 32 + (int64_t)bp - 8 * (int64_t)lead; };
+
         // what an entry says beside the code length, by symbol
         auto lit_entry = [&](uint32_t s) -> uint32_t {
             if (s < 256u) return kKindLiteral | s;
@@ -179,55 +393,61 @@ __global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restric
             return (dc & 0xFFFFu) | ((dc >> 16) << 16);
         };
         auto pre_entry = [&](uint32_t s) -> uint32_t { return s; };
-        // the next symbol's entry (valid bit set), or 0 when the bits are no code of the set
-        auto decode = [&](const uint32_t *tab, int bits, const uint16_t *cnt, const uint16_t *sorted, auto entry_of) -> uint32_t {
-            const uint32_t e = uni(tab[(uint32_t)bb & ((1u << bits) - 1u)]);
-            if (e & kValid) { const int l = (int)((e >> 27) & 15u); bb >>= l; bc -= l; return e; }
+        // a code longer than its first-level table (rare in text): the canonical code one bit at a time from `view` (the bits from the
+        // symbol's first); cnt_v: lane l holds the number of codes of length l.  The entry with the code's length, or 0: no code.
+        auto slow = [&](uint32_t view, uint32_t cnt_v, const uint16_t *sorted, auto entry_of) -> uint32_t {
             int code = 0, first = 0, index = 0;
+#pragma unroll 1
             for (int l = 1; l <= 15; ++l) {
-                code |= (int)(bb & 1ull); bb >>= 1; bc -= 1;
-                const int count = (int)uni(cnt[l]);
-                if (code - count < first) return kValid | uni(entry_of((uint32_t)uni(sorted[index + (code - first)])));
+                code |= (int)(view & 1u); view >>= 1;
+                const int count = (int)rl(cnt_v, (uint32_t)l);
+                if (code - count < first)
+                    return kValid | ((uint32_t)l << 27) | uni(entry_of((uint32_t)uni(sorted[index + (code - first)])));
                 index += count; first += count; first <<= 1; code <<= 1;
             }
             return 0u;
         };
-        auto flush_full = [&]() {
-            while (o - flushed >= 1024u) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t at = flushed + 16u * (uint32_t)lane;
-                const uint32_t *src = &L.win[(at & kWinMask) >> 2];
-                uint32_t v[4] = {src[0], src[1], src[2], src[3]};
-                __builtin_memcpy(out + o0 + at, v, 16);
-                flushed += 1024u;
-            }
+        // one symbol at the reader's position (the code-length alphabet; everything serial)
+        auto decode_serial = [&](const uint32_t *tab, int bits, uint32_t cnt_v, const uint16_t *sorted, auto entry_of) -> uint32_t {
+            ensure();
+            const uint32_t v = peek();
+            uint32_t e = uni(tab[v & ((1u << bits) - 1u)]);
+            if (!(e & kValid)) e = slow(v, cnt_v, sorted, entry_of);
+            bp += (e >> 27) & 15u;
+            return e;
         };
 
-        refill();
-        if (lead) take((int)(8u * lead));
+        // a full KiB of output leaves the ring (every caller adds at most 258 bytes between two checks: once is enough)
+        auto flush_full = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t at = flushed + 16u * (uint32_t)lane;
+            const uint32_t *src = &L.win[(at & kWinMask) >> 2];
+            uint32_t v[4] = {src[0], src[1], src[2], src[3]};
+            __builtin_memcpy(out + o0 + at, v, 16);
+            flushed = uni(flushed + 1024u);
+        };
+
         bool last = false;
         while (!last && err == kOk) {
-            refill();
             last = take(1) != 0u;
             const uint32_t type = take(2);
-            if (type == 0u) {                                    // stored
-                take(bc & 7);
-                refill();
+            if (type == 0u) {                                    // stored: the bytes straight from the block, 64 at a time
+                ensure();
+                bp = (bp + 7u) & ~7u;
                 const uint32_t len = take(16);
-                refill();
                 const uint32_t nlen = take(16);
                 if ((len ^ 0xFFFFu) != nlen) { err = kErrStored; break; }
                 if (o + len > isize) { err = kErrOutput; break; }
-                for (uint32_t i = 0; i < len; ++i) {
-                    refill();
-                    const uint32_t c = take(8);
-                    if (lane == 0) win8[o & kWinMask] = (uint8_t)c;
-                    ++o;
-                    if ((o & 1023u) == 0u) flush_full();
+                const uint64_t byte0 = ((uint64_t)wbase * 32u + bp) >> 3;
+                if (byte0 + len > (uint64_t)lead + clen) { err = kErrInput; break; }   // (they must have come from inside the BGZF block too)
+                const uint32_t ob = o;
+                for (uint32_t i0 = 0; i0 < len; i0 += (uint32_t)kWave) {
+                    const uint32_t i = i0 + (uint32_t)lane;
+                    if (i < len) win8[(ob + i) & kWinMask] = reinterpret_cast<const uint8_t *>(cbase32)[byte0 + i];
+                    o += len - i0 < (uint32_t)kWave ? len - i0 : (uint32_t)kWave;
+                    if (o - flushed >= 1024u) flush_full();
                 }
-                // (the bytes of a stored block must have come from inside the BGZF block too)
-                if ((int64_t)next_word * 32 - bc - 8 * (int64_t)lead > (int64_t)clen * 8) err = kErrInput;
+                seek((uint64_t)wbase * 32u + bp + 8ull * len);
                 continue;
             }
             if (type == 3u) { err = kErrType; break; }
@@ -245,18 +465,17 @@ __global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restric
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 for (int i = 0; i < hclen; ++i) {
-                    refill();
                     const uint32_t v = take(3);
                     if (lane == 0) L.lens[kPreOrder[i]] = (uint8_t)v;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 if (!build_code(L, L.lens, 19, L.pre_tab, kPreBits, L.pre_cnt, L.pre_sorted, false, lane, pre_entry)) { err = kErrCodes; break; }
+                const uint32_t pre_cnt_v = lane < 16 ? (uint32_t)L.pre_cnt[lane] : 0u;
                 int n = 0;
                 uint32_t prev = 0;
                 while (n < hlit + hdist && err == kOk) {
-                    refill();
-                    const uint32_t pe = decode(L.pre_tab, kPreBits, L.pre_cnt, L.pre_sorted, pre_entry);
+                    const uint32_t pe = decode_serial(L.pre_tab, kPreBits, pre_cnt_v, L.pre_sorted, pre_entry);
                     const int sym = (int)(pe & 0xFFFFu);
                     if (pe == 0u || sym > 18) { err = kErrHeader; break; }
                     if (sym < 16) { if (lane == 0) L.lens[n] = (uint8_t)sym; prev = (uint32_t)sym; ++n; continue; }
@@ -280,52 +499,114 @@ __global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restric
             // (the code-length table shares L.lens' front with nothing: the literal/length lengths start at 0 only now)
             if (!build_code(L, L.lens, hlit, L.lit_tab, kLitBits, L.lit_cnt, L.lit_sorted, true, lane, lit_entry) ||
                 !build_code(L, L.lens + hlit, hdist, L.dist_tab, kDistBits, L.dist_cnt, L.dist_sorted, true, lane, dist_entry)) { err = kErrCodes; break; }
-            // ---- the block's symbols
-            for (;;) {
-                refill();
-                const uint32_t e = decode(L.lit_tab, kLitBits, L.lit_cnt, L.lit_sorted, lit_entry);
-                if (e == 0u) { err = kErrSymbol; break; }
-                const uint32_t kind = e & kKindMask;
-                if (kind == kKindLiteral) {
-                    if (o >= isize) { err = kErrOutput; break; }
-                    if (lane == 0) win8[o & kWinMask] = (uint8_t)e;
-                    ++o;
-                    if ((o & 1023u) == 0u) flush_full();
-                    continue;
+            const uint32_t lit_cnt_v = lane < 16 ? (uint32_t)L.lit_cnt[lane] : 0u, dist_cnt_v = lane < 16 ? (uint32_t)L.dist_cnt[lane] : 0u;
+
+            // (No lane-dependent BRANCH inside this loop: a lane that has nothing to write writes behind the ring (kDump) instead.  With one in it the
+            // compiler structurises the whole loop -- every uniform branch becomes a chain of mask moves and flow blocks -- and a
+            // single wavefront pays four cycles an instruction and more for every taken branch.)
+            // ---- the block's symbols.  One LDS round trip serves the symbols of the next ~64 bits: lane j looks up the 32 bits that
+            // start j bits ahead in BOTH first-level tables, and the walk from symbol to symbol -- the serial part -- reads those
+            // entries with v_readlane (a few cycles a hop instead of an LDS latency).
+            uint32_t view = 0u, le = 0u, de = 0u;               // of the batch at bp (lane j: j bits further on)
+            auto gather = [&]() {
+                ensure();
+                const uint32_t k = bp >> 5, b0 = bp & 31u;
+                const uint32_t w0 = word_at(k), w1 = word_at(k + 1u), w2 = word_at(k + 2u), w3 = word_at(k + 3u);
+                const uint32_t t = b0 + (uint32_t)lane, sel = t >> 5;
+                const uint32_t lo = sel == 0u ? w0 : (sel == 1u ? w1 : w2), hi = sel == 0u ? w1 : (sel == 1u ? w2 : w3);
+                view = __builtin_amdgcn_alignbit(hi, lo, t & 31u);
+                le = L.lit_tab[view & ((1u << kLitBits) - 1u)];
+                de = L.dist_tab[view & ((1u << kDistBits) - 1u)];
+            };
+            gather();
+            uint32_t off = 0u;
+            bool end_block = false;
+            // fast_symbols() runs literals, simple matches and the step from batch to batch, and comes back for the rest
+            while (!end_block && err == kOk) {
+                uint32_t what, len, dist;
+                fast_symbols(cw0, (uint32_t)lane, isize, flushed, le, de, view, bp, off, o, what, len, dist);
+                if (o - flushed >= 1024u) flush_full();
+                if (what == 3u) continue;
+                if (what == 4u) { gather(); continue; }          // (bp has taken `off` up: the window moves, the batch is looked up here)
+                if (what == 7u) { err = kErrOutput; break; }
+                if (what == 2u) {
+                    // one symbol, every case
+                    uint32_t e = rl(le, off);
+                    if (!(e & kValid)) {
+                        e = slow(rl(view, off), lit_cnt_v, L.lit_sorted, lit_entry);
+                        if (e == 0u) { err = kErrSymbol; break; }
+                    }
+                    const uint32_t l = (e >> 27) & 15u, kind = e & kKindMask;
+                    if (kind == kKindLiteral) {
+                        if (o >= isize) { err = kErrOutput; break; }
+                        win8[pick(lane == 0, o & kWinMask, kDump + (uint32_t)lane)] = (uint8_t)e;
+                        ++o;
+                        off += l;
+                        continue;
+                    }
+                    if (kind == kKindEnd) { off += l; end_block = true; break; }
+                    if (kind == kKindBad) { err = kErrSymbol; break; }
+                    // a match: every read below must lie in the batch's 64 offsets, else the batch is looked up again FROM this symbol
+                    // (from offset 0 a length / distance pair, at most 15 + 5 + 15 + 13 bits, always fits)
+                    const uint32_t xb = (e >> 16) & 15u, p1 = off + l, p2 = p1 + xb;
+                    uint32_t d = 0u, p3 = 64u;
+                    if (p2 <= 63u) {
+                        d = rl(de, p2);
+                        if (!(d & kValid)) {
+                            d = slow(rl(view, p2), dist_cnt_v, L.dist_sorted, dist_entry);
+                            if (d == 0u) { err = kErrSymbol; break; }
+                        }
+                        p3 = p2 + ((d >> 27) & 15u);
+                    }
+                    if (p3 > 63u) { bp += off; off = 0u; gather(); continue; }
+                    if (d & kKindMask) { err = kErrSymbol; break; }
+                    const uint32_t dxb = (d >> 16) & 15u;
+                    len = (e & 0xFFFFu) + (rl(view, p1) & ((1u << xb) - 1u));
+                    dist = (d & 0xFFFFu) + (rl(view, p3) & ((1u << dxb) - 1u));
+                    off = p3 + dxb;
                 }
-                if (kind == kKindEnd) break;
-                if (kind == kKindBad) { err = kErrSymbol; break; }
-                const uint32_t len = (e & 0xFFFFu) + take((int)((e >> 16) & 15u));
-                refill();
-                const uint32_t d = decode(L.dist_tab, kDistBits, L.dist_cnt, L.dist_sorted, dist_entry);
-                if (d == 0u || (d & kKindMask)) { err = kErrSymbol; break; }
-                const uint32_t dist = (d & 0xFFFFu) + take((int)((d >> 16) & 15u));
+                // a match to copy (what == 1, or the one just decoded)
                 if (dist > o) { err = kErrDistance; break; }
                 if (o + len > isize) { err = kErrOutput; break; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                if (dist + len + 64u <= kWinBytes) {
-                    // source and destination are in the ring (and stay there while the match is written)
-                    const bool pow2 = (dist & (dist - 1u)) == 0u;
-                    for (uint32_t i = (uint32_t)lane; i < len; i += kWave) {
-                        const uint32_t k = dist >= len ? i : (pow2 ? (i & (dist - 1u)) : i % dist);
-                        win8[(o + i) & kWinMask] = win8[(o - dist + k) & kWinMask];
+                if (kWholeWindow || dist + len + 64u <= kWinBytes) {
+                    // source and destination are in the ring; a match shorter than its distance, or a run, is the same expression:
+                    // source byte i mod distance.  (With the whole 32 KiB window in the ring byte i + (32768 - dist) of the match
+                    // lands where source byte i was: a later byte of an ascending copy, every step reads before it writes.)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (dist >= len) {
+                        for (uint32_t i0 = 0; i0 < len; i0 += (uint32_t)kWave) {
+                            const uint32_t i = i0 + (uint32_t)lane;
+                            const uint8_t b = win8[(o - dist + i) & kWinMask];
+                            win8[pick(i < len, (o + i) & kWinMask, kDump + (uint32_t)lane)] = b;
+                        }
+                    } else {                                   // a run: the last `dist` bytes over and over
+                        const bool pow2 = (dist & (dist - 1u)) == 0u;
+                        for (uint32_t i0 = 0; i0 < len; i0 += (uint32_t)kWave) {
+                            const uint32_t i = i0 + (uint32_t)lane;
+                            const uint8_t b = win8[(o - dist + (pow2 ? (i & (dist - 1u)) : i % dist)) & kWinMask];
+                            win8[pick(i < len, (o + i) & kWinMask, kDump + (uint32_t)lane)] = b;
+                        }
                     }
                 } else {
-                    // the source has left the ring: it is in the block's output in global memory, written by this wavefront's flushes at
-                    // least kWinBytes - 2 * 258 - 64 bytes of output ago (dist > len here: no overlap with the destination)
-                    // (workgroup scope: the stores and the loads are this wavefront's own and go through the same L1 and L2 -- the fence is
-                    // a wait for the stores in flight; at agent scope it is a write-back of the XCD's L2 and the loads bypass it: 5 x slower)
+                    // (rings smaller than the window only) the source has left the ring: it is in the block's output in global memory,
+                    // written by this wavefront's flushes at least kWinBytes - 2 * 258 - 64 bytes of output ago (dist > len here: no
+                    // overlap with the destination).  Workgroup scope: the stores and the loads are this wavefront's own and go
+                    // through the same L1 and L2 -- the fence is a wait for the stores in flight; at agent scope it is a write-back of
+                    // the XCD's L2 and the loads bypass it: 5 x slower
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     const uint8_t *src = out + o0 + (o - dist);
-                    for (uint32_t i = (uint32_t)lane; i < len; i += kWave)
-                        win8[(o + i) & kWinMask] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (uint32_t i0 = 0; i0 < len; i0 += (uint32_t)kWave) {
+                        const uint32_t i = i0 + (uint32_t)lane;
+                        const uint8_t b = __hip_atomic_load(src + (i < len ? i : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        win8[pick(i < len, (o + i) & kWinMask, kDump + (uint32_t)lane)] = b;
+                    }
                 }
                 o += len;
                 if (o - flushed >= 1024u) flush_full();
             }
+            bp += off;
             // the input of this deflate block must have come from inside the BGZF block
-            if (err == kOk && (int64_t)next_word * 32 - bc - 8 * (int64_t)lead > (int64_t)clen * 8) err = kErrInput;
+            if (err == kOk && consumed_bits() > (int64_t)clen * 8) err = kErrInput;
         }
         if (err == kOk && o != isize) err = kErrSize;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");

@@ -524,6 +524,64 @@ __global__ void indel_text_kernel(const uint8_t *__restrict__ text, bvc_pileup_i
     }
 }
 
+// ---- the entries of the CALLED positions only (what WriteVcf reads, src/BaseVarC.cpp:664; the CVG line of every position needs the
+// tallies and the indel records alone): called_off[t] = entries of the called positions before t, called_off[n_pos] = their total
+__global__ __launch_bounds__(1024) void called_scan_kernel(int64_t n_pos, const bvc_site_result *__restrict__ results,
+                                                           const int64_t *__restrict__ entry_off, int64_t *__restrict__ called_off)
+{
+    __shared__ int64_t wave_sum[16];
+    __shared__ int64_t running;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    for (int64_t t0 = 0; t0 < n_pos; t0 += 1024) {
+        const int64_t t = t0 + threadIdx.x;
+        const int64_t mine = (t < n_pos && results[t].called) ? entry_off[t + 1] - entry_off[t] : 0;
+        int64_t incl = mine;
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int64_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == kWave - 1) wave_sum[wave] = incl;
+        __syncthreads();
+        int64_t before = running;
+        for (int w = 0; w < wave; ++w) before += wave_sum[w];
+        if (t < n_pos) called_off[t] = before + incl - mine;
+        __syncthreads();
+        if (threadIdx.x == 1023) running = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) called_off[n_pos] = running;
+}
+
+__global__ void called_gather_kernel(int64_t n_pos, const int64_t *__restrict__ entry_off, const int64_t *__restrict__ called_off,
+                                     const bvc_pileup_entry *__restrict__ entries, const int32_t *__restrict__ samples,
+                                     bvc_pileup_entry *__restrict__ out_entries, int32_t *__restrict__ out_samples)
+{
+    for (int64_t t = blockIdx.x; t < n_pos; t += gridDim.x) {
+        const int64_t at = called_off[t], n = called_off[t + 1] - at, from = entry_off[t];
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+            out_entries[at + i] = entries[from + i];
+            out_samples[at + i] = samples[from + i];
+        }
+    }
+}
+
+hipError_t launch_called_scan(hipStream_t stream, const PileupTile &P, const bvc_site_result *results, int64_t *called_off)
+{
+    hipLaunchKernelGGL(called_scan_kernel, dim3(1), dim3(1024), 0, stream, (int64_t)P.n_pos, results, P.entry_off, called_off);
+    return hipGetLastError();
+}
+
+hipError_t launch_called_gather(hipStream_t stream, const PileupTile &P, const int64_t *called_off, bvc_pileup_entry *out_entries,
+                                int32_t *out_samples)
+{
+    if (P.n_pos <= 0) return hipSuccess;
+    hipLaunchKernelGGL(called_gather_kernel, dim3((unsigned)(P.n_pos < 16384 ? P.n_pos : 16384)), dim3(256), 0, stream, (int64_t)P.n_pos,
+                       P.entry_off, called_off, P.entries, P.samples, out_entries, out_samples);
+    return hipGetLastError();
+}
+
 hipError_t launch_region_carry(hipStream_t stream, const uint8_t *old_text, uint8_t *text, const bvc_pileup_region *regions, int32_t n_batches)
 {
     if (n_batches <= 0) return hipSuccess;

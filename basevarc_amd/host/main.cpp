@@ -10,7 +10,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
+#include <iomanip>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -243,6 +245,7 @@ struct Tile {
     std::vector<char> text;
     std::vector<uint32_t> line_start;    // [n_batches][n_pos + 1]
     std::vector<int64_t> entry_off;
+    std::vector<int64_t> called_off;     // where the entries of a CALLED position are in ent / samples (empty: entry_off says, every position's are there)
     std::vector<int32_t> tally, samples;
     std::vector<bvc_pileup_entry> ent;
     std::vector<bvc_pileup_indel> indels;
@@ -395,10 +398,23 @@ struct TileRunner {
         T.gres.resize(T.n_pos * (size_t)ng);
         if (text_on_device) T.text.resize((size_t)ind_bytes + 1);
         uint8_t carry_out[5];
-        const int rc = bvc_pileup_finish(ctx, T.refs.data(), min_af, carry, carry_out, ng ? groups->of_sample.data() : nullptr,
-                                         ng ? (int64_t)groups->of_sample.size() : 0, ng, T.entry_off.data(), T.tally.data(), T.ent.data(),
-                                         T.samples.data(), T.indels.data(), text_on_device ? T.text.data() : nullptr, T.res.data(),
-                                         ng ? T.gres.data() : nullptr);
+        // the entries come back for the called positions only (WriteVcf is their one reader, src/BaseVarC.cpp:664; BVC_HOST_CALLED_ONLY=0:
+        // for every position, as up to round 5's first form of this feed)
+        static const bool called_only = !(getenv("BVC_HOST_CALLED_ONLY") && atoi(getenv("BVC_HOST_CALLED_ONLY")) == 0);
+        int rc;
+        if (called_only) {
+            T.called_off.resize(T.n_pos + 1);
+            rc = bvc_pileup_finish_called(ctx, T.refs.data(), min_af, carry, carry_out, ng ? groups->of_sample.data() : nullptr,
+                                          ng ? (int64_t)groups->of_sample.size() : 0, ng, T.entry_off.data(), T.tally.data(), T.called_off.data(),
+                                          n_ent, T.ent.data(), T.samples.data(), T.indels.data(), text_on_device ? T.text.data() : nullptr,
+                                          T.res.data(), ng ? T.gres.data() : nullptr);
+        } else {
+            T.called_off.clear();
+            rc = bvc_pileup_finish(ctx, T.refs.data(), min_af, carry, carry_out, ng ? groups->of_sample.data() : nullptr,
+                                   ng ? (int64_t)groups->of_sample.size() : 0, ng, T.entry_off.data(), T.tally.data(), T.ent.data(),
+                                   T.samples.data(), T.indels.data(), text_on_device ? T.text.data() : nullptr, T.res.data(),
+                                   ng ? T.gres.data() : nullptr);
+        }
         if (rc != BVC_OK) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(ctx));
         std::memcpy(carry, carry_out, 5);
         T.indels.resize((size_t)n_ind);
@@ -531,8 +547,10 @@ struct TileRunner {
                     ind_text.emplace_back(T.text.data() + T.indels[ii].text_off, (size_t)T.indels[ii].len);
                 SiteView v;
                 v.pos = T.pos[t];
-                v.aiv = reinterpret_cast<const Entry *>(&T.ent[(size_t)e0]);
-                v.sample = &T.samples[(size_t)e0];
+                // (a position that is not called: the CVG line reads the tallies and the indel strings only)
+                const int64_t a0 = T.called_off.empty() ? e0 : T.called_off[t];
+                v.aiv = reinterpret_cast<const Entry *>(&T.ent[(size_t)a0]);
+                v.sample = &T.samples[(size_t)a0];
                 v.n = (size_t)(e1 - e0);
                 v.cnt = cnt; v.fwd = fwd; v.rev = rev;
                 v.indels = ind_text.data(); v.n_indels = ind_text.size();
@@ -859,7 +877,7 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
         for (size_t b = 0; b < nb; ++b) skip[b] = (int32_t)fpiv[b]->names.size() + 1;      // the names line and its newline
         for (auto fp : fpiv) delete fp;
         fpiv.clear();
-        const double tile_mb = getenv("BVC_HOST_TILE_MB") ? std::max(1, atoi(getenv("BVC_HOST_TILE_MB"))) : 32;
+        const double tile_mb = getenv("BVC_HOST_TILE_MB") ? std::max(1, atoi(getenv("BVC_HOST_TILE_MB"))) : 128;
         const double blocks_per_batch = std::max(1.0, tile_mb * 1048576.0 / (65280.0 * (double)std::max<size_t>(1, nb)));
         RawBlockFeed feed(ftmp_v, (size_t)(2 * blocks_per_batch) + 4);
         static const bool check_crc = getenv("BVC_HOST_NO_CRC") == nullptr;     // (the CRC32 of every block is compared on the device, as htslib does)
@@ -871,6 +889,10 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
         std::vector<bvc_bgzf_block> blocks;
         bool first = true;
         int64_t target = 1;                                             // positions the next tile should hold
+        // BVC_HOST_PROFILE=2: what every tile cost this thread (positions, compressed bytes, gathering its blocks, waiting for a device
+        // slot, bvc_pileup_begin_bgzf, bvc_pileup_finish)
+        const bool tile_log = getenv("BVC_HOST_PROFILE") && atoi(getenv("BVC_HOST_PROFILE")) >= 2;
+        std::vector<std::array<double, 6>> tile_times;
         for (size_t ip = lo; ip < hi;) {
             const double t0 = StageClock::now();
             // every batch's new blocks: enough for `target` lines going by its lines per block so far (the first call: the names line and
@@ -902,6 +924,7 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
                 any_new = any_new || took > 0;
             }
             tr.clk.read += StageClock::now() - t0;
+            const double t_wait = StageClock::now();
             g_device_slots.acquire(device);
             struct SlotGuard { int d; ~SlotGuard() { g_device_slots.release(d); } } slot_guard{device};
             const double t1 = StageClock::now();
@@ -913,6 +936,7 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
                                                  first ? skip.data() : nullptr, tr.sample0.data(), tr.n_in_batch.data(), (int32_t)nb, max_pos,
                                                  first ? 1 : 0, &T, lines.data(), &n_ent, &n_ind, &ind_bytes);
             first = false;
+            const double t_begun = StageClock::now();
             if (rc < 0) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(tr.ctx) + " (BVC_HOST_DEVICE_INFLATE=0 inflates on the CPU)");
             for (size_t b = 0; b < nb; ++b) {
                 lines_seen[b] += lines[b] - left_lines[b];
@@ -946,6 +970,7 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
                 tr.finish_tile(tl, n_ent, n_ind, ind_bytes, true);
             }
             tr.clk_dev.gpu += StageClock::now() - t1;
+            if (tile_log) tile_times.push_back({(double)T, (double)comp.size(), t_wait - t0, t1 - t_wait, t_begun - t1, StageClock::now() - t_begun});
             // the tile after this one: the positions that ~tile_mb of text hold, going by the batch with the fewest lines per block
             double lpb_min = 1e30;
             for (size_t b = 0; b < nb; ++b) if (lines_per_block[b] > 0) lpb_min = std::min(lpb_min, lines_per_block[b]);
@@ -955,6 +980,14 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
             if (tr.failed()) { std::lock_guard<std::mutex> g(tr.err_mu); throw std::runtime_error(tr.err); }
             tr.out_q.push(tr.cur);
             tr.cur = tr.free_q.pop();
+        }
+        if (tile_log) {
+            std::ostringstream os;
+            os << "[profile] thread " << ithread << " tiles (positions, comp MB, gather ms, slot wait ms, begin ms, finish ms):";
+            for (auto const &t : tile_times)
+                os << " (" << t[0] << ", " << std::fixed << std::setprecision(1) << t[1] / 1048576.0 << ", " << t[2] * 1e3 << ", " << t[3] * 1e3 << ", "
+                   << t[4] * 1e3 << ", " << t[5] * 1e3 << ")";
+            std::cerr << os.str() << std::endl;
         }
     } else if (dev_parse) {
         // a tile: --tile positions at most, and about BVC_HOST_TILE_MB of text (default 32) going by the tile before it
@@ -1158,6 +1191,9 @@ static void run_basetype(int argc, char **argv)                          // src/
 int main(int argc, char **argv)
 {
     if (argc <= 1) { std::cerr << BASEVARC_USAGE_MESSAGE; return 0; }
+    // every thread drives the device through a stream of its own: as many hardware queues as threads that may be inside the device's
+    // part of a tile at a time (the runtime's default is four, two streams then share a queue; profiles/r05_host/README.txt)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     const std::string command(argv[1]);
     try {
         if (command == "basetype") run_basetype(argc - 1, argv + 1);

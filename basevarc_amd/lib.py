@@ -51,7 +51,7 @@ EXPORTS = [
     "bvc_synchronize", "bvc_set_overlap", "bvc_join", "bvc_set_profiling", "bvc_get_profile", "bvc_lrt_dense", "bvc_lrt_dense_groups",
     "bvc_lrt_csr", "bvc_lrt_csr_comb", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense", "bvc_stream_read_ms", "bvc_set_tuning",
     "bvc_lrt_dense_packed", "bvc_pack_dense", "bvc_hist_dense_packed", "bvc_lrt_dense_groups_packed",
-    "bvc_lrt_csr_packed", "bvc_lrt_csr_groups", "bvc_pileup_begin", "bvc_pileup_finish", "bvc_inflate_blocks", "bvc_pileup_begin_bgzf", "bvc_pileup_text",
+    "bvc_lrt_csr_packed", "bvc_lrt_csr_groups", "bvc_pileup_begin", "bvc_pileup_finish", "bvc_pileup_finish_called", "bvc_inflate_blocks", "bvc_pileup_begin_bgzf", "bvc_pileup_text",
 ]
 
 _lib = None
@@ -119,6 +119,8 @@ def load_library():
     L.bvc_pileup_begin.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     L.bvc_pileup_finish.restype = C.c_int
     L.bvc_pileup_finish.argtypes = [vp, vp, dbl, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.bvc_pileup_finish_called.restype = C.c_int
+    L.bvc_pileup_finish_called.argtypes = [vp, vp, dbl, vp, vp, vp, i64, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]
     L.bvc_pileup_begin_bgzf.restype = C.c_int
     L.bvc_pileup_begin_bgzf.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(i32), vp, C.POINTER(i64), C.POINTER(i64),
                                         C.POINTER(i64)]
@@ -279,7 +281,7 @@ class Context:
         return res, gres
 
     def pileup_tile(self, text, line_start, sample0, n_in_batch, ref_base, min_af, carry_in=(0, 0, 0, 0, 0), group_of_sample=None,
-                    n_groups=0):
+                    n_groups=0, called_only=False):
         """bvc_pileup_begin + bvc_pileup_finish on one tile of temp-batch pileup text (include/bvc.h).  text: bytes;
         line_start: uint32 [n_batches, n_positions + 1].  Returns None when a line is not regular (BVC_PILEUP_IRREGULAR), else a
         dict: entry_off, tally [T, 32], entries (structured), samples, indels (sorted by entry), results, grp_results, carry_out."""
@@ -294,9 +296,12 @@ class Context:
         if rc == 1:
             return None
         self._check(rc)
-        return self._pileup_finish(T, ne.value, ni.value, 0, ref_base, min_af, carry_in, group_of_sample, n_groups)
+        return self._pileup_finish(T, ne.value, ni.value, 0, ref_base, min_af, carry_in, group_of_sample, n_groups, called_only)
 
-    def _pileup_finish(self, T, n_entries, n_indels, indel_text_bytes, ref_base, min_af, carry_in, group_of_sample, n_groups):
+    def _pileup_finish(self, T, n_entries, n_indels, indel_text_bytes, ref_base, min_af, carry_in, group_of_sample, n_groups,
+                       called_only=False, called_cap=None):
+        """called_only: bvc_pileup_finish_called -- `entries` / `samples` hold the called positions' entries only, position t's at
+        called_off[t] .. called_off[t + 1] (key "called_off")."""
         ENTRY = np.dtype([("base", "u1"), ("mapq", "u1"), ("qual", "u1"), ("rpr", "u1"), ("strand", "u1"), ("is_indel", "u1"), ("pad", "<u2")])
         INDEL = np.dtype([("entry", "<i8"), ("text_off", "<i8"), ("len", "<i4"), ("pad", "<i4")])
         r = np.ascontiguousarray(ref_base, dtype=np.int8)
@@ -312,6 +317,20 @@ class Context:
         g = np.ascontiguousarray(group_of_sample, dtype=np.uint8) if n_groups else np.zeros(0, dtype=np.uint8)
         cin = np.asarray(carry_in, dtype=np.uint8)
         cout = np.zeros(5, dtype=np.uint8)
+        if called_only:
+            called_off = np.zeros(T + 1, dtype=np.int64)
+            cap = n_entries if called_cap is None else int(called_cap)
+            self._check(self._L.bvc_pileup_finish_called(self._h, _np_ptr(r), float(min_af), _np_ptr(cin), _np_ptr(cout),
+                                                         _np_ptr(g) if n_groups else None, len(g), int(n_groups), _np_ptr(entry_off), _np_ptr(tally),
+                                                         _np_ptr(called_off), cap, _np_ptr(entries), _np_ptr(samples), _np_ptr(indels),
+                                                         _np_ptr(itext) if indel_text_bytes else None, _np_ptr(res),
+                                                         _np_ptr(gres) if n_groups else None))
+            n_c = int(called_off[T])
+            ind = indels[:n_indels]
+            ind = ind[np.argsort(ind["entry"], kind="stable")]
+            return dict(entry_off=entry_off, called_off=called_off, tally=tally, entries=entries[:n_c], samples=samples[:n_c], indels=ind,
+                        results=res, grp_results=gres if n_groups else None, carry_out=[int(x) for x in cout],
+                        indel_text=itext[:indel_text_bytes].tobytes())
         self._check(self._L.bvc_pileup_finish(self._h, _np_ptr(r), float(min_af), _np_ptr(cin), _np_ptr(cout), _np_ptr(g) if n_groups else None,
                                               len(g), int(n_groups), _np_ptr(entry_off), _np_ptr(tally), _np_ptr(entries), _np_ptr(samples),
                                               _np_ptr(indels), _np_ptr(itext) if indel_text_bytes else None, _np_ptr(res),

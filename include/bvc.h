@@ -278,6 +278,22 @@ int bvc_pileup_finish(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const
                       int64_t *entry_off, int32_t *tally, bvc_pileup_entry *entries, int32_t *samples,
                       bvc_pileup_indel *indels, char *indel_text, bvc_site_result *results, bvc_group_result *grp_results);
 /*
+ * bvc_pileup_finish with the entries of the CALLED positions only (results[t].called != 0).  Of a position that is not called the
+ * reference reads the tallies and the indel strings alone (the CVG line, src/BaseVarC.cpp:560-610); the entries themselves are read
+ * by WriteVcf (:664), i.e. for the few per cent of the positions that are called -- at 1e5 samples and 10 % coverage the entries are
+ * 120 KB per position that a caller otherwise receives and never looks at.
+ *   called_off [n_positions + 1]  entries / samples of position t = [called_off[t] .. called_off[t + 1]) (empty unless called);
+ *                                 gathered on the device, in position order
+ *   called_cap                    room in entries / samples, in entries (n_entries of the begin call always suffices; BVC_ERR_ARG when
+ *                                 the called positions hold more)
+ * entry_off, indels (records' entry = index among ALL entries, as before) and everything else as bvc_pileup_finish.
+ */
+int bvc_pileup_finish_called(bvc_ctx *ctx, const int8_t *ref_base, double min_af, const uint8_t carry_in[5], uint8_t carry_out[5],
+                             const uint8_t *group_of_sample, int64_t n_samples, int32_t n_groups,
+                             int64_t *entry_off, int32_t *tally, int64_t *called_off, int64_t called_cap, bvc_pileup_entry *entries,
+                             int32_t *samples, bvc_pileup_indel *indels, char *indel_text, bvc_site_result *results,
+                             bvc_group_result *grp_results);
+/*
  * The same from the COMPRESSED temp batches: the BGZF blocks go to the device as they are in the files (a fifth of the bytes of
  * their text), are inflated there (bvc_inflate_blocks) and the text never exists on the host.  The caller no longer knows where the
  * lines are, so the call decides the tile's positions itself: every batch's text so far = what the previous call left of it (kept

@@ -85,6 +85,18 @@ def check_tile(ctx, batch_lines, n_in_batch, ref, min_af, parser, carry_in, wher
     assert out["results"].tobytes() == want.tobytes(), where
     ai = parser.ai
     assert out["carry_out"] == [ai["base"], ai["mapq"], ai["qual"], ai["rpr"], ai["strand"]], where
+    # bvc_pileup_finish_called: everything the same, the entries of the called positions only (gathered on the device)
+    co = ctx.pileup_tile(text, ls, sample0, n_in_batch, ref, min_af, carry_in=carry_in, called_only=True)
+    for key in ("entry_off", "tally", "results", "indels"):
+        assert co[key].tobytes() == out[key].tobytes(), (where, key)
+    assert co["carry_out"] == out["carry_out"]
+    coff, called = co["called_off"], out["results"]["called"]
+    assert coff[0] == 0 and coff[T] == len(co["entries"]) == len(co["samples"]) == sum(int(eoff[t + 1] - eoff[t]) for t in range(T) if called[t])
+    for t in range(T):
+        n_t = int(eoff[t + 1] - eoff[t]) if called[t] else 0
+        assert coff[t + 1] - coff[t] == n_t, (where, t)
+        assert co["entries"][coff[t]:coff[t + 1]].tobytes() == out["entries"][eoff[t]:eoff[t] + n_t].tobytes(), (where, t)
+        assert co["samples"][coff[t]:coff[t + 1]].tolist() == out["samples"][eoff[t]:eoff[t] + n_t].tolist(), (where, t)
     return out, sites
 
 
