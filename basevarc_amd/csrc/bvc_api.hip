@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "bvc_internal.h"
@@ -454,6 +455,18 @@ int run_group_stages(bvc_ctx *ctx, int64_t ns, int n_groups, bool long_rows, Sta
     return BVC_OK;
 }
 
+// bvc_host_alloc's allocations: a transfer from / to a buffer inside one of them needs no bounce buffer
+std::mutex g_pinned_mu;
+std::vector<std::pair<const char *, size_t>> g_pinned;
+bool in_pinned(const void *p, size_t n)
+{
+    std::lock_guard<std::mutex> g(g_pinned_mu);
+    const char *c = static_cast<const char *>(p);
+    for (auto const &r : g_pinned)
+        if (c >= r.first && c + n <= r.first + r.second) return true;
+    return false;
+}
+
 // Transfers of one call through the context's pinned buffers: h2d copies the caller's bytes into pinned memory and enqueues the DMA,
 // d2h enqueues a DMA into pinned memory and deliver() -- after the stream has been waited for -- copies the bytes to the caller.
 struct PinIO {
@@ -486,6 +499,7 @@ struct PinIO {
     hipError_t h2d(void *dev, const void *host, size_t n)
     {
         if (n == 0) return hipSuccess;
+        if (in_pinned(host, n)) return hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, ctx->stream);
         if (up_used + n > ctx->up_cap) return hipErrorOutOfMemory;
         char *p = ctx->h_up + up_used;
         std::memcpy(p, host, n);
@@ -617,6 +631,27 @@ int bvc_create(bvc_ctx **out, int device)
     ctx->stream = ctx->own_stream;
     *out = ctx;
     return BVC_OK;
+}
+
+void *bvc_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0) bytes = 1;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> g(g_pinned_mu);
+    g_pinned.push_back({static_cast<const char *>(p), bytes});
+    return p;
+}
+
+void bvc_host_free(void *p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_pinned_mu);
+        for (size_t i = 0; i < g_pinned.size(); ++i)
+            if (g_pinned[i].first == p) { g_pinned.erase(g_pinned.begin() + (long)i); break; }
+    }
+    (void)hipHostFree(p);
 }
 
 void bvc_destroy(bvc_ctx *ctx)
@@ -1386,7 +1421,8 @@ int bvc_pileup_begin_bgzf(bvc_ctx *ctx, const uint8_t *comp, int64_t comp_bytes,
         if (e__ != hipSuccess) return drained(fail(ctx, BVC_ERR_DEVICE, #call, e__));     \
     } while (0)
     PinIO io(ctx);
-    rc = io.reserve((size_t)comp_bytes + (size_t)n_blocks * sizeof(bvc_bgzf_block) + nb * (sizeof(bvc_pileup_region) + 12) + 1024,
+    rc = io.reserve((n_blocks > 0 && in_pinned(comp, (size_t)comp_bytes) ? 0 : (size_t)comp_bytes) + (size_t)n_blocks * sizeof(bvc_bgzf_block) +
+                        nb * (sizeof(bvc_pileup_region) + 12) + 1024,
                     (size_t)n_blocks * 4 + nb * 8 + 1024);
     if (rc != BVC_OK) return rc;
     BVC_HIP_D(hipMemsetAsync(P.status, 0, st_al + 2 * off_al + tal_al, ctx->stream));

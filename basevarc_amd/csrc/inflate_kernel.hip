@@ -5,17 +5,25 @@
 // spend their time on -- ~200 us per position of 1e5 samples, 300 us when sixteen threads share the box's quota -- and BGZF blocks are
 // independent (<= 64 KiB of output each, window inside the block): thousands of them decode side by side.
 //
-// A block's symbol stream is serial, so the decode is not data-parallel inside a block: every lane of the wavefront follows the same
-// (wave-uniform) control flow -- bit buffer, table look-ups in LDS -- and the lanes share the work that IS parallel: staging the
-// compressed bytes (1 KiB per refill, 16 bytes a lane), filling the first-level decoding tables, copying matches (lane i copies byte
-// i of the match; a match shorter than its distance, or a run, is the same expression: source byte i mod distance), and writing the
-// output (1 KiB at a time, 16 bytes a lane).  The block's last 4 KiB of output live in an LDS ring: nearly every match of pileup text
-// reaches back less than that (a line is 1-2 KiB) and is copied LDS to LDS; a match that reaches further back -- deflate allows 32 KiB
-// -- reads its source from the block's output in global memory, which left the ring at least 3 KiB ago (loads behind a
-// release fence: the bytes were written by this wavefront's own stores).  10 KiB of LDS per wavefront instead of the 36 KiB a whole
-// window takes: sixteen blocks in flight per CU instead of four, and the decode is a chain of LDS round trips that only other
-// wavefronts can hide (round 5, pileup text at 10 % coverage deflated at zlib's level 6: 3.0 ms per block
-// either way; 8192 blocks in 9.7 ms = 55 GB/s of text with the 4 KiB ring, 45 with 8 KiB, 34 with 16, 22 with all 32: profiles/r05_inflate.txt).
+// A block's symbol stream is serial, so the decode is not data-parallel inside a block, and a wavefront alone on its SIMD issues one
+// instruction in four cycles: a block's time is the instruction count of its symbol loop (profiles/r05_inflate.txt: 3.3 ms a block
+// with the compiler's loop at ~130 instructions and ~26 branches a symbol, 1.9 ms with this one).  What the lanes share:
+//  * the compressed bytes: the next 64 words of the block live in ONE register (lane j: word j), the bit position is wave-uniform,
+//    a word is a v_readlane away; no staging buffer, no round trip to read bits;
+//  * the table look-ups: lane j looks up the 32 bits that start j bits ahead in BOTH first-level tables (one LDS round trip for the
+//    symbols of the next ~64 bits) and the serial walk from symbol to symbol reads those entries with v_readlane -- hand-written
+//    (fast_symbols: ~10 instructions a literal, ~55 a match), since the compiler turns every uniform branch of this kernel into
+//    mask arithmetic;
+//  * the copies: literals are collected in a lane mask and written together (lane j: its entry's byte at its rank); lane i copies
+//    byte i of a match, its LDS read left in flight while the next symbols are decoded; a match shorter than its distance, or a
+//    run, is the same expression (source byte i mod distance) in the general path;
+//  * the output: 1 KiB at a time, 16 bytes a lane, from an LDS ring of the block's last BVC_INFLATE_WINDOW bytes (4 KiB).  A match
+//    that reaches further back -- deflate allows 32 KiB, and pileup text at zlib's level 6 uses all of it: 55 % of its matches reach
+//    beyond 4 KiB -- reads its source from the block's output in global memory, which left the ring at least 3 KiB ago (this
+//    wavefront's own stores, through the same L1 and L2); that load is left in flight like the LDS read of a near match.  9 KiB of
+//    LDS per wavefront instead of the 37 KiB a whole window takes: eighteen blocks in flight per CU instead of four.  Round 5,
+//    pileup text at 10 % coverage, zlib level 6: a block alone takes 1.9 ms with any ring; 8192 blocks 6.1 ms = 87 GB/s of text with
+//    the 4 KiB ring, 72 / 54 / 38 with 8 / 16 / 32 KiB (profiles/r05_inflate.txt; the round's first kernel: 3.2 ms and 50).
 //
 // Decoding tables: 9-bit (literal/length) and 7-bit (distance, code lengths) first-level tables of 32-bit entries
 // [valid | code length | kind | extra bits | value] -- a length's or distance's base and extra-bit count ride in the entry, so a
@@ -28,7 +36,7 @@
 #include <hip/hip_runtime.h>
 
 #ifndef BVC_INFLATE_WINDOW
-#define BVC_INFLATE_WINDOW 8192
+#define BVC_INFLATE_WINDOW 4096
 #endif
 
 #include "bvc_device.h"
@@ -139,7 +147,8 @@ __device__ bool build_code(InflateLds &L, const uint8_t *lens, int n, uint32_t *
 //   off              bits of the batch consumed (the next symbol starts at lane `off`); the stream is at bp + off
 //   o                bytes of output so far
 // Literals are collected in a lane mask and written together (EXEC = the mask: lane j writes its entry's byte at its rank).  A match
-// with len <= 63, dist >= len, dist <= o, o + len <= isize (and inside the ring) is copied here, lane i byte i, its LDS read left IN
+// with len <= 63, dist >= len, dist <= o, o + len <= isize is copied here, lane i byte i, its read (LDS; the block's output in global
+// memory when the source has left a ring smaller than the window) left IN
 // FLIGHT while the next symbols are decoded: the write follows when the next match (or the way out) asks for it -- LDS operations of
 // a wavefront are performed in order, so a later read sees it.  A batch that is used up is followed by the next one (two cross-lane
 // reads of cw0 and the two table look-ups) without leaving.  The way out, `what`: 1 a match decoded and not copied (len, dist), 2 a
@@ -148,9 +157,9 @@ __device__ bool build_code(InflateLds &L, const uint8_t *lens, int n, uint32_t *
 // beyond ISIZE.  The ring is kWinBytes at LDS address 0, the tables where InflateLds has them.
 // Temporaries with fixed names: s[84:85] (the literal mask: its halves are named); everything else is the compiler's choice.
 constexpr uint32_t kLitTabOff = (kWinBytes / 4 + kWave / 4) * 4, kDistTabOff = kLitTabOff + (4u << kLitBits);
-__device__ __forceinline__ void fast_symbols(uint32_t cw0, uint32_t lane, uint32_t isize, uint32_t flushed, uint32_t &le, uint32_t &de,
-                                             uint32_t &view, uint32_t &bp, uint32_t &off, uint32_t &o, uint32_t &what, uint32_t &len,
-                                             uint32_t &dist)
+__device__ __forceinline__ void fast_symbols(uint32_t cw0, uint32_t lane, uint32_t isize, uint32_t flushed, const uint8_t *block_out,
+                                             uint32_t &le, uint32_t &de, uint32_t &view, uint32_t &bp, uint32_t &off, uint32_t &o,
+                                             uint32_t &what, uint32_t &len, uint32_t &dist)
 {
     uint32_t e, l, t, p, xb, x, msk, d, pl, va, vb, vc, vs, vt;
     uint64_t m64;
@@ -177,14 +186,36 @@ __device__ __forceinline__ void fast_symbols(uint32_t cw0, uint32_t lane, uint32
     "s_cmp_eq_u32 %[pl], 0\n"                                                               \
     "s_cbranch_scc1 " done "\n"                                                             \
     "s_bfm_b64 exec, %[pl], 0\n"                                                            \
-    "s_waitcnt lgkmcnt(0)\n"                                                                \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                       \
     "ds_write_b8 %[vb], %[va]\n"                                                            \
     "s_mov_b64 exec, -1\n"                                                                  \
     "s_mov_b32 %[pl], 0\n"
+    // a ring smaller than the window: a match whose source has left it reads the block's own output in global memory, written by this
+    // wavefront's flushes at least kWinBytes - 1.2 KiB of output ago (the wait: for those stores, should one still be on its way;
+    // one wavefront's stores and loads to the same addresses go through the same L1 and L2, in order); the load is left in flight
+    // like the LDS read of a near match
 #if BVC_INFLATE_WINDOW == 32768
 #define BVC_NEAR_CHECK ""
+#define BVC_FAR_COPY ""
 #else
-#define BVC_NEAR_CHECK "s_add_u32 %[x], %[dist], %[len]\n s_cmp_gt_u32 %[x], %[lim]\n s_cbranch_scc1 4f\n"
+#define BVC_NEAR_CHECK "s_add_u32 %[x], %[dist], %[len]\n s_cmp_gt_u32 %[x], %[lim]\n s_cbranch_scc1 20f\n"
+#define BVC_FAR_COPY                                                                        \
+    "20:\n"                                                                                 \
+    "s_sub_u32 %[x], %[o], %[dist]\n"                                                       \
+    "v_add_u32 %[va], %[x], %[lane]\n"                                                      \
+    "v_add_u32 %[vb], %[o], %[lane]\n"                                                      \
+    "v_and_b32 %[vb], %[mask], %[vb]\n"                                                     \
+    "s_waitcnt vmcnt(0)\n"                                                                  \
+    "s_bfm_b64 exec, %[len], 0\n"                                                           \
+    "global_load_ubyte %[va], %[va], %[outb] sc0\n"                                           \
+    "s_mov_b64 exec, -1\n"                                                                  \
+    "s_mov_b32 %[pl], %[len]\n"                                                             \
+    "s_mov_b32 %[o], %[t]\n"                                                                \
+    "s_sub_u32 %[x], %[o], %[flushed]\n"                                                    \
+    "s_cmp_ge_u32 %[x], 0x400\n"                                                            \
+    "s_cbranch_scc0 1b\n"                                                                   \
+    "s_mov_b32 %[what], 3\n"                                                                \
+    "s_branch 6f\n"
 #endif
     asm volatile(
         "s_mov_b64 s[84:85], 0\n"
@@ -258,6 +289,7 @@ __device__ __forceinline__ void fast_symbols(uint32_t cw0, uint32_t lane, uint32
         "s_cbranch_scc0 1b\n"
         "s_mov_b32 %[what], 3\n"
         "s_branch 6f\n"
+        BVC_FAR_COPY
         "4:\n"
         "s_mov_b32 %[what], 1\n"
         "s_branch 6f\n"
@@ -303,9 +335,11 @@ __device__ __forceinline__ void fast_symbols(uint32_t cw0, uint32_t lane, uint32
           [dist] "=&s"(dist), [e] "=&s"(e), [l] "=&s"(l), [t] "=&s"(t), [p] "=&s"(p), [xb] "=&s"(xb), [x] "=&s"(x), [msk] "=&s"(msk),
           [d] "=&s"(d), [pl] "=&s"(pl), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [vs] "=&v"(vs), [vt] "=&v"(vt), [m] "=&s"(m64)
         : [cw0] "v"(cw0), [lane] "v"(lane), [isize] "s"(isize), [flushed] "s"(flushed), [mask] "s"(mask), [lim] "s"(kWinBytes - 64u),
+          [outb] "s"(block_out),
           [lit_off] "i"(kLitTabOff), [dist_off] "i"(kDistTabOff)
         : "memory", "scc", "vcc", "s84", "s85");
 #undef BVC_NEAR_CHECK
+#undef BVC_FAR_COPY
 #undef BVC_FINISH_COPY
 #undef BVC_EMIT_LITERALS
 }
@@ -524,7 +558,7 @@ __global__ __launch_bounds__(kWave) void inflate_kernel(const uint8_t *__restric
             // fast_symbols() runs literals, simple matches and the step from batch to batch, and comes back for the rest
             while (!end_block && err == kOk) {
                 uint32_t what, len, dist;
-                fast_symbols(cw0, (uint32_t)lane, isize, flushed, le, de, view, bp, off, o, what, len, dist);
+                fast_symbols(cw0, (uint32_t)lane, isize, flushed, out + o0, le, de, view, bp, off, o, what, len, dist);
                 if (o - flushed >= 1024u) flush_full();
                 if (what == 3u) continue;
                 if (what == 4u) { gather(); continue; }          // (bp has taken `off` up: the window moves, the batch is looked up here)

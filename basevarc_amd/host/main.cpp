@@ -885,7 +885,31 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
         std::vector<int64_t> blocks_sent(nb, 0), lines_seen(nb, 0);
         std::vector<int32_t> left_lines(nb, 0), lines(nb, 0), send(nb, 0);
         std::vector<char> ended(nb, 0);
-        std::vector<unsigned char> comp;
+        // the tile's compressed blocks, one after the other, in page-locked memory of the library's: they go over the link from here
+        struct PinnedBytes {
+            unsigned char *p = nullptr;
+            size_t n = 0, cap = 0;
+            ~PinnedBytes() { bvc_host_free(p); }
+            size_t size() const { return n; }
+            bool empty() const { return n == 0; }
+            unsigned char *data() { return p; }
+            void clear() { n = 0; }
+            void append(const unsigned char *src, size_t len)
+            {
+                const size_t need = ((n + len + 3) & ~(size_t)3) + 16;
+                if (need > cap) {
+                    const size_t want = std::max(need + need / 2, (size_t)1 << 20);
+                    unsigned char *q = static_cast<unsigned char *>(bvc_host_alloc(want));
+                    if (!q) throw std::runtime_error("ERROR: page-locked host memory is not to be had (bvc_host_alloc)");
+                    if (n) std::memcpy(q, p, n);
+                    bvc_host_free(p);
+                    p = q; cap = want;
+                }
+                std::memcpy(p + n, src, len);
+                n += len;
+                while (n & 3) p[n++] = 0;                                // every payload from a 4-byte boundary
+            }
+        } comp;
         std::vector<bvc_bgzf_block> blocks;
         bool first = true;
         int64_t target = 1;                                             // positions the next tile should hold
@@ -914,8 +938,7 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
                     bvc_bgzf_block blk;
                     blk.comp_off = (int64_t)comp.size(); blk.out_off = 0; blk.comp_len = (int32_t)rb.payload.size(); blk.isize = (int32_t)rb.isize;
                     blk.crc32 = rb.crc32; blk.check_crc = check_crc ? 1u : 0u;
-                    comp.insert(comp.end(), rb.payload.begin(), rb.payload.end());
-                    comp.resize((comp.size() + 3) & ~(size_t)3);
+                    comp.append(rb.payload.data(), rb.payload.size());
                     blocks.push_back(blk);
                     ++took;
                 }

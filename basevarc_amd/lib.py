@@ -52,6 +52,7 @@ EXPORTS = [
     "bvc_lrt_csr", "bvc_lrt_csr_comb", "bvc_hist_dense", "bvc_lrt_hist", "bvc_synth_dense", "bvc_stream_read_ms", "bvc_set_tuning",
     "bvc_lrt_dense_packed", "bvc_pack_dense", "bvc_hist_dense_packed", "bvc_lrt_dense_groups_packed",
     "bvc_lrt_csr_packed", "bvc_lrt_csr_groups", "bvc_pileup_begin", "bvc_pileup_finish", "bvc_pileup_finish_called", "bvc_inflate_blocks", "bvc_pileup_begin_bgzf", "bvc_pileup_text",
+    "bvc_host_alloc", "bvc_host_free",
 ]
 
 _lib = None

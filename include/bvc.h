@@ -28,6 +28,7 @@
 #ifndef BVC_H
 #define BVC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -97,6 +98,16 @@ const char *bvc_version(void);
 int  bvc_device_count(void);
 int  bvc_create(bvc_ctx **out, int device);
 void bvc_destroy(bvc_ctx *ctx);
+
+/*
+ * Additive: page-locked host memory for the buffers a caller hands to the calls that take HOST pointers.  A transfer from or to a
+ * buffer that lies inside such an allocation goes straight over the link; any other host buffer goes through the context's own
+ * page-locked bounce buffer (one memcpy of the bytes more).  The host program assembles the compressed blocks of a tile there
+ * (bvc_pileup_begin_bgzf: a fifth of a tile's bytes, and the largest transfer of the feed).  Any thread, any device; NULL when the
+ * allocation fails.  bvc_host_free(NULL) is a no-op.
+ */
+void *bvc_host_alloc(size_t bytes);
+void bvc_host_free(void *p);
 const char *bvc_last_error(const bvc_ctx *ctx);
 /* Run on the caller's HIP stream (hipStream_t passed as void*; NULL = the device's default stream).  A new context works on a
  * stream of its own (a blocking stream: ordered against the device's default stream, concurrent with other contexts' streams). */

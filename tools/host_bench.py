@@ -82,7 +82,8 @@ def main():
             size = sum(os.path.getsize(os.path.join(dp, f)) for t in range(thread)
                        for dp, _, fs in os.walk(f"{out}.tmp.thread.{t}") for f in fs)
             for ii, (infl, var) in enumerate(runs):
-                env = dict(os.environ, BVC_HOST_PROFILE="1", **var)
+                env = dict(os.environ, BVC_HOST_PROFILE="1")
+                env.update(var)
                 keep = ["--keep_tmp"] if ii + 1 < len(runs) else []       # the batches serve every run of the sweep
                 if infl:
                     env["BVC_HOST_INFLATE_THREADS"] = infl
