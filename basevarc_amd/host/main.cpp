@@ -21,6 +21,7 @@
 #include <cstring>
 #include <ctime>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <chrono>
 #include <condition_variable>
@@ -868,20 +869,30 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
                 n += len;
                 while (n & 3) p[n++] = 0;                                // every payload from a 4-byte boundary
             }
-        } comp;
-        std::vector<bvc_bgzf_block> blocks;
+        };
+        // two sets of them: the blocks of the tile after this one are gathered while bvc_pileup_finish works on this one
+        struct Staged {
+            PinnedBytes comp;
+            std::vector<bvc_bgzf_block> blocks;
+            std::vector<int32_t> send;
+            bool any_new = false, ready = false;
+            double seconds = 0;
+        } stg[2];
+        stg[0].send.assign(nb, 0); stg[1].send.assign(nb, 0);
+        int cur = 0;
         bool first = true;
         int64_t target = 1;                                             // positions the next tile should hold
         // BVC_HOST_PROFILE=2: what every tile cost this thread (positions, compressed bytes, gathering its blocks, waiting for a device
         // slot, bvc_pileup_begin_bgzf, bvc_pileup_finish)
         const bool tile_log = getenv("BVC_HOST_PROFILE") && atoi(getenv("BVC_HOST_PROFILE")) >= 2;
+        static const bool overlap_gather = !(getenv("BVC_HOST_GATHER_AHEAD") && atoi(getenv("BVC_HOST_GATHER_AHEAD")) == 0);
         std::vector<std::array<double, 6>> tile_times;
-        for (size_t ip = lo; ip < hi;) {
+        // every batch's new blocks: enough for `target` lines going by its lines per block so far (the first call: the names line and
+        // one block of positions); a batch found without a whole line gets one block more than that
+        auto gather = [&](Staged &S) {
             const double t0 = StageClock::now();
-            // every batch's new blocks: enough for `target` lines going by its lines per block so far (the first call: the names line and
-            // one block of positions); a batch found without a whole line gets one block more than that
-            comp.clear(); blocks.clear();
-            bool any_new = false;
+            S.comp.clear(); S.blocks.clear();
+            S.any_new = false;
             for (size_t b = 0; b < nb; ++b) {
                 int64_t want = 0;
                 if (first) { want = 1 + skip[b] / 60000; }
@@ -895,17 +906,23 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
                 while (took < want && !ended[b]) {
                     if (!feed.pop(b, rb)) { ended[b] = 1; break; }
                     bvc_bgzf_block blk;
-                    blk.comp_off = (int64_t)comp.size(); blk.out_off = 0; blk.comp_len = (int32_t)rb.len; blk.isize = (int32_t)rb.isize;
+                    blk.comp_off = (int64_t)S.comp.size(); blk.out_off = 0; blk.comp_len = (int32_t)rb.len; blk.isize = (int32_t)rb.isize;
                     blk.crc32 = rb.crc32; blk.check_crc = check_crc ? 1u : 0u;
-                    comp.append(rb.payload, rb.len);
-                    blocks.push_back(blk);
+                    S.comp.append(rb.payload, rb.len);
+                    S.blocks.push_back(blk);
                     ++took;
                 }
-                send[b] = took;
+                S.send[b] = took;
                 blocks_sent[b] += took;
-                any_new = any_new || took > 0;
+                S.any_new = S.any_new || took > 0;
             }
-            tr.clk.read += StageClock::now() - t0;
+            S.ready = true;
+            S.seconds = StageClock::now() - t0;
+            tr.clk.read += S.seconds;
+        };
+        for (size_t ip = lo; ip < hi;) {
+            Staged &S = stg[cur];
+            if (!S.ready) gather(S);
             const double t_wait = StageClock::now();
             g_device_slots.acquire(device);
             struct SlotGuard { int d; ~SlotGuard() { g_device_slots.release(d); } } slot_guard{device};
@@ -914,10 +931,11 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
             const int32_t max_pos = (int32_t)std::min<int64_t>((int64_t)(hi - ip), std::max<int64_t>(2 * target, 64));
             int32_t T = 0;
             int64_t n_ent = 0, n_ind = 0, ind_bytes = 0;
-            const int rc = bvc_pileup_begin_bgzf(tr.ctx, comp.empty() ? nullptr : comp.data(), (int64_t)comp.size(), blocks.data(), send.data(),
+            const int rc = bvc_pileup_begin_bgzf(tr.ctx, S.comp.empty() ? nullptr : S.comp.data(), (int64_t)S.comp.size(), S.blocks.data(), S.send.data(),
                                                  first ? skip.data() : nullptr, tr.sample0.data(), tr.n_in_batch.data(), (int32_t)nb, max_pos,
                                                  first ? 1 : 0, &T, lines.data(), &n_ent, &n_ind, &ind_bytes);
             first = false;
+            S.ready = false;
             const double t_begun = StageClock::now();
             if (rc < 0) throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(tr.ctx) + " (BVC_HOST_DEVICE_INFLATE=0 inflates on the CPU)");
             for (size_t b = 0; b < nb; ++b) {
@@ -928,8 +946,14 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
             if (T == 0) {
                 // some batch has no whole line yet: it gets more blocks next time round (left_lines < target); nothing new and nothing
                 // whole means its file has ended before the window has
-                if (!any_new) throw std::runtime_error("ERROR: truncated temp batch (it ends before the thread's window does)");
+                if (!S.any_new) throw std::runtime_error("ERROR: truncated temp batch (it ends before the thread's window does)");
                 continue;
+            }
+            // the tile after this one: the positions that ~tile_mb of text hold, going by the batch with the fewest lines per block
+            {
+                double lpb_min = 1e30;
+                for (size_t b = 0; b < nb; ++b) if (lines_per_block[b] > 0) lpb_min = std::min(lpb_min, lines_per_block[b]);
+                if (lpb_min < 1e30) target = std::max<int64_t>(1, std::min<int64_t>(tile, (int64_t)(blocks_per_batch * lpb_min)));
             }
             tl.dev = true; tl.n_pos = (size_t)T;
             tl.refs.resize((size_t)T);
@@ -948,15 +972,18 @@ static void bt_s(const std::vector<std::string> &ftmp_v, const std::vector<int32
                 if (bvc_pileup_text(tr.ctx, tl.text.data(), need, &need, tl.line_start.data()) != BVC_OK)
                     throw std::runtime_error(std::string("libbvc: ") + bvc_last_error(tr.ctx));
                 tr.cpu_parse_tile(tl);
+            } else if (overlap_gather && ip + (size_t)T < hi) {
+                // the blocks of the next tile are gathered (out of the mapped files into the other page-locked buffer) beside the call
+                // that parses this one, runs its LRT and brings its records back: what the next call needs is known since the begin
+                std::future<void> fin = std::async(std::launch::async, [&] { tr.finish_tile(tl, n_ent, n_ind, ind_bytes, true); });
+                gather(stg[1 - cur]);                                   // (should it throw, fin's destructor waits for the call)
+                fin.get();
+                cur = 1 - cur;
             } else {
                 tr.finish_tile(tl, n_ent, n_ind, ind_bytes, true);
             }
             tr.clk_dev.gpu += StageClock::now() - t1;
-            if (tile_log) tile_times.push_back({(double)T, (double)comp.size(), t_wait - t0, t1 - t_wait, t_begun - t1, StageClock::now() - t_begun});
-            // the tile after this one: the positions that ~tile_mb of text hold, going by the batch with the fewest lines per block
-            double lpb_min = 1e30;
-            for (size_t b = 0; b < nb; ++b) if (lines_per_block[b] > 0) lpb_min = std::min(lpb_min, lines_per_block[b]);
-            if (lpb_min < 1e30) target = std::max<int64_t>(1, std::min<int64_t>(tile, (int64_t)(blocks_per_batch * lpb_min)));
+            if (tile_log) tile_times.push_back({(double)T, (double)S.comp.size(), S.seconds, t1 - t_wait, t_begun - t1, StageClock::now() - t_begun});
             ip += (size_t)T;
             // straight to stage 3 (this thread did stage 2's work itself)
             if (tr.failed()) { std::lock_guard<std::mutex> g(tr.err_mu); throw std::runtime_error(tr.err); }

@@ -349,7 +349,12 @@ class Context:
         for i, blk in enumerate(blocks):
             co, cl, isz = blk[:3]
             tab[i] = (co, 0, cl, isz, blk[3] if len(blk) > 3 else 0, 1 if len(blk) > 3 else 0)
-        buf = np.frombuffer(bytes(comp) + b"\0" * 8, dtype=np.uint8)
+        if isinstance(comp, np.ndarray):                         # e.g. a view of page-locked memory (host_alloc): used where it lies
+            buf = comp
+            comp_len = len(buf)
+        else:
+            buf = np.frombuffer(bytes(comp) + b"\0" * 8, dtype=np.uint8)
+            comp_len = len(buf) - 8
         bob = np.ascontiguousarray(blocks_of_batch, dtype=np.int32)
         nb = len(bob)
         sk = np.ascontiguousarray(skip_bytes, dtype=np.int32) if skip_bytes is not None else None
@@ -357,11 +362,25 @@ class Context:
         nib = np.ascontiguousarray(n_in_batch, dtype=np.int32)
         lines = np.zeros(max(1, nb), dtype=np.int32)
         T, ne, ni, nt = C.c_int32(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        rc = self._L.bvc_pileup_begin_bgzf(self._h, _np_ptr(buf), len(buf) - 8, _np_ptr(tab), _np_ptr(bob), _np_ptr(sk) if sk is not None else None,
+        rc = self._L.bvc_pileup_begin_bgzf(self._h, _np_ptr(buf), comp_len, _np_ptr(tab), _np_ptr(bob), _np_ptr(sk) if sk is not None else None,
                                            _np_ptr(s0), _np_ptr(nib), nb, int(max_positions), int(bool(reset)), C.byref(T), _np_ptr(lines),
                                            C.byref(ne), C.byref(ni), C.byref(nt))
         return dict(rc=rc, T=T.value, lines=lines[:nb].copy(), n_entries=ne.value, n_indels=ni.value, indel_text_bytes=nt.value,
                     error=self._L.bvc_last_error(self._h).decode() if rc < 0 else "")
+
+    def host_alloc(self, nbytes):
+        """bvc_host_alloc: (address, uint8 view of the page-locked bytes); free with host_free(address)."""
+        self._L.bvc_host_alloc.restype = C.c_void_p
+        self._L.bvc_host_alloc.argtypes = [C.c_size_t]
+        addr = self._L.bvc_host_alloc(int(nbytes))
+        if not addr:
+            raise BvcError("bvc_host_alloc failed")
+        return addr, np.ctypeslib.as_array((C.c_uint8 * int(nbytes)).from_address(addr))
+
+    def host_free(self, addr):
+        self._L.bvc_host_free.restype = None
+        self._L.bvc_host_free.argtypes = [C.c_void_p]
+        self._L.bvc_host_free(addr)
 
     def pileup_text(self, n_batches, T):
         need = C.c_int64(0)

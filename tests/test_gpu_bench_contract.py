@@ -26,7 +26,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert "workload" in d["config"] and "model" not in d["config"]
     # (outside the timed region) the same steps with every subset of every level run; at BASELINE size the two are equal (the histogram
     # pass bounds the call), on this small workload stage 2 shows
-    assert 0 < d["value_with_every_subset_run"] <= 1.05 * d["value"]
+    assert 0 < d["value_with_every_subset_run"] and (d.get("diagnostic_build") or d["value_with_every_subset_run"] <= 1.05 * d["value"])
     # a step is one pass over the whole resident workload (8000 sites here, in calls of 2000)
     assert d["config"]["sites_per_step"] == 8000 and d["config"]["sites_per_call"] == 2000
     assert d["value"] == pytest.approx(8000 / (d["ms_per_step"] / 1e3), rel=1e-3)
@@ -73,7 +73,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         leg = legs[name]
         assert leg["records_identical_with_every_subset_run_except_the_run_counts"] is True, name
         assert leg["roofline"]["em_passes_per_site"] < leg["em_passes_per_site_of_the_reference"], name
-        assert leg["value"] > 0.95 * leg["value_with_every_subset_run"] > 0, name
+        assert leg["value_with_every_subset_run"] > 0, name
+        if not d.get("diagnostic_build"):                        # (a rate against a rate: not under the poisoned, bound-checked build)
+            assert leg["value"] > 0.95 * leg["value_with_every_subset_run"], name
     assert legs["csr_coverage10pct"]["roofline"]["bound"] == "fp64_valu_issue" and legs["csr_coverage10pct"]["hist_roofline"]["bound"] == "hbm"
     # the ragged histogram pass is reported twice: underneath stage 2 and with the chip to itself (faster alone)
     hr = legs["csr_coverage10pct"]["hist_roofline"]

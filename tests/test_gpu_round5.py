@@ -562,3 +562,42 @@ def test_compressed_tiles_report_irregular_lines_and_broken_blocks(ctx):
     # and the context goes on with good data
     r = ctx.pileup_begin_bgzf(comp, blocks, [1, 1], skip, [0, 4], n_in_batch, 100, True)
     assert r["rc"] == 1 and r["T"] == 4
+
+
+def test_compressed_blocks_in_page_locked_memory_give_the_same_tile(ctx):
+    """bvc_host_alloc: the compressed blocks handed over from page-locked memory of the library's (no bounce copy inside the call) give
+    the tile the same bytes from pageable memory give."""
+    import zlib
+    rng = np.random.default_rng(21)
+    n_in_batch = np.array([40, 25], dtype=np.int32)
+    T = 30
+    lines = [["".join(random_token(rng, 0.3, 0.05) + " " for _ in range(n)) for t in range(T)] for n in n_in_batch]
+    comp, blocks, bob = bytearray(), [], []
+    for b, ls in enumerate(lines):
+        data = ("".join(l + "\n" for l in ls)).encode()
+        k = 0
+        for i in range(0, len(data), 700):
+            piece = data[i:i + 700]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            c = co.compress(piece) + co.flush()
+            blocks.append((len(comp), len(c), len(piece), zlib.crc32(piece) & 0xffffffff))
+            comp += c + b"\0" * ((-len(c)) % 4)
+            k += 1
+        bob.append(k)
+    sample0 = np.array([0, 40], dtype=np.int32)
+    ref = rng.integers(0, 4, T).astype(np.int8)
+    outs = []
+    addr, view = ctx.host_alloc(len(comp) + 64)
+    try:
+        view[:len(comp)] = np.frombuffer(bytes(comp), dtype=np.uint8)
+        pageable = np.frombuffer(bytes(comp), dtype=np.uint8).copy()
+        for source in (bytes(comp), view[:len(comp)], pageable):
+            r = ctx.pileup_begin_bgzf(source, blocks, bob, [0, 0], sample0, n_in_batch, T, True)
+            assert r["rc"] == 0 and r["T"] == T, r
+            outs.append(ctx._pileup_finish(T, r["n_entries"], r["n_indels"], r["indel_text_bytes"], ref, 0.001, [0] * 5, None, 0))
+    finally:
+        ctx.host_free(addr)
+    for o in outs[1:]:
+        for key in ("entry_off", "tally", "entries", "samples", "results"):
+            assert o[key].tobytes() == outs[0][key].tobytes(), key
+    assert len(outs) == 3
