@@ -94,41 +94,52 @@ static const size_t kBlockIn = 0xff00;          // uncompressed bytes per block
 static const unsigned char kEofMarker[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0,
                                              0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-BgzfWriter::BgzfWriter(const std::string &path, int level, bool background)
+BgzfWriter::BgzfWriter(const std::string &path, int level, bool background, int workers)
     : fp_(std::fopen(path.c_str(), "wb")), level_(level), failed_(false), background_(background && fp_ != nullptr)
 {
     buf_.reserve(kBlockIn);
     if (background_)
-        worker_ = std::thread([this] {
-            for (;;) {
-                std::vector<unsigned char> blk;
-                {
-                    std::unique_lock<std::mutex> g(mu_);
-                    cv_.wait(g, [&] { return !pending_.empty() || closing_; });
-                    if (pending_.empty()) return;
-                    blk.swap(pending_.front());
-                    pending_.pop_front();
+        for (int w = 0; w < (workers > 1 ? workers : 1); ++w)
+            workers_.emplace_back([this] {
+                std::vector<unsigned char> blk, out;
+                for (;;) {
+                    uint64_t seq;
+                    {
+                        std::unique_lock<std::mutex> g(mu_);
+                        cv_.wait(g, [&] { return !pending_.empty() || closing_; });
+                        if (pending_.empty()) return;
+                        blk.swap(pending_.front());
+                        pending_.pop_front();
+                        seq = taken_++;
+                    }
+                    cv_.notify_all();               // room for the producer
+                    out.clear();
+                    deflate_block(blk, out);
+                    {
+                        std::unique_lock<std::mutex> g(mu_);
+                        cv_.wait(g, [&] { return written_ == seq; });     // in the order the blocks were handed over
+                        if (!out.empty() && std::fwrite(out.data(), 1, out.size(), fp_) != out.size()) failed_ = true;
+                        ++written_;
+                    }
+                    cv_.notify_all();
                 }
-                cv_.notify_all();                   // room for the producer
-                deflate_and_write(blk);
-            }
-        });
+            });
 }
 
 BgzfWriter::~BgzfWriter() { if (fp_) close(); }
 
-// One or more BGZF blocks from `in` (all of it), written to the file.
-void BgzfWriter::deflate_and_write(std::vector<unsigned char> &in)
+// One or more BGZF blocks from `in` (all of it), appended to `out`.
+void BgzfWriter::deflate_block(const std::vector<unsigned char> &in, std::vector<unsigned char> &outv)
 {
     size_t n = in.size();
-    if (!fp_ || n == 0) return;
+    if (n == 0) return;
     unsigned char out[0x10000];
     size_t at = 0;
     for (size_t take = n;;) {                   // shrink the input if the deflated block would not fit 64 KiB
         z_stream zs;
         std::memset(&zs, 0, sizeof zs);
         if (deflateInit2(&zs, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { failed_ = true; return; }
-        zs.next_in = in.data() + at;
+        zs.next_in = const_cast<unsigned char *>(in.data()) + at;
         zs.avail_in = (uInt)take;
         zs.next_out = out + 18;
         zs.avail_out = (uInt)(sizeof out - 18 - 8);
@@ -144,11 +155,19 @@ void BgzfWriter::deflate_and_write(std::vector<unsigned char> &in)
         const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in.data() + at, (uInt)take);
         const uint32_t isize = (uint32_t)take;
         for (int i = 0; i < 4; ++i) { out[18 + clen + i] = (crc >> (8 * i)) & 0xff; out[22 + clen + i] = (isize >> (8 * i)) & 0xff; }
-        if (std::fwrite(out, 1, bsize, fp_) != bsize) failed_ = true;
+        outv.insert(outv.end(), out, out + bsize);
         at += take;
         if (at == n) return;
         take = n - at;
     }
+}
+
+void BgzfWriter::deflate_and_write(std::vector<unsigned char> &in)
+{
+    if (!fp_ || in.empty()) return;
+    std::vector<unsigned char> out;
+    deflate_block(in, out);
+    if (!out.empty() && std::fwrite(out.data(), 1, out.size(), fp_) != out.size()) failed_ = true;
 }
 
 void BgzfWriter::flush_block(size_t n)
@@ -167,10 +186,11 @@ void BgzfWriter::flush_block(size_t n)
 // Background mode: every block handed over so far has reached the file.
 void BgzfWriter::drain()
 {
-    if (!background_ || !worker_.joinable()) return;
+    if (!background_ || workers_.empty()) return;
     { std::lock_guard<std::mutex> g(mu_); closing_ = true; }
     cv_.notify_all();
-    worker_.join();
+    for (auto &w : workers_) w.join();
+    workers_.clear();
     background_ = false;
 }
 

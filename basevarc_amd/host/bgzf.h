@@ -22,7 +22,9 @@ class BgzfWriter {
  public:
     // background = true: full blocks are deflated and written by a thread of the writer's own, in order; write() only
     // copies bytes.  (The compute phase's outputs: deflating the CVG text was the largest single item of its last stage.)
-    explicit BgzfWriter(const std::string &path, int level = 6, bool background = false);
+    // workers > 1 (background mode): that many threads deflate, each block is written when the ones before it have been (round 5:
+    // one thread deflating the VCF text -- 400 KB a called position at 1e5 samples -- was what a position loop ended up waiting for).
+    explicit BgzfWriter(const std::string &path, int level = 6, bool background = false, int workers = 1);
     ~BgzfWriter();
     bool ok() const { return fp_ != nullptr && !failed_; }
     void write(const char *data, size_t n);
@@ -33,6 +35,7 @@ class BgzfWriter {
     bool append_file(const std::string &path);
  private:
     void flush_block(size_t n);
+    void deflate_block(const std::vector<unsigned char> &in, std::vector<unsigned char> &out);
     void deflate_and_write(std::vector<unsigned char> &in);
     void drain();
     FILE *fp_;
@@ -41,10 +44,11 @@ class BgzfWriter {
     std::vector<unsigned char> buf_;
     // background mode
     bool background_;
-    std::thread worker_;
+    std::vector<std::thread> workers_;
     std::mutex mu_;
     std::condition_variable cv_;
     std::deque<std::vector<unsigned char>> pending_;
+    uint64_t taken_ = 0, written_ = 0;          // blocks handed to a worker / whose bytes are in the file
     bool closing_ = false;
 };
 

@@ -270,7 +270,7 @@ size_t bvchost_pileup_tokens(const char *reads, const int32_t *positions, int32_
 // closes it.  Returns 1 when the writer reports success.
 int bvchost_bgzf_write(const char *path, const char *data, int64_t n, int64_t piece, int level, int background)
 {
-    BgzfWriter w(path, level, background != 0);
+    BgzfWriter w(path, level, background != 0, background);        // background = the number of deflating threads (0: the caller's)
     if (!w.ok()) return 0;
     for (int64_t i = 0; i < n; i += piece) w.write(data + i, (size_t)(n - i < piece ? n - i : piece));
     return w.close() ? 1 : 0;

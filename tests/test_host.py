@@ -505,9 +505,10 @@ def test_rerun_resumes_extraction_at_the_first_incomplete_batch(tmp_path):
     assert all(os.path.getmtime(f) > old + 1800 for f in files.values())
 
 
-@pytest.mark.parametrize("background", [0, 1])
+@pytest.mark.parametrize("background", [0, 1, 3])
 def test_bgzf_writer_with_its_own_deflate_thread_writes_the_same_stream(H, tmp_path, background):
-    """The compute phase's output writers deflate on a thread of their own (BgzfWriter, background mode).  Whatever the
+    """The compute phase's output writers deflate on a thread of their own, the VCF writer on three (BgzfWriter, background mode:
+    `background` = the number of deflating threads; blocks reach the file in the order they were handed over).  Whatever the
     piece size of the writes, the file is valid BGZF with the EOF block and inflates to exactly the bytes written; the
     background and the foreground writer produce identical files (blocks are cut at the same 0xff00-byte marks)."""
     import gzip
