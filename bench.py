@@ -688,7 +688,150 @@ def run_legs(ctx, a, tiles, tile_sizes, stride, min_af, np, torch, dev):
         "em_passes_per_site_of_the_reference": ref_passes / ns1,
         "records_identical_with_every_subset_run_except_the_run_counts": bool(_same_but_run_counts(rec, rec_all)),
     }
+    del t1, res
+    legs["producer_bgzf_1e5_coverage10pct"] = producer_leg(ctx, min_af, np, torch, dev)
     return legs
+
+
+def producer_leg(ctx, min_af, np, torch, dev, n=100_000, cov=0.1, batch=500, tile_pos=435, n_tiles=2):
+    """SURVEY 8(f1), the producer of the hot path's input: temp-batch BGZF blocks -> inflate -> line index -> token
+    parse -> LRT -> records, tile by tile through bvc_pileup_begin_bgzf / bvc_pileup_finish_called as the host program calls them
+    (compressed blocks in page-locked memory, host pointers: the link is inside the timed region).  The batches are written by the
+    host library's generator (the reference's text form, zlib level 6); the tiles are cut where the host program would cut them.
+    The inflate kernel is then timed alone on the same blocks, device-resident."""
+    import ctypes as C
+    import shutil
+    import tempfile
+    import zlib
+    from basevarc_amd import build as bld
+    from basevarc_amd.lib import BVC_PTR_DEVICE, _dev_ptr
+    _, hostlib = bld.build_host()
+    H = C.CDLL(hostlib)
+    H.bvchost_write_synth_batches.restype = C.c_int64
+    H.bvchost_write_synth_batches.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32]
+    npos = tile_pos * n_tiles
+    d = tempfile.mkdtemp(prefix="bvc_bench_producer_")
+    try:
+        out = os.path.join(d, "p.out")
+        os.makedirs(out + ".tmp.thread.0", exist_ok=True)
+        entries = H.bvchost_write_synth_batches(out.encode(), n, npos, 1, batch, int(round(cov * 1000)), 11, 0)
+        assert entries > 0
+        files = sorted(os.listdir(out + ".tmp.thread.0"), key=lambda f: int(f.split(".")[1]))       # batch.<i>: sample order
+        per_batch = []                                           # per batch: [(payload, isize, crc, lines ending in the block)], skip, samples
+        for f in files:
+            raw = open(os.path.join(out + ".tmp.thread.0", f), "rb").read()
+            at, blks, first = 0, [], True
+            skip = n_in = 0
+            while at < len(raw):
+                bsize = (raw[at + 16] | (raw[at + 17] << 8)) + 1
+                payload = raw[at + 18:at + bsize - 8]
+                crc, isize = int.from_bytes(raw[at + bsize - 8:at + bsize - 4], "little"), int.from_bytes(raw[at + bsize - 4:at + bsize], "little")
+                at += bsize
+                if isize == 0:
+                    continue
+                text = zlib.decompress(payload, -15)
+                if first:
+                    skip = text.index(b"\n") + 1
+                    n_in = text[:skip].count(b"\t")
+                    first = False
+                    nl = text.count(b"\n") - 1
+                else:
+                    nl = text.count(b"\n")
+                blks.append((payload, isize, crc, nl))
+            per_batch.append((blks, skip, n_in))
+        nb = len(per_batch)
+        sample0 = np.concatenate([[0], np.cumsum([p[2] for p in per_batch])[:-1]]).astype(np.int32)
+        n_in_batch = np.array([p[2] for p in per_batch], dtype=np.int32)
+        assert int(n_in_batch.sum()) == n
+        # tile k takes, of every batch, the blocks up to the one in which its last line ends (what is left of that block stays on the device)
+        tiles = []
+        used = [0] * nb
+        for k in range(n_tiles):
+            comp, blocks, bob = bytearray(), [], []
+            for b, (blks, _, _) in enumerate(per_batch):
+                want, have, took = (k + 1) * tile_pos, sum(x[3] for x in blks[:used[b]]), 0
+                while have < want and used[b] < len(blks):
+                    payload, isize, crc, nl = blks[used[b]]
+                    blocks.append((len(comp), len(payload), isize, crc))
+                    comp += payload + b"\0" * ((-len(payload)) % 4)
+                    have += nl; used[b] += 1; took += 1
+                bob.append(took)
+            tiles.append((comp, blocks, bob))
+        text_bytes = sum(x[1] for blks, _, _ in per_batch for x in blks)
+        comp_bytes = sum(len(t[0]) for t in tiles)
+        n_blocks = sum(len(t[1]) for t in tiles)
+        cap = max(len(t[0]) for t in tiles) + 64
+        addr, pinned = ctx.host_alloc(cap)
+        skips = [p[1] for p in per_batch]
+        ref = np.zeros(tile_pos, dtype=np.int8)
+
+        def one_pass():
+            called = got = 0
+            for k, (comp, blocks, bob) in enumerate(tiles):
+                pinned[:len(comp)] = np.frombuffer(bytes(comp), dtype=np.uint8)
+                t0 = time.perf_counter()
+                r = ctx.pileup_begin_bgzf(pinned[:len(comp)], blocks, bob, skips if k == 0 else None, sample0, n_in_batch, tile_pos, k == 0)
+                assert r["rc"] == 0 and r["T"] == tile_pos, (k, r["rc"], r["T"], r["error"])
+                o = ctx._pileup_finish(tile_pos, r["n_entries"], r["n_indels"], r["indel_text_bytes"], ref, min_af, [0] * 5, None, 0,
+                                       called_only=True)
+                one_pass.seconds += time.perf_counter() - t0
+                called += int(o["results"]["called"].sum()); got += int(o["entry_off"][-1])
+            return called, got
+        try:
+            one_pass.seconds = 0.0
+            one_pass()                                           # warm-up: the context's buffers
+            one_pass.seconds = 0.0
+            reps = 3
+            for _ in range(reps):
+                called, got = one_pass()
+            dt = one_pass.seconds / reps
+        finally:
+            ctx.host_free(addr)
+        assert got > 0 and called > 0, (got, called)
+        # the inflate kernel alone on the same blocks, device-resident (bvc_inflate_blocks: inflate_kernel + crc32_kernel)
+        BLOCK = np.dtype([("comp_off", "<i8"), ("out_off", "<i8"), ("comp_len", "<i4"), ("isize", "<i4"), ("crc32", "<u4"), ("check_crc", "<u4")])
+        tab = np.zeros(n_blocks, dtype=BLOCK)
+        allc, i, oat = bytearray(), 0, 0
+        for comp, blocks, _ in tiles:
+            for (co, cl, isz, crc) in blocks:
+                tab[i] = (len(allc) + co, oat, cl, isz, crc, 1)
+                oat += isz; i += 1
+            allc += comp
+        d_comp = torch.from_numpy(np.frombuffer(bytes(allc) + b"\0" * 16, dtype=np.uint8).copy()).to(dev)
+        d_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+        d_out = torch.empty(oat + 64, dtype=torch.uint8, device=dev)
+        d_st = torch.empty(n_blocks, dtype=torch.int32, device=dev)
+
+        def infl():
+            ctx._check(ctx._L.bvc_inflate_blocks(ctx._h, _dev_ptr(d_comp), d_comp.numel(), _dev_ptr(d_tab), n_blocks, _dev_ptr(d_out), d_out.numel(),
+                                                 _dev_ptr(d_st), BVC_PTR_DEVICE))
+        infl(); ctx.synchronize()
+        assert int(d_st.abs().sum()) == 0
+        t0 = time.perf_counter()
+        for _ in range(5):
+            infl()
+        ctx.synchronize()
+        dti = (time.perf_counter() - t0) / 5
+        alg = float(comp_bytes + text_bytes)                     # a compressed byte read and a text byte written per text byte
+        return {
+            "workload": f"temp-batch BGZF blocks of N = {n} samples at {cov:.0%} coverage ({nb} batches of {batch}, text form, zlib level 6): "
+                        f"{n_tiles} tiles of {tile_pos} positions = {n_blocks} blocks, {comp_bytes / 1e6:.1f} MB compressed, {text_bytes / 1e6:.1f} MB of text; "
+                        "bvc_pileup_begin_bgzf + bvc_pileup_finish_called per tile, one context, host pointers (compressed blocks page-locked)",
+            "value": npos / dt, "unit": "positions/s", "ms_per_tile": dt / n_tiles * 1e3, "entries_parsed": int(got), "entries_written_by_the_generator": int(entries),
+            "called_positions": int(called),
+            "text_GBs": text_bytes / dt / 1e9, "compressed_GBs_over_the_link": comp_bytes / dt / 1e9,
+            "bound_by": "the calls' two round trips and the inflate kernel's latency (one wavefront's serial walk per block); the host program "
+                        "runs several contexts side by side (profiles/r05_host/README.txt)",
+            "roofline": {"bound": "hbm", "kernel": "inflate_kernel (+ crc32_kernel), alone on the same blocks, device-resident",
+                         "achieved": alg / dti / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / dti / 1e9 / HBM_PEAK_GBS,
+                         "avg_launch_ms": dti * 1e3, "text_GBs": text_bytes / dti / 1e9, "blocks": int(n_blocks),
+                         "algorithmic_bytes_per_launch": alg,
+                         "note": "1 compressed + 1 text byte per text byte; the kernel is bound by SCALAR INSTRUCTION ISSUE, not by HBM -- "
+                                 "475 k instructions per 64 KiB block, one wavefront per block (DESIGN.md 3.8, profiles/r05_inflate.txt) -- so "
+                                 "the fraction of the HBM peak is small by construction; the figure to read is text_GBs"},
+        }
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def legs_summary(legs):

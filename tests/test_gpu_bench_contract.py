@@ -63,6 +63,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert pk["value"] > 0 and pk["records_identical_to_two_byte_path"] is True and pk["roofline"]["bytes_per_sample"] == 1
     for name in ("packed_groups5_interleaved", "packed_groups5_ordered"):
         assert legs[name]["value"] > 0 and legs[name]["records_identical_to_two_byte_path"] is True, name
+    # the producer of the path's input on the device, tile by tile as the host program calls it, and its inflate kernel alone
+    pr = legs["producer_bgzf_1e5_coverage10pct"]
+    assert pr["unit"] == "positions/s" and pr["value"] > 0 and pr["called_positions"] > 0 and pr["entries_parsed"] > 0
+    assert pr["roofline"]["text_GBs"] > pr["text_GBs"] > 0 and 0 < pr["roofline"]["frac"] < 1
     hp = legs["host_pointer_one_byte"]
     assert hp["bound"] == "pcie" and 0 < hp["ragged_one_byte"]["frac"] < 1 and 0 < hp["dense_one_byte"]["frac"] < 1
     assert hp["ragged_one_byte"]["records_identical_to_device_pointer_call"] is True
