@@ -389,11 +389,22 @@ std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int8_t r
     for (int i = 0; i < bt.n_alt; ++i) { alt_gt[bt.alt_base[i] & 7] = "./" + std::to_string(i + 1); has_gt[bt.alt_base[i] & 7] = true; }
     int ref_fwd = 0, ref_rev = 0, alt_fwd = 0, alt_rev = 0;
     std::vector<double> ref_quals, ref_mapqs, ref_rprs, alt_quals, alt_mapqs, alt_rprs;
+    // one field per SAMPLE: "./.\t" for a sample without an entry -- nine in ten at the coverage this tool is for, so the runs between
+    // the covered samples are appended whole from a block of the pattern (the sample loop below visits the covered ones only)
+    static const std::string kNoCall = [] { std::string p; for (int i = 0; i < 4096; ++i) p += "./.\t"; return p; }();
+    auto no_calls = [](std::string &s, int64_t n) {
+        for (; n > 0; n -= 4096) s.append(kNoCall, 0, (size_t)(n < 4096 ? n : 4096) * 4);
+    };
     std::string samgt;
-    size_t k = 0;
-    for (int32_t i = 0; i < n_samples; ++i) {
-        if (k >= site.n || site.sample[k] != i) { samgt += "./.\t"; continue; }
-        const Entry &a = site.aiv[k++];
+    samgt.reserve((size_t)n_samples * 4 + site.n * 16 + 16);
+    int32_t next = 0;                                              // first sample not written yet
+    for (size_t k = 0; k < site.n; ++k) {
+        const int32_t i = site.sample[k];
+        if (i < next || i >= n_samples) break;                    // (entries are in sample order, one per sample: what bt_s builds;
+                                                                   //  an entry out of order would hold every later one back)
+        no_calls(samgt, i - next);
+        next = i + 1;
+        const Entry &a = site.aiv[k];
         if (!has_gt[a.base]) { alt_gt[a.base] = "./."; has_gt[a.base] = true; }
         const std::string &gt = (a.base == ref_base) ? std::string("0/.") : alt_gt[a.base];
         // BASE2CHAR has four entries in the reference (src/BaseType.h:24); an indel entry carrying an N base
@@ -411,6 +422,7 @@ std::string vcf_line(const bvc_site_result &bt, const std::string &chr, int8_t r
         if (a.strand == 1) { if (a.base == ref_base) ref_fwd += 1; else if (alt) alt_fwd += 1; }
         else { if (a.base == ref_base) ref_rev += 1; else if (alt) alt_rev += 1; }
     }
+    no_calls(samgt, n_samples - next);
     const double phred_mapq = RankSumTest(ref_mapqs, alt_mapqs);
     const double phred_qual = RankSumTest(ref_quals, alt_quals);
     const double phred_rpr = RankSumTest(ref_rprs, alt_rprs);
