@@ -740,6 +740,24 @@ def producer_leg(ctx, min_af, np, torch, dev, n=100_000, cov=0.1, batch=500, til
                 blks.append((payload, isize, crc, nl))
             per_batch.append((blks, skip, n_in))
         nb = len(per_batch)
+        # the CPU path beside it: the host library's own block inflate and token parser (what the host program's CPU feed runs per
+        # position loop) on the first eight batches, one thread, scaled to all of them
+        H.bvchost_bench_inflate.restype = C.c_double
+        H.bvchost_bench_inflate.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_int64)]
+        H.bvchost_bench_parse.restype = C.c_double
+        H.bvchost_bench_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_int64)]
+        cpu_infl = cpu_parse = 0.0
+        n_cpu = min(8, nb)
+        for f in files[:n_cpu]:
+            raw = open(os.path.join(out + ".tmp.thread.0", f), "rb").read()
+            ob, ne = C.c_int64(0), C.c_int64(0)
+            t_i = H.bvchost_bench_inflate(raw, len(raw), 1, C.byref(ob))
+            text = b"".join(zlib.decompress(raw[a:b], -15) for a, b in _bgzf_payload_ranges(raw))
+            text = text[text.index(b"\n") + 1:]
+            t_p = H.bvchost_bench_parse(text, len(text), 1, C.byref(ne))
+            assert t_i > 0 and t_p > 0 and ob.value > 0
+            cpu_infl += t_i; cpu_parse += t_p
+        cpu_seconds = (cpu_infl + cpu_parse) * nb / n_cpu
         sample0 = np.concatenate([[0], np.cumsum([p[2] for p in per_batch])[:-1]]).astype(np.int32)
         n_in_batch = np.array([p[2] for p in per_batch], dtype=np.int32)
         assert int(n_in_batch.sum()) == n
@@ -820,6 +838,10 @@ def producer_leg(ctx, min_af, np, torch, dev, n=100_000, cov=0.1, batch=500, til
             "value": npos / dt, "unit": "positions/s", "ms_per_tile": dt / n_tiles * 1e3, "entries_parsed": int(got), "entries_written_by_the_generator": int(entries),
             "called_positions": int(called),
             "text_GBs": text_bytes / dt / 1e9, "compressed_GBs_over_the_link": comp_bytes / dt / 1e9,
+            "cpu_path": {"value": npos / cpu_seconds, "unit": "positions/s", "cores": 1,
+                         "inflate_s": cpu_infl * nb / n_cpu, "parse_s": cpu_parse * nb / n_cpu,
+                         "what": f"host/inflate.cpp + host/pileup.cpp (the host program's CPU feed) on {n_cpu} of the {nb} batches, one thread, "
+                                 "scaled to all of them; no LRT, no link"},
             "bound_by": "the calls' two round trips and the inflate kernel's latency (one wavefront's serial walk per block); the host program "
                         "runs several contexts side by side (profiles/r05_host/README.txt)",
             "roofline": {"bound": "hbm", "kernel": "inflate_kernel (+ crc32_kernel), alone on the same blocks, device-resident",
@@ -832,6 +854,15 @@ def producer_leg(ctx, min_af, np, torch, dev, n=100_000, cov=0.1, batch=500, til
         }
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def _bgzf_payload_ranges(raw):
+    at = 0
+    while at < len(raw):
+        bsize = (raw[at + 16] | (raw[at + 17] << 8)) + 1
+        if int.from_bytes(raw[at + bsize - 4:at + bsize], "little"):
+            yield at + 18, at + bsize - 8
+        at += bsize
 
 
 def legs_summary(legs):
