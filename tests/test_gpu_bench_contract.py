@@ -66,8 +66,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     # the producer of the path's input on the device, tile by tile as the host program calls it, and its inflate kernel alone
     pr = legs["producer_bgzf_1e5_coverage10pct"]
     assert pr["unit"] == "positions/s" and pr["value"] > 0 and pr["called_positions"] > 0 and pr["entries_parsed"] > 0
-    assert pr["roofline"]["text_GBs"] > pr["text_GBs"] > 0 and 0 < pr["roofline"]["frac"] < 1
-    assert pr["cpu_path"]["cores"] == 1 and 0 < pr["cpu_path"]["value"] < pr["value"]          # the same tiles on one CPU core
+    assert pr["roofline"]["text_GBs"] > 0 and pr["text_GBs"] > 0 and 0 < pr["roofline"]["frac"] < 1
+    assert pr["cpu_path"]["cores"] == 1 and pr["cpu_path"]["value"] > 0                          # the same tiles on one CPU core
+    if not d.get("diagnostic_build"):                            # (rates against rates: not under the poisoned, bound-checked build)
+        assert pr["roofline"]["text_GBs"] > pr["text_GBs"] and pr["cpu_path"]["value"] < pr["value"]
     hp = legs["host_pointer_one_byte"]
     assert hp["bound"] == "pcie" and 0 < hp["ragged_one_byte"]["frac"] < 1 and 0 < hp["dense_one_byte"]["frac"] < 1
     assert hp["ragged_one_byte"]["records_identical_to_device_pointer_call"] is True
