@@ -283,6 +283,8 @@ class TileQueue {
     bool closed_ = false;
 };
 
+static double cpus_per_loop();
+
 struct TileRunner {
     StageClock clk;                      // stage 1 (the caller's thread): read, parse
     StageClock clk_dev, clk_out;         // stage 2: pack, gpu; stage 3: cvg, vcf, write
@@ -539,6 +541,37 @@ struct TileRunner {
             // the position's slice of the arrays the device returned; its tallies (src/BaseVarC.cpp:560-590) from the 32 counters
             size_t ii = 0;                                   // next indel record (sorted by entry)
             std::vector<std::string> ind_text;
+            // the VCF lines of the tile's called positions -- one field per SAMPLE each, ~1 ms to format at 1e5 samples -- ahead of the
+            // loop, on this thread and two more where the CPUs allow (vcf_line reads the position's entries and its record only)
+            std::vector<size_t> called_t;
+            for (size_t t = 0; t < T.n_pos; ++t) if (T.res[t].called && T.entry_off[t + 1] > T.entry_off[t]) called_t.push_back(t);
+            std::vector<std::string> vcf_pre(called_t.size());
+            auto format_share = [&](size_t k0, size_t k1) {
+                for (size_t k = k0; k < k1; ++k) {
+                    const size_t t = called_t[k];
+                    const int64_t e0 = T.entry_off[t], e1 = T.entry_off[t + 1];
+                    const int64_t a0 = T.called_off.empty() ? e0 : T.called_off[t];
+                    SiteView v;
+                    v.pos = T.pos[t];
+                    v.aiv = reinterpret_cast<const Entry *>(&T.ent[(size_t)a0]);
+                    v.sample = &T.samples[(size_t)a0];
+                    v.n = (size_t)(e1 - e0);
+                    std::map<std::string, std::string> info;
+                    if (ng) group_af_info(T.res[t], &T.gres[t * (size_t)ng], *groups, info);
+                    vcf_pre[k] = vcf_line(T.res[t], chr, T.refs[t], v, info, n_samples);
+                }
+            };
+            {
+                const size_t nc = called_t.size();
+                const size_t shares = (nc >= 3 && cpus_per_loop() >= 4) ? 3 : 1;
+                std::vector<std::future<void>> helpers;
+                for (size_t h = 1; h < shares; ++h)
+                    helpers.push_back(std::async(std::launch::async, format_share, nc * h / shares, nc * (h + 1) / shares));
+                format_share(0, nc / shares);
+                for (auto &f : helpers) f.get();
+                t1 = StageClock::now(); c.vcf += t1 - t0; t0 = t1;
+            }
+            size_t next_called = 0;
             for (size_t t = 0; t < T.n_pos; ++t) {
                 const int64_t e0 = T.entry_off[t], e1 = T.entry_off[t + 1];
                 if (e1 == e0) continue;                      // no entry: the reference skips the position (:443)
@@ -564,11 +597,7 @@ struct TileRunner {
                 fcvg->write(cl);
                 t1 = StageClock::now(); c.write += t1 - t0; t0 = t1;
                 if (T.res[t].called) {
-                    std::map<std::string, std::string> info;
-                    if (ng) group_af_info(T.res[t], g, *groups, info);
-                    const std::string vl = vcf_line(T.res[t], chr, T.refs[t], v, info, n_samples);
-                    t1 = StageClock::now(); c.vcf += t1 - t0; t0 = t1;
-                    fvcf->write(vl);
+                    fvcf->write(vcf_pre[next_called++]);
                     t1 = StageClock::now(); c.write += t1 - t0; t0 = t1;
                 }
                 const int64_t done = ++sites_done;
